@@ -1,0 +1,379 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY) -- numpy restatement of the deepards cnn_linear hot path.
+
+This module restates, in plain numpy (float64 by default), the arithmetic the reference executes
+through stock ``torch.nn`` modules on the path named by BASELINE.json's ``north_star``.  It is the
+*checker* for the HIP kernels in ``deepards_amd/csrc``: only ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s ``cpu_baseline`` leg may import it.  The product path never does.
+
+Pinned by: ``tests/golden/*.npz`` (logits / loss / grads / post-step params captured from the real
+reference imported in the build container, see ``oracle/make_golden.py``).  The reference's own tests
+hold no golden vectors for this path so the goldens come from that import.
+
+Layout here is the reference's own: activations ``(rows, C, L)`` ("NCL"), conv weights
+``(C_out, C_in, k)``.  All functions are pure.
+
+Reference citations (relative to /root/reference/deepards):
+  * models/resnet.py:5-8,11-40,81-163      conv2x2 / BasicBlock / ResNet.forward
+  * models/densenet.py:18-44,68-81,83-194   _DenseLayer / _Transition / DenseNet.forward
+  * models/torch_cnn_linear_network.py:92-113  CNNLinearNetwork.forward (per-window loop)
+  * train_ards_detector.py:161-173,416-422,474-476,526-532  loss / optimiser / clamp hooks
+"""
+import numpy as np
+
+EPS = 1e-5
+
+
+# --------------------------------------------------------------------------------------------
+# leaf ops (each one == the torch.nn op the reference reaches)
+# --------------------------------------------------------------------------------------------
+def conv1d_fwd(x, w, stride=1, pad=0):
+    """nn.Conv1d(bias=False).  x (N,Ci,L), w (Co,Ci,k) -> (N,Co,Lo).  resnet.py:5-8,86-87."""
+    n, ci, l = x.shape
+    co, ci2, k = w.shape
+    assert ci == ci2
+    lo = (l + 2 * pad - k) // stride + 1
+    xp = np.zeros((n, ci, l + 2 * pad), dtype=x.dtype)
+    xp[:, :, pad:pad + l] = x
+    y = np.zeros((n, co, lo), dtype=np.result_type(x, w))
+    for t in range(k):
+        xs = xp[:, :, t:t + (lo - 1) * stride + 1:stride]          # (N,Ci,Lo)
+        y += np.einsum('oc,ncl->nol', w[:, :, t], xs, optimize=True)
+    return y
+
+
+def conv1d_bwd(x, w, dy, stride=1, pad=0, need_dx=True):
+    """Gradients of conv1d_fwd: returns (dx, dw)."""
+    n, ci, l = x.shape
+    co, _, k = w.shape
+    lo = dy.shape[2]
+    xp = np.zeros((n, ci, l + 2 * pad), dtype=x.dtype)
+    xp[:, :, pad:pad + l] = x
+    dxp = np.zeros_like(xp, dtype=np.result_type(x, w))
+    dw = np.zeros_like(w)
+    for t in range(k):
+        sl = slice(t, t + (lo - 1) * stride + 1, stride)
+        dw[:, :, t] = np.einsum('nol,ncl->oc', dy, xp[:, :, sl], optimize=True)
+        if need_dx:
+            dxp[:, :, sl] += np.einsum('oc,nol->ncl', w[:, :, t], dy, optimize=True)
+    dx = dxp[:, :, pad:pad + l] if need_dx else None
+    return dx, dw
+
+
+def bn_window_fwd(x, gamma, beta, rows_per_window, eps=EPS):
+    """Train-mode nn.BatchNorm1d applied one window at a time (torch_cnn_linear_network.py:108-113
+    calls breath_block(x[i]) per window, so the batch statistics are over (rows_per_window, L) per
+    channel *per window*; SURVEY.md finding 3).  Returns y, (mean, invstd) with shape (W, C)."""
+    n, c, l = x.shape
+    w = n // rows_per_window
+    xv = x.reshape(w, rows_per_window, c, l)
+    mean = xv.mean(axis=(1, 3))                                     # (W,C)
+    var = xv.var(axis=(1, 3))                                       # biased
+    invstd = 1.0 / np.sqrt(var + eps)
+    xhat = (xv - mean[:, None, :, None]) * invstd[:, None, :, None]
+    y = xhat * gamma[None, None, :, None] + beta[None, None, :, None]
+    return y.reshape(n, c, l), (mean, invstd)
+
+
+def bn_window_bwd(x, gamma, stats, dy, rows_per_window):
+    """Backward of bn_window_fwd.  Returns dx, dgamma, dbeta (param grads summed over windows)."""
+    n, c, l = x.shape
+    w = n // rows_per_window
+    mean, invstd = stats
+    xv = x.reshape(w, rows_per_window, c, l)
+    dv = dy.reshape(w, rows_per_window, c, l)
+    xhat = (xv - mean[:, None, :, None]) * invstd[:, None, :, None]
+    cnt = rows_per_window * l
+    s1 = dv.sum(axis=(1, 3))                                        # (W,C)
+    s2 = (dv * xhat).sum(axis=(1, 3))
+    dx = (gamma * invstd)[:, None, :, None] * (dv - s1[:, None, :, None] / cnt
+                                               - xhat * s2[:, None, :, None] / cnt)
+    return dx.reshape(n, c, l), s2.sum(axis=0), s1.sum(axis=0)
+
+
+def bn_running_update(running_mean, running_var, stats, count, momentum=0.1, eps=EPS):
+    """Sequential per-window running-stat update (SURVEY.md finding 5): unbiased var, momentum .1."""
+    mean, invstd = stats
+    var_b = 1.0 / (invstd ** 2) - eps
+    rm, rv = running_mean.copy(), running_var.copy()
+    for i in range(mean.shape[0]):
+        rm = (1 - momentum) * rm + momentum * mean[i]
+        rv = (1 - momentum) * rv + momentum * var_b[i] * count / (count - 1)
+    return rm, rv
+
+
+def relu(x):
+    return np.maximum(x, 0)
+
+
+def maxpool3s2p1_fwd(x):
+    """nn.MaxPool1d(3,2,1) (resnet.py:100-102, densenet.py:123).  Returns y and argmax index
+    (first max wins, as ATen)."""
+    n, c, l = x.shape
+    lo = (l + 2 - 3) // 2 + 1
+    xp = np.full((n, c, l + 2), -np.inf, dtype=x.dtype)
+    xp[:, :, 1:l + 1] = x
+    cand = np.stack([xp[:, :, t:t + (lo - 1) * 2 + 1:2] for t in range(3)], axis=-1)  # (N,C,Lo,3)
+    arg = cand.argmax(axis=-1)
+    y = np.take_along_axis(cand, arg[..., None], axis=-1)[..., 0]
+    idx = np.arange(lo)[None, None, :] * 2 - 1 + arg                # position in un-padded x
+    return y, idx
+
+
+def maxpool3s2p1_bwd(dy, idx, l):
+    n, c, lo = dy.shape
+    dx = np.zeros((n, c, l), dtype=dy.dtype)
+    nn_, cc = np.meshgrid(np.arange(n), np.arange(c), indexing='ij')
+    for j in range(lo):
+        np.add.at(dx, (nn_, cc, idx[:, :, j]), dy[:, :, j])
+    return dx
+
+
+def avgpool_fwd(x, k, stride):
+    """nn.AvgPool1d(k, stride) no padding (resnet.py:112, densenet.py:79,167)."""
+    n, c, l = x.shape
+    lo = (l - k) // stride + 1
+    y = np.zeros((n, c, lo), dtype=x.dtype)
+    for t in range(k):
+        y += x[:, :, t:t + (lo - 1) * stride + 1:stride]
+    return y / k
+
+
+def avgpool_bwd(dy, k, stride, l):
+    n, c, lo = dy.shape
+    dx = np.zeros((n, c, l), dtype=dy.dtype)
+    for t in range(k):
+        dx[:, :, t:t + (lo - 1) * stride + 1:stride] += dy / k
+    return dx
+
+
+def avgpool3s2p1_fwd(x):
+    """nn.AvgPool1d(3,2,1) (resnet first_pool_type='avg', resnet.py:103-104; count_include_pad)."""
+    n, c, l = x.shape
+    xp = np.zeros((n, c, l + 2), dtype=x.dtype)
+    xp[:, :, 1:l + 1] = x
+    return avgpool_fwd(xp, 3, 2)
+
+
+def avgpool3s2p1_bwd(dy, l):
+    return avgpool_bwd(dy, 3, 2, l + 2)[:, :, 1:l + 1]
+
+
+def linear_fwd(x, w, b):
+    return x @ w.T + b
+
+
+def bce_with_logits(x, t):
+    """torch.nn.BCEWithLogitsLoss() mean reduction (train_ards_detector.py:530,929-930).
+    Returns loss, dloss/dx."""
+    loss = np.maximum(x, 0) - x * t + np.log1p(np.exp(-np.abs(x)))
+    sig = 1.0 / (1.0 + np.exp(-x))
+    return loss.mean(), (sig - t) / x.size
+
+
+def clamp_grad(g, clip):
+    """register_hook(lambda g: torch.clamp(g, -clip, clip)) (train_ards_detector.py:474-476)."""
+    return np.clip(g, -clip, clip)
+
+
+def sgd_nesterov_step(p, g, buf, lr=1e-3, momentum=0.9, wd=1e-4, first=False):
+    """torch.optim.SGD(momentum=.9, weight_decay, nesterov=True) (train_ards_detector.py:421).
+    Returns new p, new buf."""
+    g = g + wd * p
+    buf = g.copy() if first or buf is None else momentum * buf + g
+    g = g + momentum * buf
+    return p - lr * g, buf
+
+
+def adam_step(p, g, m, v, step, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam(lr) defaults (train_ards_detector.py:419).  step counts from 1."""
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    mhat = m / (1 - b1 ** step)
+    vhat = v / (1 - b2 ** step)
+    return p - lr * mhat / (np.sqrt(vhat) + eps), m, v
+
+
+# --------------------------------------------------------------------------------------------
+# network assembly: a tiny tape so forward and backward stay in one place
+# --------------------------------------------------------------------------------------------
+class _Tape(object):
+    """Records closures; backward replays them in reverse.  Values are numpy arrays."""
+
+    def __init__(self, params, rows_per_window):
+        self.p = params
+        self.g = {}
+        self.R = rows_per_window
+        self.stats = {}
+
+    def acc(self, name, g):
+        self.g[name] = self.g.get(name, 0) + g
+
+
+def _conv(t, x, name, stride, pad, need_dx=True):
+    w = t.p[name]
+    y = conv1d_fwd(x, w, stride, pad)
+
+    def bwd(dy):
+        dx, dw = conv1d_bwd(x, w, dy, stride, pad, need_dx)
+        t.acc(name, dw)
+        return dx
+    return y, bwd
+
+
+def _bn(t, x, prefix):
+    gname, bname = prefix + '.weight', prefix + '.bias'
+    y, st = bn_window_fwd(x, t.p[gname], t.p[bname], t.R)
+    t.stats[prefix] = (st, t.R * x.shape[2])
+
+    def bwd(dy):
+        dx, dg, db = bn_window_bwd(x, t.p[gname], st, dy, t.R)
+        t.acc(gname, dg)
+        t.acc(bname, db)
+        return dx
+    return y, bwd
+
+
+def _relu(x):
+    y = relu(x)
+    return y, (lambda dy: dy * (y > 0))
+
+
+def _stem(t, x, conv, bn, pool_type='max'):
+    y0, b_conv = _conv(t, x, conv, 2, 3, need_dx=False)
+    y1, b_bn = _bn(t, y0, bn)
+    y2, b_relu = _relu(y1)
+    if pool_type == 'max':
+        y3, idx = maxpool3s2p1_fwd(y2)
+        b_pool = lambda d: maxpool3s2p1_bwd(d, idx, y2.shape[2])
+    else:
+        y3 = avgpool3s2p1_fwd(y2)
+        b_pool = lambda d: avgpool3s2p1_bwd(d, y2.shape[2])
+    return y3, (lambda d: b_conv(b_bn(b_relu(b_pool(d)))))
+
+
+def resnet18_features(t, x, prefix='breath_block.', first_pool_type='max'):
+    """ResNet.forward (resnet.py:141-163) with BasicBlock (resnet.py:24-40), layers [2,2,2,2]."""
+    h, b_stem = _stem(t, x, prefix + 'conv1.weight', prefix + 'bn1', first_pool_type)
+    backs = [b_stem]
+    inpl = 64
+    for li, planes in enumerate([64, 128, 256, 512]):
+        for bi in range(2):
+            stride = 2 if (li > 0 and bi == 0) else 1
+            bp = '%slayer%d.%d.' % (prefix, li + 1, bi)
+            xin = h
+            o, b1 = _conv(t, xin, bp + 'conv1.weight', stride, 1)
+            o, b2 = _bn(t, o, bp + 'bn1')
+            o, b3 = _relu(o)
+            o, b4 = _conv(t, o, bp + 'conv2.weight', 1, 1)
+            o, b5 = _bn(t, o, bp + 'bn2')
+            if stride != 1 or inpl != planes:
+                r, d1 = _conv(t, xin, bp + 'downsample.0.weight', stride, 0)
+                r, d2 = _bn(t, r, bp + 'downsample.1')
+                b_res = (lambda d1, d2: (lambda d: d1(d2(d))))(d1, d2)
+            else:
+                r = xin
+                b_res = lambda d: d
+            h, b6 = _relu(o + r)
+
+            def blk_bwd(d, b1=b1, b2=b2, b3=b3, b4=b4, b5=b5, b6=b6, b_res=b_res):
+                dz = b6(d)
+                return b1(b2(b3(b4(b5(dz))))) + b_res(dz)
+            backs.append(blk_bwd)
+            inpl = planes
+    feat = avgpool_fwd(h, 7, 1)
+    lh = h.shape[2]
+    n = x.shape[0]
+    out = feat.reshape(n, -1)
+
+    def bwd(dout):
+        d = avgpool_bwd(dout.reshape(feat.shape), 7, 1, lh)
+        for b in reversed(backs):
+            d = b(d)
+        return d
+    return out, bwd
+
+
+def densenet18_features(t, x, prefix='breath_block.', drop_masks=None):
+    """DenseNet.forward (densenet.py:179-189): stem, 4 blocks x 2 _DenseLayer (densenet.py:18-41,
+    pre-activation BN->ReLU->conv1x1->BN->ReLU->conv3 -> dropout -> cat), _Transition
+    (densenet.py:68-79), norm5 -> relu -> AvgPool1d(7,1).  Dropout is OFF unless explicit
+    keep-masks (already scaled by 1/(1-p)) are passed: drop_masks[(block, layer)] (N,32,L)."""
+    fp = prefix + 'features.'
+    h, b_stem = _stem(t, x, fp + 'conv0.weight', fp + 'norm0', 'max')
+    backs = [b_stem]
+    for bi in range(1, 5):
+        for li in range(1, 3):
+            lp = '%sdenseblock%d.denselayer%d.' % (fp, bi, li)
+            xin = h
+            o, b1 = _bn(t, xin, lp + 'norm1')
+            o, b2 = _relu(o)
+            o, b3 = _conv(t, o, lp + 'conv1.weight', 1, 0)
+            o, b4 = _bn(t, o, lp + 'norm2')
+            o, b5 = _relu(o)
+            o, b6 = _conv(t, o, lp + 'conv2.weight', 1, 1)
+            mask = None if drop_masks is None else drop_masks.get((bi, li))
+            if mask is not None:
+                o = o * mask
+            cin = xin.shape[1]
+            h = np.concatenate([xin, o], axis=1)
+
+            def lay_bwd(d, b1=b1, b2=b2, b3=b3, b4=b4, b5=b5, b6=b6, cin=cin, mask=mask):
+                dnew = d[:, cin:]
+                if mask is not None:
+                    dnew = dnew * mask
+                return d[:, :cin] + b1(b2(b3(b4(b5(b6(dnew))))))
+            backs.append(lay_bwd)
+        if bi != 4:
+            tp = '%stransition%d.' % (fp, bi)
+            o, b1 = _bn(t, h, tp + 'norm')
+            o, b2 = _relu(o)
+            o, b3 = _conv(t, o, tp + 'conv.weight', 1, 0)
+            lin = o.shape[2]
+            h = avgpool_fwd(o, 2, 2)
+            backs.append((lambda b1, b2, b3, lin: (lambda d: b1(b2(b3(avgpool_bwd(d, 2, 2, lin))))))(b1, b2, b3, lin))
+    o, b1 = _bn(t, h, fp + 'norm5')
+    o, b2 = _relu(o)
+    lh = o.shape[2]
+    feat = avgpool_fwd(o, 7, 1)
+    n = x.shape[0]
+    out = feat.reshape(n, -1)
+
+    def bwd(dout):
+        d = b1(b2(avgpool_bwd(dout.reshape(feat.shape), 7, 1, lh)))
+        for b in reversed(backs):
+            d = b(d)
+        return d
+    return out, bwd
+
+
+def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_batches=20,
+                                first_pool_type='max', drop_masks=None, need_grads=True):
+    """CNNLinearNetwork.forward over a batch (torch_cnn_linear_network.py:104-113) + BCE loss
+    (train_ards_detector.py:929-930) + backward.  x (B,NB,C,224); target (B,2) one-hot.
+    params: dict name -> ndarray with the reference's state_dict keys.
+    Returns dict(logits, loss, grads{name}, feat, stats)."""
+    if x.shape[-1] != 224:
+        raise Exception('input breaths must have sequence length of 224')
+    b, nb, c, l = x.shape
+    t = _Tape(params, nb)
+    rows = x.reshape(b * nb, c, l)
+    if backbone == 'resnet18':
+        feat, fbwd = resnet18_features(t, rows, first_pool_type=first_pool_type)
+    elif backbone == 'densenet18':
+        feat, fbwd = densenet18_features(t, rows, drop_masks=drop_masks)
+    else:
+        raise ValueError(backbone)
+    flat = feat.reshape(b, -1)                                       # view(-1) of (NB,F) per window
+    w, bias = params['linear_final.weight'], params['linear_final.bias']
+    logits = linear_fwd(flat, w, bias)
+    out = dict(logits=logits, feat=feat, stats=t.stats)
+    if target is None:
+        return out
+    loss, dlogits = bce_with_logits(logits, target)
+    out['loss'] = loss
+    if need_grads:
+        t.acc('linear_final.weight', dlogits.T @ flat)
+        t.acc('linear_final.bias', dlogits.sum(axis=0))
+        fbwd((dlogits @ w).reshape(feat.shape))
+        out['grads'] = t.g
+    return out

@@ -1,0 +1,87 @@
+"""CPU: pin the numpy oracle (oracle/np_ref.py) to the golden vectors captured from the real
+reference (oracle/make_golden.py).  float64 oracle vs float64 reference: tight tolerances."""
+import glob
+import os
+import numpy as np
+import pytest
+
+from oracle import np_ref
+from oracle.weights import seeded_params, digest, DEAD_RESNET_PARAMS
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*.npz')))
+
+
+def _load(path):
+    z = np.load(path, allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize('path', GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_np_oracle_matches_reference(path):
+    g = _load(path)
+    backbone = str(g['backbone'])
+    params = {k: v.astype(np.float64) for k, v in seeded_params(backbone, int(g['seed'])).items()}
+    out = np_ref.cnn_linear_forward_backward(params, g['x'].astype(np.float64), g['target'].astype(np.float64),
+                                             backbone=backbone, first_pool_type=str(g['first_pool_type']))
+    np.testing.assert_allclose(out['logits'], g['logits64'], rtol=0, atol=1e-10)
+    assert abs(out['loss'] - float(g['loss64'])) < 1e-12
+    checked = 0
+    for k in g:
+        if k.startswith('grad64/'):
+            name = k[len('grad64/'):]
+            np.testing.assert_allclose(digest(out['grads'][name]), g[k], rtol=1e-8, atol=1e-11, err_msg=name)
+            checked += 1
+    dead = [n for n in DEAD_RESNET_PARAMS if n in params]
+    assert checked == len(params) - (len(dead) if backbone == 'resnet18' else 0)
+    # the fp32 reference sits within 1e-5 of the fp64 one: the 1e-4 parity budget is meaningful
+    assert np.abs(g['logits32'] - g['logits64']).max() < 1e-5
+
+
+def test_np_oracle_sgd_trajectory():
+    g = _load([p for p in GOLD if 'resnet18_b2_randn' in p][0])
+    params = {k: v.astype(np.float64) for k, v in seeded_params('resnet18', 0).items()}
+    x, t = g['x'].astype(np.float64), g['target'].astype(np.float64)
+    bufs = {}
+    losses = []
+    for step in range(3):
+        out = np_ref.cnn_linear_forward_backward(params, x, t, backbone='resnet18')
+        losses.append(out['loss'])
+        for n in out['grads']:
+            gr = np_ref.clamp_grad(out['grads'][n], 0.01)
+            params[n], bufs[n] = np_ref.sgd_nesterov_step(params[n], gr, bufs.get(n), first=(step == 0))
+    np.testing.assert_allclose(losses, g['sgd_losses64'], rtol=0, atol=1e-10)
+    for k in g:
+        if k.startswith('sgd_p64/'):
+            name = k[len('sgd_p64/'):]
+            np.testing.assert_allclose(digest(params[name]), g[k], rtol=1e-9, atol=1e-12, err_msg=name)
+
+
+def test_np_oracle_adam_trajectory():
+    g = _load([p for p in GOLD if 'densenet18_b2_randn' in p][0])
+    params = {k: v.astype(np.float64) for k, v in seeded_params('densenet18', 0).items()}
+    x, t = g['x'].astype(np.float64), g['target'].astype(np.float64)
+    m, v = {}, {}
+    for step in range(3):
+        out = np_ref.cnn_linear_forward_backward(params, x, t, backbone='densenet18')
+        for n in out['grads']:
+            gr = np_ref.clamp_grad(out['grads'][n], 0.01)
+            params[n], m[n], v[n] = np_ref.adam_step(params[n], gr, m.get(n, 0.0), v.get(n, 0.0), step + 1)
+    for k in g:
+        if k.startswith('adam_p64/'):
+            name = k[len('adam_p64/'):]
+            np.testing.assert_allclose(digest(params[name]), g[k], rtol=1e-7, atol=1e-10, err_msg=name)
+
+
+def test_running_stats_closed_form():
+    g = _load([p for p in GOLD if 'resnet18_b2_randn' in p][0])
+    params = {k: v.astype(np.float64) for k, v in seeded_params('resnet18', 0).items()}
+    out = np_ref.cnn_linear_forward_backward(params, g['x'].astype(np.float64), None, backbone='resnet18')
+    for short, full in (('bn1', 'breath_block.bn1'), ('layer4.1.bn2', 'breath_block.layer4.1.bn2')):
+        st, cnt = out['stats'][full]
+        c = st[0].shape[1]
+        rm, rv = np_ref.bn_running_update(np.zeros(c), np.ones(c), st, cnt)
+        # the golden ran forward twice: model(x) for the whole batch and breath_block(x[0]) -> 3 updates
+        st0 = (st[0][:1], st[1][:1])
+        rm, rv = np_ref.bn_running_update(rm, rv, st0, cnt)
+        np.testing.assert_allclose(rm, g['rm64/' + short], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(rv, g['rv64/' + short], rtol=1e-9, atol=1e-12)
