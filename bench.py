@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- breath-sequences/sec of one cnn_linear TRAIN step (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = zero-grad + forward + BCE-with-logits + backward + (+-0.01 clamp, weight decay, SGD-Nesterov
+update) over one synthetic batch of (B, 20, 1, 224) fp32 windows already resident in HBM -- the
+reference's run_train_epoch body (train_ards_detector.py:139-173).  N > 1: one process per GPU,
+each rank owns B windows (weak scaling), one RCCL all-reduce of the flat gradient bucket per step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel family (implicit-GEMM conv on the fp32 MFMA pipe): algorithmic
+                  FLOPs of its launches / their HIP-event durations, measured live on the launch stream
+  cpu_baseline -- the reference's CPU path (oracle/torch_ref.py, stock ATen ops, all host threads)
+                  timed on a bounded sample of the same workload (N=1, rank 0 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per breath-sequence: FLOPs train, activation bytes train fp32, #params
+WORK = {
+    'resnet18': dict(flops=228.665e6, act_bytes=1421.1e3, params=3864386),
+    'densenet18': dict(flops=33.404e6, act_bytes=1052.8e3, params=214850),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--backbone', default='resnet18', choices=sorted(WORK))
+    ap.add_argument('--batch', type=int, default=64, help='windows per GPU (BASELINE configs[1]: B=64)')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    return ap.parse_args()
+
+
+class KernelTimer(object):
+    """Wraps C-ABI entry points with HIP events recorded on the launch stream (eager mode only)."""
+
+    def __init__(self, lib, torch):
+        self.lib, self.torch = lib, torch
+        self.records = {}
+        self.orig = {}
+
+    def flops_of(self, name, a):
+        if name == 'da_conv_gemm':       # x,w,y,rows,Lm,Lsrc,ldx,C,Ldst,ldy,N,...,ntaps at index 14
+            return 2.0 * a[3] * a[4] * a[7] * a[10] * a[14]
+        if name == 'da_conv_wgrad':      # dy,x,dw,ws,rows,Lm,Ldy,lddy,N,Lx,ldx,C,...,ntaps at index 15
+            return 2.0 * a[4] * a[5] * a[8] * a[11] * a[15]
+        return 0.0
+
+    def install(self, names):
+        for n in names:
+            fn = getattr(self.lib, n)
+            self.orig[n] = fn
+
+            def wrapped(*a, _fn=fn, _n=n):
+                e0 = self.torch.cuda.Event(enable_timing=True)
+                e1 = self.torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = _fn(*a)
+                e1.record()
+                self.records.setdefault(_n, []).append((e0, e1, self.flops_of(_n, a)))
+                return rc
+            setattr(self.lib, n, wrapped)
+
+    def remove(self):
+        for n, fn in self.orig.items():
+            setattr(self.lib, n, fn)
+
+    def summary(self):
+        self.torch.cuda.synchronize()
+        out = {}
+        for n, recs in self.records.items():
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+            out[n] = dict(calls=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs), flops=sum(r[2] for r in recs))
+        return out
+
+
+def cpu_baseline(backbone, batch, seconds):
+    """Reference CPU path (stock ATen ops through oracle/torch_ref.py) on the host cores."""
+    import torch
+    from oracle import torch_ref
+    from oracle.weights import seeded_params
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    p = {k: torch.from_numpy(v) for k, v in seeded_params(backbone, 0).items()}
+    tr = torch_ref.CpuReferenceTrainer(p, backbone, drop_rate=0.2 if backbone == 'densenet18' else 0.0)
+    g = torch.Generator().manual_seed(0)
+    b = min(batch, 16)                                   # reference default batch (defaults.yml:17) bounds the sample
+    x = torch.randn(b, 20, 1, 224, generator=g)
+    t = torch.zeros(b, 2)
+    t[torch.arange(b), torch.randint(0, 2, (b,), generator=g)] = 1
+    tr.step(x, t)                                        # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tr.step(x, t)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds and n >= 2:
+            break
+    return dict(value=round(n * b * 20 / dt, 2), unit='breath-sequences/s', cores=cores, kind='port',
+                sample='%d train steps of B=%d windows (20x1x224) in %.1f s, %s, torch %s CPU, %d threads' %
+                       (n, b, dt, backbone, torch.__version__, cores))
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`' % (args.gpus, args.gpus))
+        raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the product path')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from deepards_amd import _lib
+    lib = _lib.lib()                                     # fail loudly if the HIP library is missing
+    import deepards_amd.models as M
+    from deepards_amd.train import HotPathTrainer
+
+    torch.manual_seed(0)                                 # same init on every rank (replicas start identical)
+    bb = M.resnet18() if args.backbone == 'resnet18' else M.densenet18()
+    model = M.CNNLinearNetwork(bb, 20, 0).to(dev)
+    B = args.batch
+    g = torch.Generator().manual_seed(1000 + rank)       # each rank its own shard of the global batch
+    x = torch.randn(B, 20, 1, 224, generator=g).to(dev)
+    t = torch.zeros(B, 2)
+    t[torch.arange(B), torch.randint(0, 2, (B,), generator=g)] = 1
+    t = t.to(dev)
+    tr = HotPathTrainer(model, optimizer='sgd', world_size=world, rank=rank, use_graph=not args.no_graph)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2)):                 # >= 2: eager first step + graph capture
+        tr.train_step(x, t)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.train_step(x, t)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    loss = float(tr.last_loss)
+
+    seqs = world * B * 20 * args.steps
+    value = seqs / dt
+    w = WORK[args.backbone]
+    out = {
+        'metric': 'breath-sequences/sec (train step) cnn_linear nb20 seq224',
+        'value': round(value, 1), 'unit': 'breath-sequences/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': max(args.warmup, 2), 'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) fp32 train step '
+                               '(BASELINE configs[1])' % (args.backbone, B),
+                   'backbone': args.backbone, 'batch_per_gpu': B, 'global_batch': B * world, 'n_sub_batches': 20,
+                   'seq_len': 224, 'optimizer': 'sgd-nesterov+clamp', 'parallelism': 'dp%d' % world,
+                   'hipgraph': not args.no_graph},
+        'final_loss': round(loss, 6),
+    }
+    step_flops = w['flops'] * B * 20
+    step_bytes = (w['act_bytes'] * B * 20) + 8 * 4 * w['params']
+    per_gpu_dt = dt / args.steps
+    out['step_roofline'] = {
+        'alg_tflops': round(step_flops / per_gpu_dt / 1e12, 2), 'peak_tflops_fp32_mfma': PEAK_FP32_MFMA_TFLOPS,
+        'frac_compute': round(step_flops / per_gpu_dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+        'alg_gbs': round(step_bytes / per_gpu_dt / 1e9, 1), 'peak_gbs': PEAK_HBM_GBS,
+        'frac_hbm': round(step_bytes / per_gpu_dt / 1e9 / PEAK_HBM_GBS, 4), 'binding': 'compute(fp32 mfma)'}
+
+    if rank == 0 and not args.no_roofline:
+        # instrumented EAGER steps: HIP events around every C-ABI launch, on the launch stream
+        kt = KernelTimer(lib, torch)
+        names = [n for n in _lib.SIGNATURES if n not in ('da_version', 'da_conv_wgrad_workspace', 'da_stem_wgrad_workspace')]
+        tr_e = HotPathTrainer(model, optimizer='sgd', use_graph=False)
+        tr_e.bucket, tr_e.state = tr.bucket, tr.state
+        tr_e._eager_step(x, t)                           # untimed
+        kt.install(names)
+        nprof = 3
+        for _ in range(nprof):
+            tr_e._eager_step(x, t)
+        summ = kt.summary()
+        kt.remove()
+        dom = summ['da_conv_gemm']
+        ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_gemm_kernel<*> (da_conv_gemm: conv fwd + dgrad implicit GEMM, '
+                                                       'v_mfma_f32_32x32x2_f32)',
+                           'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                           'launches_per_step': dom['calls'] // nprof, 'avg_launch_us': round(dom['avg_us'], 2),
+                           'alg_flops_per_launch': round(dom['flops'] / dom['calls'], 1)}
+        tot = sum(v['total_ms'] for v in summ.values())
+        out['kernel_time_share'] = {k: round(v['total_ms'] / tot, 4) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]['total_ms'])}
+        wg = summ.get('da_conv_wgrad')
+        if wg:
+            out['wgrad_tflops'] = round(wg['flops'] / (wg['total_ms'] * 1e-3) / 1e12, 2)
+        out['eager_kernel_ms_per_step'] = round(tot / nprof, 3)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(args.backbone, B, args.cpu_seconds)
+        out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,88 @@
+"""Build + load libdeepards_hip.so (the C-ABI of include/deepards_hip.h) with ctypes.
+
+There is NO fallback: if the library is missing or a symbol cannot be bound the import of any
+compute entry point raises.  PyTorch is used only for device memory and streams.
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(_HERE, 'libdeepards_hip.so')
+HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'deepards_hip.h')
+SOURCES = ['conv_gemm.hip', 'bn.hip', 'stem_pool.hip', 'head_optim.hip']
+
+_P, _I, _F, _Z, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_uint
+_IP = ctypes.POINTER(ctypes.c_int)
+
+# name -> (restype, argtypes); must list exactly the symbols the header declares (tests check it)
+SIGNATURES = {
+    'da_version': (_I, []),
+    'da_conv_gemm': (_I, [_P, _P, _P] + [_I] * 12 + [_IP, _IP, _I, _P]),
+    'da_conv_wgrad_workspace': (_Z, [_I] * 5),
+    'da_conv_wgrad': (_I, [_P, _P, _P, _P] + [_I] * 12 + [_IP, _I, _P]),
+    'da_repack_conv_weight': (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    'da_stem_conv_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    'da_stem_wgrad_workspace': (_Z, [_I, _I]),
+    'da_stem_conv_wgrad': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'da_bn_stats': (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _P]),
+    'da_bn_running_update': (_I, [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P]),
+    'da_bn_apply': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
+    'da_bn_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
+    'da_bn_relu_pool_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
+    'da_pool_bwd': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
+    'da_avgpool_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    'da_avgpool_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    'da_linear2_fwd': (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    'da_bce_logits': (_I, [_P, _P, _I, _F, _P, _P, _P]),
+    'da_linear2_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'da_clamp_sgd_nesterov': (_I, [_P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _P]),
+    'da_clamp_adam': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _F, _F, _P]),
+    'da_concat2': (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _Z, _P]),
+    'da_slice_copy': (_I, [_P, _I, _I, _P, _I, _I, _Z, _I, _P]),
+    'da_dropout': (_I, [_P, _P, _Z, _P, _U, _F, _P]),
+}
+
+
+def header_symbols():
+    """Function names declared in include/deepards_hip.h."""
+    txt = open(HEADER).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(da_[a-z0-9_]+)\s*\(', txt)))
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 every csrc/*.hip into deepards_amd/libdeepards_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, 'common.h')]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not os.path.exists(hipcc):
+        hipcc = 'hipcc'
+    cmd = [hipcc, '-O3', '--offload-arch=gfx950', '-fPIC', '-shared', '-std=c++17', '-o', LIB_PATH] + srcs
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library with argtypes bound.  Raises (never falls back) if it cannot be loaded."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libdeepards_hip.so is not built: run `python -c "import __graft_entry__ as g; '
+                               'g.build()"` (hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the symbol is missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib

@@ -1,0 +1,44 @@
+// Shared device/host helpers for the deepards MI355X (gfx950) kernels.
+//
+// Data layout used by every kernel in this directory ("RLC", channels-last rows):
+//   activation[row][l][c]   row = window*rows_per_window + sub_batch_row, l = sample position,
+//                           c = channel; channel pitch `ld` floats (>= C, multiple of 4).
+// A *window* (the unit BatchNorm statistics are taken over, reference
+// models/torch_cnn_linear_network.py:108-113) is rows_per_window consecutive rows, i.e. one
+// contiguous [rows_per_window*L][ld] slab of HBM.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DA_OK 0
+#define DA_EINVAL (-1)
+
+#define DA_CHECK_LAUNCH()                          \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+
+// q = m / d for m*d < 2^32 via one v_mul_hi_u32 (magic = floor(2^32/d)+1, d >= 2; d == 1 handled).
+struct FastDiv {
+  uint32_t magic;
+  uint32_t d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  f.magic = d <= 1 ? 0u : (uint32_t)((0x100000000ull / d) + 1ull);
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t m, FastDiv f) {
+  return f.d <= 1 ? m : __umulhi(m, f.magic);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

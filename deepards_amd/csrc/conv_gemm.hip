@@ -1,0 +1,408 @@
+// Conv1d forward / data-gradient / weight-gradient as implicit GEMMs on the fp32 matrix cores.
+//
+// Replaces the nn.Conv1d calls of reference models/resnet.py:5-8,16-19,126-128 (conv2x2, BasicBlock
+// convs, 1x1 stride-2 downsample) and models/densenet.py:25-32,75-76 (1x1 bottleneck, k3 growth conv,
+// transition conv), forward and backward.
+//
+// gfx950 has an exact-f32 MFMA (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, one rounding per
+// product, same rate as the f32 VALU peak but one operand VGPR per lane and the VALU left free), so
+// the contraction keeps the reference's fp32 arithmetic while running on the matrix pipe.
+//
+// Layout: activations RLC (see common.h).  Packed weights Wp[tap][n][c] (c contiguous): the forward
+// conv uses Wp_f[k][co][ci], the data gradient Wp_d[k][ci][co] (repack kernels in elementwise.hip).
+//
+//   fwd/dgrad:  Y[m][n] (+)= sum_t sum_c X[src(m,t)][c] * Wp[wtap_t][n][c]
+//               m -> (row, j) = (m / Lm, m % Lm);  src position = j*src_stride + src_off_t (zero
+//               outside [0,Lsrc));  dst position = j*dst_stride + dst_off.
+//   wgrad:      dWp[t][n][c] = sum_m dY[m][n] * X[src(m,t)][c], split over position chunks into
+//               slabs that a reduce kernel sums deterministically (no float atomics).
+//
+// Tiling: 256 threads = 4 waves; a wave owns TM x TN tiles of 32x32; one K step = 32 reduction
+// channels of one tap staged through LDS (pitch 36 floats: conflict-free ds_read_b128, each lane
+// reads 4 consecutive k of its row, lane half h takes k = 8*c8 + 4*h + e, the same permutation for
+// both operands, so each MFMA pairs identical k on A and B).
+#include "common.h"
+
+struct ConvGemmArgs {
+  const float* x;
+  const float* w;
+  float* y;
+  int M, Lsrc, ldx, C;
+  int Ldst, ldy, N;
+  int dst_stride, dst_off, src_stride;
+  int ntaps, so0, so1, so2, wt0, wt1, wt2;
+  int accumulate;
+  FastDiv divLm;  // Lm
+};
+
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
+  constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32, PITCH = 36;
+  static_assert(WGM * WGN == 4, "4 waves");
+  __shared__ float lds[(BM + BN) * PITCH];
+  float* As = lds;
+  float* Bs = lds + BM * PITCH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
+  const int lr = tid >> 3, lq = tid & 7;
+  const int Lm = (int)a.divLm.d;
+
+  constexpr int AP = BM / 32, BP = BN / 32;
+  int a_rowoff[AP], a_j[AP];
+  bool a_ok[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    int m = m_blk + lr + 32 * p;
+    a_ok[p] = m < a.M;
+    uint32_t row = fdiv((uint32_t)(a_ok[p] ? m : 0), a.divLm);
+    int j = (a_ok[p] ? m : 0) - (int)row * Lm;
+    a_rowoff[p] = (int)row * a.Lsrc;
+    a_j[p] = j * a.src_stride;
+  }
+
+  const int kc = a.C >> 5;
+  const int nk = a.ntaps * kc;
+  f32x4 ra[AP], rb[BP];
+
+  auto gload = [&](int it) {
+    int t = it / kc;
+    int c0 = (it - t * kc) << 5;
+    int so = t == 0 ? a.so0 : (t == 1 ? a.so1 : a.so2);
+    int wt = t == 0 ? a.wt0 : (t == 1 ? a.wt1 : a.wt2);
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      int ls = a_j[p] + so;
+      bool ok = a_ok[p] && ls >= 0 && ls < a.Lsrc;
+      const float* src = a.x + (size_t)(a_rowoff[p] + (ok ? ls : 0)) * a.ldx + c0 + lq * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(src);
+      ra[p] = v;
+    }
+    const float* wtp = a.w + (size_t)wt * a.N * a.C;
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+      int n = n_blk + lr + 32 * p;
+      rb[p] = *reinterpret_cast<const f32x4*>(wtp + (size_t)n * a.C + c0 + lq * 4);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  const int frow = lane & 31, fh = lane >> 5;
+  for (int it = 0; it < nk; ++it) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4*>(&As[(lr + 32 * p) * PITCH + lq * 4]) = ra[p];
+#pragma unroll
+    for (int p = 0; p < BP; ++p) *reinterpret_cast<f32x4*>(&Bs[(lr + 32 * p) * PITCH + lq * 4]) = rb[p];
+    __syncthreads();
+    if (it + 1 < nk) gload(it + 1);
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * TM + i) * 32 + frow) * PITCH + c8 * 8 + fh * 4]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * TN + j) * 32 + frow) * PITCH + c8 * 8 + fh * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // epilogue: lane holds output channel n (column), 16 positions (rows) per 32x32 tile
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int mrow = (r & 3) + 8 * (r >> 2) + 4 * fh;
+      int m = m_blk + (wm * TM + i) * 32 + mrow;
+      if (m < a.M) {
+        uint32_t row = fdiv((uint32_t)m, a.divLm);
+        int jj = m - (int)row * Lm;
+        size_t off = ((size_t)row * a.Ldst + (size_t)(jj * a.dst_stride + a.dst_off)) * a.ldy;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          int n = n_blk + (wn * TN + j) * 32 + frow;
+          float v = acc[i][j][r];
+          if (a.accumulate) v += a.y[off + n];
+          a.y[off + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int TM, int TN, int WGM, int WGN>
+static int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
+  constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32;
+  dim3 grid((a.M + BM - 1) / BM, a.N / BN);
+  hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, WGM, WGN>), grid, dim3(256), 0, s, a);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+static int conv_gemm_dispatch(const ConvGemmArgs& a, hipStream_t s) {
+  if (a.M <= 0) return DA_OK;
+  if (a.C % 32 || a.N % 32 || a.ldx % 4 || a.ntaps < 1 || a.ntaps > 3) return DA_EINVAL;
+  if ((uint64_t)a.M * (uint64_t)a.divLm.d >= 0xffffffffull) return DA_EINVAL;
+  // tile choice: wide N tiles when N allows; halve BM when the grid would not fill 256 CUs twice over
+  if (a.N % 128 == 0) {
+    long wg128 = (long)((a.M + 127) / 128) * (a.N / 128);
+    if (wg128 >= 1024) return launch_conv_gemm<2, 2, 2, 2>(a, s);  // 128 x 128
+    return launch_conv_gemm<1, 2, 2, 2>(a, s);                      // 64 x 128
+  }
+  if (a.N % 64 == 0) return launch_conv_gemm<1, 2, 4, 1>(a, s);     // 128 x 64
+  return launch_conv_gemm<1, 1, 4, 1>(a, s);                        // 128 x 32
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* dy;
+  const float* x;
+  float* slab;  // [splits][ntaps][N][C]
+  int M, Ldy, lddy, N;
+  int Lx, ldx, C;
+  int dy_stride, dy_off, src_stride;
+  int ntaps, so0, so1, so2;
+  int kchunk;  // positions per split, multiple of 32
+  FastDiv divLm;
+};
+
+// output tile (TM*WGM*32 co) x (TN*WGN*32 ci); K = positions, 32 per step; LDS tiles stored as they
+// sit in HBM ([pos][channel]): lane (i, h) reads T[2*kk + h][i] -- 32 consecutive floats per half.
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32;
+  static_assert(WGM * WGN == 4, "4 waves");
+  __shared__ float lds[32 * (BM + BN)];
+  float* Ys = lds;             // [32][BM]
+  float* Xs = lds + 32 * BM;   // [32][BN]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int ntn = a.C / BN, ntm = a.N / BM;
+  int bx = blockIdx.x;
+  const int t = bx / (ntm * ntn);
+  bx -= t * ntm * ntn;
+  const int n_blk = (bx / ntn) * BM, c_blk = (bx % ntn) * BN;
+  const int split = blockIdx.y;
+  const int so = t == 0 ? a.so0 : (t == 1 ? a.so1 : a.so2);
+  const int Lm = (int)a.divLm.d;
+  const int k_beg = split * a.kchunk;
+  const int k_end = min(a.M, k_beg + a.kchunk);
+
+  constexpr int YQ = BM / 4, XQ = BN / 4;          // float4 per tile row
+  constexpr int YP = (32 * YQ) / 256, XP = (32 * XQ) / 256;
+  static_assert((32 * YQ) % 256 == 0 && (32 * XQ) % 256 == 0, "tile/thread mapping");
+  f32x4 ry[YP], rx[XP];
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < YP; ++p) {
+      int idx = tid + 256 * p;
+      int pos = idx / YQ, q = idx % YQ;
+      int m = k0 + pos;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < k_end) {
+        uint32_t row = fdiv((uint32_t)m, a.divLm);
+        int j = m - (int)row * Lm;
+        v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)row * a.Ldy + (size_t)(j * a.dy_stride + a.dy_off)) * a.lddy +
+                                            n_blk + q * 4);
+      }
+      ry[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      int idx = tid + 256 * p;
+      int pos = idx / XQ, q = idx % XQ;
+      int m = k0 + pos;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < k_end) {
+        uint32_t row = fdiv((uint32_t)m, a.divLm);
+        int j = m - (int)row * Lm;
+        int ls = j * a.src_stride + so;
+        if (ls >= 0 && ls < a.Lx)
+          v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)row * a.Lx + ls) * a.ldx + c_blk + q * 4);
+      }
+      rx[p] = v;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, fh = lane >> 5;
+  if (k_beg < k_end) gload(k_beg);
+  for (int k0 = k_beg; k0 < k_end; k0 += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < YP; ++p) {
+      int idx = tid + 256 * p;
+      *reinterpret_cast<f32x4*>(&Ys[(idx / YQ) * BM + (idx % YQ) * 4]) = ry[p];
+    }
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      int idx = tid + 256 * p;
+      *reinterpret_cast<f32x4*>(&Xs[(idx / XQ) * BN + (idx % XQ) * 4]) = rx[p];
+    }
+    __syncthreads();
+    if (k0 + 32 < k_end) gload(k0 + 32);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = Ys[(2 * kk + fh) * BM + (wm * TM + i) * 32 + frow];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Xs[(2 * kk + fh) * BN + (wn * TN + j) * 32 + frow];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  float* out = a.slab + ((size_t)split * a.ntaps + t) * a.N * a.C;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int n = n_blk + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        int c = c_blk + (wn * TN + j) * 32 + frow;
+        out[(size_t)n * a.C + c] = acc[i][j][r];
+      }
+}
+
+// dW[co][ci][k] (torch layout) (+)= sum_split slab[split][k][co][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int ntaps,
+                                    int N, int C, int accumulate) {
+  int total = ntaps * N * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += slab[(size_t)sp * total + i];
+    int t = i / (N * C);
+    int rem = i - t * N * C;  // co*C + ci
+    size_t o = (size_t)rem * ntaps + t;
+    dw[o] = accumulate ? dw[o] + s : s;
+  }
+}
+
+template <int TM, int TN, int WGM, int WGN>
+static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t s) {
+  constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32;
+  dim3 grid((a.N / BM) * (a.C / BN) * a.ntaps, splits);
+  hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, WGM, WGN>), grid, dim3(256), 0, s, a);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// tile edge for one wgrad output dimension
+static inline int wg_tile(int n) { return n % 128 == 0 ? 128 : (n % 64 == 0 ? 64 : 32); }
+
+static void wgrad_plan(int M, int N, int C, int ntaps, int* splits, int* kchunk) {
+  int tiles = (N / wg_tile(N)) * (C / wg_tile(C)) * ntaps;
+  int want = (1024 + tiles - 1) / tiles;            // aim at ~1024 workgroups
+  int maxs = (M + 255) / 256;                        // at least 256 positions per split
+  int sp = want < 1 ? 1 : (want > maxs ? maxs : want);
+  if (sp < 1) sp = 1;
+  int kc = ((M + sp - 1) / sp + 31) / 32 * 32;
+  sp = (M + kc - 1) / kc;
+  *splits = sp;
+  *kchunk = kc;
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+// Forward conv / generic implicit GEMM.  Every pointer is a device pointer; returns 0 on success.
+//   rows: B*NB sequences.  x: [rows][Lsrc][ldx] first C channels used.  w: packed [ntaps_w][N][C].
+//   y: [rows][Ldst][ldy] first N channels written.  Lm output positions per row are produced at
+//   dst position j*dst_stride+dst_off from src positions j*src_stride+src_off[t] with weight tap wtap[t].
+int da_conv_gemm(const float* x, const float* w, float* y, int rows, int Lm, int Lsrc, int ldx, int C, int Ldst,
+                 int ldy, int N, int dst_stride, int dst_off, int src_stride, int ntaps, const int* src_off,
+                 const int* wtap, int accumulate, hipStream_t stream) {
+  if (!x || !w || !y || rows < 0 || Lm < 1 || ntaps < 1 || ntaps > 3) return DA_EINVAL;
+  ConvGemmArgs a;
+  a.x = x; a.w = w; a.y = y;
+  a.M = rows * Lm; a.Lsrc = Lsrc; a.ldx = ldx; a.C = C;
+  a.Ldst = Ldst; a.ldy = ldy; a.N = N;
+  a.dst_stride = dst_stride; a.dst_off = dst_off; a.src_stride = src_stride;
+  a.ntaps = ntaps;
+  a.so0 = src_off[0]; a.so1 = ntaps > 1 ? src_off[1] : 0; a.so2 = ntaps > 2 ? src_off[2] : 0;
+  a.wt0 = wtap[0]; a.wt1 = ntaps > 1 ? wtap[1] : 0; a.wt2 = ntaps > 2 ? wtap[2] : 0;
+  a.accumulate = accumulate;
+  a.divLm = make_fastdiv((uint32_t)Lm);
+  return conv_gemm_dispatch(a, stream);
+}
+
+// Bytes of slab workspace da_conv_wgrad needs for this shape.
+size_t da_conv_wgrad_workspace(int rows, int Lm, int N, int C, int ntaps) {
+  int sp, kc;
+  wgrad_plan(rows * Lm, N, C, ntaps, &sp, &kc);
+  return (size_t)sp * ntaps * N * C * sizeof(float);
+}
+
+// dW[co][ci][k] (torch layout, k = ntaps) (+)= sum over positions dY[m][co] * X[src(m,k)][ci].
+int da_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, int rows, int Lm, int Ldy, int lddy,
+                  int N, int Lx, int ldx, int C, int dy_stride, int dy_off, int src_stride, int ntaps,
+                  const int* src_off, int accumulate, hipStream_t stream) {
+  if (!dy || !x || !dw || !workspace || ntaps < 1 || ntaps > 3) return DA_EINVAL;
+  if (C % 32 || N % 32 || lddy % 4 || ldx % 4) return DA_EINVAL;
+  WgradArgs a;
+  a.dy = dy; a.x = x; a.slab = workspace;
+  a.M = rows * Lm; a.Ldy = Ldy; a.lddy = lddy; a.N = N;
+  a.Lx = Lx; a.ldx = ldx; a.C = C;
+  a.dy_stride = dy_stride; a.dy_off = dy_off; a.src_stride = src_stride;
+  a.ntaps = ntaps;
+  a.so0 = src_off[0]; a.so1 = ntaps > 1 ? src_off[1] : 0; a.so2 = ntaps > 2 ? src_off[2] : 0;
+  a.divLm = make_fastdiv((uint32_t)Lm);
+  if ((uint64_t)a.M * (uint64_t)Lm >= 0xffffffffull) return DA_EINVAL;
+  int sp, kc;
+  wgrad_plan(a.M, N, C, ntaps, &sp, &kc);
+  a.kchunk = kc;
+  int tn = wg_tile(N), tc = wg_tile(C), rc;
+  if (tn == 128 && tc == 128) rc = launch_wgrad<2, 2, 2, 2>(a, sp, stream);
+  else if (tn == 128 && tc == 64) rc = launch_wgrad<2, 1, 2, 2>(a, sp, stream);
+  else if (tn == 64 && tc == 128) rc = launch_wgrad<1, 2, 2, 2>(a, sp, stream);
+  else if (tn == 64 && tc == 64) rc = launch_wgrad<1, 1, 2, 2>(a, sp, stream);
+  else if (tn == 128 && tc == 32) rc = launch_wgrad<1, 1, 4, 1>(a, sp, stream);
+  else if (tn == 32 && tc == 128) rc = launch_wgrad<1, 1, 1, 4>(a, sp, stream);
+  else rc = DA_EINVAL;
+  if (rc) return rc;
+  int total = ntaps * N * C;
+  int blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, dw, sp, ntaps, N, C,
+                     accumulate);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+}  // extern "C"

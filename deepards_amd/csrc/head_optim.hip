@@ -1,0 +1,330 @@
+// Classifier head (flatten -> Linear(NB*F, 2)), BCE-with-logits, fused clamp+optimiser steps and the
+// small layout/elementwise helpers.
+//
+// Replaces: reference models/torch_cnn_linear_network.py:102,110-112 (linear_final on view(-1) of the
+// (NB, F) feature block), train_ards_detector.py:530,929-930 (BCEWithLogitsLoss, mean over B*2),
+// :474-476 (clamp(g, +-clip) hooks), :419-421 (Adam / SGD momentum .9 nesterov weight-decay),
+// models/densenet.py:37-40 (F.dropout + torch.cat).
+#include "common.h"
+
+// logits[b][o] = bias[o] + sum_i flat[b][i] * W[o][i], o in {0,1}.  flat[b] is the window's (NB, F)
+// feature block, contiguous (row r, feature f at r*F + f) -- exactly view(-1).
+__global__ __launch_bounds__(256) void linear2_fwd_kernel(const float* __restrict__ flat, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ logits,
+                                                          int K) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.x;
+  const float* f = flat + (size_t)b * K;
+  float a0 = 0.f, a1 = 0.f;
+  for (int i = threadIdx.x * 4; i < K; i += blockDim.x * 4) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(f + i);
+    f32x4 w0 = *reinterpret_cast<const f32x4*>(W + i);
+    f32x4 w1 = *reinterpret_cast<const f32x4*>(W + K + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a0 = fmaf(v[e], w0[e], a0);
+      a1 = fmaf(v[e], w1[e], a1);
+    }
+  }
+  a0 = wave_sum(a0);
+  a1 = wave_sum(a1);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[0][wave] = a0;
+    red[1][wave] = a1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    float s = bias[threadIdx.x];
+    for (int k = 0; k < 4; ++k) s += red[threadIdx.x][k];
+    logits[(size_t)b * 2 + threadIdx.x] = s;
+  }
+}
+
+// loss = mean(max(x,0) - x t + log1p(exp(-|x|)));  dlogits = (sigmoid(x) - t) * gscale / n
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ x, const float* __restrict__ t, int n,
+                                                  float gscale, float* __restrict__ loss, float* __restrict__ dx) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float inv = 1.0f / (float)n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float v = x[i], tt = t[i];
+    acc += fmaxf(v, 0.f) - v * tt + log1pf(expf(-fabsf(v)));
+    if (dx) {
+      float sg = 1.0f / (1.0f + expf(-v));
+      dx[i] = (sg - tt) * inv * gscale;
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) * inv;
+}
+
+// dflat[b][i] = dl[b][0] W[0][i] + dl[b][1] W[1][i]
+__global__ __launch_bounds__(256) void linear2_bwd_input_kernel(const float* __restrict__ dl, const float* __restrict__ W,
+                                                                float* __restrict__ dflat, int B, int K) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)B * (K / 4);
+  if (idx >= total) return;
+  int b = (int)(idx / (K / 4));
+  int i = (int)(idx % (K / 4)) * 4;
+  float d0 = dl[b * 2], d1 = dl[b * 2 + 1];
+  f32x4 w0 = *reinterpret_cast<const f32x4*>(W + i);
+  f32x4 w1 = *reinterpret_cast<const f32x4*>(W + K + i);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = d0 * w0[e] + d1 * w1[e];
+  *reinterpret_cast<f32x4*>(dflat + (size_t)b * K + i) = o;
+}
+
+// dW[o][i] (+)= sum_b dl[b][o] flat[b][i];  dbias[o] (+)= sum_b dl[b][o]   (b in order: deterministic)
+__global__ __launch_bounds__(256) void linear2_bwd_weight_kernel(const float* __restrict__ dl,
+                                                                 const float* __restrict__ flat, float* __restrict__ dW,
+                                                                 float* __restrict__ dbias, int B, int K,
+                                                                 int accumulate) {
+  int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i < K) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(flat + (size_t)b * K + i);
+      float d0 = dl[b * 2], d1 = dl[b * 2 + 1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a0[e] = fmaf(d0, v[e], a0[e]);
+        a1[e] = fmaf(d1, v[e], a1[e]);
+      }
+    }
+    if (accumulate) {
+      f32x4 p0 = *reinterpret_cast<const f32x4*>(dW + i);
+      f32x4 p1 = *reinterpret_cast<const f32x4*>(dW + K + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a0[e] += p0[e];
+        a1[e] += p1[e];
+      }
+    }
+    *reinterpret_cast<f32x4*>(dW + i) = a0;
+    *reinterpret_cast<f32x4*>(dW + K + i) = a1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 2) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dl[b * 2 + threadIdx.x];
+    dbias[threadIdx.x] = accumulate ? dbias[threadIdx.x] + s : s;
+  }
+}
+
+// g <- clamp(g*gscale, +-clip); g += wd*p; buf = first ? g : mom*buf + g; p -= lr*(g + mom*buf)
+__global__ __launch_bounds__(256) void clamp_sgd_nesterov_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                                 float* __restrict__ buf, size_t n, float lr, float mom,
+                                                                 float wd, float clip, float gscale, int first) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+    float pi = p[i];
+    gi = fmaf(wd, pi, gi);
+    float bi = first ? gi : fmaf(mom, buf[i], gi);
+    buf[i] = bi;
+    p[i] = pi - lr * fmaf(mom, bi, gi);
+  }
+}
+
+// torch.optim.Adam (no weight decay, no amsgrad): bc1 = 1-b1^t, bc2 = 1-b2^t supplied by the host
+__global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                         float lr, float b1, float b2, float eps, float bc1, float bc2,
+                                                         float clip, float gscale) {
+  const float step = lr / bc1;
+  const float rs = 1.0f / sqrtf(bc2);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) * rs + eps;
+    p[i] -= step * (mi / denom);
+  }
+}
+
+// W[co][ci][k] (torch) -> Wf[k][co][ci] and Wd[k][ci][co]
+__global__ __launch_bounds__(256) void repack_conv_weight_kernel(const float* __restrict__ W, float* __restrict__ Wf,
+                                                                 float* __restrict__ Wd, int Co, int Ci, int K) {
+  int total = Co * Ci * K;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int k = i % K;
+    int ci = (i / K) % Ci;
+    int co = i / (K * Ci);
+    float v = W[i];
+    if (Wf) Wf[((size_t)k * Co + co) * Ci + ci] = v;
+    if (Wd) Wd[((size_t)k * Ci + ci) * Co + co] = v;
+  }
+}
+
+// out[pos][0:C1] = a[pos][0:C1]; out[pos][C1:C1+C2] = b[pos][0:C2]
+__global__ __launch_bounds__(256) void concat2_kernel(const float* __restrict__ a, int lda, int C1,
+                                                      const float* __restrict__ b, int ldb, int C2,
+                                                      float* __restrict__ out, int ldo, size_t npos) {
+  const int nq = (C1 + C2) >> 2;
+  size_t total = npos * nq;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    int q = (int)(idx % nq);
+    size_t pos = idx / nq;
+    int c = q * 4;
+    f32x4 v = c < C1 ? *reinterpret_cast<const f32x4*>(a + pos * lda + c)
+                     : *reinterpret_cast<const f32x4*>(b + pos * ldb + (c - C1));
+    *reinterpret_cast<f32x4*>(out + pos * ldo + c) = v;
+  }
+}
+
+// strided channel-slice copy / add: dst[pos][0:C] (+)= src[pos][off:off+C]
+__global__ __launch_bounds__(256) void slice_copy_kernel(const float* __restrict__ src, int lds, int off,
+                                                         float* __restrict__ dst, int ldd, int C, size_t npos,
+                                                         int accumulate) {
+  const int nq = C >> 2;
+  size_t total = npos * nq;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    int q = (int)(idx % nq);
+    size_t pos = idx / nq;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src + pos * lds + off + q * 4);
+    float* d = dst + pos * ldd + q * 4;
+    if (accumulate) {
+      f32x4 o = *reinterpret_cast<const f32x4*>(d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += o[e];
+    }
+    *reinterpret_cast<f32x4*>(d) = v;
+  }
+}
+
+// counter-based keep mask: keep iff hash(seed, idx) >= p * 2^32; y = x * keep / (1-p).  The mask is
+// regenerated from (seed, idx) in backward, nothing is stored.
+__device__ __forceinline__ uint32_t mix32(uint32_t a, uint32_t b) {
+  uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u);
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
+                                                      const int64_t* __restrict__ seed_ptr, uint32_t salt, float p) {
+  const uint32_t seed = (uint32_t)seed_ptr[0] ^ (uint32_t)(seed_ptr[0] >> 32);
+  const uint32_t thr = (uint32_t)(p * 4294967296.0);
+  const float scale = 1.0f / (1.0f - p);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t h = mix32(mix32(seed, salt), (uint32_t)i ^ (uint32_t)(i >> 32) * 0x27d4eb2fu);
+    y[i] = h >= thr ? x[i] * scale : 0.f;
+  }
+}
+
+static inline int grid_for(size_t total, int bs, int cap) {
+  size_t g = (total + bs - 1) / bs;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" {
+
+int da_version(void) { return 100; }
+
+// flat: [B][K] (K = NB*F, K % 4 == 0).  W: [2][K], bias: [2].  logits: [B][2].
+int da_linear2_fwd(const float* flat, const float* W, const float* bias, float* logits, int B, int K,
+                   hipStream_t stream) {
+  if (!flat || !W || !bias || !logits || K % 4) return DA_EINVAL;
+  if (B == 0) return DA_OK;
+  hipLaunchKernelGGL(linear2_fwd_kernel, dim3(B), dim3(256), 0, stream, flat, W, bias, logits, K);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// loss: 1 float.  dlogits may be null (test epoch).  gscale multiplies the gradient (1 normally).
+int da_bce_logits(const float* logits, const float* target, int n, float gscale, float* loss, float* dlogits,
+                  hipStream_t stream) {
+  if (!logits || !target || !loss || n < 1) return DA_EINVAL;
+  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, stream, logits, target, n, gscale, loss, dlogits);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+int da_linear2_bwd(const float* dlogits, const float* flat, const float* W, float* dflat, float* dW, float* dbias,
+                   int B, int K, int accumulate, hipStream_t stream) {
+  if (!dlogits || !flat || !W || K % 4) return DA_EINVAL;
+  if (B == 0) return DA_OK;
+  if (dflat) {
+    size_t total = (size_t)B * (K / 4);
+    hipLaunchKernelGGL(linear2_bwd_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dlogits,
+                       W, dflat, B, K);
+    DA_CHECK_LAUNCH();
+  }
+  if (dW && dbias) {
+    hipLaunchKernelGGL(linear2_bwd_weight_kernel, dim3((K / 4 + 255) / 256), dim3(256), 0, stream, dlogits, flat, dW,
+                       dbias, B, K, accumulate);
+    DA_CHECK_LAUNCH();
+  }
+  return DA_OK;
+}
+
+int da_clamp_sgd_nesterov(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay,
+                          float clip, float gscale, int first, hipStream_t stream) {
+  if (!p || !g || !buf) return DA_EINVAL;
+  if (n == 0) return DA_OK;
+  hipLaunchKernelGGL(clamp_sgd_nesterov_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, p, g, buf, n, lr,
+                     momentum, weight_decay, clip, gscale, first);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+int da_clamp_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                  int step, float clip, float gscale, hipStream_t stream) {
+  if (!p || !g || !m || !v || step < 1) return DA_EINVAL;
+  if (n == 0) return DA_OK;
+  float bc1 = 1.0f - powf(beta1, (float)step);
+  float bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(clamp_adam_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1,
+                     beta2, eps, bc1, bc2, clip, gscale);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// W: [Co][Ci][K] torch layout; Wf: [K][Co][Ci]; Wd: [K][Ci][Co] (either may be null).
+int da_repack_conv_weight(const float* W, float* Wf, float* Wd, int Co, int Ci, int K, hipStream_t stream) {
+  if (!W || (!Wf && !Wd)) return DA_EINVAL;
+  size_t total = (size_t)Co * Ci * K;
+  hipLaunchKernelGGL(repack_conv_weight_kernel, dim3(grid_for(total, 256, 2048)), dim3(256), 0, stream, W, Wf, Wd, Co,
+                     Ci, K);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+int da_concat2(const float* a, int lda, int C1, const float* b, int ldb, int C2, float* out, int ldo, size_t npos,
+               hipStream_t stream) {
+  if (!a || !b || !out || C1 % 4 || C2 % 4 || lda % 4 || ldb % 4 || ldo % 4) return DA_EINVAL;
+  if (npos == 0) return DA_OK;
+  hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(npos * ((C1 + C2) / 4), 256, 8192)), dim3(256), 0, stream, a, lda,
+                     C1, b, ldb, C2, out, ldo, npos);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+int da_slice_copy(const float* src, int lds, int off, float* dst, int ldd, int C, size_t npos, int accumulate,
+                  hipStream_t stream) {
+  if (!src || !dst || C % 4 || lds % 4 || ldd % 4 || off % 4) return DA_EINVAL;
+  if (npos == 0) return DA_OK;
+  hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(npos * (C / 4), 256, 8192)), dim3(256), 0, stream, src, lds, off,
+                     dst, ldd, C, npos, accumulate);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// y = dropout(x) with keep-prob 1-p; the same (seed, salt) reproduces the mask (used by backward).
+int da_dropout(const float* x, float* y, size_t n, const int64_t* seed, unsigned salt, float p, hipStream_t stream) {
+  if (!x || !y || !seed || p < 0.f || p >= 1.f) return DA_EINVAL;
+  if (n == 0) return DA_OK;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, stream, x, y, n, seed, salt, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,321 @@
+// Stem convolution (C_in = 1, k7 s2 p3), the stem's BN+ReLU+pool(3,2,1) fusion, and the average pools.
+//
+// Replaces: reference models/resnet.py:86-87,100-104,141-153 (conv1 -> bn1 -> relu -> first_pool),
+// models/densenet.py:118-124 (conv0/norm0/relu0/pool0), resnet.py:112,159 / densenet.py:167,183
+// (AvgPool1d(7, stride=1) -> view) and densenet.py:79 (transition AvgPool1d(2,2)), fwd + bwd.
+//
+// The stem conv has C_in = 1: 7 MACs per output against 4 B written -- pure bandwidth, so it is a
+// plain coalesced kernel (lane = output channel, the raw waveform row staged in LDS and read by
+// broadcast), not a GEMM.
+#include "common.h"
+
+// y[row][l][co] = sum_k w[co][k] * x[row][2l + k - 3];  block = one waveform row.
+__global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ y, int Lin, int Lout, int C0, int ldy) {
+  extern __shared__ float xs[];  // Lin + 6
+  const int row = blockIdx.x;
+  for (int i = threadIdx.x; i < Lin + 6; i += blockDim.x) {
+    int s = i - 3;
+    xs[i] = (s >= 0 && s < Lin) ? x[(size_t)row * Lin + s] : 0.f;
+  }
+  __syncthreads();
+  const int co = threadIdx.x % C0, slot = threadIdx.x / C0, nslots = blockDim.x / C0;
+  if (slot >= nslots) return;
+  float wk[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) wk[k] = w[co * 7 + k];
+  for (int l = slot; l < Lout; l += nslots) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc = fmaf(wk[k], xs[2 * l + k], acc);
+    y[((size_t)row * Lout + l) * ldy + co] = acc;
+  }
+}
+
+// partial[blk][co][k] = sum over this block's rows, positions of dy[row][l][co] * x[row][2l+k-3]
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ dy, int lddy,
+                                                         const float* __restrict__ x, float* __restrict__ partial,
+                                                         int rows, int Lin, int Lout, int C0) {
+  extern __shared__ float sm[];  // xs[Lin+6] then red[nslots][C0*7]
+  float* xs = sm;
+  float* red = sm + (Lin + 6);
+  const int co = threadIdx.x % C0, slot = threadIdx.x / C0, nslots = blockDim.x / C0;
+  float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < Lin + 6; i += blockDim.x) {
+      int s = i - 3;
+      xs[i] = (s >= 0 && s < Lin) ? x[(size_t)row * Lin + s] : 0.f;
+    }
+    __syncthreads();
+    if (slot < nslots) {
+      for (int l = slot; l < Lout; l += nslots) {
+        float g = dy[((size_t)row * Lout + l) * lddy + co];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc[k] = fmaf(g, xs[2 * l + k], acc[k]);
+      }
+    }
+  }
+  __syncthreads();
+  if (slot < nslots) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) red[(slot * C0 + co) * 7 + k] = acc[k];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C0 * 7; i += blockDim.x) {
+    float s = 0.f;
+    for (int sl = 0; sl < nslots; ++sl) s += red[sl * C0 * 7 + i];
+    partial[(size_t)blockIdx.x * C0 * 7 + i] = s;
+  }
+}
+
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int n, float* __restrict__ dw,
+                                         int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * n + i];
+  dw[i] = accumulate ? dw[i] + s : s;
+}
+
+// out[row][j][c] = pool_{l in {2j-1,2j,2j+1}} relu(bn(y[row][l][c]));  pool_mode 0 = max (-inf pad),
+// 1 = avg (count_include_pad, zeros).  One thread per (output position, channel quad).
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ y, int ldy,
+                                                               float* __restrict__ out, int ldo, int rows, int R,
+                                                               int Lin, int Lout, int C, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int pool_mode) {
+  const int nq = C >> 2;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)rows * Lout * nq;
+  if (idx >= total) return;
+  int q = (int)(idx % nq);
+  size_t po = idx / nq;
+  int j = (int)(po % Lout);
+  int row = (int)(po / Lout);
+  int w = row / R;
+  int c0 = q * 4;
+  f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
+  f32x4 is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * C + c0);
+  f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
+  f32x4 be = *reinterpret_cast<const f32x4*>(beta + c0);
+  f32x4 o;
+  if (pool_mode == 0) o = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  else o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    int l = 2 * j - 1 + t;
+    if (l < 0 || l >= Lin) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(y + ((size_t)row * Lin + l) * ldy + c0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float z = fmaxf((v[e] - mu[e]) * is[e] * ga[e] + be[e], 0.f);
+      o[e] = pool_mode == 0 ? fmaxf(o[e], z) : o[e] + z;
+    }
+  }
+  if (pool_mode == 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] *= (1.0f / 3.0f);
+  }
+  *reinterpret_cast<f32x4*>(out + po * ldo + c0) = o;
+}
+
+// Gradient w.r.t. the ReLU output at stem resolution: dz[row][l][c] = sum over the (<= 2) pooling
+// windows j that contain l of [argmax_j == l] * dout[row][j][c]  (max; first maximum wins, as ATen)
+// or dout[row][j][c]/3 (avg).  The ReLU mask and BN backward are applied afterwards by da_bn_bwd
+// (mask_mode 1), so no index tensor is ever stored: the argmax is recomputed from y.
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dout, int ldd,
+                                                       const float* __restrict__ y, int ldy, float* __restrict__ dz,
+                                                       int lddz, int rows, int R, int Lin, int Lout, int C,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int pool_mode) {
+  const int nq = C >> 2;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)rows * Lin * nq;
+  if (idx >= total) return;
+  int q = (int)(idx % nq);
+  size_t pi = idx / nq;
+  int l = (int)(pi % Lin);
+  int row = (int)(pi / Lin);
+  int w = row / R;
+  int c0 = q * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // windows containing l: j with 2j-1 <= l <= 2j+1
+  int j_lo = (l) / 2;            // ceil((l-1)/2) for l >= 0
+  int j_hi = (l + 1) / 2;        // floor((l+1)/2)
+  if (pool_mode == 1) {
+    for (int j = j_lo; j <= j_hi; ++j) {
+      if (j >= Lout) continue;
+      f32x4 g = *reinterpret_cast<const f32x4*>(dout + ((size_t)row * Lout + j) * ldd + c0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += g[e] * (1.0f / 3.0f);
+    }
+  } else {
+    f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
+    f32x4 is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * C + c0);
+    f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
+    f32x4 be = *reinterpret_cast<const f32x4*>(beta + c0);
+    for (int j = j_lo; j <= j_hi; ++j) {
+      if (j >= Lout) continue;
+      // argmax over t = 0..2 (position 2j-1+t), first max wins
+      float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int barg[4] = {-1, -1, -1, -1};
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        int ll = 2 * j - 1 + t;
+        if (ll < 0 || ll >= Lin) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(y + ((size_t)row * Lin + ll) * ldy + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float z = fmaxf((v[e] - mu[e]) * is[e] * ga[e] + be[e], 0.f);
+          if (z > best[e]) {
+            best[e] = z;
+            barg[e] = ll;
+          }
+        }
+      }
+      f32x4 g = *reinterpret_cast<const f32x4*>(dout + ((size_t)row * Lout + j) * ldd + c0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (barg[e] == l) acc[e] += g[e];
+    }
+  }
+  *reinterpret_cast<f32x4*>(dz + pi * lddz + c0) = acc;
+}
+
+// generic AvgPool1d(k, stride=k) (k=2 transition) and AvgPool1d(L, 1) on an L-long row (k = L -> 1).
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out,
+                                                          int ldo, int rows, int Lin, int Lout, int k, int C) {
+  const int nq = C >> 2;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)rows * Lout * nq;
+  if (idx >= total) return;
+  int q = (int)(idx % nq);
+  size_t po = idx / nq;
+  int j = (int)(po % Lout);
+  int row = (int)(po / Lout);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < k; ++t) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)row * Lin + j * k + t) * ldx + q * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += v[e];
+  }
+  const float inv = 1.0f / (float)k;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] *= inv;
+  *reinterpret_cast<f32x4*>(out + po * ldo + q * 4) = acc;
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dout, int ldd, float* __restrict__ dx,
+                                                          int lddx, int rows, int Lin, int Lout, int k, int C) {
+  const int nq = C >> 2;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)rows * Lin * nq;
+  if (idx >= total) return;
+  int q = (int)(idx % nq);
+  size_t pi = idx / nq;
+  int l = (int)(pi % Lin);
+  int row = (int)(pi / Lin);
+  int j = l / k;
+  f32x4 g = {0.f, 0.f, 0.f, 0.f};
+  if (j < Lout) {
+    g = *reinterpret_cast<const f32x4*>(dout + ((size_t)row * Lout + j) * ldd + q * 4);
+    const float inv = 1.0f / (float)k;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] *= inv;
+  }
+  *reinterpret_cast<f32x4*>(dx + pi * lddx + q * 4) = g;
+}
+
+static inline int grid1d(size_t total, int bs) { return (int)((total + bs - 1) / bs); }
+
+extern "C" {
+
+// x: [rows][Lin] raw waveform (C_in = 1).  w: [C0][1][7] (torch layout).  y: [rows][Lin/2][ldy].
+int da_stem_conv_fwd(const float* x, const float* w, float* y, int rows, int Lin, int C0, int ldy,
+                     hipStream_t stream) {
+  if (!x || !w || !y || Lin < 2 || Lin % 2 || C0 < 1 || C0 > 256 || 256 % C0) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  hipLaunchKernelGGL(stem_conv_fwd_kernel, dim3(rows), dim3(256), (Lin + 6) * sizeof(float), stream, x, w, y, Lin,
+                     Lin / 2, C0, ldy);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+size_t da_stem_wgrad_workspace(int rows, int C0) {
+  int nblk = rows < 512 ? rows : 512;
+  return (size_t)nblk * C0 * 7 * sizeof(float);
+}
+
+int da_stem_conv_wgrad(const float* dy, int lddy, const float* x, float* dw, float* workspace, int rows, int Lin,
+                       int C0, int accumulate, hipStream_t stream) {
+  if (!dy || !x || !dw || !workspace || Lin % 2 || C0 < 1 || C0 > 256 || 256 % C0) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  int nblk = rows < 512 ? rows : 512;
+  int nslots = 256 / C0;
+  size_t shm = ((Lin + 6) + (size_t)nslots * C0 * 7) * sizeof(float);
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), shm, stream, dy, lddy, x, workspace, rows, Lin, Lin / 2,
+                     C0);
+  DA_CHECK_LAUNCH();
+  int n = C0 * 7;
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, workspace, nblk, n, dw,
+                     accumulate);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// Lout = (Lin + 2 - 3)/2 + 1.  R = rows per BN window.  pool_mode 0 max / 1 avg.
+int da_bn_relu_pool_fwd(const float* y, int ldy, float* out, int ldo, int rows, int R, int Lin, int C,
+                        const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode,
+                        hipStream_t stream) {
+  if (!y || !out || C % 4 || ldy % 4 || ldo % 4 || R < 1 || rows % R) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  int Lout = (Lin - 1) / 2 + 1;
+  size_t total = (size_t)rows * Lout * (C / 4);
+  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, stream, y, ldy, out, ldo, rows, R,
+                     Lin, Lout, C, mean, invstd, gamma, beta, pool_mode);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+int da_pool_bwd(const float* dout, int ldd, const float* y, int ldy, float* dz, int lddz, int rows, int R, int Lin,
+                int C, const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode,
+                hipStream_t stream) {
+  if (!dout || !y || !dz || C % 4 || ldd % 4 || ldy % 4 || lddz % 4 || R < 1 || rows % R) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  int Lout = (Lin - 1) / 2 + 1;
+  size_t total = (size_t)rows * Lin * (C / 4);
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, stream, dout, ldd, y, ldy, dz, lddz, rows,
+                     R, Lin, Lout, C, mean, invstd, gamma, beta, pool_mode);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// AvgPool1d(k, stride=k) with Lout = Lin / k (floor); k == Lin gives the global pool.
+int da_avgpool_fwd(const float* x, int ldx, float* out, int ldo, int rows, int Lin, int k, int C,
+                   hipStream_t stream) {
+  if (!x || !out || C % 4 || ldx % 4 || ldo % 4 || k < 1 || k > Lin) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  int Lout = Lin / k;
+  size_t total = (size_t)rows * Lout * (C / 4);
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, stream, x, ldx, out, ldo, rows, Lin,
+                     Lout, k, C);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+int da_avgpool_bwd(const float* dout, int ldd, float* dx, int lddx, int rows, int Lin, int k, int C,
+                   hipStream_t stream) {
+  if (!dout || !dx || C % 4 || ldd % 4 || lddx % 4 || k < 1 || k > Lin) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  int Lout = Lin / k;
+  size_t total = (size_t)rows * Lin * (C / 4);
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, stream, dout, ldd, dx, lddx, rows, Lin,
+                     Lout, k, C);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,331 @@
+"""Thin Python wrappers over the C ABI (include/deepards_hip.h): shape checks on the host, raw device
+pointers + the current HIP stream into the library.  No arithmetic happens here and there is no
+fallback -- every function launches a hand-written gfx950 kernel or raises.
+
+Activation layout "RLC": contiguous ``(rows, L, C)`` float32 CUDA tensors (channels last); a
+BatchNorm window = ``R`` consecutive rows (reference models/torch_cnn_linear_network.py:108-113).
+"""
+import ctypes
+import torch
+
+from . import _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(rc, name):
+    if rc != 0:
+        raise HipError('%s failed with code %d' % (name, rc))
+
+
+def _rlc(t, name='tensor'):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.is_contiguous()):
+        raise ValueError('%s must be a contiguous float32 CUDA (rows, L, C) tensor, got %s %s %s' %
+                         (name, tuple(t.shape), t.dtype, t.device))
+    return t
+
+
+def _f32(t, name='tensor'):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError('%s must be a contiguous float32 CUDA tensor' % name)
+    return t
+
+
+def _ints(vals):
+    return (ctypes.c_int * len(vals))(*vals)
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------------
+def repack_weight(w, need_fwd=True, need_dgrad=False):
+    """torch (Co,Ci,K) -> Wf (K,Co,Ci) and/or Wd (K,Ci,Co)."""
+    _f32(w, 'w')
+    co, ci, k = w.shape
+    wf = torch.empty((k, co, ci), device=w.device, dtype=torch.float32) if need_fwd else None
+    wd = torch.empty((k, ci, co), device=w.device, dtype=torch.float32) if need_dgrad else None
+    _chk(_lib.lib().da_repack_conv_weight(_p(w), _p(wf), _p(wd), co, ci, k, _stream()), 'da_repack_conv_weight')
+    return wf, wd
+
+
+def conv_out_len(l, k, stride, pad):
+    return (l + 2 * pad - k) // stride + 1
+
+
+def conv_fwd(x, wf, stride, pad, out=None):
+    """x (rows,L,Ci), wf packed (K,Co,Ci) -> (rows,Lo,Co).  K in {1,3}."""
+    _rlc(x, 'x')
+    k, co, ci = wf.shape
+    rows, l, c = x.shape
+    if c != ci or k > 3 or ci % 32 or co % 32:
+        raise ValueError('conv_fwd: unsupported shape x%s wf%s' % (tuple(x.shape), tuple(wf.shape)))
+    lo = conv_out_len(l, k, stride, pad)
+    if out is None:
+        out = torch.empty((rows, lo, co), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (rows, lo, co):
+        raise ValueError('conv_fwd: bad out shape')
+    so = [t - pad for t in range(k)]
+    wt = list(range(k))
+    _chk(_lib.lib().da_conv_gemm(_p(x), _p(wf), _p(out), rows, lo, l, c, ci, lo, co, co, 1, 0, stride, k,
+                                 _ints(so), _ints(wt), 0, _stream()), 'da_conv_gemm(fwd)')
+    return out
+
+
+def conv_dgrad(dy, wd, stride, pad, l_in, out=None, accumulate=False):
+    """dy (rows,Lo,Co), wd packed (K,Ci,Co) -> dx (rows,l_in,Ci).  With accumulate the result is
+    added into `out`; positions no tap reaches are left untouched (accumulate) or zeroed."""
+    _rlc(dy, 'dy')
+    k, ci, co = wd.shape
+    rows, lo, c = dy.shape
+    if c != co or k > 3 or ci % 32 or co % 32:
+        raise ValueError('conv_dgrad: unsupported shape')
+    if out is None:
+        if accumulate:
+            raise ValueError('accumulate needs out')
+        out = torch.empty((rows, l_in, ci), device=dy.device, dtype=torch.float32)
+    elif tuple(out.shape) != (rows, l_in, ci):
+        raise ValueError('conv_dgrad: bad out shape')
+    L = _lib.lib()
+    for r in range(stride):
+        lm = (l_in - r + stride - 1) // stride           # positions l_in = stride*j + r
+        if lm <= 0:
+            continue
+        taps = [t for t in range(k) if (r + pad - t) % stride == 0]
+        if not taps:
+            if not accumulate:
+                out[:, r::stride, :].zero_()
+            continue
+        so = [(r + pad - t) // stride for t in taps]
+        _chk(L.da_conv_gemm(_p(dy), _p(wd), _p(out), rows, lm, lo, co, co, l_in, ci, ci, stride, r, 1, len(taps),
+                            _ints(so), _ints(taps), 1 if accumulate else 0, _stream()), 'da_conv_gemm(dgrad)')
+    return out
+
+
+def conv_wgrad(dy, x, k, stride, pad, out=None, accumulate=False):
+    """dW (Co,Ci,K) torch layout = sum_positions dy (x) x."""
+    _rlc(dy, 'dy')
+    _rlc(x, 'x')
+    rows, lo, co = dy.shape
+    rows2, l, ci = x.shape
+    if rows != rows2 or lo != conv_out_len(l, k, stride, pad) or k > 3 or ci % 32 or co % 32:
+        raise ValueError('conv_wgrad: unsupported shape')
+    if out is None:
+        if accumulate:
+            raise ValueError('accumulate needs out')
+        out = torch.empty((co, ci, k), device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    nbytes = L.da_conv_wgrad_workspace(rows, lo, co, ci, k)
+    ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
+    so = [t - pad for t in range(k)]
+    _chk(L.da_conv_wgrad(_p(dy), _p(x), _p(out), _p(ws), rows, lo, lo, co, co, l, ci, ci, 1, 0, stride, k,
+                         _ints(so), 1 if accumulate else 0, _stream()), 'da_conv_wgrad')
+    return out
+
+
+def stem_conv_fwd(x, w):
+    """x (rows, Lin) raw waveform, w (C0,1,7) -> (rows, Lin/2, C0)."""
+    _f32(x, 'x')
+    _f32(w, 'w')
+    rows, lin = x.shape
+    c0 = w.shape[0]
+    if tuple(w.shape[1:]) != (1, 7):
+        raise ValueError('stem conv expects (C0,1,7) weights (in_channels=1)')
+    y = torch.empty((rows, lin // 2, c0), device=x.device, dtype=torch.float32)
+    _chk(_lib.lib().da_stem_conv_fwd(_p(x), _p(w), _p(y), rows, lin, c0, c0, _stream()), 'da_stem_conv_fwd')
+    return y
+
+
+def stem_conv_wgrad(dy, x, out=None, accumulate=False):
+    _rlc(dy, 'dy')
+    rows, lo, c0 = dy.shape
+    lin = x.shape[1]
+    if out is None:
+        out = torch.empty((c0, 1, 7), device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    ws = torch.empty((L.da_stem_wgrad_workspace(rows, c0) // 4,), device=x.device, dtype=torch.float32)
+    _chk(L.da_stem_conv_wgrad(_p(dy), c0, _p(x), _p(out), _p(ws), rows, lin, c0, 1 if accumulate else 0, _stream()),
+         'da_stem_conv_wgrad')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# window-grouped batch norm
+# ------------------------------------------------------------------------------------------------
+def bn_stats(x, R, eps=1e-5):
+    """-> mean, invstd of shape (W, C); window = R rows."""
+    _rlc(x, 'x')
+    rows, l, c = x.shape
+    if rows % R:
+        raise ValueError('rows %d not a multiple of rows_per_window %d' % (rows, R))
+    w = rows // R
+    mean = torch.empty((w, c), device=x.device, dtype=torch.float32)
+    invstd = torch.empty((w, c), device=x.device, dtype=torch.float32)
+    _chk(_lib.lib().da_bn_stats(_p(x), c, w, R * l, c, eps, _p(mean), _p(invstd), _stream()), 'da_bn_stats')
+    return mean, invstd
+
+
+def bn_running_update(mean, invstd, wn, running_mean, running_var, momentum=0.1, eps=1e-5):
+    w, c = mean.shape
+    _chk(_lib.lib().da_bn_running_update(_p(mean), _p(invstd), w, c, wn, eps, momentum, _p(running_mean),
+                                         _p(running_var), _stream()), 'da_bn_running_update')
+
+
+def bn_apply(x, R, mean, invstd, gamma, beta, relu=True, res=None, out=None):
+    _rlc(x, 'x')
+    rows, l, c = x.shape
+    w = rows // R
+    if out is None:
+        out = torch.empty_like(x)
+    if res is not None and tuple(res.shape) != tuple(x.shape):
+        raise ValueError('residual shape mismatch')
+    _chk(_lib.lib().da_bn_apply(_p(x), c, _p(res), c, _p(out), c, w, R * l, c, _p(mean), _p(invstd), _p(gamma),
+                                _p(beta), 1 if relu else 0, _stream()), 'da_bn_apply')
+    return out
+
+
+def bn_bwd(dout, x, R, mean, invstd, gamma, beta, mask_mode, out=None, want_g=False, dx=None,
+           dgamma=None, dbeta=None, accumulate=False):
+    """-> dx, dgamma, dbeta, g (g = masked upstream gradient, only when want_g)."""
+    _rlc(dout, 'dout')
+    _rlc(x, 'x')
+    rows, l, c = x.shape
+    w = rows // R
+    if dx is None:
+        dx = torch.empty_like(x)
+    g = torch.empty_like(x) if want_g else None
+    if dgamma is None:
+        dgamma = torch.empty((c,), device=x.device, dtype=torch.float32)
+        dbeta = torch.empty((c,), device=x.device, dtype=torch.float32)
+    scratch = torch.empty((2 * w * c,), device=x.device, dtype=torch.float32)
+    _chk(_lib.lib().da_bn_bwd(_p(dout), c, _p(x), c, _p(out), c, _p(dx), c, _p(g), c, w, R * l, c, _p(mean),
+                              _p(invstd), _p(gamma), _p(beta), mask_mode, _p(scratch), _p(dgamma), _p(dbeta),
+                              1 if accumulate else 0, _stream()), 'da_bn_bwd')
+    return dx, dgamma, dbeta, g
+
+
+# ------------------------------------------------------------------------------------------------
+# pools
+# ------------------------------------------------------------------------------------------------
+def bn_relu_pool_fwd(y, R, mean, invstd, gamma, beta, pool_mode):
+    _rlc(y, 'y')
+    rows, lin, c = y.shape
+    lout = (lin - 1) // 2 + 1
+    out = torch.empty((rows, lout, c), device=y.device, dtype=torch.float32)
+    _chk(_lib.lib().da_bn_relu_pool_fwd(_p(y), c, _p(out), c, rows, R, lin, c, _p(mean), _p(invstd), _p(gamma),
+                                        _p(beta), pool_mode, _stream()), 'da_bn_relu_pool_fwd')
+    return out
+
+
+def pool_bwd(dout, y, R, mean, invstd, gamma, beta, pool_mode):
+    _rlc(dout, 'dout')
+    _rlc(y, 'y')
+    rows, lin, c = y.shape
+    dz = torch.empty_like(y)
+    _chk(_lib.lib().da_pool_bwd(_p(dout), c, _p(y), c, _p(dz), c, rows, R, lin, c, _p(mean), _p(invstd), _p(gamma),
+                                _p(beta), pool_mode, _stream()), 'da_pool_bwd')
+    return dz
+
+
+def avgpool_fwd(x, k):
+    _rlc(x, 'x')
+    rows, lin, c = x.shape
+    out = torch.empty((rows, lin // k, c), device=x.device, dtype=torch.float32)
+    _chk(_lib.lib().da_avgpool_fwd(_p(x), c, _p(out), c, rows, lin, k, c, _stream()), 'da_avgpool_fwd')
+    return out
+
+
+def avgpool_bwd(dout, lin, k):
+    _rlc(dout, 'dout')
+    rows, lout, c = dout.shape
+    dx = torch.empty((rows, lin, c), device=dout.device, dtype=torch.float32)
+    _chk(_lib.lib().da_avgpool_bwd(_p(dout), c, _p(dx), c, rows, lin, k, c, _stream()), 'da_avgpool_bwd')
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# head / loss
+# ------------------------------------------------------------------------------------------------
+def linear2_fwd(flat, w, bias):
+    _f32(flat, 'flat')
+    b, k = flat.shape
+    if tuple(w.shape) != (2, k):
+        raise ValueError('linear_final weight must be (2, %d), got %s' % (k, tuple(w.shape)))
+    logits = torch.empty((b, 2), device=flat.device, dtype=torch.float32)
+    _chk(_lib.lib().da_linear2_fwd(_p(flat), _p(w), _p(bias), _p(logits), b, k, _stream()), 'da_linear2_fwd')
+    return logits
+
+
+def linear2_bwd(dlogits, flat, w, need_input=True, dw=None, dbias=None, accumulate=False):
+    b, k = flat.shape
+    dflat = torch.empty_like(flat) if need_input else None
+    if dw is None:
+        dw = torch.empty_like(w)
+        dbias = torch.empty((2,), device=w.device, dtype=torch.float32)
+    _chk(_lib.lib().da_linear2_bwd(_p(dlogits), _p(flat), _p(w), _p(dflat), _p(dw), _p(dbias), b, k,
+                                   1 if accumulate else 0, _stream()), 'da_linear2_bwd')
+    return dflat, dw, dbias
+
+
+def bce_logits(logits, target, want_grad=True, gscale=1.0):
+    """-> loss (1,), dlogits (same shape as logits) or None."""
+    _f32(logits, 'logits')
+    _f32(target, 'target')
+    if logits.shape != target.shape:
+        raise ValueError('BCE: logits %s vs target %s' % (tuple(logits.shape), tuple(target.shape)))
+    loss = torch.empty((1,), device=logits.device, dtype=torch.float32)
+    d = torch.empty_like(logits) if want_grad else None
+    _chk(_lib.lib().da_bce_logits(_p(logits), _p(target), logits.numel(), gscale, _p(loss), _p(d), _stream()),
+         'da_bce_logits')
+    return loss, d
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser / misc
+# ------------------------------------------------------------------------------------------------
+def clamp_sgd_nesterov_(p, g, buf, lr, momentum, weight_decay, clip, first, gscale=1.0):
+    _chk(_lib.lib().da_clamp_sgd_nesterov(_p(p), _p(g), _p(buf), p.numel(), lr, momentum, weight_decay,
+                                          clip if clip else 0.0, gscale, 1 if first else 0, _stream()),
+         'da_clamp_sgd_nesterov')
+
+
+def clamp_adam_(p, g, m, v, lr, step, clip, beta1=0.9, beta2=0.999, eps=1e-8, gscale=1.0):
+    _chk(_lib.lib().da_clamp_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step,
+                                  clip if clip else 0.0, gscale, _stream()), 'da_clamp_adam')
+
+
+def concat2(a, b):
+    _rlc(a, 'a')
+    _rlc(b, 'b')
+    rows, l, c1 = a.shape
+    c2 = b.shape[2]
+    out = torch.empty((rows, l, c1 + c2), device=a.device, dtype=torch.float32)
+    _chk(_lib.lib().da_concat2(_p(a), c1, c1, _p(b), c2, c2, _p(out), c1 + c2, rows * l, _stream()), 'da_concat2')
+    return out
+
+
+def slice_channels(src, off, c, out=None, accumulate=False):
+    """out (rows,L,c) (+)= src[:, :, off:off+c]"""
+    _rlc(src, 'src')
+    rows, l, cs = src.shape
+    if out is None:
+        out = torch.empty((rows, l, c), device=src.device, dtype=torch.float32)
+    _chk(_lib.lib().da_slice_copy(_p(src), cs, off, _p(out), c, c, rows * l, 1 if accumulate else 0, _stream()),
+         'da_slice_copy')
+    return out
+
+
+def dropout(x, seed, salt, p):
+    """seed: int64 CUDA tensor of one element (device-resident so the step stays graph-capturable)."""
+    y = torch.empty_like(x)
+    _chk(_lib.lib().da_dropout(_p(x), _p(y), x.numel(), _p(seed), salt, p, _stream()), 'da_dropout')
+    return y

@@ -1,0 +1,222 @@
+"""Host side of the training / test hot loop.
+
+Mirrors, for the cnn_linear path only, what the reference does in
+``train_ards_detector.py``: ``BaseTraining.run_train_epoch`` (:139-159),
+``handle_train_optimization`` (:161-173), ``get_optimizer`` (:416-422), the clamp hooks of
+``get_model`` (:474-476), ``run_test_epoch`` (:424-465), ``clip_odd_batch_sizes`` (:482-494) and
+``CNNLinearModel.calc_loss/_process_test_batch_results`` (:929-936).
+
+MI355X-first differences (results identical, see tests):
+  * parameters / gradients / momentum live in three flat fp32 buffers; clamp + weight decay +
+    Nesterov momentum (or Adam) is ONE fused kernel over the flat buffer instead of a hook and an
+    optimizer loop per parameter;
+  * the whole step (zero-grad, forward, BCE, backward, update) is captured once into a hipGraph and
+    replayed: ~400 kernel launches per step cost one graph launch;
+  * data parallelism is one process per GPU: each rank takes an equal shard of the windows of the
+    batch, gradients are summed with a single RCCL all-reduce of the flat bucket over xGMI, and the
+    1/world scale and the +-clip clamp are applied AFTER the reduction (SURVEY.md finding 7), inside
+    the optimizer kernel.  BatchNorm never crosses windows, so no SyncBN is needed (finding 3).
+  * no per-step device->host sync: losses stay on the device until asked for.
+"""
+import torch
+
+from . import hip_ops as H
+
+
+def clip_odd_batch_sizes(obs_idx, seq, metadata, target):
+    """train_ards_detector.py:482-494 -- drop the last item of an odd batch."""
+    if seq.shape[0] % 2 == 1:
+        n = seq.shape[0] - 1
+        return obs_idx[:n], seq[:n], metadata[:n], target[:n]
+    return obs_idx, seq, metadata, target
+
+
+def shard_windows(n_windows, world_size, rank):
+    """Equal contiguous shards of the batch's windows: rank r owns [r*B/W, (r+1)*B/W).  Equal sizes
+    make the mean of the rank-local BCE means equal the global mean."""
+    if n_windows % world_size:
+        raise ValueError('batch of %d windows does not split evenly over %d ranks' % (n_windows, world_size))
+    per = n_windows // world_size
+    return slice(rank * per, (rank + 1) * per)
+
+
+class FlatBucket(object):
+    """Flat fp32 views over the live parameters: p (weights), g (gradients)."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        align = 64                                       # floats: every parameter starts 256-B aligned (float4 loads)
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + align - 1) // align * align
+        self.numel = off
+        dev = self.params[0].device
+        self.p = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        self.g = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        for p, off in zip(self.params, self.offsets):
+            n = p.numel()
+            self.p[off:off + n].copy_(p.data.reshape(-1))
+            if p.grad is not None:
+                self.g[off:off + n].copy_(p.grad.reshape(-1))
+            p.data = self.p[off:off + n].view(p.shape)
+            p.grad = self.g[off:off + n].view(p.shape)
+
+    def zero_grad(self):
+        self.g.zero_()
+
+    def allreduce(self, group=None):
+        import torch.distributed as dist
+        dist.all_reduce(self.g, op=dist.ReduceOp.SUM, group=group)
+
+
+class HotPathTrainer(object):
+    """One model replica on one GPU.  ``train_step(inputs, target)`` == one iteration of the
+    reference's batch loop; ``test_step`` == one iteration of run_test_epoch (train-mode modules,
+    no_grad -- the reference never calls model.eval(), SURVEY.md finding 4)."""
+
+    def __init__(self, model, optimizer='sgd', learning_rate=1e-3, weight_decay=1e-4, momentum=0.9,
+                 clip_grad=True, clip_val=0.01, world_size=1, rank=0, process_group=None, use_graph=True):
+        if optimizer not in ('sgd', 'adam'):
+            raise ValueError('optimizer must be sgd or adam')
+        self.model = model
+        self.optimizer = optimizer
+        self.lr, self.wd, self.momentum = learning_rate, weight_decay, momentum
+        self.clip = clip_val if clip_grad else 0.0
+        self.world_size, self.rank, self.group = world_size, rank, process_group
+        self.use_graph = use_graph and optimizer == 'sgd'
+        self.bucket = None
+        self.state = {}
+        self.steps = 0
+        self._graph = None
+        self._static = None
+        self.last_loss = None
+        self.last_logits = None
+
+    # ---- eager pieces ------------------------------------------------------------------------
+    def _forward_backward(self, inputs, target):
+        model = self.model
+        logits = model(inputs, None)
+        loss, dlogits = H.bce_logits(logits.detach(), target, want_grad=True)
+        logits.backward(dlogits)
+        return loss, logits.detach()
+
+    def _optimizer_step(self):
+        b = self.bucket
+        gscale = 1.0 / self.world_size
+        if self.optimizer == 'sgd':
+            first = 'buf' not in self.state
+            if first:
+                self.state['buf'] = torch.empty_like(b.p)
+            H.clamp_sgd_nesterov_(b.p, b.g, self.state['buf'], self.lr, self.momentum, self.wd, self.clip, first,
+                                  gscale)
+        else:
+            if 'm' not in self.state:
+                self.state['m'] = torch.zeros_like(b.p)
+                self.state['v'] = torch.zeros_like(b.p)
+            H.clamp_adam_(b.p, b.g, self.state['m'], self.state['v'], self.lr, self.steps + 1, self.clip,
+                          gscale=gscale)
+
+    def _first_step(self, inputs, target):
+        """Eager step that discovers the live parameters (the reference's optimiser skips
+        parameters whose grad is None -- resnet's conv1_alt/conv2/bn2, SURVEY.md finding 6)."""
+        model = self.model
+        model.train()
+        for p in model.parameters():
+            p.grad = None
+        loss, logits = self._forward_backward(inputs, target)
+        live = [p for p in model.parameters() if p.requires_grad and p.grad is not None]
+        self.bucket = FlatBucket(live)
+        if self.world_size > 1:
+            self.bucket.allreduce(self.group)
+        self._optimizer_step()
+        return loss, logits
+
+    def _eager_step(self, inputs, target):
+        self.bucket.zero_grad()
+        loss, logits = self._forward_backward(inputs, target)
+        if self.world_size > 1:
+            self.bucket.allreduce(self.group)
+        self._optimizer_step()
+        return loss, logits
+
+    # ---- graph replay ------------------------------------------------------------------------
+    def _capture(self, inputs, target):
+        self._static = (inputs.clone(), target.clone())
+        # Warm the caching allocator on a side stream with a forward+backward whose side effects
+        # (BN running stats, dropout seed) are rolled back, so capture adds no training step.
+        saved = [b.clone() for b in self.model.buffers()]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.bucket.zero_grad()
+            self._forward_backward(*self._static)
+            for b, c in zip(self.model.buffers(), saved):
+                b.copy_(c)
+        torch.cuda.current_stream().wait_stream(s)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_out = self._eager_single_gpu_parts(*self._static)
+        if self.world_size > 1:
+            self._graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_opt):
+                self._optimizer_step()
+
+    def _eager_single_gpu_parts(self, inputs, target):
+        self.bucket.zero_grad()
+        loss, logits = self._forward_backward(inputs, target)
+        if self.world_size == 1:
+            self._optimizer_step()
+        return loss, logits
+
+    # ---- public ------------------------------------------------------------------------------
+    def train_step(self, inputs, target):
+        """inputs (B_local, NB, 1, 224) float32 CUDA, target (B_local, 2) one-hot float32 CUDA.
+        Returns the (device-resident) loss tensor of this rank's shard."""
+        if not inputs.is_cuda:
+            raise RuntimeError('HotPathTrainer needs CUDA (MI355X) tensors; there is no CPU fallback')
+        self.model.train()
+        if self.bucket is None:
+            loss, logits = self._first_step(inputs, target)
+        elif not self.use_graph:
+            loss, logits = self._eager_step(inputs, target)
+        else:
+            if self._graph is None or self._static[0].shape != inputs.shape:
+                # one eager warm step already happened (_first_step); capture now
+                self._capture(inputs, target)
+            self._static[0].copy_(inputs)
+            self._static[1].copy_(target)
+            self._graph.replay()
+            if self.world_size > 1:
+                self.bucket.allreduce(self.group)
+                self._graph_opt.replay()
+            loss, logits = self._static_out
+        self.steps += 1
+        self.last_loss, self.last_logits = loss, logits
+        return loss
+
+    def test_step(self, inputs, target):
+        """run_test_epoch body: no_grad forward with train-mode modules, loss, argmax predictions."""
+        self.model.train()
+        with torch.no_grad():
+            logits = self.model(inputs, None)
+            loss, _ = H.bce_logits(logits, target, want_grad=False)
+        return loss, logits, logits.argmax(dim=-1)
+
+
+def run_train_epoch(trainer, loader, batch_size=None):
+    """BaseTraining.run_train_epoch (:139-159) over an iterable of (obs_idx, seq, metadata, target).
+    Returns the list of device-resident per-batch losses (no per-step host sync)."""
+    losses = []
+    dev = next(trainer.model.parameters()).device
+    for obs_idx, seq, metadata, target in loader:
+        if batch_size != 1:
+            obs_idx, seq, metadata, target = clip_odd_batch_sizes(obs_idx, seq, metadata, target)
+        if seq.shape[0] == 0:
+            continue
+        sl = shard_windows(seq.shape[0], trainer.world_size, trainer.rank)
+        inputs = seq[sl].float().to(dev, non_blocking=True)
+        tgt = target[sl].float().to(dev, non_blocking=True)
+        losses.append(trainer.train_step(inputs, tgt).clone())
+    return losses

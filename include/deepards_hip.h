@@ -1,0 +1,120 @@
+/* deepards_hip.h -- C ABI of libdeepards_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the ONE hot path of hahnicity/deepards: cnn_linear / resnet18-1D /
+ * densenet18-1D forward + backward over (sub_batch, 1, seq_len) windows.  The reference has no
+ * FFI for this path: every op below replaces a stock torch.nn call reached from
+ * deepards/models/{resnet,densenet,torch_cnn_linear_network}.py and train_ards_detector.py
+ * (file:line cited per entry point).  The Python host in deepards_amd/ binds these with ctypes
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless said otherwise; fp32 throughout
+ *   - caller allocates outputs and workspaces; nothing is retained between calls
+ *   - all launches go to `stream`, no hidden synchronisation, graph-capturable
+ *   - return 0 on success, -1 on invalid arguments, >0 = hipError_t of a failed launch
+ *   - activation layout "RLC": act[row][l][c] with channel pitch ld (floats, multiple of 4);
+ *     a BatchNorm *window* = rows_per_window consecutive rows = Wn = rows_per_window*L positions
+ */
+#ifndef DEEPARDS_HIP_H
+#define DEEPARDS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* da_stream_t; /* == hipStream_t */
+
+int da_version(void);
+
+/* ---- Conv1d as implicit GEMM on the fp32 matrix cores ------------------------------------
+ * replaces nn.Conv1d fwd + dgrad: resnet.py:5-8 (conv2x2), :16-19,:126-128 (BasicBlock convs,
+ * 1x1 s2 downsample); densenet.py:25-32 (1x1 bottleneck, k3 growth), :75-76 (transition conv).
+ * Y[row][j*dst_stride+dst_off][n] (+)= sum_t sum_c X[row][j*src_stride+src_off[t]][c] *
+ * Wp[wtap[t]][n][c],  j in [0,Lm); reads outside [0,Lsrc) are zero.  Wp: packed [tap][N][C].
+ * C % 32 == 0, N % 32 == 0, ntaps <= 3.  src_off / wtap are HOST int arrays. */
+int da_conv_gemm(const float* x, const float* w, float* y, int rows, int Lm, int Lsrc, int ldx, int C,
+                 int Ldst, int ldy, int N, int dst_stride, int dst_off, int src_stride, int ntaps,
+                 const int* src_off, const int* wtap, int accumulate, da_stream_t stream);
+
+/* nn.Conv1d weight gradient (autograd of the calls above; train_ards_detector.py:163).
+ * dW[co][ci][k] (torch layout) (+)= sum_positions dY[row][j*dy_stride+dy_off][co] *
+ * X[row][j*src_stride+src_off[k]][ci].  workspace: da_conv_wgrad_workspace() bytes. */
+size_t da_conv_wgrad_workspace(int rows, int Lm, int N, int C, int ntaps);
+int da_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, int rows, int Lm, int Ldy,
+                  int lddy, int N, int Lx, int ldx, int C, int dy_stride, int dy_off, int src_stride, int ntaps,
+                  const int* src_off, int accumulate, da_stream_t stream);
+
+/* torch [Co][Ci][K] -> Wf [K][Co][Ci] (forward) and Wd [K][Ci][Co] (data gradient). */
+int da_repack_conv_weight(const float* W, float* Wf, float* Wd, int Co, int Ci, int K, da_stream_t stream);
+
+/* ---- stem: Conv1d(1, C0, k7, s2, p3)  resnet.py:86-87,142 ; densenet.py:118-119 ----------- */
+int da_stem_conv_fwd(const float* x, const float* w, float* y, int rows, int Lin, int C0, int ldy,
+                     da_stream_t stream);
+size_t da_stem_wgrad_workspace(int rows, int C0);
+int da_stem_conv_wgrad(const float* dy, int lddy, const float* x, float* dw, float* workspace, int rows, int Lin,
+                       int C0, int accumulate, da_stream_t stream);
+
+/* ---- window-grouped train-mode BatchNorm1d (+ReLU, +residual) ------------------------------
+ * resnet.py:27-38,143,152 ; densenet.py:23-29,72-74,146 ; per-window statistics because
+ * torch_cnn_linear_network.py:108-113 calls breath_block(x[i]) one window at a time. */
+int da_bn_stats(const float* x, int ld, int W, int Wn, int C, float eps, float* mean, float* invstd,
+                da_stream_t stream);
+int da_bn_running_update(const float* mean, const float* invstd, int W, int C, int Wn, float eps, float momentum,
+                         float* running_mean, float* running_var, da_stream_t stream);
+int da_bn_apply(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
+                const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
+                da_stream_t stream);
+/* mask_mode 0: no ReLU; 1: ReLU, mask recomputed from bn(x); 2: ReLU, mask from `out` (residual).
+ * scratch: 2*W*C floats. */
+int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
+              float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd,
+              const float* gamma, const float* beta, int mask_mode, float* scratch, float* dgamma, float* dbeta,
+              int accumulate, da_stream_t stream);
+
+/* ---- pools ------------------------------------------------------------------------------
+ * stem BN+ReLU+{Max,Avg}Pool1d(3,2,1): resnet.py:100-104,152-153 ; densenet.py:120-123 */
+int da_bn_relu_pool_fwd(const float* y, int ldy, float* out, int ldo, int rows, int R, int Lin, int C,
+                        const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        int pool_mode, da_stream_t stream);
+int da_pool_bwd(const float* dout, int ldd, const float* y, int ldy, float* dz, int lddz, int rows, int R, int Lin,
+                int C, const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode,
+                da_stream_t stream);
+/* AvgPool1d(k, stride k): densenet.py:79 (k=2) ; AvgPool1d(7,1) on L=7: resnet.py:112,159, densenet.py:167,183 */
+int da_avgpool_fwd(const float* x, int ldx, float* out, int ldo, int rows, int Lin, int k, int C,
+                   da_stream_t stream);
+int da_avgpool_bwd(const float* dout, int ldd, float* dx, int lddx, int rows, int Lin, int k, int C,
+                   da_stream_t stream);
+
+/* ---- head + loss ---------------------------------------------------------------------------
+ * linear_final on view(-1) of the (NB,F) block: torch_cnn_linear_network.py:102,110-112 ;
+ * BCEWithLogitsLoss (mean): train_ards_detector.py:530,929-930 */
+int da_linear2_fwd(const float* flat, const float* W, const float* bias, float* logits, int B, int K,
+                   da_stream_t stream);
+int da_bce_logits(const float* logits, const float* target, int n, float gscale, float* loss, float* dlogits,
+                  da_stream_t stream);
+int da_linear2_bwd(const float* dlogits, const float* flat, const float* W, float* dflat, float* dW, float* dbias,
+                   int B, int K, int accumulate, da_stream_t stream);
+
+/* ---- optimiser: clamp hook + SGD(momentum .9, nesterov, weight decay) / Adam, fused ----------
+ * train_ards_detector.py:474-476 (clamp), :419-421 (optimisers).  gscale = 1/world_size after the
+ * gradient all-reduce (the clamp runs AFTER the reduce, SURVEY.md finding 7). */
+int da_clamp_sgd_nesterov(float* p, const float* g, float* buf, size_t n, float lr, float momentum,
+                          float weight_decay, float clip, float gscale, int first, da_stream_t stream);
+int da_clamp_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                  float eps, int step, float clip, float gscale, da_stream_t stream);
+
+/* ---- densenet helpers: torch.cat([x, new], 1) and F.dropout  densenet.py:36-40 -------------- */
+int da_concat2(const float* a, int lda, int C1, const float* b, int ldb, int C2, float* out, int ldo, size_t npos,
+               da_stream_t stream);
+int da_slice_copy(const float* src, int lds, int off, float* dst, int ldd, int C, size_t npos, int accumulate,
+                  da_stream_t stream);
+int da_dropout(const float* x, float* y, size_t n, const int64_t* seed, unsigned salt, float p,
+               da_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPARDS_HIP_H */

@@ -1,0 +1,289 @@
+"""GPU parity: every C-ABI kernel against the numpy oracle (oracle/np_ref.py, float64) on seeded inputs.
+
+Tolerances are for fp32 kernels against an fp64 oracle: the error of a length-K fp32 dot product is
+~1e-7 * sum|a*b|, so results are compared with atol scaled by the magnitude of the data."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def H():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from deepards_amd import hip_ops
+    return hip_ops
+
+
+def rlc(a):
+    """numpy (N,C,L) -> cuda (N,L,C) float32"""
+    return torch.from_numpy(np.ascontiguousarray(a.transpose(0, 2, 1)).astype(np.float32)).cuda()
+
+
+def ncl(t):
+    return t.detach().cpu().numpy().astype(np.float64).transpose(0, 2, 1)
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a).astype(np.float32)).cuda()
+
+
+def close(got, ref, tol=2e-6, name=''):
+    """max|got-ref| <= tol * (1 + max|ref|) * sqrt-ish slack"""
+    got = np.asarray(got, dtype=np.float64)
+    scale = 1.0 + np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    assert err <= tol * scale, '%s: max err %.3e (scale %.3e)' % (name, err, scale)
+    return err
+
+
+CONV_CASES = [
+    # ci, co, k, stride, pad, L, rows
+    (64, 64, 3, 1, 1, 56, 40),
+    (64, 128, 3, 2, 1, 56, 40),
+    (64, 128, 1, 2, 0, 56, 40),
+    (128, 128, 3, 1, 1, 28, 23),
+    (128, 256, 3, 2, 1, 28, 40),
+    (256, 512, 3, 2, 1, 14, 60),
+    (256, 512, 1, 2, 0, 14, 60),
+    (512, 512, 3, 1, 1, 7, 40),
+    (96, 128, 1, 1, 0, 56, 20),
+    (128, 32, 3, 1, 1, 28, 20),
+    (128, 64, 1, 1, 0, 14, 20),
+    (64, 64, 3, 1, 1, 56, 1),
+    (128, 32, 3, 1, 1, 9, 5),
+]
+
+
+@pytest.mark.parametrize('ci,co,k,stride,pad,L,rows', CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(H, ci, co, k, stride, pad, L, rows):
+    rng = np.random.default_rng(ci * 1000 + co + k + L)
+    x = rng.standard_normal((rows, ci, L))
+    w = rng.standard_normal((co, ci, k)) * np.sqrt(2.0 / (k * co))
+    y_ref = np_ref.conv1d_fwd(x, w, stride, pad)
+    dy = rng.standard_normal(y_ref.shape)
+    dx_ref, dw_ref = np_ref.conv1d_bwd(x, w, dy, stride, pad)
+
+    xt, wt, dyt = rlc(x), cu(w), rlc(dy)
+    wf, wd = H.repack_weight(wt, True, True)
+    assert torch.equal(wf, wt.permute(2, 0, 1).contiguous())
+    assert torch.equal(wd, wt.permute(2, 1, 0).contiguous())
+    y = H.conv_fwd(xt, wf, stride, pad)
+    close(ncl(y), y_ref, name='fwd')
+    dx = H.conv_dgrad(dyt, wd, stride, pad, L)
+    close(ncl(dx), dx_ref, name='dgrad')
+    dw = H.conv_wgrad(dyt, xt, k, stride, pad)
+    close(dw.cpu().numpy(), dw_ref, tol=3e-6, name='wgrad')
+    # accumulate forms
+    base = rng.standard_normal(dx_ref.shape)
+    bt = rlc(base)
+    H.conv_dgrad(dyt, wd, stride, pad, L, out=bt, accumulate=True)
+    close(ncl(bt), base + dx_ref, name='dgrad+acc')
+    dw2 = dw.clone()
+    H.conv_wgrad(dyt, xt, k, stride, pad, out=dw2, accumulate=True)
+    close(dw2.cpu().numpy(), 2 * dw_ref, tol=3e-6, name='wgrad+acc')
+
+
+def test_conv_mfma_layout_identity(H):
+    """A = identity-like input with an ASYMMETRIC weight: catches a transposed C/D or A/B map."""
+    ci = co = 32
+    x = np.zeros((1, ci, 40))
+    for l in range(32):
+        x[0, l, l] = 1.0                      # position l carries unit channel l
+    w = (np.arange(co)[:, None] * 100.0 + np.arange(ci)[None, :])[:, :, None]   # w[co][ci] asymmetric
+    y = H.conv_fwd(rlc(x), H.repack_weight(cu(w))[0], 1, 0)
+    ref = np_ref.conv1d_fwd(x, w, 1, 0)
+    assert np.array_equal(ncl(y), ref)
+
+
+@pytest.mark.parametrize('rows,L', [(40, 224), (3, 224), (20, 64)])
+def test_stem_conv(H, rows, L):
+    rng = np.random.default_rng(rows + L)
+    x = rng.standard_normal((rows, 1, L))
+    w = rng.standard_normal((64, 1, 7)) * 0.2
+    y_ref = np_ref.conv1d_fwd(x, w, 2, 3)
+    xt = cu(x[:, 0, :])
+    y = H.stem_conv_fwd(xt, cu(w))
+    close(ncl(y), y_ref, name='stem fwd')
+    dy = rng.standard_normal(y_ref.shape)
+    _, dw_ref = np_ref.conv1d_bwd(x, w, dy, 2, 3, need_dx=False)
+    dw = H.stem_conv_wgrad(rlc(dy), xt)
+    close(dw.cpu().numpy(), dw_ref, tol=3e-6, name='stem wgrad')
+
+
+@pytest.mark.parametrize('C,L,R,W', [(64, 56, 20, 3), (128, 28, 20, 2), (512, 7, 20, 2), (96, 56, 20, 1),
+                                     (64, 112, 20, 2), (32, 5, 3, 4)])
+def test_bn_fwd_bwd(H, C, L, R, W):
+    rng = np.random.default_rng(C + L + R)
+    rows = W * R
+    x = rng.standard_normal((rows, C, L)) * rng.uniform(0.2, 3, (1, C, 1)) + rng.uniform(-4, 4, (1, C, 1))
+    gamma = rng.uniform(0.5, 1.5, C)
+    beta = rng.standard_normal(C) * 0.3
+    res = rng.standard_normal((rows, C, L))
+    y_ref, st = np_ref.bn_window_fwd(x, gamma, beta, R)
+    xt, gt, bt = rlc(x), cu(gamma), cu(beta)
+    mean, invstd = H.bn_stats(xt, R)
+    close(mean.cpu().numpy(), st[0], name='mean')
+    close(invstd.cpu().numpy(), st[1], tol=5e-6, name='invstd')
+    # plain, relu, relu+residual
+    close(ncl(H.bn_apply(xt, R, mean, invstd, gt, bt, relu=False)), y_ref, tol=5e-6, name='bn')
+    close(ncl(H.bn_apply(xt, R, mean, invstd, gt, bt, relu=True)), np.maximum(y_ref, 0), tol=5e-6, name='bn relu')
+    out_ref = np.maximum(y_ref + res, 0)
+    out = H.bn_apply(xt, R, mean, invstd, gt, bt, relu=True, res=rlc(res))
+    close(ncl(out), out_ref, tol=5e-6, name='bn relu res')
+    # backward, three mask modes
+    dout = rng.standard_normal((rows, C, L))
+    dt = rlc(dout)
+    for mode, g_ref in ((0, dout), (1, dout * (y_ref > 0)), (2, dout * (out_ref > 0))):
+        dx_ref, dg_ref, db_ref = np_ref.bn_window_bwd(x, gamma, st, g_ref, R)
+        dx, dg, db, g = H.bn_bwd(dt, xt, R, mean, invstd, gt, bt, mode, out=out if mode == 2 else None, want_g=True)
+        # mask decisions can flip for |z| ~ 1e-7; on random data none are that close
+        close(ncl(dx), dx_ref, tol=2e-5, name='bn dx mode %d' % mode)
+        close(ncl(g), g_ref, tol=1e-6, name='bn g mode %d' % mode)
+        close(dg.cpu().numpy(), dg_ref, tol=2e-5, name='dgamma')
+        close(db.cpu().numpy(), db_ref, tol=2e-5, name='dbeta')
+    # running stats (sequential per-window momentum updates)
+    rm0, rv0 = rng.standard_normal(C), rng.uniform(0.5, 2, C)
+    rm, rv = cu(rm0), cu(rv0)
+    H.bn_running_update(mean, invstd, R * L, rm, rv)
+    # oracle closed form starts from given buffers
+    m_ref, v_ref = rm0.copy(), rv0.copy()
+    var_b = 1.0 / st[1] ** 2 - 1e-5
+    n = R * L
+    for i in range(W):
+        m_ref = 0.9 * m_ref + 0.1 * st[0][i]
+        v_ref = 0.9 * v_ref + 0.1 * var_b[i] * n / (n - 1)
+    close(rm.cpu().numpy(), m_ref, tol=5e-6, name='running mean')
+    close(rv.cpu().numpy(), v_ref, tol=2e-5, name='running var')
+
+
+@pytest.mark.parametrize('mode', [0, 1])
+def test_stem_bn_relu_pool(H, mode):
+    rng = np.random.default_rng(5 + mode)
+    rows, C, L, R = 40, 64, 112, 20
+    y0 = rng.standard_normal((rows, C, L))
+    gamma, beta = rng.uniform(0.5, 1.5, C), rng.standard_normal(C) * 0.3
+    z, st = np_ref.bn_window_fwd(y0, gamma, beta, R)
+    z = np.maximum(z, 0)
+    if mode == 0:
+        out_ref, idx = np_ref.maxpool3s2p1_fwd(z)
+    else:
+        out_ref = np_ref.avgpool3s2p1_fwd(z)
+    yt, gt, bt = rlc(y0), cu(gamma), cu(beta)
+    mean, invstd = H.bn_stats(yt, R)
+    out = H.bn_relu_pool_fwd(yt, R, mean, invstd, gt, bt, mode)
+    close(ncl(out), out_ref, tol=5e-6, name='pool fwd')
+    dout = rng.standard_normal(out_ref.shape)
+    dz_ref = np_ref.maxpool3s2p1_bwd(dout, idx, L) if mode == 0 else np_ref.avgpool3s2p1_bwd(dout, L)
+    dz = H.pool_bwd(rlc(dout), yt, R, mean, invstd, gt, bt, mode)
+    # ties (both zero after ReLU) route differently but are masked by the ReLU afterwards
+    close(ncl(dz) * (z > 0), dz_ref * (z > 0), tol=1e-6, name='pool bwd')
+
+
+def test_avgpools(H):
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((40, 128, 28))
+    close(ncl(H.avgpool_fwd(rlc(x), 2)), np_ref.avgpool_fwd(x, 2, 2), name='avg2')
+    d = rng.standard_normal((40, 128, 14))
+    close(ncl(H.avgpool_bwd(rlc(d), 28, 2)), np_ref.avgpool_bwd(d, 2, 2, 28), name='avg2 bwd')
+    x7 = rng.standard_normal((40, 512, 7))
+    close(ncl(H.avgpool_fwd(rlc(x7), 7)), np_ref.avgpool_fwd(x7, 7, 1), name='avg7')
+    d7 = rng.standard_normal((40, 512, 1))
+    close(ncl(H.avgpool_bwd(rlc(d7), 7, 7)), np_ref.avgpool_bwd(d7, 7, 1, 7), name='avg7 bwd')
+
+
+@pytest.mark.parametrize('B,K', [(4, 10240), (7, 2560), (64, 10240)])
+def test_head_and_loss(H, B, K):
+    rng = np.random.default_rng(B + K)
+    flat = rng.standard_normal((B, K))
+    w = rng.uniform(-1, 1, (2, K)) / np.sqrt(K)
+    bias = rng.uniform(-0.1, 0.1, 2)
+    tgt = np.zeros((B, 2))
+    tgt[np.arange(B), rng.integers(0, 2, B)] = 1
+    logits_ref = np_ref.linear_fwd(flat, w, bias)
+    loss_ref, dl_ref = np_ref.bce_with_logits(logits_ref, tgt)
+    ft, wt, bt = cu(flat), cu(w), cu(bias)
+    logits = H.linear2_fwd(ft, wt, bt)
+    close(logits.cpu().numpy(), logits_ref, name='logits')
+    loss, dl = H.bce_logits(logits, cu(tgt))
+    assert abs(float(loss) - loss_ref) < 1e-6
+    close(dl.cpu().numpy(), dl_ref, tol=1e-6, name='dlogits')
+    dflat, dw, db = H.linear2_bwd(dl, ft, wt)
+    close(dflat.cpu().numpy(), dl_ref @ w, tol=1e-6, name='dflat')
+    close(dw.cpu().numpy(), dl_ref.T @ flat, tol=2e-6, name='dW')
+    close(db.cpu().numpy(), dl_ref.sum(0), tol=1e-6, name='dbias')
+
+
+def test_bce_extremes(H):
+    x = np.array([[-40.0, 40.0], [0.0, 1e-4], [88.0, -88.0], [15.0, -15.0]])
+    t = np.array([[0.0, 1.0], [1.0, 0.0], [0.0, 1.0], [1.0, 0.0]])
+    loss_ref, d_ref = np_ref.bce_with_logits(x, t)
+    loss, d = H.bce_logits(cu(x), cu(t))
+    assert abs(float(loss) - loss_ref) < 1e-5 * (1 + abs(loss_ref))
+    close(d.cpu().numpy(), d_ref, tol=1e-6, name='bce extreme grads')
+
+
+def test_optimizers(H):
+    rng = np.random.default_rng(3)
+    n = 100003
+    p0 = rng.standard_normal(n) * 0.1
+    p_ref = p0.copy()
+    buf_ref = None
+    pt = cu(p0)
+    buf = torch.empty_like(pt)
+    for step in range(3):
+        g = rng.standard_normal(n) * 0.02            # about a third of the entries exceed the clip
+        gc = np_ref.clamp_grad(g, 0.01)
+        p_ref, buf_ref = np_ref.sgd_nesterov_step(p_ref, gc, buf_ref, first=(step == 0))
+        H.clamp_sgd_nesterov_(pt, cu(g), buf, 1e-3, 0.9, 1e-4, 0.01, step == 0)
+    close(pt.cpu().numpy(), p_ref, tol=1e-6, name='sgd')
+    # gscale: clamp AFTER the 1/world scaling
+    pt2, buf2 = cu(p0), torch.empty(n, device='cuda')
+    g = rng.standard_normal(n) * 0.05
+    H.clamp_sgd_nesterov_(pt2, cu(g * 4), buf2, 1e-3, 0.9, 1e-4, 0.01, True, gscale=0.25)
+    pr, _ = np_ref.sgd_nesterov_step(p0, np_ref.clamp_grad(g, 0.01), None, first=True)
+    close(pt2.cpu().numpy(), pr, tol=1e-6, name='sgd gscale')
+    # adam
+    pa, m_ref, v_ref = p0.copy(), 0.0, 0.0
+    pt3 = cu(p0)
+    m, v = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    for step in range(1, 4):
+        g = rng.standard_normal(n) * 0.02
+        pa, m_ref, v_ref = np_ref.adam_step(pa, np_ref.clamp_grad(g, 0.01), m_ref, v_ref, step)
+        H.clamp_adam_(pt3, cu(g), m, v, 1e-3, step, 0.01)
+    close(pt3.cpu().numpy(), pa, tol=2e-6, name='adam')
+
+
+def test_concat_slice_dropout(H):
+    rng = np.random.default_rng(4)
+    a, b = rng.standard_normal((20, 64, 28)), rng.standard_normal((20, 32, 28))
+    cat = H.concat2(rlc(a), rlc(b))
+    assert np.array_equal(ncl(cat), np.concatenate([a, b], 1).astype(np.float32).astype(np.float64))
+    s = H.slice_channels(cat, 64, 32)
+    assert torch.equal(s, rlc(b))
+    acc = rlc(a)
+    H.slice_channels(cat, 0, 64, out=acc, accumulate=True)
+    close(ncl(acc), 2 * a, name='slice acc')
+    x = torch.ones(1 << 20, device='cuda')
+    seed = torch.tensor([12345], dtype=torch.int64, device='cuda')
+    y1 = H.dropout(x, seed, 3, 0.2)
+    y2 = H.dropout(x, seed, 3, 0.2)
+    y3 = H.dropout(x, seed, 4, 0.2)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    keep = (y1 > 0).float().mean().item()
+    assert abs(keep - 0.8) < 0.005
+    assert torch.allclose(y1[y1 > 0], torch.tensor(1.25, device='cuda'))
+
+
+def test_bad_arguments_are_refused(H):
+    x = torch.zeros(4, 8, 48, device='cuda')               # C = 48 is not a multiple of 32
+    with pytest.raises(ValueError):
+        H.conv_fwd(x, torch.zeros(3, 32, 48, device='cuda'), 1, 1)
+    with pytest.raises(ValueError):
+        H.bn_stats(torch.zeros(5, 8, 32, device='cuda'), 2)  # rows not a multiple of R
+    with pytest.raises(ValueError):
+        H.conv_fwd(torch.zeros(4, 8, 32), torch.zeros(3, 32, 32), 1, 1)   # CPU tensors

@@ -1,0 +1,147 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol the header declares, host-side
+logic of the training loop, the model surface (state_dict keys / attributes of the reference), and
+the world_size-2 data-parallel path over gloo."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_loads_and_exports_header_symbols():
+    from deepards_amd import _lib
+    _lib.build()
+    lib = _lib.lib()
+    syms = _lib.header_symbols()
+    assert len(syms) >= 20
+    assert set(syms) == set(_lib.SIGNATURES)
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert lib.da_version() >= 100
+    # pure host helpers of the ABI (no GPU needed)
+    assert lib.da_conv_wgrad_workspace(1280, 56, 64, 64, 3) % (3 * 64 * 64 * 4) == 0
+    assert lib.da_stem_wgrad_workspace(1280, 64) == 512 * 64 * 7 * 4
+
+
+def test_product_path_refuses_cpu_tensors():
+    import deepards_amd.models as M
+    from deepards_amd import hip_ops as H
+    model = M.CNNLinearNetwork(M.resnet18(), 20, 0)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        model(torch.zeros(2, 20, 1, 224), None)
+    with pytest.raises(ValueError):
+        H.bn_stats(torch.zeros(20, 56, 64), 20)
+    # the product package never imports the oracle
+    for name, mod in list(sys.modules.items()):
+        if name.startswith('deepards_amd') and mod is not None:
+            src = getattr(mod, '__file__', None)
+            if src and src.endswith('.py'):
+                assert 'oracle' not in open(src).read().replace('oracle/', '').replace('the oracle', ''), name
+
+
+def test_model_surface_matches_reference_inventory():
+    import deepards_amd.models as M
+    from oracle.weights import param_spec
+    for backbone, ctor, nkeys, nout in (('resnet18', M.resnet18, 129, 512), ('densenet18', M.densenet18, 64, 128)):
+        bb = ctor()
+        assert bb.network_name == backbone and bb.n_out_filters == nout
+        model = M.CNNLinearNetwork(bb, 20, 0)
+        assert model.seq_size == 224 and model.breath_block is bb
+        assert tuple(model.linear_final.weight.shape) == (2, nout * 20)
+        assert [n for n, _ in model.named_parameters()] == [s[0] for s in param_spec(backbone)]
+        assert [tuple(p.shape) for _, p in model.named_parameters()] == [tuple(s[1]) for s in param_spec(backbone)]
+        assert len(model.state_dict()) == nkeys
+    d = M.densenet18()
+    assert hasattr(d, 'features') and hasattr(d, 'avgpool') and hasattr(d, 'forward_no_pool')
+    ks, st, pd = d.conv_info()
+    assert len(ks) == len(st) == len(pd) == 24 and ks[:2] == [7, 3]
+    assert all(not m.track_running_stats for m in d.modules() if isinstance(m, torch.nn.BatchNorm1d))
+    assert M.base_networks['resnet18'] is M.resnet18
+    with pytest.raises(Exception, match='sequence length of 224'):
+        M.CNNLinearNetwork(M.resnet18(), 20, 0)(torch.zeros(1, 20, 1, 100), None)
+    # reference init: conv ~ N(0, sqrt(2/(k*C_out))), BN gamma 1 / beta 0 (resnet.py:115-121)
+    r = M.resnet18()
+    w = r.layer3[0].conv1.weight
+    assert abs(float(w.std()) - np.sqrt(2.0 / (3 * 256))) < 2e-3
+    assert float(r.bn1.weight.min()) == 1.0 and float(r.bn1.bias.abs().max()) == 0.0
+
+
+def test_host_helpers():
+    from deepards_amd.train import clip_odd_batch_sizes, shard_windows
+    idx, seq, meta, tgt = torch.arange(5), torch.zeros(5, 20, 1, 224), torch.zeros(5), torch.zeros(5, 2)
+    a, b, c, d = clip_odd_batch_sizes(idx, seq, meta, tgt)
+    assert a.shape[0] == b.shape[0] == c.shape[0] == d.shape[0] == 4
+    a, b, c, d = clip_odd_batch_sizes(idx[:4], seq[:4], meta[:4], tgt[:4])
+    assert b.shape[0] == 4
+    assert shard_windows(64, 4, 1) == slice(16, 32)
+    assert [shard_windows(8, 2, r) for r in range(2)] == [slice(0, 4), slice(4, 8)]
+    with pytest.raises(ValueError):
+        shard_windows(6, 4, 0)
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from oracle import np_ref
+    from oracle.weights import seeded_params, seeded_batch
+    from deepards_amd.train import FlatBucket, shard_windows
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    params64 = {k: v.astype(np.float64) for k, v in seeded_params('densenet18', 0).items()}
+    x, t = seeded_batch(world * 1, 20, 5)
+    sl = shard_windows(x.shape[0], world, rank)
+    out = np_ref.cnn_linear_forward_backward(params64, x[sl].astype(np.float64), t[sl].astype(np.float64),
+                                             backbone='densenet18')
+    names = sorted(out['grads'])
+    tens = [torch.nn.Parameter(torch.from_numpy(params64[n].copy())) for n in names]
+    for p, n in zip(tens, names):
+        p.grad = torch.from_numpy(np.ascontiguousarray(out['grads'][n]))
+    # FlatBucket is fp32 on the device of the params; here fp32 CPU
+    tens32 = [torch.nn.Parameter(p.detach().float()) for p in tens]
+    for p32, p in zip(tens32, tens):
+        p32.grad = p.grad.float()
+    bucket = FlatBucket(tens32)
+    bucket.allreduce()
+    gflat = (bucket.g / world).numpy().astype(np.float64)
+    assert all(off % 64 == 0 for off in bucket.offsets)          # 256-B aligned segments
+    # clamp AFTER the reduce, then the optimiser step -- identical on every rank
+    newp, gs = [], []
+    for n, p, off in zip(names, tens32, bucket.offsets):
+        k = p.numel()
+        gs.append(gflat[off:off + k])
+        gi = np_ref.clamp_grad(gflat[off:off + k].reshape(p.shape), 0.01)
+        pn, _ = np_ref.sgd_nesterov_step(params64[n], gi, None, first=True)
+        newp.append(pn.ravel())
+    q.put((rank, np.concatenate(gs), np.concatenate(newp), names))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gloo_world2_matches_full_batch():
+    """Sharding windows over 2 ranks + sum-all-reduce of the flat bucket + 1/W scale reproduces the
+    full-batch gradient (BN never crosses windows; loss is a mean over equal shards)."""
+    import torch.multiprocessing as mp
+    from oracle import np_ref
+    from oracle.weights import seeded_params, seeded_batch
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    res.sort(key=lambda r: r[0])
+    (_, g0, p0, names), (_, g1, p1, _) = res
+    assert np.array_equal(g0, g1) and np.array_equal(p0, p1)          # replicas stay bit-identical
+    params64 = {k: v.astype(np.float64) for k, v in seeded_params('densenet18', 0).items()}
+    x, t = seeded_batch(2, 20, 5)
+    full = np_ref.cnn_linear_forward_backward(params64, x.astype(np.float64), t.astype(np.float64), backbone='densenet18')
+    ref = np.concatenate([full['grads'][n].ravel() for n in names])
+    assert np.abs(g0 - ref).max() < 1e-6 * (1 + np.abs(ref).max())

@@ -85,3 +85,50 @@ def test_running_stats_closed_form():
         rm, rv = np_ref.bn_running_update(rm, rv, st0, cnt)
         np.testing.assert_allclose(rm, g['rm64/' + short], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(rv, g['rv64/' + short], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('path', GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_torch_oracle_matches_reference(path):
+    """oracle/torch_ref.py (the CPU-baseline path) against the fp32 reference goldens."""
+    import torch
+    from oracle import torch_ref
+    g = _load(path)
+    backbone = str(g['backbone'])
+    p = {k: torch.from_numpy(v) for k, v in seeded_params(backbone, int(g['seed'])).items()}
+    out = torch_ref.cnn_linear(p, torch.from_numpy(g['x']), backbone, str(g['first_pool_type']))
+    assert np.abs(out.detach().numpy() - g['logits32']).max() < 2e-6
+
+
+def test_torch_oracle_sgd_matches_reference():
+    import torch
+    from oracle import torch_ref
+    g = _load([p for p in GOLD if 'resnet18_b2_randn' in p][0])
+    p = {k: torch.from_numpy(v) for k, v in seeded_params('resnet18', 0).items()}
+    tr = torch_ref.CpuReferenceTrainer(p, 'resnet18')
+    x, t = torch.from_numpy(g['x']), torch.from_numpy(g['target'])
+    losses = [float(tr.step(x, t)) for _ in range(3)]
+    assert np.abs(np.array(losses) - g['sgd_losses32']).max() < 2e-6
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/deepards/models'), reason='reference only in the build container')
+def test_torch_oracle_bitwise_vs_reference_import():
+    """In the build container only: same ATen ops in the same order => bit-identical logits."""
+    import sys
+    import torch
+    from oracle import torch_ref
+    sys.path.insert(0, '/root/reference')
+    try:
+        from deepards.models.resnet import resnet18
+        from deepards.models.densenet import densenet18
+        from deepards.models.torch_cnn_linear_network import CNNLinearNetwork
+    finally:
+        sys.path.remove('/root/reference')
+    x = torch.from_numpy(_load(GOLD[0])['x'])
+    for backbone, ctor in (('resnet18', lambda: resnet18()), ('densenet18', lambda: densenet18(drop_rate=0))):
+        ref = CNNLinearNetwork(ctor(), 20, 0)
+        p = {k: torch.from_numpy(v) for k, v in seeded_params(backbone, 5).items()}
+        ref.load_state_dict(p, strict=False)
+        with torch.no_grad():
+            a = ref.train()(x, None)
+            b = torch_ref.cnn_linear(p, x, backbone)
+        assert torch.equal(a, b), backbone
