@@ -23,9 +23,15 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+import os
+_DEBUG_SYNC = os.environ.get('DEEPARDS_DEBUG_SYNC') == '1'
+
+
 def _chk(rc, name):
     if rc != 0:
         raise HipError('%s failed with code %d' % (name, rc))
+    if _DEBUG_SYNC:                      # debugging aid: serialise every launch
+        torch.cuda.synchronize()
 
 
 def _rlc(t, name='tensor'):

@@ -25,7 +25,7 @@ OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
 CLIP, LR, MOM, WD = 0.01, 1e-3, 0.9, 1e-4
 
 
-def build(backbone, seed, dtype, first_pool_type='max'):
+def build(backbone, seed, dtype, first_pool_type='max', shift=0.0):
     if backbone == 'resnet18':
         bb = resnet18(first_pool_type=first_pool_type)
     else:
@@ -36,19 +36,19 @@ def build(backbone, seed, dtype, first_pool_type='max'):
     assert names == [s[0] for s in spec], 'param_spec order differs from the reference'
     for (n, shp, _), (_, p) in zip(spec, model.named_parameters()):
         assert tuple(p.shape) == tuple(shp), (n, p.shape, shp)
-    sd = {k: torch.from_numpy(v) for k, v in seeded_params(backbone, seed).items()}
+    sd = {k: torch.from_numpy(v) for k, v in seeded_params(backbone, seed, bn_bias_shift=shift).items()}
     missing = model.load_state_dict(sd, strict=False)
     assert not missing.unexpected_keys
     assert all(('running_' in k or 'num_batches' in k) for k in missing.missing_keys), missing
     return model.to(dtype).train()
 
 
-def run_case(tag, backbone, b, seed, kind, first_pool_type='max'):
+def run_case(tag, backbone, b, seed, kind, first_pool_type='max', shift=0.0):
     x, tgt = seeded_batch(b, 20, seed, kind)
     rec = dict(x=x, target=tgt, backbone=backbone, seed=seed, b=b,
-               first_pool_type=first_pool_type, kind=kind)
+               first_pool_type=first_pool_type, kind=kind, bn_bias_shift=shift)
     for dt, sfx in ((torch.float64, '64'), (torch.float32, '32')):
-        model = build(backbone, seed, dt, first_pool_type)
+        model = build(backbone, seed, dt, first_pool_type, shift)
         xt, tt = torch.from_numpy(x).to(dt), torch.from_numpy(tgt).to(dt)
         out = model(xt, None)
         loss = torch.nn.BCEWithLogitsLoss()(out, tt)
@@ -70,7 +70,7 @@ def run_case(tag, backbone, b, seed, kind, first_pool_type='max'):
 
         # optimiser trajectories with the clamp hooks (train_ards_detector.py:416-422,474-476)
         for opt_name in ('sgd', 'adam'):
-            model = build(backbone, seed, dt, first_pool_type)
+            model = build(backbone, seed, dt, first_pool_type, shift)
             for p in model.parameters():
                 p.register_hook(lambda g: torch.clamp(g, -CLIP, CLIP))
             if opt_name == 'sgd':
@@ -107,3 +107,6 @@ if __name__ == '__main__':
     run_case('resnet18_b2_avgpool', 'resnet18', 2, 2, 'randn', first_pool_type='avg')
     run_case('densenet18_b2_randn', 'densenet18', 2, 0, 'randn')
     run_case('densenet18_b4_flow', 'densenet18', 4, 1, 'flow')
+    # every ReLU active (BN beta += 6): no activation decision can flip under fp32 rounding
+    run_case('resnet18_b2_active', 'resnet18', 2, 3, 'randn', first_pool_type='avg', shift=6.0)
+    run_case('densenet18_b2_active', 'densenet18', 2, 3, 'randn', shift=6.0)

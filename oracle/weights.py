@@ -75,10 +75,13 @@ DEAD_RESNET_PARAMS = ('breath_block.conv1_alt.weight', 'breath_block.conv2.weigh
                       'breath_block.bn2.weight', 'breath_block.bn2.bias')
 
 
-def seeded_params(backbone, seed=0, n_sub_batches=20, dtype=np.float32):
+def seeded_params(backbone, seed=0, n_sub_batches=20, dtype=np.float32, bn_bias_shift=0.0):
     """Deterministic weights: conv ~ N(0, sqrt(2/(k*C_out))) as the reference's init
     (resnet.py:115-118, densenet.py:154-157); BN gamma ~ U(.5,1.5), beta ~ N(0,.1) (NOT the
-    reference's 1/0 -- randomised so that parity tests see gamma/beta); linear ~ U(+-1/sqrt(in))."""
+    reference's 1/0 -- randomised so that parity tests see gamma/beta); linear ~ U(+-1/sqrt(in)).
+    bn_bias_shift > 0 moves every BN beta up so that (almost) every ReLU is active: the network then has
+    no activation decisions an fp32 rounding could flip, which makes whole-model GRADIENT parity a
+    well-posed 1e-4 comparison (see tests/test_model_gpu.py)."""
     params = {}
     for name, shape, kind in param_spec(backbone, n_sub_batches):
         rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
@@ -88,7 +91,7 @@ def seeded_params(backbone, seed=0, n_sub_batches=20, dtype=np.float32):
         elif kind == 'bn_w':
             a = rng.uniform(0.5, 1.5, shape)
         elif kind == 'bn_b':
-            a = rng.standard_normal(shape) * 0.1
+            a = rng.standard_normal(shape) * 0.1 + bn_bias_shift
         elif kind == 'lin_w':
             bound = 1.0 / np.sqrt(shape[1])
             a = rng.uniform(-bound, bound, shape)

@@ -56,6 +56,11 @@ CONV_CASES = [
     (128, 64, 1, 1, 0, 14, 20),
     (64, 64, 3, 1, 1, 56, 1),
     (128, 32, 3, 1, 1, 9, 5),
+    (256, 256, 3, 1, 1, 14, 40),
+    (96, 128, 1, 1, 0, 7, 40),
+    (128, 32, 3, 1, 1, 7, 40),
+    (128, 128, 3, 1, 1, 28, 40),
+    (128, 64, 1, 1, 0, 56, 40),
 ]
 
 
@@ -146,6 +151,12 @@ def test_bn_fwd_bwd(H, C, L, R, W):
         close(ncl(g), g_ref, tol=1e-6, name='bn g mode %d' % mode)
         close(dg.cpu().numpy(), dg_ref, tol=2e-5, name='dgamma')
         close(db.cpu().numpy(), db_ref, tol=2e-5, name='dbeta')
+    # in-place form used by the block functions: dx aliases dout
+    g_ref = dout * (y_ref > 0)
+    dx_ref, _, _ = np_ref.bn_window_bwd(x, gamma, st, g_ref, R)
+    d2 = dt.clone()
+    H.bn_bwd(d2, xt, R, mean, invstd, gt, bt, 1, dx=d2)
+    close(ncl(d2), dx_ref, tol=2e-5, name='bn dx in-place')
     # running stats (sequential per-window momentum updates)
     rm0, rv0 = rng.standard_normal(C), rng.uniform(0.5, 2, C)
     rm, rv = cu(rm0), cu(rv0)
