@@ -91,16 +91,35 @@ class KernelTimer(object):
         return out
 
 
-def cpu_baseline(backbone, batch, seconds):
-    """Reference CPU path (stock ATen ops through oracle/torch_ref.py) on the host cores."""
-    import torch
-    from oracle import torch_ref
-    from oracle.weights import seeded_params
+def host_cores():
+    """CPUs this process may really use: min(affinity mask, cgroup cpu.max quota)."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    cores = min(cores, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return cores
+
+
+def cpu_baseline(backbone, batch, seconds):
+    """Reference CPU path (stock ATen ops through oracle/torch_ref.py) on the host cores."""
+    import torch
+    from oracle import torch_ref
+    from oracle.weights import seeded_params
+    cores = host_cores()
     torch.set_num_threads(cores)
     p = {k: torch.from_numpy(v) for k, v in seeded_params(backbone, 0).items()}
     tr = torch_ref.CpuReferenceTrainer(p, backbone, drop_rate=0.2 if backbone == 'densenet18' else 0.0)
@@ -109,7 +128,9 @@ def cpu_baseline(backbone, batch, seconds):
     x = torch.randn(b, 20, 1, 224, generator=g)
     t = torch.zeros(b, 2)
     t[torch.arange(b), torch.randint(0, 2, (b,), generator=g)] = 1
+    say('cpu baseline: %d threads' % cores)
     tr.step(x, t)                                        # warm-up
+    say('cpu baseline: warm-up step done')
     n, t0 = 0, time.perf_counter()
     while True:
         tr.step(x, t)
@@ -122,8 +143,14 @@ def cpu_baseline(backbone, batch, seconds):
                        (n, b, dt, backbone, torch.__version__, cores))
 
 
+def say(*a):
+    print('[bench]', *a, file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
+    import faulthandler
+    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)
     import torch
     import torch.distributed as dist
 
@@ -163,8 +190,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 2)):                 # >= 2: eager first step + graph capture
+    say('model built; warmup')
+    for i in range(max(args.warmup, 2)):                 # >= 2: eager first step + graph capture
         tr.train_step(x, t)
+        torch.cuda.synchronize()
+        say('warmup step', i, 'done')
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -176,6 +206,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     loss = float(tr.last_loss)
+    say('timed region done: %.3f ms/step' % (1e3 * dt / args.steps))
 
     seqs = world * B * 20 * args.steps
     value = seqs / dt
@@ -214,6 +245,7 @@ def main():
             tr_e._eager_step(x, t)
         summ = kt.summary()
         kt.remove()
+        say('roofline pass done')
         dom = summ['da_conv_gemm']
         ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
         out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_gemm_kernel<*> (da_conv_gemm: conv fwd + dgrad implicit GEMM, '
@@ -230,6 +262,7 @@ def main():
         out['eager_kernel_ms_per_step'] = round(tot / nprof, 3)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        say('cpu baseline ...')
         out['cpu_baseline'] = cpu_baseline(args.backbone, B, args.cpu_seconds)
         out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
 

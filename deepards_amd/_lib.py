@@ -20,6 +20,7 @@ _IP = ctypes.POINTER(ctypes.c_int)
 # name -> (restype, argtypes); must list exactly the symbols the header declares (tests check it)
 SIGNATURES = {
     'da_version': (_I, []),
+    'da_hip_runtime_symbol': (_P, []),
     'da_conv_gemm': (_I, [_P, _P, _P] + [_I] * 12 + [_IP, _IP, _I, _P]),
     'da_conv_wgrad_workspace': (_Z, [_I] * 5),
     'da_conv_wgrad': (_I, [_P, _P, _P, _P] + [_I] * 12 + [_IP, _I, _P]),
@@ -79,10 +80,30 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError('libdeepards_hip.so is not built: run `python -c "import __graft_entry__ as g; '
                                'g.build()"` (hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+        import torch  # noqa: F401  (first: its bundled HIP runtime must be the one we bind to)
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError if the symbol is missing: fail loudly
             fn.restype = res
             fn.argtypes = args
+        _check_same_runtime(l)
         _lib = l
     return _lib
+
+
+def _check_same_runtime(l):
+    """PyTorch wheels bundle their own libamdhip64.so; this library must bind to the SAME runtime
+    (streams, graph capture and ordering are per runtime).  torch is imported first so that its HIP
+    runtime sits in the global symbol scope; verify, and refuse to run on a mismatch."""
+    import sys
+    torch = sys.modules.get('torch')
+    if torch is None:
+        return
+    tlib = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+    if not os.path.exists(tlib):
+        return
+    theirs = ctypes.cast(ctypes.CDLL(tlib).hipGetLastError, ctypes.c_void_p).value
+    ours = l.da_hip_runtime_symbol()
+    if ours != theirs:
+        raise RuntimeError('libdeepards_hip.so is bound to a different HIP runtime (%#x) than PyTorch (%#x): '
+                           'import torch before deepards_amd' % (ours or 0, theirs or 0))

@@ -213,6 +213,7 @@ extern "C" {
 // mean/invstd: [W][C].  x: [W*Wn][ld].  C % 32 == 0, ld % 4 == 0.
 int da_bn_stats(const float* x, int ld, int W, int Wn, int C, float eps, float* mean, float* invstd,
                 hipStream_t stream) {
+  DA_ENTER();
   if (!x || !mean || !invstd || C % CG || ld % 4 || Wn < 1) return DA_EINVAL;
   if (W == 0) return DA_OK;
   hipLaunchKernelGGL(bn_stats_kernel, dim3(W, C / CG), dim3(256), 0, stream, x, ld, Wn, C, eps, mean, invstd);
@@ -222,6 +223,7 @@ int da_bn_stats(const float* x, int ld, int W, int Wn, int C, float eps, float* 
 
 int da_bn_running_update(const float* mean, const float* invstd, int W, int C, int Wn, float eps, float momentum,
                          float* running_mean, float* running_var, hipStream_t stream) {
+  DA_ENTER();
   if (!mean || !invstd || !running_mean || !running_var || Wn < 2) return DA_EINVAL;
   hipLaunchKernelGGL(bn_running_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, mean, invstd, W, C, Wn, eps,
                      momentum, running_mean, running_var);
@@ -232,6 +234,7 @@ int da_bn_running_update(const float* mean, const float* invstd, int W, int C, i
 int da_bn_apply(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
                 const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
                 hipStream_t stream) {
+  DA_ENTER();
   if (!x || !out || !mean || !invstd || !gamma || !beta || C % CG || ldx % 4 || ldo % 4 || (res && ldr % 4))
     return DA_EINVAL;
   if (W == 0) return DA_OK;
@@ -248,6 +251,7 @@ int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* 
               float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd, const float* gamma,
               const float* beta, int mask_mode, float* scratch, float* dgamma, float* dbeta, int accumulate,
               hipStream_t stream) {
+  DA_ENTER();
   if (!dout || !x || !dx || !mean || !invstd || !gamma || !beta || !scratch || !dgamma || !dbeta) return DA_EINVAL;
   if (C % CG || ldd % 4 || ldx % 4 || lddx % 4 || (gout && ldg % 4) || mask_mode < 0 || mask_mode > 2)
     return DA_EINVAL;

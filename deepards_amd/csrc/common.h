@@ -16,6 +16,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define DA_OK 0
 #define DA_EINVAL (-1)
 
+// hipGetLastError() is sticky per thread: clear whatever an earlier runtime call (ours or PyTorch's)
+// left behind before judging our own launches.
+#define DA_ENTER() (void)hipGetLastError()
+
 #define DA_CHECK_LAUNCH()                          \
   do {                                             \
     hipError_t e__ = hipGetLastError();            \

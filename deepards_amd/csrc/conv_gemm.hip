@@ -348,6 +348,7 @@ extern "C" {
 int da_conv_gemm(const float* x, const float* w, float* y, int rows, int Lm, int Lsrc, int ldx, int C, int Ldst,
                  int ldy, int N, int dst_stride, int dst_off, int src_stride, int ntaps, const int* src_off,
                  const int* wtap, int accumulate, hipStream_t stream) {
+  DA_ENTER();
   if (!x || !w || !y || rows < 0 || Lm < 1 || ntaps < 1 || ntaps > 3) return DA_EINVAL;
   ConvGemmArgs a;
   a.x = x; a.w = w; a.y = y;
@@ -373,6 +374,7 @@ size_t da_conv_wgrad_workspace(int rows, int Lm, int N, int C, int ntaps) {
 int da_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, int rows, int Lm, int Ldy, int lddy,
                   int N, int Lx, int ldx, int C, int dy_stride, int dy_off, int src_stride, int ntaps,
                   const int* src_off, int accumulate, hipStream_t stream) {
+  DA_ENTER();
   if (!dy || !x || !dw || !workspace || ntaps < 1 || ntaps > 3) return DA_EINVAL;
   if (C % 32 || N % 32 || lddy % 4 || ldx % 4) return DA_EINVAL;
   WgradArgs a;

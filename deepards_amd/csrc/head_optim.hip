@@ -229,9 +229,14 @@ extern "C" {
 
 int da_version(void) { return 100; }
 
+// Address of the HIP runtime entry point this library is bound to: the Python loader compares it with
+// the runtime PyTorch uses, because two HIP runtimes in one process do not share streams or ordering.
+const void* da_hip_runtime_symbol(void) { return (const void*)&hipGetLastError; }
+
 // flat: [B][K] (K = NB*F, K % 4 == 0).  W: [2][K], bias: [2].  logits: [B][2].
 int da_linear2_fwd(const float* flat, const float* W, const float* bias, float* logits, int B, int K,
                    hipStream_t stream) {
+  DA_ENTER();
   if (!flat || !W || !bias || !logits || K % 4) return DA_EINVAL;
   if (B == 0) return DA_OK;
   hipLaunchKernelGGL(linear2_fwd_kernel, dim3(B), dim3(256), 0, stream, flat, W, bias, logits, K);
@@ -242,6 +247,7 @@ int da_linear2_fwd(const float* flat, const float* W, const float* bias, float* 
 // loss: 1 float.  dlogits may be null (test epoch).  gscale multiplies the gradient (1 normally).
 int da_bce_logits(const float* logits, const float* target, int n, float gscale, float* loss, float* dlogits,
                   hipStream_t stream) {
+  DA_ENTER();
   if (!logits || !target || !loss || n < 1) return DA_EINVAL;
   hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, stream, logits, target, n, gscale, loss, dlogits);
   DA_CHECK_LAUNCH();
@@ -250,6 +256,7 @@ int da_bce_logits(const float* logits, const float* target, int n, float gscale,
 
 int da_linear2_bwd(const float* dlogits, const float* flat, const float* W, float* dflat, float* dW, float* dbias,
                    int B, int K, int accumulate, hipStream_t stream) {
+  DA_ENTER();
   if (!dlogits || !flat || !W || K % 4) return DA_EINVAL;
   if (B == 0) return DA_OK;
   if (dflat) {
@@ -268,6 +275,7 @@ int da_linear2_bwd(const float* dlogits, const float* flat, const float* W, floa
 
 int da_clamp_sgd_nesterov(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay,
                           float clip, float gscale, int first, hipStream_t stream) {
+  DA_ENTER();
   if (!p || !g || !buf) return DA_EINVAL;
   if (n == 0) return DA_OK;
   hipLaunchKernelGGL(clamp_sgd_nesterov_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, p, g, buf, n, lr,
@@ -278,6 +286,7 @@ int da_clamp_sgd_nesterov(float* p, const float* g, float* buf, size_t n, float 
 
 int da_clamp_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                   int step, float clip, float gscale, hipStream_t stream) {
+  DA_ENTER();
   if (!p || !g || !m || !v || step < 1) return DA_EINVAL;
   if (n == 0) return DA_OK;
   float bc1 = 1.0f - powf(beta1, (float)step);
@@ -290,6 +299,7 @@ int da_clamp_adam(float* p, const float* g, float* m, float* v, size_t n, float 
 
 // W: [Co][Ci][K] torch layout; Wf: [K][Co][Ci]; Wd: [K][Ci][Co] (either may be null).
 int da_repack_conv_weight(const float* W, float* Wf, float* Wd, int Co, int Ci, int K, hipStream_t stream) {
+  DA_ENTER();
   if (!W || (!Wf && !Wd)) return DA_EINVAL;
   size_t total = (size_t)Co * Ci * K;
   hipLaunchKernelGGL(repack_conv_weight_kernel, dim3(grid_for(total, 256, 2048)), dim3(256), 0, stream, W, Wf, Wd, Co,
@@ -300,6 +310,7 @@ int da_repack_conv_weight(const float* W, float* Wf, float* Wd, int Co, int Ci, 
 
 int da_concat2(const float* a, int lda, int C1, const float* b, int ldb, int C2, float* out, int ldo, size_t npos,
                hipStream_t stream) {
+  DA_ENTER();
   if (!a || !b || !out || C1 % 4 || C2 % 4 || lda % 4 || ldb % 4 || ldo % 4) return DA_EINVAL;
   if (npos == 0) return DA_OK;
   hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(npos * ((C1 + C2) / 4), 256, 8192)), dim3(256), 0, stream, a, lda,
@@ -310,6 +321,7 @@ int da_concat2(const float* a, int lda, int C1, const float* b, int ldb, int C2,
 
 int da_slice_copy(const float* src, int lds, int off, float* dst, int ldd, int C, size_t npos, int accumulate,
                   hipStream_t stream) {
+  DA_ENTER();
   if (!src || !dst || C % 4 || lds % 4 || ldd % 4 || off % 4) return DA_EINVAL;
   if (npos == 0) return DA_OK;
   hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(npos * (C / 4), 256, 8192)), dim3(256), 0, stream, src, lds, off,
@@ -320,6 +332,7 @@ int da_slice_copy(const float* src, int lds, int off, float* dst, int ldd, int C
 
 // y = dropout(x) with keep-prob 1-p; the same (seed, salt) reproduces the mask (used by backward).
 int da_dropout(const float* x, float* y, size_t n, const int64_t* seed, unsigned salt, float p, hipStream_t stream) {
+  DA_ENTER();
   if (!x || !y || !seed || p < 0.f || p >= 1.f) return DA_EINVAL;
   if (n == 0) return DA_OK;
   hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, stream, x, y, n, seed, salt, p);

@@ -236,6 +236,7 @@ extern "C" {
 // x: [rows][Lin] raw waveform (C_in = 1).  w: [C0][1][7] (torch layout).  y: [rows][Lin/2][ldy].
 int da_stem_conv_fwd(const float* x, const float* w, float* y, int rows, int Lin, int C0, int ldy,
                      hipStream_t stream) {
+  DA_ENTER();
   if (!x || !w || !y || Lin < 2 || Lin % 2 || C0 < 1 || C0 > 256 || 256 % C0) return DA_EINVAL;
   if (rows == 0) return DA_OK;
   hipLaunchKernelGGL(stem_conv_fwd_kernel, dim3(rows), dim3(256), (Lin + 6) * sizeof(float), stream, x, w, y, Lin,
@@ -251,6 +252,7 @@ size_t da_stem_wgrad_workspace(int rows, int C0) {
 
 int da_stem_conv_wgrad(const float* dy, int lddy, const float* x, float* dw, float* workspace, int rows, int Lin,
                        int C0, int accumulate, hipStream_t stream) {
+  DA_ENTER();
   if (!dy || !x || !dw || !workspace || Lin % 2 || C0 < 1 || C0 > 256 || 256 % C0) return DA_EINVAL;
   if (rows == 0) return DA_OK;
   int nblk = rows < 512 ? rows : 512;
@@ -270,6 +272,7 @@ int da_stem_conv_wgrad(const float* dy, int lddy, const float* x, float* dw, flo
 int da_bn_relu_pool_fwd(const float* y, int ldy, float* out, int ldo, int rows, int R, int Lin, int C,
                         const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode,
                         hipStream_t stream) {
+  DA_ENTER();
   if (!y || !out || C % 4 || ldy % 4 || ldo % 4 || R < 1 || rows % R) return DA_EINVAL;
   if (rows == 0) return DA_OK;
   int Lout = (Lin - 1) / 2 + 1;
@@ -283,6 +286,7 @@ int da_bn_relu_pool_fwd(const float* y, int ldy, float* out, int ldo, int rows, 
 int da_pool_bwd(const float* dout, int ldd, const float* y, int ldy, float* dz, int lddz, int rows, int R, int Lin,
                 int C, const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode,
                 hipStream_t stream) {
+  DA_ENTER();
   if (!dout || !y || !dz || C % 4 || ldd % 4 || ldy % 4 || lddz % 4 || R < 1 || rows % R) return DA_EINVAL;
   if (rows == 0) return DA_OK;
   int Lout = (Lin - 1) / 2 + 1;
@@ -296,6 +300,7 @@ int da_pool_bwd(const float* dout, int ldd, const float* y, int ldy, float* dz, 
 // AvgPool1d(k, stride=k) with Lout = Lin / k (floor); k == Lin gives the global pool.
 int da_avgpool_fwd(const float* x, int ldx, float* out, int ldo, int rows, int Lin, int k, int C,
                    hipStream_t stream) {
+  DA_ENTER();
   if (!x || !out || C % 4 || ldx % 4 || ldo % 4 || k < 1 || k > Lin) return DA_EINVAL;
   if (rows == 0) return DA_OK;
   int Lout = Lin / k;
@@ -308,6 +313,7 @@ int da_avgpool_fwd(const float* x, int ldx, float* out, int ldo, int rows, int L
 
 int da_avgpool_bwd(const float* dout, int ldd, float* dx, int lddx, int rows, int Lin, int k, int C,
                    hipStream_t stream) {
+  DA_ENTER();
   if (!dout || !dx || C % 4 || ldd % 4 || lddx % 4 || k < 1 || k > Lin) return DA_EINVAL;
   if (rows == 0) return DA_OK;
   int Lout = Lin / k;

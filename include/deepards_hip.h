@@ -28,6 +28,8 @@ extern "C" {
 typedef struct ihipStream_t* da_stream_t; /* == hipStream_t */
 
 int da_version(void);
+/* address of hipGetLastError as bound by this library (loader sanity check: same HIP runtime as the host) */
+const void* da_hip_runtime_symbol(void);
 
 /* ---- Conv1d as implicit GEMM on the fp32 matrix cores ------------------------------------
  * replaces nn.Conv1d fwd + dgrad: resnet.py:5-8 (conv2x2), :16-19,:126-128 (BasicBlock convs,
