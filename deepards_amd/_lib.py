@@ -29,7 +29,7 @@ SIGNATURES = {
     'da_stem_wgrad_workspace': (_Z, [_I, _I]),
     'da_stem_conv_wgrad': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     'da_bn_stats': (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _P]),
-    'da_bn_running_update': (_I, [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P]),
+    'da_bn_running_update': (_I, [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
     'da_bn_apply': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     'da_bn_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
     'da_bn_relu_pool_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),

@@ -67,21 +67,40 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 }
 
 // running stats: r <- (1-mom) r + mom * stat_w, one update per window, in window order
-// (SURVEY.md finding 5; unbiased variance n/(n-1)).
-__global__ void bn_running_kernel(const float* __restrict__ mean, const float* __restrict__ invstd, int W, int C, int Wn,
-                                  float eps, float momentum, float* __restrict__ rmean, float* __restrict__ rvar) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float rm = rmean[c], rv = rvar[c];
+// (SURVEY.md finding 5; unbiased variance n/(n-1)).  Closed form of the W sequential updates:
+//   r_W = (1-mom)^W r_0 + mom * sum_w (1-mom)^(W-1-w) stat_w
+// block = 32 channels x 8 window slots, folded through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void bn_running_kernel(const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         int W, int C, int Wn, float eps, float momentum,
+                                                         float* __restrict__ rmean, float* __restrict__ rvar,
+                                                         long long* __restrict__ num_batches_tracked) {
+  __shared__ float red[2][8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), slot = threadIdx.x >> 5;
+  const float keep = 1.f - momentum;
   const float unb = (float)Wn / (float)(Wn - 1);
-  for (int w = 0; w < W; ++w) {
-    float is = invstd[(size_t)w * C + c];
-    float var = 1.0f / (is * is) - eps;
-    rm = (1.f - momentum) * rm + momentum * mean[(size_t)w * C + c];
-    rv = (1.f - momentum) * rv + momentum * var * unb;
+  float am = 0.f, av = 0.f;
+  if (c < C) {
+    for (int w = slot; w < W; w += 8) {
+      float wt = momentum * powf(keep, (float)(W - 1 - w));
+      float is = invstd[(size_t)w * C + c];
+      am = fmaf(wt, mean[(size_t)w * C + c], am);
+      av = fmaf(wt, (1.0f / (is * is) - eps) * unb, av);
+    }
   }
-  rmean[c] = rm;
-  rvar[c] = rv;
+  red[0][slot][threadIdx.x & 31] = am;
+  red[1][slot][threadIdx.x & 31] = av;
+  __syncthreads();
+  if (threadIdx.x < 32 && c < C) {
+    float sm = 0.f, sv = 0.f;
+    for (int k = 0; k < 8; ++k) {
+      sm += red[0][k][threadIdx.x];
+      sv += red[1][k][threadIdx.x];
+    }
+    const float decay = powf(keep, (float)W);
+    rmean[c] = fmaf(decay, rmean[c], sm);
+    rvar[c] = fmaf(decay, rvar[c], sv);
+  }
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += W;
 }
 
 // out = act( (x-mean)*invstd*gamma + beta (+ res) )
@@ -195,17 +214,32 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ d
 }
 
 // dbeta[c] (+)= sum_w s1[w][c];  dgamma[c] (+)= sum_w s2[w][c]   (fixed order: deterministic)
-__global__ void bn_param_grad_kernel(const float* __restrict__ s1, const float* __restrict__ s2, int W, int C,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// block = 32 channels x 8 window slots.
+__global__ __launch_bounds__(256) void bn_param_grad_kernel(const float* __restrict__ s1, const float* __restrict__ s2,
+                                                            int W, int C, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int accumulate) {
+  __shared__ float red[2][8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), slot = threadIdx.x >> 5;
   float a = 0.f, b = 0.f;
-  for (int w = 0; w < W; ++w) {
-    a += s1[(size_t)w * C + c];
-    b += s2[(size_t)w * C + c];
+  if (c < C) {
+    for (int w = slot; w < W; w += 8) {
+      a += s1[(size_t)w * C + c];
+      b += s2[(size_t)w * C + c];
+    }
   }
-  dbeta[c] = accumulate ? dbeta[c] + a : a;
-  dgamma[c] = accumulate ? dgamma[c] + b : b;
+  red[0][slot][threadIdx.x & 31] = a;
+  red[1][slot][threadIdx.x & 31] = b;
+  __syncthreads();
+  if (threadIdx.x < 32 && c < C) {
+    a = 0.f;
+    b = 0.f;
+    for (int k = 0; k < 8; ++k) {
+      a += red[0][k][threadIdx.x];
+      b += red[1][k][threadIdx.x];
+    }
+    dbeta[c] = accumulate ? dbeta[c] + a : a;
+    dgamma[c] = accumulate ? dgamma[c] + b : b;
+  }
 }
 
 extern "C" {
@@ -222,11 +256,12 @@ int da_bn_stats(const float* x, int ld, int W, int Wn, int C, float eps, float* 
 }
 
 int da_bn_running_update(const float* mean, const float* invstd, int W, int C, int Wn, float eps, float momentum,
-                         float* running_mean, float* running_var, hipStream_t stream) {
+                         float* running_mean, float* running_var, long long* num_batches_tracked,
+                         hipStream_t stream) {
   DA_ENTER();
   if (!mean || !invstd || !running_mean || !running_var || Wn < 2) return DA_EINVAL;
-  hipLaunchKernelGGL(bn_running_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, mean, invstd, W, C, Wn, eps,
-                     momentum, running_mean, running_var);
+  hipLaunchKernelGGL(bn_running_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, mean, invstd, W, C, Wn, eps,
+                     momentum, running_mean, running_var, num_batches_tracked);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -262,7 +297,7 @@ int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* 
   hipLaunchKernelGGL(bn_bwd_kernel, dim3(W, C / CG), dim3(256), 0, stream, dout, ldd, x, ldx, out, ldo, dx, lddx, gout,
                      ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2);
   DA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, s1, s2, W, C, dgamma, dbeta,
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, s1, s2, W, C, dgamma, dbeta,
                      accumulate);
   DA_CHECK_LAUNCH();
   return DA_OK;

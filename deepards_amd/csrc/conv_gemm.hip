@@ -299,12 +299,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 // dW[co][ci][k] (torch layout) (+)= sum_split slab[split][k][co][ci]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int ntaps,
-                                    int N, int C, int accumulate) {
-  int total = ntaps * N * C;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += slab[(size_t)sp * total + i];
+// block = 32 consecutive slab elements x 8 split slots, folded through LDS in a fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                           int splits, int ntaps, int N, int C, int accumulate) {
+  __shared__ float red[8][32];
+  const int total = ntaps * N * C;
+  const int i = blockIdx.x * 32 + (threadIdx.x & 31), slot = threadIdx.x >> 5;
+  float s = 0.f;
+  if (i < total)
+    for (int sp = slot; sp < splits; sp += 8) s += slab[(size_t)sp * total + i];
+  red[slot][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (threadIdx.x < 32 && i < total) {
+    s = 0.f;
+    for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
     int t = i / (N * C);
     int rem = i - t * N * C;  // co*C + ci
     size_t o = (size_t)rem * ntaps + t;
@@ -399,10 +407,8 @@ int da_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, 
   else rc = DA_EINVAL;
   if (rc) return rc;
   int total = ntaps * N * C;
-  int blocks = (total + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, dw, sp, ntaps, N, C,
-                     accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, workspace, dw, sp, ntaps, N,
+                     C, accumulate);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

@@ -69,13 +69,20 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   }
 }
 
-__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int n, float* __restrict__ dw,
-                                         int accumulate) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int n,
+                                                                float* __restrict__ dw, int accumulate) {
+  __shared__ float red[8][32];
+  const int i = blockIdx.x * 32 + (threadIdx.x & 31), slot = threadIdx.x >> 5;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * n + i];
-  dw[i] = accumulate ? dw[i] + s : s;
+  if (i < n)
+    for (int b = slot; b < nblk; b += 8) s += partial[(size_t)b * n + i];
+  red[slot][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (threadIdx.x < 32 && i < n) {
+    s = 0.f;
+    for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+    dw[i] = accumulate ? dw[i] + s : s;
+  }
 }
 
 // out[row][j][c] = pool_{l in {2j-1,2j,2j+1}} relu(bn(y[row][l][c]));  pool_mode 0 = max (-inf pad),
@@ -262,7 +269,7 @@ int da_stem_conv_wgrad(const float* dy, int lddy, const float* x, float* dw, flo
                      C0);
   DA_CHECK_LAUNCH();
   int n = C0 * 7;
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, workspace, nblk, n, dw,
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, stream, workspace, nblk, n, dw,
                      accumulate);
   DA_CHECK_LAUNCH();
   return DA_OK;

@@ -6,6 +6,8 @@ WHOLE batch of windows at once -- the reference's Python loop over windows
 Every unit is a single autograd node with explicit gradient accumulation inside, so the autograd
 graph of a model is a plain chain and no PyTorch arithmetic kernel runs on the hot path.
 """
+import contextlib
+
 import torch
 from torch.autograd import Function
 
@@ -26,13 +28,50 @@ class BNState(object):
         self.eps = bn.eps
 
 
+# ---- per-step packed-weight cache -------------------------------------------------------------------
+# The GEMMs read weights as Wf[k][co][ci] (forward) / Wd[k][ci][co] (data gradient).  Inside
+# ``weight_pack_cache()`` (one training step: the weights do not change between its forward and
+# backward) each conv weight is repacked ONCE, by one launch that writes both layouts.
+_PACK = {'on': False, 'cache': {}}
+
+
+@contextlib.contextmanager
+def weight_pack_cache():
+    _PACK['on'], _PACK['cache'] = True, {}
+    try:
+        yield
+    finally:
+        _PACK['on'], _PACK['cache'] = False, {}
+
+
+def _wf(w):
+    if _PACK['on']:
+        e = _PACK['cache'].get(w.data_ptr())
+        if e is None:
+            e = _PACK['cache'][w.data_ptr()] = H.repack_weight(w, True, True)
+        return e[0]
+    return H.repack_weight(w, True, False)[0]
+
+
+def _wd(w):
+    e = _PACK['cache'].get(w.data_ptr()) if _PACK['on'] else None
+    return e[1] if e is not None else H.repack_weight(w, False, True)[1]
+
+
+def _tgt(*params):
+    """Gradient destinations a trainer attached to the Parameters (``p._da_grad``: a view into its flat
+    gradient bucket).  With a destination the backward kernels accumulate straight into it and autograd
+    gets None (no AccumulateGrad add kernel); without, gradients are returned the usual way."""
+    return tuple(None if p is None else getattr(p, '_da_grad', None) for p in params)
+
+
 def _stats(x, R, st):
     """Per-window batch statistics + the reference's sequential running-stat update
     (one momentum step per window: SURVEY.md finding 5)."""
     mean, invstd = H.bn_stats(x, R, st.eps)
     if st.running_mean is not None:
-        H.bn_running_update(mean, invstd, R * x.shape[1], st.running_mean, st.running_var, st.momentum, st.eps)
-        st.num_batches_tracked.add_(mean.shape[0])
+        H.bn_running_update(mean, invstd, R * x.shape[1], st.running_mean, st.running_var, st.momentum, st.eps,
+                            st.num_batches_tracked)
     return mean, invstd
 
 
@@ -47,15 +86,31 @@ class StemFunction(Function):
         out = H.bn_relu_pool_fwd(y0, R, mean, invstd, gamma, beta, pool_mode)
         ctx.save_for_backward(x2d, y0, mean, invstd, gamma, beta)
         ctx.R, ctx.pool_mode = R, pool_mode
+        ctx.gt = _tgt(w, gamma, beta)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x2d, y0, mean, invstd, gamma, beta = ctx.saved_tensors
+        tw, tg, tb = ctx.gt
         dz = H.pool_bwd(dout.contiguous(), y0, ctx.R, mean, invstd, gamma, beta, ctx.pool_mode)
-        dy0, dgamma, dbeta, _ = H.bn_bwd(dz, y0, ctx.R, mean, invstd, gamma, beta, 1, dx=dz)
-        dw = H.stem_conv_wgrad(dy0, x2d)
-        return None, dw, dgamma, dbeta, None, None, None
+        dy0, dgamma, dbeta = _bn_bwd(dz, y0, ctx.R, mean, invstd, gamma, beta, 1, tg, tb, dx=dz)
+        dw = H.stem_conv_wgrad(dy0, x2d, out=tw, accumulate=tw is not None)
+        return None, None if tw is not None else dw, dgamma, dbeta, None, None, None
+
+
+def _bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, tg, tb, out=None, dx=None, want_g=False):
+    """bn_bwd with optional direct gradient destinations; returns (dx, dgamma|None, dbeta|None[, g])."""
+    direct = tg is not None and tb is not None
+    dx, dg, db, g = H.bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, out=out, want_g=want_g, dx=dx,
+                             dgamma=tg if direct else None, dbeta=tb if direct else None, accumulate=direct)
+    res = (dx, None if direct else dg, None if direct else db)
+    return res + (g,) if want_g else res
+
+
+def _wgrad(dy, x, k, stride, pad, tw):
+    dw = H.conv_wgrad(dy, x, k, stride, pad, out=tw, accumulate=tw is not None)
+    return None if tw is not None else dw
 
 
 class BasicBlockFunction(Function):
@@ -64,16 +119,13 @@ class BasicBlockFunction(Function):
 
     @staticmethod
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, R, st1, st2, std):
-        wf1, _ = H.repack_weight(w1)
-        y1 = H.conv_fwd(x, wf1, stride, 1)
+        y1 = H.conv_fwd(x, _wf(w1), stride, 1)
         m1, i1 = _stats(y1, R, st1)
         h1 = H.bn_apply(y1, R, m1, i1, g1, b1, relu=True)
-        wf2, _ = H.repack_weight(w2)
-        y2 = H.conv_fwd(h1, wf2, 1, 1)
+        y2 = H.conv_fwd(h1, _wf(w2), 1, 1)
         m2, i2 = _stats(y2, R, st2)
         if wd is not None:
-            wfd, _ = H.repack_weight(wd)
-            yd = H.conv_fwd(x, wfd, stride, 0)
+            yd = H.conv_fwd(x, _wf(wd), stride, 0)
             md, idd = _stats(yd, R, std)
             res = H.bn_apply(yd, R, md, idd, gd, bd, relu=False)
         else:
@@ -82,6 +134,7 @@ class BasicBlockFunction(Function):
         out = H.bn_apply(y2, R, m2, i2, g2, b2, relu=True, res=res)
         ctx.has_ds = wd is not None
         ctx.stride, ctx.R = stride, R
+        ctx.gt = _tgt(w1, g1, b1, w2, g2, b2, wd, gd, bd)
         saved = [x, w1, g1, b1, w2, g2, b2, y1, m1, i1, h1, y2, m2, i2, out]
         if ctx.has_ds:
             saved += [wd, gd, bd, yd, md, idd]
@@ -92,27 +145,25 @@ class BasicBlockFunction(Function):
     def backward(ctx, dout):
         s = ctx.saved_tensors
         x, w1, g1, b1, w2, g2, b2, y1, m1, i1, h1, y2, m2, i2, out = s[:15]
+        tw1, tg1, tb1, tw2, tg2, tb2, twd, tgd, tbd = ctx.gt
         R, stride = ctx.R, ctx.stride
         lin = x.shape[1]
         dout = dout.contiguous()
         # relu + residual add + bn2
-        dy2, dg2, db2, g = H.bn_bwd(dout, y2, R, m2, i2, g2, b2, 2, out=out, want_g=True)
-        dw2 = H.conv_wgrad(dy2, h1, 3, 1, 1)
-        _, wdd2 = H.repack_weight(w2, need_fwd=False, need_dgrad=True)
-        dh1 = H.conv_dgrad(dy2, wdd2, 1, 1, h1.shape[1])
-        dy1, dg1, db1, _ = H.bn_bwd(dh1, y1, R, m1, i1, g1, b1, 1, dx=dh1)
-        dw1 = H.conv_wgrad(dy1, x, 3, stride, 1)
-        _, wdd1 = H.repack_weight(w1, need_fwd=False, need_dgrad=True)
+        dy2, dg2, db2, g = _bn_bwd(dout, y2, R, m2, i2, g2, b2, 2, tg2, tb2, out=out, want_g=True)
+        dw2 = _wgrad(dy2, h1, 3, 1, 1, tw2)
+        dh1 = H.conv_dgrad(dy2, _wd(w2), 1, 1, h1.shape[1])
+        dy1, dg1, db1 = _bn_bwd(dh1, y1, R, m1, i1, g1, b1, 1, tg1, tb1, dx=dh1)
+        dw1 = _wgrad(dy1, x, 3, stride, 1, tw1)
         if ctx.has_ds:
             wd, gd, bd, yd, md, idd = s[15:]
-            dyd, dgd, dbd, _ = H.bn_bwd(g, yd, R, md, idd, gd, bd, 0, dx=g)
-            dwd = H.conv_wgrad(dyd, x, 1, stride, 0)
-            dx = H.conv_dgrad(dy1, wdd1, stride, 1, lin)
-            _, wddd = H.repack_weight(wd, need_fwd=False, need_dgrad=True)
-            H.conv_dgrad(dyd, wddd, stride, 0, lin, out=dx, accumulate=True)
+            dyd, dgd, dbd = _bn_bwd(g, yd, R, md, idd, gd, bd, 0, tgd, tbd, dx=g)
+            dwd = _wgrad(dyd, x, 1, stride, 0, twd)
+            dx = H.conv_dgrad(dy1, _wd(w1), stride, 1, lin)
+            H.conv_dgrad(dyd, _wd(wd), stride, 0, lin, out=dx, accumulate=True)
         else:
             dwd = dgd = dbd = None
-            dx = H.conv_dgrad(dy1, wdd1, stride, 1, lin, out=g, accumulate=True)   # identity grad + conv path
+            dx = H.conv_dgrad(dy1, _wd(w1), stride, 1, lin, out=g, accumulate=True)   # identity grad + conv path
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None
 
 
@@ -124,36 +175,34 @@ class DenseLayerFunction(Function):
     def forward(ctx, x, g1, b1, w1, g2, b2, w2, R, st1, st2, drop_p, seed, salt):
         m1, i1 = _stats(x, R, st1)
         h = H.bn_apply(x, R, m1, i1, g1, b1, relu=True)
-        wf1, _ = H.repack_weight(w1)
-        y1 = H.conv_fwd(h, wf1, 1, 0)
+        y1 = H.conv_fwd(h, _wf(w1), 1, 0)
         m2, i2 = _stats(y1, R, st2)
         h2 = H.bn_apply(y1, R, m2, i2, g2, b2, relu=True)
-        wf2, _ = H.repack_weight(w2)
-        new = H.conv_fwd(h2, wf2, 1, 1)
+        new = H.conv_fwd(h2, _wf(w2), 1, 1)
         if drop_p > 0:
             new = H.dropout(new, seed, salt, drop_p)
         out = H.concat2(x, new)
         ctx.R, ctx.drop_p, ctx.salt = R, drop_p, salt
+        ctx.gt = _tgt(g1, b1, w1, g2, b2, w2)
         ctx.save_for_backward(x, g1, b1, w1, g2, b2, w2, m1, i1, h, y1, m2, i2, h2, seed)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, g1, b1, w1, g2, b2, w2, m1, i1, h, y1, m2, i2, h2, seed = ctx.saved_tensors
+        tg1, tb1, tw1, tg2, tb2, tw2 = ctx.gt
         R = ctx.R
         cin = x.shape[2]
         dout = dout.contiguous()
         dnew = H.slice_channels(dout, cin, w2.shape[0])
         if ctx.drop_p > 0:
             dnew = H.dropout(dnew, seed, ctx.salt, ctx.drop_p)
-        dw2 = H.conv_wgrad(dnew, h2, 3, 1, 1)
-        _, wdd2 = H.repack_weight(w2, need_fwd=False, need_dgrad=True)
-        dh2 = H.conv_dgrad(dnew, wdd2, 1, 1, h2.shape[1])
-        dy1, dg2, db2, _ = H.bn_bwd(dh2, y1, R, m2, i2, g2, b2, 1, dx=dh2)
-        dw1 = H.conv_wgrad(dy1, h, 1, 1, 0)
-        _, wdd1 = H.repack_weight(w1, need_fwd=False, need_dgrad=True)
-        dh = H.conv_dgrad(dy1, wdd1, 1, 0, h.shape[1])
-        dx, dg1, db1, _ = H.bn_bwd(dh, x, R, m1, i1, g1, b1, 1, dx=dh)
+        dw2 = _wgrad(dnew, h2, 3, 1, 1, tw2)
+        dh2 = H.conv_dgrad(dnew, _wd(w2), 1, 1, h2.shape[1])
+        dy1, dg2, db2 = _bn_bwd(dh2, y1, R, m2, i2, g2, b2, 1, tg2, tb2, dx=dh2)
+        dw1 = _wgrad(dy1, h, 1, 1, 0, tw1)
+        dh = H.conv_dgrad(dy1, _wd(w1), 1, 0, h.shape[1])
+        dx, dg1, db1 = _bn_bwd(dh, x, R, m1, i1, g1, b1, 1, tg1, tb1, dx=dh)
         H.slice_channels(dout, 0, cin, out=dx, accumulate=True)                     # pass-through half of the cat
         return dx, dg1, db1, dw1, dg2, db2, dw2, None, None, None, None, None, None
 
@@ -165,21 +214,21 @@ class TransitionFunction(Function):
     def forward(ctx, x, g, b, w, R, st):
         m, i = _stats(x, R, st)
         h = H.bn_apply(x, R, m, i, g, b, relu=True)
-        wf, _ = H.repack_weight(w)
-        y = H.conv_fwd(h, wf, 1, 0)
+        y = H.conv_fwd(h, _wf(w), 1, 0)
         out = H.avgpool_fwd(y, 2)
         ctx.R = R
+        ctx.gt = _tgt(g, b, w)
         ctx.save_for_backward(x, g, b, w, m, i, h)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, g, b, w, m, i, h = ctx.saved_tensors
+        tg, tb, tw = ctx.gt
         dy = H.avgpool_bwd(dout.contiguous(), x.shape[1], 2)
-        dw = H.conv_wgrad(dy, h, 1, 1, 0)
-        _, wdd = H.repack_weight(w, need_fwd=False, need_dgrad=True)
-        dh = H.conv_dgrad(dy, wdd, 1, 0, h.shape[1])
-        dx, dg, db, _ = H.bn_bwd(dh, x, ctx.R, m, i, g, b, 1, dx=dh)
+        dw = _wgrad(dy, h, 1, 1, 0, tw)
+        dh = H.conv_dgrad(dy, _wd(w), 1, 0, h.shape[1])
+        dx, dg, db = _bn_bwd(dh, x, ctx.R, m, i, g, b, 1, tg, tb, dx=dh)
         return dx, dg, db, dw, None, None
 
 
@@ -191,13 +240,15 @@ class NormReluFunction(Function):
         m, i = _stats(x, R, st)
         out = H.bn_apply(x, R, m, i, g, b, relu=True)
         ctx.R = R
+        ctx.gt = _tgt(g, b)
         ctx.save_for_backward(x, g, b, m, i)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, g, b, m, i = ctx.saved_tensors
-        dx, dg, db, _ = H.bn_bwd(dout.contiguous(), x, ctx.R, m, i, g, b, 1)
+        tg, tb = ctx.gt
+        dx, dg, db = _bn_bwd(dout.contiguous(), x, ctx.R, m, i, g, b, 1, tg, tb)
         return dx, dg, db, None, None
 
 
@@ -222,13 +273,17 @@ class Linear2Function(Function):
     @staticmethod
     def forward(ctx, flat, w, bias):
         ctx.save_for_backward(flat, w)
+        ctx.gt = _tgt(w, bias)
         return H.linear2_fwd(flat, w, bias)
 
     @staticmethod
     def backward(ctx, dlogits):
         flat, w = ctx.saved_tensors
-        dflat, dw, dbias = H.linear2_bwd(dlogits.contiguous(), flat, w, need_input=ctx.needs_input_grad[0])
-        return dflat, dw, dbias
+        tw, tb = ctx.gt
+        direct = tw is not None and tb is not None
+        dflat, dw, dbias = H.linear2_bwd(dlogits.contiguous(), flat, w, need_input=ctx.needs_input_grad[0],
+                                         dw=tw if direct else None, dbias=tb if direct else None, accumulate=direct)
+        return dflat, None if direct else dw, None if direct else dbias
 
 
 class BCEWithLogitsFunction(Function):

@@ -180,10 +180,12 @@ def bn_stats(x, R, eps=1e-5):
     return mean, invstd
 
 
-def bn_running_update(mean, invstd, wn, running_mean, running_var, momentum=0.1, eps=1e-5):
+def bn_running_update(mean, invstd, wn, running_mean, running_var, momentum=0.1, eps=1e-5, num_batches_tracked=None):
     w, c = mean.shape
+    if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
+        raise ValueError('num_batches_tracked must be int64')
     _chk(_lib.lib().da_bn_running_update(_p(mean), _p(invstd), w, c, wn, eps, momentum, _p(running_mean),
-                                         _p(running_var), _stream()), 'da_bn_running_update')
+                                         _p(running_var), _p(num_batches_tracked), _stream()), 'da_bn_running_update')
 
 
 def bn_apply(x, R, mean, invstd, gamma, beta, relu=True, res=None, out=None):

@@ -20,6 +20,7 @@ MI355X-first differences (results identical, see tests):
 """
 import torch
 
+from . import functional as F_
 from . import hip_ops as H
 
 
@@ -62,6 +63,7 @@ class FlatBucket(object):
                 self.g[off:off + n].copy_(p.grad.reshape(-1))
             p.data = self.p[off:off + n].view(p.shape)
             p.grad = self.g[off:off + n].view(p.shape)
+            p._da_grad = p.grad                          # backward kernels accumulate straight into the bucket
 
     def zero_grad(self):
         self.g.zero_()
@@ -96,10 +98,10 @@ class HotPathTrainer(object):
 
     # ---- eager pieces ------------------------------------------------------------------------
     def _forward_backward(self, inputs, target):
-        model = self.model
-        logits = model(inputs, None)
-        loss, dlogits = H.bce_logits(logits.detach(), target, want_grad=True)
-        logits.backward(dlogits)
+        with F_.weight_pack_cache():                     # weights are constant within one step
+            logits = self.model(inputs, None)
+            loss, dlogits = H.bce_logits(logits.detach(), target, want_grad=True)
+            logits.backward(dlogits)
         return loss, logits.detach()
 
     def _optimizer_step(self):

@@ -64,8 +64,10 @@ int da_stem_conv_wgrad(const float* dy, int lddy, const float* x, float* dw, flo
  * torch_cnn_linear_network.py:108-113 calls breath_block(x[i]) one window at a time. */
 int da_bn_stats(const float* x, int ld, int W, int Wn, int C, float eps, float* mean, float* invstd,
                 da_stream_t stream);
+/* W sequential momentum updates in closed form; num_batches_tracked (int64, may be NULL) += W */
 int da_bn_running_update(const float* mean, const float* invstd, int W, int C, int Wn, float eps, float momentum,
-                         float* running_mean, float* running_var, da_stream_t stream);
+                         float* running_mean, float* running_var, long long* num_batches_tracked,
+                         da_stream_t stream);
 int da_bn_apply(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
                 const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
                 da_stream_t stream);
