@@ -24,6 +24,7 @@ SIGNATURES = {
     'da_conv_gemm': (_I, [_P, _P, _P] + [_I] * 12 + [_IP, _IP, _I, _P]),
     'da_conv_wgrad_workspace': (_Z, [_I] * 5),
     'da_conv_wgrad': (_I, [_P, _P, _P, _P] + [_I] * 12 + [_IP, _I, _P]),
+    'da_debug_set': (_I, [_I, _I]),
     'da_repack_conv_weight': (_I, [_P, _P, _P, _I, _I, _I, _P]),
     'da_stem_conv_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'da_stem_wgrad_workspace': (_Z, [_I, _I]),

@@ -148,6 +148,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
   }
 }
 
+// tuning knobs (benchmark use): 0 = automatic
+static int g_force_conv_tile = 0;
+static int g_wgrad_target_blocks = 0;
+
 template <int TM, int TN, int WGM, int WGN>
 static int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
   constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32;
@@ -157,18 +161,44 @@ static int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
   return DA_OK;
 }
 
+// Tile choice.  Measured on MI355X: every tile shape below runs at about the same per-block MFMA
+// efficiency, so the choice is about balance: blocks are work-conserving on a CU, the makespan is
+// max-blocks-per-CU / mean-blocks-per-CU.  Pick the largest tile whose grid keeps that ratio high.
+static double balance(long blocks) {
+  double per = (double)blocks / 256.0;
+  double mx = (double)((blocks + 255) / 256);
+  return per / mx;
+}
+
 static int conv_gemm_dispatch(const ConvGemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return DA_OK;
   if (a.C % 32 || a.N % 32 || a.ldx % 4 || a.ntaps < 1 || a.ntaps > 3) return DA_EINVAL;
   if ((uint64_t)a.M * (uint64_t)a.divLm.d >= 0xffffffffull) return DA_EINVAL;
-  // tile choice: wide N tiles when N allows; halve BM when the grid would not fill 256 CUs twice over
-  if (a.N % 128 == 0) {
-    long wg128 = (long)((a.M + 127) / 128) * (a.N / 128);
-    if (wg128 >= 1024) return launch_conv_gemm<2, 2, 2, 2>(a, s);  // 128 x 128
-    return launch_conv_gemm<1, 2, 2, 2>(a, s);                      // 64 x 128
+  // candidates: id, BM, BN, relative per-block efficiency
+  struct Cand { int id, bm, bn; double eff; };
+  static const Cand cands[] = {{1, 128, 128, 1.00}, {2, 64, 128, 0.99}, {3, 128, 64, 0.97}, {4, 64, 64, 0.93},
+                               {5, 128, 32, 0.85}, {6, 32, 128, 0.85}};
+  int best = 0;
+  double best_score = -1.0;
+  for (const Cand& c : cands) {
+    if (a.N % c.bn) continue;
+    if (g_force_conv_tile && g_force_conv_tile != c.id) continue;
+    long blocks = (long)((a.M + c.bm - 1) / c.bm) * (a.N / c.bn);
+    double score = c.eff * balance(blocks);
+    if (score > best_score) {
+      best_score = score;
+      best = c.id;
+    }
   }
-  if (a.N % 64 == 0) return launch_conv_gemm<1, 2, 4, 1>(a, s);     // 128 x 64
-  return launch_conv_gemm<1, 1, 4, 1>(a, s);                        // 128 x 32
+  switch (best) {
+    case 1: return launch_conv_gemm<2, 2, 2, 2>(a, s);
+    case 2: return launch_conv_gemm<1, 2, 2, 2>(a, s);
+    case 3: return launch_conv_gemm<1, 2, 4, 1>(a, s);
+    case 4: return launch_conv_gemm<1, 1, 2, 2>(a, s);
+    case 5: return launch_conv_gemm<1, 1, 4, 1>(a, s);
+    case 6: return launch_conv_gemm<1, 1, 1, 4>(a, s);
+    default: return DA_EINVAL;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -329,25 +359,62 @@ static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t s) {
   return DA_OK;
 }
 
-// tile edge for one wgrad output dimension
-static inline int wg_tile(int n) { return n % 128 == 0 ? 128 : (n % 64 == 0 ? 64 : 32); }
+// wgrad plan: output tile (tn x tc) and number of position splits.  Cost model (MI355X measurements):
+// MFMA time at ~120 TF/s scaled by CU balance and a per-tile efficiency, plus the slab round trip
+// (written once, read once by the reduce) at ~4 TB/s.  Small outputs (layer1/2) prefer small tiles and
+// few splits; large outputs (layer3/4) prefer 128x128 tiles.
+struct WgradPlan {
+  int tn, tc, splits, kchunk;
+};
 
-static void wgrad_plan(int M, int N, int C, int ntaps, int* splits, int* kchunk) {
-  int tiles = (N / wg_tile(N)) * (C / wg_tile(C)) * ntaps;
-  int want = (1024 + tiles - 1) / tiles;            // aim at ~1024 workgroups
-  int maxs = (M + 255) / 256;                        // at least 256 positions per split
-  int sp = want < 1 ? 1 : (want > maxs ? maxs : want);
-  if (sp < 1) sp = 1;
-  int kc = ((M + sp - 1) / sp + 31) / 32 * 32;
-  sp = (M + kc - 1) / kc;
-  *splits = sp;
-  *kchunk = kc;
+static WgradPlan wgrad_plan(int M, int N, int C, int ntaps) {
+  static const int opts[] = {128, 64, 32};
+  WgradPlan best = {0, 0, 1, ((M + 31) / 32) * 32};
+  double best_t = 1e30;
+  static const int targets[] = {512, 768, 1024};
+  for (int target0 : targets)
+  for (int tn : opts) {
+    if (N % tn) continue;
+    for (int tc : opts) {
+      if (C % tc) continue;
+      int target = g_wgrad_target_blocks > 0 ? g_wgrad_target_blocks : target0;
+      // kernels exist for these pairs only
+      bool ok = (tn == 128 && tc == 128) || (tn == 128 && tc == 64) || (tn == 64 && tc == 128) ||
+                (tn == 64 && tc == 64) || (tn == 128 && tc == 32) || (tn == 32 && tc == 128);
+      if (!ok) continue;
+      int tiles = (N / tn) * (C / tc) * ntaps;
+      int sp = target / tiles;
+      int maxs = (M + 127) / 128;
+      if (sp > maxs) sp = maxs;
+      if (sp < 1) sp = 1;
+      int kc = ((M + sp - 1) / sp + 31) / 32 * 32;
+      sp = (M + kc - 1) / kc;
+      double eff = (tn * tc >= 128 * 128) ? 1.0 : (tn * tc >= 64 * 128 ? 0.95 : (tn * tc >= 64 * 64 ? 0.88 : 0.8));
+      double flops = 2.0 * M * N * C * ntaps;
+      double t = flops / (120e12 * eff * balance((long)tiles * sp)) +
+                 2.0 * sp * (double)ntaps * N * C * 4.0 / 4e12 + 3e-6;
+      if (t < best_t) {
+        best_t = t;
+        best = {tn, tc, sp, kc};
+      }
+    }
+  }
+  return best;
 }
 
 // =============================================================================================
 // C ABI
 // =============================================================================================
 extern "C" {
+
+// Benchmark-only tuning knobs.  key 0: force the conv GEMM tile (0 auto, 1 128x128, 2 64x128, 3 128x64,
+// 4 64x64, 5 128x32, 6 32x128).  key 1: wgrad target block count (0 = 1024).
+int da_debug_set(int key, int value) {
+  if (key == 0) g_force_conv_tile = value;
+  else if (key == 1) g_wgrad_target_blocks = value;
+  else return DA_EINVAL;
+  return DA_OK;
+}
 
 // Forward conv / generic implicit GEMM.  Every pointer is a device pointer; returns 0 on success.
 //   rows: B*NB sequences.  x: [rows][Lsrc][ldx] first C channels used.  w: packed [ntaps_w][N][C].
@@ -373,9 +440,8 @@ int da_conv_gemm(const float* x, const float* w, float* y, int rows, int Lm, int
 
 // Bytes of slab workspace da_conv_wgrad needs for this shape.
 size_t da_conv_wgrad_workspace(int rows, int Lm, int N, int C, int ntaps) {
-  int sp, kc;
-  wgrad_plan(rows * Lm, N, C, ntaps, &sp, &kc);
-  return (size_t)sp * ntaps * N * C * sizeof(float);
+  WgradPlan p = wgrad_plan(rows * Lm, N, C, ntaps);
+  return (size_t)p.splits * ntaps * N * C * sizeof(float);
 }
 
 // dW[co][ci][k] (torch layout, k = ntaps) (+)= sum over positions dY[m][co] * X[src(m,k)][ci].
@@ -394,10 +460,11 @@ int da_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, 
   a.so0 = src_off[0]; a.so1 = ntaps > 1 ? src_off[1] : 0; a.so2 = ntaps > 2 ? src_off[2] : 0;
   a.divLm = make_fastdiv((uint32_t)Lm);
   if ((uint64_t)a.M * (uint64_t)Lm >= 0xffffffffull) return DA_EINVAL;
-  int sp, kc;
-  wgrad_plan(a.M, N, C, ntaps, &sp, &kc);
-  a.kchunk = kc;
-  int tn = wg_tile(N), tc = wg_tile(C), rc;
+  WgradPlan pl = wgrad_plan(a.M, N, C, ntaps);
+  if (!pl.tn) return DA_EINVAL;
+  a.kchunk = pl.kchunk;
+  int sp = pl.splits;
+  int tn = pl.tn, tc = pl.tc, rc;
   if (tn == 128 && tc == 128) rc = launch_wgrad<2, 2, 2, 2>(a, sp, stream);
   else if (tn == 128 && tc == 64) rc = launch_wgrad<2, 1, 2, 2>(a, sp, stream);
   else if (tn == 64 && tc == 128) rc = launch_wgrad<1, 2, 2, 2>(a, sp, stream);

@@ -49,6 +49,9 @@ int da_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, 
                   int lddy, int N, int Lx, int ldx, int C, int dy_stride, int dy_off, int src_stride, int ntaps,
                   const int* src_off, int accumulate, da_stream_t stream);
 
+/* benchmark-only tuning knobs: key 0 = force conv tile id, key 1 = wgrad target blocks (0 = automatic) */
+int da_debug_set(int key, int value);
+
 /* torch [Co][Ci][K] -> Wf [K][Co][Ci] (forward) and Wd [K][Ci][Co] (data gradient). */
 int da_repack_conv_weight(const float* W, float* Wf, float* Wd, int Co, int Ci, int K, da_stream_t stream);
 
