@@ -17,6 +17,24 @@ SOURCES = ['conv_gemm.hip', 'bn.hip', 'stem_pool.hip', 'head_optim.hip']
 _P, _I, _F, _Z, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_uint
 _IP = ctypes.POINTER(ctypes.c_int)
 
+
+class BnRunningDesc(ctypes.Structure):
+    _fields_ = [('mean', _P), ('invstd', _P), ('running_mean', _P), ('running_var', _P), ('num_batches_tracked', _P),
+                ('W', _I), ('C', _I), ('Wn', _I), ('eps', _F), ('momentum', _F)]
+
+
+class BnPgradDesc(ctypes.Structure):
+    _fields_ = [('s1', _P), ('s2', _P), ('dgamma', _P), ('dbeta', _P), ('W', _I), ('C', _I)]
+
+
+class WgradReduceDesc(ctypes.Structure):
+    _fields_ = [('slab', _P), ('dw', _P), ('splits', _I), ('ntaps', _I), ('N', _I), ('C', _I)]
+
+
+class RepackDesc(ctypes.Structure):
+    _fields_ = [('W', _P), ('Wf', _P), ('Wd', _P), ('Co', _I), ('Ci', _I), ('K', _I)]
+
+
 # name -> (restype, argtypes); must list exactly the symbols the header declares (tests check it)
 SIGNATURES = {
     'da_version': (_I, []),
@@ -29,10 +47,17 @@ SIGNATURES = {
     'da_stem_conv_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'da_stem_wgrad_workspace': (_Z, [_I, _I]),
     'da_stem_conv_wgrad': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
-    'da_bn_stats': (_I, [_P, _I, _I, _I, _I, _F, _P, _P, _P]),
-    'da_bn_running_update': (_I, [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
-    'da_bn_apply': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
-    'da_bn_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P]),
+    'da_bn_chunks': (None, [_I, _I, _I, _IP, _IP]),
+    'da_bn_workspace': (_Z, [_I, _I, _I]),
+    'da_bn_stats_partial': (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    'da_bn_stats_merge': (_I, [_P, _I, _I, _I, _F, _P, _P, _P]),
+    'da_bn_running_multi': (_I, [ctypes.POINTER(BnRunningDesc), _I, _P]),
+    'da_bn_apply': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _F, _P]),
+    'da_bn_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
+    'da_bn_param_grad_multi': (_I, [ctypes.POINTER(BnPgradDesc), _I, _I, _P]),
+    'da_conv_wgrad_splits': (_I, [_I] * 5),
+    'da_wgrad_reduce_multi': (_I, [ctypes.POINTER(WgradReduceDesc), _I, _I, _P]),
+    'da_repack_multi': (_I, [ctypes.POINTER(RepackDesc), _I, _P]),
     'da_bn_relu_pool_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     'da_pool_bwd': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     'da_avgpool_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),

@@ -30,24 +30,29 @@ __device__ __forceinline__ void block_fold(float (&v)[4], float* red, int slot, 
   for (int e = 0; e < 4; ++e) out[e] = red[SLOTS * CG + q * 4 + e];
 }
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int ld, int Wn, int C, float eps,
-                                                       float* __restrict__ mean, float* __restrict__ invstd) {
+// Statistics in two fully parallel stages (a window slab is up to 573 KB: one block per (window,
+// 32-channel group) would leave most CUs idle on the wide early layers):
+//   stage 1  grid (W, C/32, P): chunk-local mean and centred M2 over <= `chunk` positions
+//   stage 2  bn_stats_merge: Chan's pairwise update over the P chunks in order -> mean, invstd
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, int ld, int Wn, int C,
+                                                               int chunk, float* __restrict__ part) {
   __shared__ float red[(SLOTS + 1) * CG];
-  const int w = blockIdx.x, cg = blockIdx.y;
+  const int w = blockIdx.x, cg = blockIdx.y, pc = blockIdx.z, P = gridDim.z;
   const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  const int p_beg = pc * chunk, p_end = min(Wn, p_beg + chunk);
   const float* base = x + (size_t)w * Wn * ld + cg * CG + q * 4;
   float s[4] = {0.f, 0.f, 0.f, 0.f}, m[4];
-  for (int p = slot; p < Wn; p += SLOTS) {
+  for (int p = p_beg + slot; p < p_end; p += SLOTS) {
     f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * ld);
 #pragma unroll
     for (int e = 0; e < 4; ++e) s[e] += v[e];
   }
   block_fold(s, red, slot, q, m);
-  const float inv_n = 1.0f / (float)Wn;
+  const float inv_n = 1.0f / (float)(p_end - p_beg);
 #pragma unroll
   for (int e = 0; e < 4; ++e) m[e] *= inv_n;
-  float s2[4] = {0.f, 0.f, 0.f, 0.f}, var[4];
-  for (int p = slot; p < Wn; p += SLOTS) {
+  float s2[4] = {0.f, 0.f, 0.f, 0.f}, m2[4];
+  for (int p = p_beg + slot; p < p_end; p += SLOTS) {
     f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * ld);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -55,36 +60,78 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
       s2[e] += d * d;
     }
   }
-  block_fold(s2, red, slot, q, var);
+  block_fold(s2, red, slot, q, m2);
   if (slot == 0) {
+    float* o = part + (((size_t)w * P + pc) * 2) * C + cg * CG + q * 4;   // [w][p][{mean,M2}][C]
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      int c = cg * CG + q * 4 + e;
-      mean[(size_t)w * C + c] = m[e];
-      invstd[(size_t)w * C + c] = 1.0f / sqrtf(var[e] * inv_n + eps);
+      o[e] = m[e];
+      o[C + e] = m2[e];
     }
   }
 }
 
-// running stats: r <- (1-mom) r + mom * stat_w, one update per window, in window order
-// (SURVEY.md finding 5; unbiased variance n/(n-1)).  Closed form of the W sequential updates:
-//   r_W = (1-mom)^W r_0 + mom * sum_w (1-mom)^(W-1-w) stat_w
+// merge the P chunk records of one (window, channel) in chunk order (Chan's update)
+__device__ __forceinline__ void bn_merge_chunks(const float* __restrict__ pp, int P, int C, int Wn, int chunk,
+                                                float eps, float& mean, float& invstd) {
+  float n = (float)min(chunk, Wn), mu = pp[0], m2 = pp[C];
+  for (int p = 1; p < P; ++p) {
+    float nb = (float)(min(Wn, (p + 1) * chunk) - p * chunk);
+    float mb = pp[(size_t)p * 2 * C], m2b = pp[(size_t)p * 2 * C + C];
+    float d = mb - mu, nt = n + nb;
+    mu += d * (nb / nt);
+    m2 += m2b + d * d * (n * nb / nt);
+    n = nt;
+  }
+  mean = mu;
+  invstd = 1.0f / sqrtf(m2 / (float)Wn + eps);
+}
+
+// stage 2 (standalone form): one thread per (window, channel)
+__global__ __launch_bounds__(256) void bn_stats_merge_kernel(const float* __restrict__ part, int W, int P, int C, int Wn,
+                                                             int chunk, float eps, float* __restrict__ mean,
+                                                             float* __restrict__ invstd) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= W * C) return;
+  int w = idx / C, c = idx - w * C;
+  float mu, is;
+  bn_merge_chunks(part + (size_t)w * P * 2 * C + c, P, C, Wn, chunk, eps, mu, is);
+  mean[idx] = mu;
+  invstd[idx] = is;
+}
+
+// Running statistics of up to 32 BatchNorms in one launch (blockIdx.y = which BN).  The reference
+// updates them once per window, in window order (SURVEY.md finding 5); closed form of the W updates:
+//   r_W = (1-mom)^W r_0 + mom * sum_w (1-mom)^(W-1-w) stat_w      (unbiased variance n/(n-1))
 // block = 32 channels x 8 window slots, folded through LDS in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void bn_running_kernel(const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                         int W, int C, int Wn, float eps, float momentum,
-                                                         float* __restrict__ rmean, float* __restrict__ rvar,
-                                                         long long* __restrict__ num_batches_tracked) {
+struct BnRunningDesc {
+  const float* mean;
+  const float* invstd;
+  float* rmean;
+  float* rvar;
+  long long* nbt;
+  int W, C, Wn;
+  float eps, momentum;
+};
+struct BnRunningTable {
+  BnRunningDesc d[32];
+};
+
+__global__ __launch_bounds__(256) void bn_running_multi_kernel(BnRunningTable t) {
+  const BnRunningDesc& d = t.d[blockIdx.y];
+  if ((int)blockIdx.x * 32 >= d.C) return;
   __shared__ float red[2][8][32];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), slot = threadIdx.x >> 5;
-  const float keep = 1.f - momentum;
-  const float unb = (float)Wn / (float)(Wn - 1);
+  const int W = d.W, C = d.C;
+  const float keep = 1.f - d.momentum;
+  const float unb = d.Wn > 1 ? (float)d.Wn / (float)(d.Wn - 1) : 1.f;
   float am = 0.f, av = 0.f;
   if (c < C) {
     for (int w = slot; w < W; w += 8) {
-      float wt = momentum * powf(keep, (float)(W - 1 - w));
-      float is = invstd[(size_t)w * C + c];
-      am = fmaf(wt, mean[(size_t)w * C + c], am);
-      av = fmaf(wt, (1.0f / (is * is) - eps) * unb, av);
+      float wt = d.momentum * powf(keep, (float)(W - 1 - w));
+      float is = d.invstd[(size_t)w * C + c];
+      am = fmaf(wt, d.mean[(size_t)w * C + c], am);
+      av = fmaf(wt, (1.0f / (is * is) - d.eps) * unb, av);
     }
   }
   red[0][slot][threadIdx.x & 31] = am;
@@ -97,10 +144,10 @@ __global__ __launch_bounds__(256) void bn_running_kernel(const float* __restrict
       sv += red[1][k][threadIdx.x];
     }
     const float decay = powf(keep, (float)W);
-    rmean[c] = fmaf(decay, rmean[c], sm);
-    rvar[c] = fmaf(decay, rvar[c], sv);
+    d.rmean[c] = fmaf(decay, d.rmean[c], sm);
+    d.rvar[c] = fmaf(decay, d.rvar[c], sv);
   }
-  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += W;
+  if (d.nbt && blockIdx.x == 0 && threadIdx.x == 0) d.nbt[0] += W;
 }
 
 // out = act( (x-mean)*invstd*gamma + beta (+ res) )
@@ -108,12 +155,29 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        int ldr, float* __restrict__ out, int ldo, int Wn, int C,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       int relu, int chunk) {
+                                                       int relu, int chunk, const float* __restrict__ part, int P,
+                                                       int schunk, float eps, float* __restrict__ mean_out,
+                                                       float* __restrict__ invstd_out) {
   const int w = blockIdx.x, cg = blockIdx.y;
   const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
   const int c0 = cg * CG + q * 4;
-  f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
-  f32x4 is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * C + c0);
+  f32x4 mu, is;
+  if (part) {   // statistics arrive as chunk records: merge them here, publish mean/invstd once
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float m_, i_;
+      bn_merge_chunks(part + (size_t)w * P * 2 * C + c0 + e, P, C, Wn, schunk, eps, m_, i_);
+      mu[e] = m_;
+      is[e] = i_;
+    }
+    if (blockIdx.z == 0 && slot == 0) {
+      *reinterpret_cast<f32x4*>(mean_out + (size_t)w * C + c0) = mu;
+      *reinterpret_cast<f32x4*>(invstd_out + (size_t)w * C + c0) = is;
+    }
+  } else {
+    mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
+    is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * C + c0);
+  }
   f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
   f32x4 be = *reinterpret_cast<const f32x4*>(beta + c0);
   const int p_beg = blockIdx.z * chunk;
@@ -137,43 +201,52 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
 }
 
-// Backward of out = act(bn(x) (+res)).
+// Backward of out = act(bn(x) (+res)), in two fully parallel stages over (window, 32 channels, chunk):
 //   mask_mode 0: no ReLU            g = dout
 //             1: ReLU, no residual  g = dout * [bn(x) > 0]      (mask recomputed, `out` not read)
 //             2: ReLU with residual g = dout * [out > 0]
-//   dx = gamma*invstd*(g - mean_w(g) - xhat*mean_w(g*xhat));  gout (optional) = g  (residual branch)
-//   ds1[w][c] = sum g, ds2[w][c] = sum g*xhat  (folded over windows into dbeta/dgamma afterwards)
-__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dout, int ldd, const float* __restrict__ x,
-                                                     int ldx, const float* __restrict__ outp, int ldo,
-                                                     float* __restrict__ dx, int lddx, float* __restrict__ gout, int ldg,
-                                                     int Wn, int C, const float* __restrict__ mean,
-                                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, int mask_mode,
-                                                     float* __restrict__ ds1, float* __restrict__ ds2) {
+//   reduce: part[w][p][{s1,s2}][C] = sum over the chunk of g, g*xhat
+//   apply : dx = gamma*invstd*(g - mean_w(g) - xhat*mean_w(g*xhat));  gout (optional) = g;
+//           chunk 0 also stores the window totals ds1/ds2 for dbeta/dgamma.
+__device__ __forceinline__ f32x4 bn_masked_g(f32x4 g, const f32x4& xh, const f32x4& ga, const f32x4& be, int mask_mode,
+                                             const float* __restrict__ outp, size_t off) {
+  if (mask_mode == 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = (xh[e] * ga[e] + be[e] > 0.f) ? g[e] : 0.f;
+  } else if (mask_mode == 2) {
+    f32x4 o = *reinterpret_cast<const f32x4*>(outp + off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = (o[e] > 0.f) ? g[e] : 0.f;
+  }
+  return g;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dout, int ldd,
+                                                            const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ outp, int ldo, int Wn, int C,
+                                                            int chunk, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int mask_mode,
+                                                            float* __restrict__ part) {
   __shared__ float red[(SLOTS + 1) * CG];
-  const int w = blockIdx.x, cg = blockIdx.y;
+  const int w = blockIdx.x, cg = blockIdx.y, pc = blockIdx.z, P = gridDim.z;
   const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
   const int c0 = cg * CG + q * 4;
   f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
   f32x4 is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * C + c0);
   f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
   f32x4 be = *reinterpret_cast<const f32x4*>(beta + c0);
+  const int p_beg = pc * chunk, p_end = min(Wn, p_beg + chunk);
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int p = slot; p < Wn; p += SLOTS) {
+  for (int p = p_beg + slot; p < p_end; p += SLOTS) {
     size_t pos = (size_t)w * Wn + p;
     f32x4 g = *reinterpret_cast<const f32x4*>(dout + pos * ldd + c0);
     f32x4 v = *reinterpret_cast<const f32x4*>(x + pos * ldx + c0);
     f32x4 xh;
 #pragma unroll
     for (int e = 0; e < 4; ++e) xh[e] = (v[e] - mu[e]) * is[e];
-    if (mask_mode == 1) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = (xh[e] * ga[e] + be[e] > 0.f) ? g[e] : 0.f;
-    } else if (mask_mode == 2) {
-      f32x4 o = *reinterpret_cast<const f32x4*>(outp + pos * ldo + c0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = (o[e] > 0.f) ? g[e] : 0.f;
-    }
+    g = bn_masked_g(g, xh, ga, be, mask_mode, outp, pos * ldo + c0);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       s1[e] += g[e];
@@ -184,28 +257,58 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ d
   block_fold(s1, red, slot, q, t1);
   block_fold(s2, red, slot, q, t2);
   if (slot == 0) {
+    float* o = part + (((size_t)w * P + pc) * 2) * C + c0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      ds1[(size_t)w * C + c0 + e] = t1[e];
-      ds2[(size_t)w * C + c0 + e] = t2[e];
+      o[e] = t1[e];
+      o[C + e] = t2[e];
     }
   }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, int ldd,
+                                                           const float* __restrict__ x, int ldx,
+                                                           const float* __restrict__ outp, int ldo,
+                                                           float* __restrict__ dx, int lddx, float* __restrict__ gout,
+                                                           int ldg, int Wn, int C, int chunk,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int mask_mode,
+                                                           const float* __restrict__ part, float* __restrict__ ds1,
+                                                           float* __restrict__ ds2) {
+  const int w = blockIdx.x, cg = blockIdx.y, pc = blockIdx.z, P = gridDim.z;
+  const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  const int c0 = cg * CG + q * 4;
+  f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
+  f32x4 is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * C + c0);
+  f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
+  f32x4 be = *reinterpret_cast<const f32x4*>(beta + c0);
+  f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < P; ++p) {                       // chunk order: deterministic totals
+    const float* o = part + (((size_t)w * P + p) * 2) * C + c0;
+    f32x4 a = *reinterpret_cast<const f32x4*>(o);
+    f32x4 b = *reinterpret_cast<const f32x4*>(o + C);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      t1[e] += a[e];
+      t2[e] += b[e];
+    }
+  }
+  if (pc == 0 && slot == 0) {
+    *reinterpret_cast<f32x4*>(ds1 + (size_t)w * C + c0) = t1;
+    *reinterpret_cast<f32x4*>(ds2 + (size_t)w * C + c0) = t2;
+  }
   const float inv_n = 1.0f / (float)Wn;
-  for (int p = slot; p < Wn; p += SLOTS) {
+  const int p_beg = pc * chunk, p_end = min(Wn, p_beg + chunk);
+  for (int p = p_beg + slot; p < p_end; p += SLOTS) {
     size_t pos = (size_t)w * Wn + p;
     f32x4 g = *reinterpret_cast<const f32x4*>(dout + pos * ldd + c0);
     f32x4 v = *reinterpret_cast<const f32x4*>(x + pos * ldx + c0);
     f32x4 xh, d;
 #pragma unroll
     for (int e = 0; e < 4; ++e) xh[e] = (v[e] - mu[e]) * is[e];
-    if (mask_mode == 1) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = (xh[e] * ga[e] + be[e] > 0.f) ? g[e] : 0.f;
-    } else if (mask_mode == 2) {
-      f32x4 o = *reinterpret_cast<const f32x4*>(outp + pos * ldo + c0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = (o[e] > 0.f) ? g[e] : 0.f;
-    }
+    g = bn_masked_g(g, xh, ga, be, mask_mode, outp, pos * ldo + c0);
 #pragma unroll
     for (int e = 0; e < 4; ++e) d[e] = ga[e] * is[e] * (g[e] - t1[e] * inv_n - xh[e] * t2[e] * inv_n);
     *reinterpret_cast<f32x4*>(dx + pos * lddx + c0) = d;
@@ -213,93 +316,202 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ d
   }
 }
 
-// dbeta[c] (+)= sum_w s1[w][c];  dgamma[c] (+)= sum_w s2[w][c]   (fixed order: deterministic)
-// block = 32 channels x 8 window slots.
-__global__ __launch_bounds__(256) void bn_param_grad_kernel(const float* __restrict__ s1, const float* __restrict__ s2,
-                                                            int W, int C, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int accumulate) {
+// dbeta[c] (+)= sum_w s1[w][c];  dgamma[c] (+)= sum_w s2[w][c] for up to 32 BatchNorms in one launch
+// (blockIdx.y = which BN); block = 32 channels x 8 window slots, fixed order (deterministic).
+struct BnPgradDesc {
+  const float* s1;
+  const float* s2;
+  float* dgamma;
+  float* dbeta;
+  int W, C;
+};
+struct BnPgradTable {
+  BnPgradDesc d[32];
+};
+
+__global__ __launch_bounds__(256) void bn_param_grad_multi_kernel(BnPgradTable t, int accumulate) {
+  const BnPgradDesc& d = t.d[blockIdx.y];
+  if ((int)blockIdx.x * 32 >= d.C) return;
   __shared__ float red[2][8][32];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), slot = threadIdx.x >> 5;
   float a = 0.f, b = 0.f;
-  if (c < C) {
-    for (int w = slot; w < W; w += 8) {
-      a += s1[(size_t)w * C + c];
-      b += s2[(size_t)w * C + c];
+  if (c < d.C) {
+    for (int w = slot; w < d.W; w += 8) {
+      a += d.s1[(size_t)w * d.C + c];
+      b += d.s2[(size_t)w * d.C + c];
     }
   }
   red[0][slot][threadIdx.x & 31] = a;
   red[1][slot][threadIdx.x & 31] = b;
   __syncthreads();
-  if (threadIdx.x < 32 && c < C) {
+  if (threadIdx.x < 32 && c < d.C) {
     a = 0.f;
     b = 0.f;
     for (int k = 0; k < 8; ++k) {
       a += red[0][k][threadIdx.x];
       b += red[1][k][threadIdx.x];
     }
-    dbeta[c] = accumulate ? dbeta[c] + a : a;
-    dgamma[c] = accumulate ? dgamma[c] + b : b;
+    d.dbeta[c] = accumulate ? d.dbeta[c] + a : a;
+    d.dgamma[c] = accumulate ? d.dgamma[c] + b : b;
   }
+}
+
+// chunking of a window's Wn positions so that (W * C/32 * P) fills the chip (~4 blocks per CU)
+static void bn_chunks(int W, int Wn, int C, int* P, int* chunk) {
+  long base = (long)W * (C / CG);
+  int p = (int)((1024 + base - 1) / base);
+  int maxp = (Wn + 127) / 128;                   // at least 128 positions (4 per slot) per chunk
+  if (p > maxp) p = maxp;
+  if (p < 1) p = 1;
+  int ch = ((Wn + p - 1) / p + 31) / 32 * 32;
+  *P = (Wn + ch - 1) / ch;
+  *chunk = ch;
 }
 
 extern "C" {
 
-// mean/invstd: [W][C].  x: [W*Wn][ld].  C % 32 == 0, ld % 4 == 0.
-int da_bn_stats(const float* x, int ld, int W, int Wn, int C, float eps, float* mean, float* invstd,
-                hipStream_t stream) {
+// Host-side descriptor of one BatchNorm for the batched small kernels (HOST arrays of these are passed).
+typedef struct {
+  const float* mean;
+  const float* invstd;
+  float* running_mean;
+  float* running_var;
+  long long* num_batches_tracked;
+  int W, C, Wn;
+  float eps, momentum;
+} da_bn_running_desc;
+
+typedef struct {
+  const float* s1;
+  const float* s2;
+  float* dgamma;
+  float* dbeta;
+  int W, C;
+} da_bn_pgrad_desc;
+
+// chunk geometry shared by da_bn_stats_partial / da_bn_apply(part) / da_bn_bwd: P chunks of `chunk` positions
+void da_bn_chunks(int W, int Wn, int C, int* P, int* chunk) { bn_chunks(W, Wn, C, P, chunk); }
+
+// floats of scratch the statistics / backward stages need: 2*W*C*P
+size_t da_bn_workspace(int W, int Wn, int C) {
+  int P, chunk;
+  bn_chunks(W, Wn, C, &P, &chunk);
+  return (size_t)2 * W * C * P * sizeof(float);
+}
+
+// stage 1 of the statistics: part[w][p][{mean,M2}][C] chunk records (da_bn_workspace() bytes).
+int da_bn_stats_partial(const float* x, int ld, int W, int Wn, int C, float* part, hipStream_t stream) {
   DA_ENTER();
-  if (!x || !mean || !invstd || C % CG || ld % 4 || Wn < 1) return DA_EINVAL;
+  if (!x || !part || C % CG || ld % 4 || Wn < 1) return DA_EINVAL;
   if (W == 0) return DA_OK;
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(W, C / CG), dim3(256), 0, stream, x, ld, Wn, C, eps, mean, invstd);
+  int P, chunk;
+  bn_chunks(W, Wn, C, &P, &chunk);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(W, C / CG, P), dim3(256), 0, stream, x, ld, Wn, C, chunk, part);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
 
-int da_bn_running_update(const float* mean, const float* invstd, int W, int C, int Wn, float eps, float momentum,
-                         float* running_mean, float* running_var, long long* num_batches_tracked,
-                         hipStream_t stream) {
+// stage 2, standalone: mean/invstd [W][C] from the chunk records.
+int da_bn_stats_merge(const float* part, int W, int Wn, int C, float eps, float* mean, float* invstd,
+                      hipStream_t stream) {
   DA_ENTER();
-  if (!mean || !invstd || !running_mean || !running_var || Wn < 2) return DA_EINVAL;
-  hipLaunchKernelGGL(bn_running_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, mean, invstd, W, C, Wn, eps,
-                     momentum, running_mean, running_var, num_batches_tracked);
+  if (!part || !mean || !invstd || C % CG) return DA_EINVAL;
+  if (W == 0) return DA_OK;
+  int P, chunk;
+  bn_chunks(W, Wn, C, &P, &chunk);
+  hipLaunchKernelGGL(bn_stats_merge_kernel, dim3((W * C + 255) / 256), dim3(256), 0, stream, part, W, P, C, Wn, chunk,
+                     eps, mean, invstd);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
 
+// running-stat updates of n BatchNorms (descs: HOST array), 32 per launch.
+int da_bn_running_multi(const da_bn_running_desc* descs, int n, hipStream_t stream) {
+  DA_ENTER();
+  if (n < 0 || (n && !descs)) return DA_EINVAL;
+  for (int base = 0; base < n; base += 32) {
+    BnRunningTable t;
+    int m = n - base < 32 ? n - base : 32, maxc = 0;
+    for (int i = 0; i < m; ++i) {
+      const da_bn_running_desc& s = descs[base + i];
+      if (!s.mean || !s.invstd || !s.running_mean || !s.running_var || s.Wn < 1) return DA_EINVAL;
+      t.d[i] = {s.mean, s.invstd, s.running_mean, s.running_var, s.num_batches_tracked, s.W, s.C, s.Wn, s.eps, s.momentum};
+      if (s.C > maxc) maxc = s.C;
+    }
+    hipLaunchKernelGGL(bn_running_multi_kernel, dim3((maxc + 31) / 32, m), dim3(256), 0, stream, t);
+    DA_CHECK_LAUNCH();
+  }
+  return DA_OK;
+}
+
+// dgamma/dbeta of n BatchNorms from their per-window totals (descs: HOST array), 32 per launch.
+int da_bn_param_grad_multi(const da_bn_pgrad_desc* descs, int n, int accumulate, hipStream_t stream) {
+  DA_ENTER();
+  if (n < 0 || (n && !descs)) return DA_EINVAL;
+  for (int base = 0; base < n; base += 32) {
+    BnPgradTable t;
+    int m = n - base < 32 ? n - base : 32, maxc = 0;
+    for (int i = 0; i < m; ++i) {
+      const da_bn_pgrad_desc& s = descs[base + i];
+      if (!s.s1 || !s.s2 || !s.dgamma || !s.dbeta) return DA_EINVAL;
+      t.d[i] = {s.s1, s.s2, s.dgamma, s.dbeta, s.W, s.C};
+      if (s.C > maxc) maxc = s.C;
+    }
+    hipLaunchKernelGGL(bn_param_grad_multi_kernel, dim3((maxc + 31) / 32, m), dim3(256), 0, stream, t, accumulate);
+    DA_CHECK_LAUNCH();
+  }
+  return DA_OK;
+}
+
+// out = act(bn(x) (+res)).  Statistics either as mean/invstd [W][C], or (part != NULL) as the chunk
+// records of da_bn_stats_partial: they are merged on the fly and mean/invstd are WRITTEN as a by-product.
 int da_bn_apply(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
-                const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
-                hipStream_t stream) {
+                float* mean, float* invstd, const float* gamma, const float* beta, int relu, const float* part,
+                float eps, hipStream_t stream) {
   DA_ENTER();
   if (!x || !out || !mean || !invstd || !gamma || !beta || C % CG || ldx % 4 || ldo % 4 || (res && ldr % 4))
     return DA_EINVAL;
   if (W == 0) return DA_OK;
   int chunk = 256;
   int nz = (Wn + chunk - 1) / chunk;
+  int P, schunk;
+  bn_chunks(W, Wn, C, &P, &schunk);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(W, C / CG, nz), dim3(256), 0, stream, x, ldx, res, ldr, out, ldo, Wn, C,
-                     mean, invstd, gamma, beta, relu, chunk);
+                     mean, invstd, gamma, beta, relu, chunk, part, P, schunk, eps, mean, invstd);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
 
-// scratch: 2*W*C floats.  dgamma/dbeta: [C] (accumulated when accumulate != 0).
+// scratch: da_bn_workspace() bytes.  ds: [2][W][C] per-window totals (sum g, sum g*xhat), always written.
+// dgamma/dbeta: [C]; when both are non-NULL they are computed here (accumulated when accumulate != 0),
+// when NULL the caller folds ds later with da_bn_param_grad_multi.
 int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
               float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd, const float* gamma,
-              const float* beta, int mask_mode, float* scratch, float* dgamma, float* dbeta, int accumulate,
+              const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma, float* dbeta, int accumulate,
               hipStream_t stream) {
   DA_ENTER();
-  if (!dout || !x || !dx || !mean || !invstd || !gamma || !beta || !scratch || !dgamma || !dbeta) return DA_EINVAL;
+  if (!dout || !x || !dx || !mean || !invstd || !gamma || !beta || !scratch || !ds) return DA_EINVAL;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return DA_EINVAL;
   if (C % CG || ldd % 4 || ldx % 4 || lddx % 4 || (gout && ldg % 4) || mask_mode < 0 || mask_mode > 2)
     return DA_EINVAL;
   if (mask_mode == 2 && (!out || ldo % 4)) return DA_EINVAL;
   if (W == 0) return DA_OK;
-  float* s1 = scratch;
-  float* s2 = scratch + (size_t)W * C;
-  hipLaunchKernelGGL(bn_bwd_kernel, dim3(W, C / CG), dim3(256), 0, stream, dout, ldd, x, ldx, out, ldo, dx, lddx, gout,
-                     ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2);
+  int P, chunk;
+  bn_chunks(W, Wn, C, &P, &chunk);
+  float* s1 = ds;
+  float* s2 = ds + (size_t)W * C;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(W, C / CG, P), dim3(256), 0, stream, dout, ldd, x, ldx, out, ldo, Wn, C,
+                     chunk, mean, invstd, gamma, beta, mask_mode, scratch);
   DA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, s1, s2, W, C, dgamma, dbeta,
-                     accumulate);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(W, C / CG, P), dim3(256), 0, stream, dout, ldd, x, ldx, out, ldo, dx,
+                     lddx, gout, ldg, Wn, C, chunk, mean, invstd, gamma, beta, mask_mode, scratch, s1, s2);
   DA_CHECK_LAUNCH();
+  if (dgamma) {
+    BnPgradTable t;
+    t.d[0] = {s1, s2, dgamma, dbeta, W, C};
+    hipLaunchKernelGGL(bn_param_grad_multi_kernel, dim3((C + 31) / 32, 1), dim3(256), 0, stream, t, accumulate);
+    DA_CHECK_LAUNCH();
+  }
   return DA_OK;
 }
 

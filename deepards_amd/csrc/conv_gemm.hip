@@ -350,6 +350,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// the same reduction for up to 32 convolutions in one launch (blockIdx.y = which conv)
+struct WgradReduceDesc {
+  const float* slab;
+  float* dw;
+  int splits, ntaps, N, C;
+};
+struct WgradReduceTable {
+  WgradReduceDesc d[32];
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgradReduceTable t, int accumulate) {
+  const WgradReduceDesc& d = t.d[blockIdx.y];
+  const int total = d.ntaps * d.N * d.C;
+  if ((int)blockIdx.x * 32 >= total) return;
+  __shared__ float red[8][32];
+  const int i = blockIdx.x * 32 + (threadIdx.x & 31), slot = threadIdx.x >> 5;
+  float s = 0.f;
+  if (i < total)
+    for (int sp = slot; sp < d.splits; sp += 8) s += d.slab[(size_t)sp * total + i];
+  red[slot][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (threadIdx.x < 32 && i < total) {
+    s = 0.f;
+    for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+    int tap = i / (d.N * d.C);
+    int rem = i - tap * d.N * d.C;
+    size_t o = (size_t)rem * d.ntaps + tap;
+    d.dw[o] = accumulate ? d.dw[o] + s : s;
+  }
+}
+
 template <int TM, int TN, int WGM, int WGN>
 static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t s) {
   constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32;
@@ -444,12 +475,44 @@ size_t da_conv_wgrad_workspace(int rows, int Lm, int N, int C, int ntaps) {
   return (size_t)p.splits * ntaps * N * C * sizeof(float);
 }
 
+// number of slabs da_conv_wgrad writes for this shape (workspace = splits * ntaps*N*C floats)
+int da_conv_wgrad_splits(int rows, int Lm, int N, int C, int ntaps) {
+  return wgrad_plan(rows * Lm, N, C, ntaps).splits;
+}
+
+typedef struct {
+  const float* slab;
+  float* dw;
+  int splits, ntaps, N, C;
+} da_wgrad_reduce_desc;
+
+// dW (+)= sum of slabs for n convolutions (descs: HOST array), 32 per launch.
+int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumulate, hipStream_t stream) {
+  DA_ENTER();
+  if (n < 0 || (n && !descs)) return DA_EINVAL;
+  for (int base = 0; base < n; base += 32) {
+    WgradReduceTable t;
+    int m = n - base < 32 ? n - base : 32, maxtot = 0;
+    for (int i = 0; i < m; ++i) {
+      const da_wgrad_reduce_desc& s = descs[base + i];
+      if (!s.slab || !s.dw || s.splits < 1) return DA_EINVAL;
+      t.d[i] = {s.slab, s.dw, s.splits, s.ntaps, s.N, s.C};
+      int tot = s.ntaps * s.N * s.C;
+      if (tot > maxtot) maxtot = tot;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((maxtot + 31) / 32, m), dim3(256), 0, stream, t, accumulate);
+    DA_CHECK_LAUNCH();
+  }
+  return DA_OK;
+}
+
 // dW[co][ci][k] (torch layout, k = ntaps) (+)= sum over positions dY[m][co] * X[src(m,k)][ci].
+// dw == NULL: only the slabs are produced (deferred reduction).
 int da_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, int rows, int Lm, int Ldy, int lddy,
                   int N, int Lx, int ldx, int C, int dy_stride, int dy_off, int src_stride, int ntaps,
                   const int* src_off, int accumulate, hipStream_t stream) {
   DA_ENTER();
-  if (!dy || !x || !dw || !workspace || ntaps < 1 || ntaps > 3) return DA_EINVAL;
+  if (!dy || !x || !workspace || ntaps < 1 || ntaps > 3) return DA_EINVAL;
   if (C % 32 || N % 32 || lddy % 4 || ldx % 4) return DA_EINVAL;
   WgradArgs a;
   a.dy = dy; a.x = x; a.slab = workspace;
@@ -473,6 +536,7 @@ int da_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, 
   else if (tn == 32 && tc == 128) rc = launch_wgrad<1, 1, 1, 4>(a, sp, stream);
   else rc = DA_EINVAL;
   if (rc) return rc;
+  if (!dw) return DA_OK;   // caller reduces the slabs later (da_wgrad_reduce_multi)
   int total = ntaps * N * C;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, stream, workspace, dw, sp, ntaps, N,
                      C, accumulate);

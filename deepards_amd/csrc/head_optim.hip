@@ -162,6 +162,29 @@ __global__ __launch_bounds__(256) void repack_conv_weight_kernel(const float* __
   }
 }
 
+// the same repack for up to 32 weights in one launch (blockIdx.y = which weight)
+struct RepackDesc {
+  const float* W;
+  float* Wf;
+  float* Wd;
+  int Co, Ci, K;
+};
+struct RepackTable {
+  RepackDesc d[32];
+};
+__global__ __launch_bounds__(256) void repack_multi_kernel(RepackTable t) {
+  const RepackDesc& d = t.d[blockIdx.y];
+  int total = d.Co * d.Ci * d.K;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int k = i % d.K;
+    int ci = (i / d.K) % d.Ci;
+    int co = i / (d.K * d.Ci);
+    float v = d.W[i];
+    if (d.Wf) d.Wf[((size_t)k * d.Co + co) * d.Ci + ci] = v;
+    if (d.Wd) d.Wd[((size_t)k * d.Ci + ci) * d.Co + co] = v;
+  }
+}
+
 // out[pos][0:C1] = a[pos][0:C1]; out[pos][C1:C1+C2] = b[pos][0:C2]
 __global__ __launch_bounds__(256) void concat2_kernel(const float* __restrict__ a, int lda, int C1,
                                                       const float* __restrict__ b, int ldb, int C2,
@@ -305,6 +328,31 @@ int da_repack_conv_weight(const float* W, float* Wf, float* Wd, int Co, int Ci, 
   hipLaunchKernelGGL(repack_conv_weight_kernel, dim3(grid_for(total, 256, 2048)), dim3(256), 0, stream, W, Wf, Wd, Co,
                      Ci, K);
   DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+typedef struct {
+  const float* W;
+  float* Wf;
+  float* Wd;
+  int Co, Ci, K;
+} da_repack_desc;
+
+// repack n conv weights (descs: HOST array) with one launch per 32.
+int da_repack_multi(const da_repack_desc* descs, int n, hipStream_t stream) {
+  DA_ENTER();
+  if (n < 0 || (n && !descs)) return DA_EINVAL;
+  for (int base = 0; base < n; base += 32) {
+    RepackTable t;
+    int m = n - base < 32 ? n - base : 32;
+    for (int i = 0; i < m; ++i) {
+      const da_repack_desc& s = descs[base + i];
+      if (!s.W || (!s.Wf && !s.Wd)) return DA_EINVAL;
+      t.d[i] = {s.W, s.Wf, s.Wd, s.Co, s.Ci, s.K};
+    }
+    hipLaunchKernelGGL(repack_multi_kernel, dim3(256, m), dim3(256), 0, stream, t);
+    DA_CHECK_LAUNCH();
+  }
   return DA_OK;
 }
 

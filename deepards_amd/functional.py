@@ -28,33 +28,54 @@ class BNState(object):
         self.eps = bn.eps
 
 
-# ---- per-step packed-weight cache -------------------------------------------------------------------
-# The GEMMs read weights as Wf[k][co][ci] (forward) / Wd[k][ci][co] (data gradient).  Inside
-# ``weight_pack_cache()`` (one training step: the weights do not change between its forward and
-# backward) each conv weight is repacked ONCE, by one launch that writes both layouts.
-_PACK = {'on': False, 'cache': {}}
+# ---- per-step context: packed-weight cache + deferred small kernels -----------------------------------
+# Inside ``training_step(model)`` (one step: the weights do not change between its forward and backward)
+#   * every conv weight is repacked ONCE, all of them by one batched launch (Wf[k][co][ci], Wd[k][ci][co]);
+#   * the ~60 tiny per-layer launches -- BN running statistics, BN dgamma/dbeta folds, split-K slab
+#     reductions of the weight gradients -- are queued and served by three batched launches.
+# Outside it (plain autograd use, tests) everything runs immediately.
+_STEP = {'on': False, 'pack': {}, 'running': [], 'pgrad': [], 'wgrad': []}
 
 
 @contextlib.contextmanager
-def weight_pack_cache():
-    _PACK['on'], _PACK['cache'] = True, {}
+def training_step(model=None):
+    _STEP.update(on=True, pack={}, running=[], pgrad=[], wgrad=[])
     try:
+        if model is not None:
+            ws = [m.weight for m in model.modules()
+                  if isinstance(m, torch.nn.Conv1d) and m.kernel_size[0] <= 3 and m.in_channels % 32 == 0
+                  and m.weight.is_cuda]
+            for w, e in zip(ws, H.repack_multi(ws)):
+                _STEP['pack'][w.data_ptr()] = e
         yield
     finally:
-        _PACK['on'], _PACK['cache'] = False, {}
+        _STEP.update(on=False, pack={}, running=[], pgrad=[], wgrad=[])
+
+
+def flush_forward():
+    """Run the queued BN running-statistics updates (call after the forward of the step)."""
+    H.bn_running_multi(_STEP['running'])
+    _STEP['running'] = []
+
+
+def flush_backward():
+    """Run the queued parameter-gradient folds (call after the backward, before the optimiser)."""
+    H.bn_param_grad_multi(_STEP['pgrad'], accumulate=True)
+    H.wgrad_reduce_multi(_STEP['wgrad'], accumulate=True)
+    _STEP['pgrad'], _STEP['wgrad'] = [], []
 
 
 def _wf(w):
-    if _PACK['on']:
-        e = _PACK['cache'].get(w.data_ptr())
+    if _STEP['on']:
+        e = _STEP['pack'].get(w.data_ptr())
         if e is None:
-            e = _PACK['cache'][w.data_ptr()] = H.repack_weight(w, True, True)
+            e = _STEP['pack'][w.data_ptr()] = H.repack_weight(w, True, True)
         return e[0]
     return H.repack_weight(w, True, False)[0]
 
 
 def _wd(w):
-    e = _PACK['cache'].get(w.data_ptr()) if _PACK['on'] else None
+    e = _STEP['pack'].get(w.data_ptr()) if _STEP['on'] else None
     return e[1] if e is not None else H.repack_weight(w, False, True)[1]
 
 
@@ -65,14 +86,36 @@ def _tgt(*params):
     return tuple(None if p is None else getattr(p, '_da_grad', None) for p in params)
 
 
+class _Stats(object):
+    """Per-window statistics of one BatchNorm input: chunk records now, mean/invstd once a consumer ran."""
+    __slots__ = ('part', 'mean', 'invstd')
+
+
 def _stats(x, R, st):
-    """Per-window batch statistics + the reference's sequential running-stat update
-    (one momentum step per window: SURVEY.md finding 5)."""
-    mean, invstd = H.bn_stats(x, R, st.eps)
-    if st.running_mean is not None:
-        H.bn_running_update(mean, invstd, R * x.shape[1], st.running_mean, st.running_var, st.momentum, st.eps,
-                            st.num_batches_tracked)
-    return mean, invstd
+    s = _Stats()
+    s.part = H.bn_stats_partial(x, R)
+    w = x.shape[0] // R
+    s.mean = torch.empty((w, x.shape[2]), device=x.device, dtype=torch.float32)
+    s.invstd = torch.empty_like(s.mean)
+    return s
+
+
+def _bn_apply(x, R, s, st, gamma, beta, relu, res=None):
+    """act(bn(x)(+res)); merges the chunk records (fills s.mean / s.invstd) and books the running update."""
+    out = H.bn_apply(x, R, s.mean, s.invstd, gamma, beta, relu=relu, res=res, part=s.part, eps=st.eps)
+    _running(x, R, s, st)
+    return out
+
+
+def _running(x, R, s, st):
+    if st.running_mean is None:
+        return
+    item = (s.mean, s.invstd, R * x.shape[1], st.running_mean, st.running_var, st.num_batches_tracked, st.momentum,
+            st.eps)
+    if _STEP['on']:
+        _STEP['running'].append(item)
+    else:
+        H.bn_running_multi([item])
 
 
 class StemFunction(Function):
@@ -82,8 +125,11 @@ class StemFunction(Function):
     @staticmethod
     def forward(ctx, x2d, w, gamma, beta, R, pool_mode, st):
         y0 = H.stem_conv_fwd(x2d, w)
-        mean, invstd = _stats(y0, R, st)
+        mean, invstd = H.bn_stats(y0, R, st.eps)
         out = H.bn_relu_pool_fwd(y0, R, mean, invstd, gamma, beta, pool_mode)
+        s_ = _Stats()
+        s_.mean, s_.invstd = mean, invstd
+        _running(y0, R, s_, st)
         ctx.save_for_backward(x2d, y0, mean, invstd, gamma, beta)
         ctx.R, ctx.pool_mode = R, pool_mode
         ctx.gt = _tgt(w, gamma, beta)
@@ -102,13 +148,20 @@ class StemFunction(Function):
 def _bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, tg, tb, out=None, dx=None, want_g=False):
     """bn_bwd with optional direct gradient destinations; returns (dx, dgamma|None, dbeta|None[, g])."""
     direct = tg is not None and tb is not None
-    dx, dg, db, g = H.bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, out=out, want_g=want_g, dx=dx,
-                             dgamma=tg if direct else None, dbeta=tb if direct else None, accumulate=direct)
+    defer = direct and _STEP['on']
+    dx, dg, db, g, ds = H.bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, out=out, want_g=want_g, dx=dx,
+                                 dgamma=tg if direct else None, dbeta=tb if direct else None, accumulate=direct,
+                                 defer_param_grads=defer)
+    if defer:
+        _STEP['pgrad'].append((ds, tg, tb))
     res = (dx, None if direct else dg, None if direct else db)
     return res + (g,) if want_g else res
 
 
 def _wgrad(dy, x, k, stride, pad, tw):
+    if tw is not None and _STEP['on']:
+        _STEP['wgrad'].append((H.conv_wgrad(dy, x, k, stride, pad, defer=True), tw))
+        return None
     dw = H.conv_wgrad(dy, x, k, stride, pad, out=tw, accumulate=tw is not None)
     return None if tw is not None else dw
 
@@ -120,18 +173,20 @@ class BasicBlockFunction(Function):
     @staticmethod
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, R, st1, st2, std):
         y1 = H.conv_fwd(x, _wf(w1), stride, 1)
-        m1, i1 = _stats(y1, R, st1)
-        h1 = H.bn_apply(y1, R, m1, i1, g1, b1, relu=True)
+        s1 = _stats(y1, R, st1)
+        h1 = _bn_apply(y1, R, s1, st1, g1, b1, True)
         y2 = H.conv_fwd(h1, _wf(w2), 1, 1)
-        m2, i2 = _stats(y2, R, st2)
+        s2 = _stats(y2, R, st2)
         if wd is not None:
             yd = H.conv_fwd(x, _wf(wd), stride, 0)
-            md, idd = _stats(yd, R, std)
-            res = H.bn_apply(yd, R, md, idd, gd, bd, relu=False)
+            sd = _stats(yd, R, std)
+            res = _bn_apply(yd, R, sd, std, gd, bd, False)
+            md, idd = sd.mean, sd.invstd
         else:
             yd = md = idd = None
             res = x
-        out = H.bn_apply(y2, R, m2, i2, g2, b2, relu=True, res=res)
+        out = _bn_apply(y2, R, s2, st2, g2, b2, True, res=res)
+        m1, i1, m2, i2 = s1.mean, s1.invstd, s2.mean, s2.invstd
         ctx.has_ds = wd is not None
         ctx.stride, ctx.R = stride, R
         ctx.gt = _tgt(w1, g1, b1, w2, g2, b2, wd, gd, bd)
@@ -173,11 +228,12 @@ class DenseLayerFunction(Function):
 
     @staticmethod
     def forward(ctx, x, g1, b1, w1, g2, b2, w2, R, st1, st2, drop_p, seed, salt):
-        m1, i1 = _stats(x, R, st1)
-        h = H.bn_apply(x, R, m1, i1, g1, b1, relu=True)
+        s1 = _stats(x, R, st1)
+        h = _bn_apply(x, R, s1, st1, g1, b1, True)
         y1 = H.conv_fwd(h, _wf(w1), 1, 0)
-        m2, i2 = _stats(y1, R, st2)
-        h2 = H.bn_apply(y1, R, m2, i2, g2, b2, relu=True)
+        s2 = _stats(y1, R, st2)
+        h2 = _bn_apply(y1, R, s2, st2, g2, b2, True)
+        m1, i1, m2, i2 = s1.mean, s1.invstd, s2.mean, s2.invstd
         new = H.conv_fwd(h2, _wf(w2), 1, 1)
         if drop_p > 0:
             new = H.dropout(new, seed, salt, drop_p)
@@ -212,8 +268,9 @@ class TransitionFunction(Function):
 
     @staticmethod
     def forward(ctx, x, g, b, w, R, st):
-        m, i = _stats(x, R, st)
-        h = H.bn_apply(x, R, m, i, g, b, relu=True)
+        s_ = _stats(x, R, st)
+        h = _bn_apply(x, R, s_, st, g, b, True)
+        m, i = s_.mean, s_.invstd
         y = H.conv_fwd(h, _wf(w), 1, 0)
         out = H.avgpool_fwd(y, 2)
         ctx.R = R
@@ -237,8 +294,9 @@ class NormReluFunction(Function):
 
     @staticmethod
     def forward(ctx, x, g, b, R, st):
-        m, i = _stats(x, R, st)
-        out = H.bn_apply(x, R, m, i, g, b, relu=True)
+        s_ = _stats(x, R, st)
+        out = _bn_apply(x, R, s_, st, g, b, True)
+        m, i = s_.mean, s_.invstd
         ctx.R = R
         ctx.gt = _tgt(g, b)
         ctx.save_for_backward(x, g, b, m, i)

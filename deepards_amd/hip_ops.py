@@ -117,25 +117,58 @@ def conv_dgrad(dy, wd, stride, pad, l_in, out=None, accumulate=False):
     return out
 
 
-def conv_wgrad(dy, x, k, stride, pad, out=None, accumulate=False):
-    """dW (Co,Ci,K) torch layout = sum_positions dy (x) x."""
+def conv_wgrad(dy, x, k, stride, pad, out=None, accumulate=False, defer=False):
+    """dW (Co,Ci,K) torch layout = sum_positions dy (x) x.  defer=True: only the split-K slabs are produced;
+    returns (slab, splits, k, co, ci) for wgrad_reduce_multi."""
     _rlc(dy, 'dy')
     _rlc(x, 'x')
     rows, lo, co = dy.shape
     rows2, l, ci = x.shape
     if rows != rows2 or lo != conv_out_len(l, k, stride, pad) or k > 3 or ci % 32 or co % 32:
         raise ValueError('conv_wgrad: unsupported shape')
-    if out is None:
-        if accumulate:
-            raise ValueError('accumulate needs out')
-        out = torch.empty((co, ci, k), device=x.device, dtype=torch.float32)
     L = _lib.lib()
     nbytes = L.da_conv_wgrad_workspace(rows, lo, co, ci, k)
     ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
     so = [t - pad for t in range(k)]
+    if defer:
+        _chk(L.da_conv_wgrad(_p(dy), _p(x), None, _p(ws), rows, lo, lo, co, co, l, ci, ci, 1, 0, stride, k,
+                             _ints(so), 0, _stream()), 'da_conv_wgrad')
+        return ws, L.da_conv_wgrad_splits(rows, lo, co, ci, k), k, co, ci
+    if out is None:
+        if accumulate:
+            raise ValueError('accumulate needs out')
+        out = torch.empty((co, ci, k), device=x.device, dtype=torch.float32)
     _chk(L.da_conv_wgrad(_p(dy), _p(x), _p(out), _p(ws), rows, lo, lo, co, co, l, ci, ci, 1, 0, stride, k,
                          _ints(so), 1 if accumulate else 0, _stream()), 'da_conv_wgrad')
     return out
+
+
+def wgrad_reduce_multi(items, accumulate=True):
+    """items: ((slab, splits, k, co, ci), dw) -- one launch per 32 convolutions."""
+    if not items:
+        return
+    arr = (_lib.WgradReduceDesc * len(items))()
+    for d, ((slab, splits, k, co, ci), dw) in zip(arr, items):
+        if tuple(dw.shape) != (co, ci, k):
+            raise ValueError('wgrad_reduce_multi: bad dw shape')
+        d.slab, d.dw, d.splits, d.ntaps, d.N, d.C = slab.data_ptr(), dw.data_ptr(), splits, k, co, ci
+    _chk(_lib.lib().da_wgrad_reduce_multi(arr, len(items), 1 if accumulate else 0, _stream()), 'da_wgrad_reduce_multi')
+
+
+def repack_multi(weights):
+    """[(Co,Ci,K) weights] -> [(wf, wd)] with one launch per 32 weights."""
+    outs = []
+    arr = (_lib.RepackDesc * len(weights))()
+    for d, w in zip(arr, weights):
+        _f32(w, 'w')
+        co, ci, k = w.shape
+        wf = torch.empty((k, co, ci), device=w.device, dtype=torch.float32)
+        wd = torch.empty((k, ci, co), device=w.device, dtype=torch.float32)
+        d.W, d.Wf, d.Wd, d.Co, d.Ci, d.K = w.data_ptr(), wf.data_ptr(), wd.data_ptr(), co, ci, k
+        outs.append((wf, wd))
+    if weights:
+        _chk(_lib.lib().da_repack_multi(arr, len(weights), _stream()), 'da_repack_multi')
+    return outs
 
 
 def stem_conv_fwd(x, w):
@@ -167,28 +200,53 @@ def stem_conv_wgrad(dy, x, out=None, accumulate=False):
 # ------------------------------------------------------------------------------------------------
 # window-grouped batch norm
 # ------------------------------------------------------------------------------------------------
-def bn_stats(x, R, eps=1e-5):
-    """-> mean, invstd of shape (W, C); window = R rows."""
+def _bn_ws(w, wn, c, dev):
+    return torch.empty((_lib.lib().da_bn_workspace(w, wn, c) // 4,), device=dev, dtype=torch.float32)
+
+
+def bn_stats_partial(x, R):
+    """Stage 1 of the per-window statistics: chunk records part[w][p][{mean,M2}][C] (opaque tensor)."""
     _rlc(x, 'x')
     rows, l, c = x.shape
     if rows % R:
         raise ValueError('rows %d not a multiple of rows_per_window %d' % (rows, R))
     w = rows // R
+    part = _bn_ws(w, R * l, c, x.device)
+    _chk(_lib.lib().da_bn_stats_partial(_p(x), c, w, R * l, c, _p(part), _stream()), 'da_bn_stats_partial')
+    return part
+
+
+def bn_running_multi(items):
+    """items: (mean, invstd, Wn, running_mean, running_var, num_batches_tracked|None, momentum, eps).
+    One launch per 32 BatchNorms: the reference's one momentum update per window, in window order."""
+    if not items:
+        return
+    arr = (_lib.BnRunningDesc * len(items))()
+    for d, (mean, invstd, wn, rm, rv, nbt, mom, eps) in zip(arr, items):
+        if nbt is not None and nbt.dtype != torch.int64:
+            raise ValueError('num_batches_tracked must be int64')
+        d.mean, d.invstd, d.running_mean, d.running_var = mean.data_ptr(), invstd.data_ptr(), rm.data_ptr(), rv.data_ptr()
+        d.num_batches_tracked = None if nbt is None else nbt.data_ptr()
+        d.W, d.C, d.Wn, d.eps, d.momentum = mean.shape[0], mean.shape[1], wn, eps, mom
+    _chk(_lib.lib().da_bn_running_multi(arr, len(items), _stream()), 'da_bn_running_multi')
+
+
+def bn_stats(x, R, eps=1e-5, running_mean=None, running_var=None, num_batches_tracked=None, momentum=0.1):
+    """-> mean, invstd of shape (W, C); window = R rows (standalone form: partial + merge).  With running
+    buffers the reference's per-window momentum updates are applied to them in place."""
+    part = bn_stats_partial(x, R)
+    rows, l, c = x.shape
+    w = rows // R
     mean = torch.empty((w, c), device=x.device, dtype=torch.float32)
     invstd = torch.empty((w, c), device=x.device, dtype=torch.float32)
-    _chk(_lib.lib().da_bn_stats(_p(x), c, w, R * l, c, eps, _p(mean), _p(invstd), _stream()), 'da_bn_stats')
+    _chk(_lib.lib().da_bn_stats_merge(_p(part), w, R * l, c, eps, _p(mean), _p(invstd), _stream()), 'da_bn_stats_merge')
+    if running_mean is not None:
+        bn_running_multi([(mean, invstd, R * l, running_mean, running_var, num_batches_tracked, momentum, eps)])
     return mean, invstd
 
 
-def bn_running_update(mean, invstd, wn, running_mean, running_var, momentum=0.1, eps=1e-5, num_batches_tracked=None):
-    w, c = mean.shape
-    if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
-        raise ValueError('num_batches_tracked must be int64')
-    _chk(_lib.lib().da_bn_running_update(_p(mean), _p(invstd), w, c, wn, eps, momentum, _p(running_mean),
-                                         _p(running_var), _p(num_batches_tracked), _stream()), 'da_bn_running_update')
-
-
-def bn_apply(x, R, mean, invstd, gamma, beta, relu=True, res=None, out=None):
+def bn_apply(x, R, mean, invstd, gamma, beta, relu=True, res=None, out=None, part=None, eps=1e-5):
+    """out = act(bn(x) (+res)).  With `part` (bn_stats_partial) mean/invstd are OUTPUTS filled on the way."""
     _rlc(x, 'x')
     rows, l, c = x.shape
     w = rows // R
@@ -196,14 +254,17 @@ def bn_apply(x, R, mean, invstd, gamma, beta, relu=True, res=None, out=None):
         out = torch.empty_like(x)
     if res is not None and tuple(res.shape) != tuple(x.shape):
         raise ValueError('residual shape mismatch')
+    if tuple(mean.shape) != (w, c) or tuple(invstd.shape) != (w, c):
+        raise ValueError('mean/invstd must be (W, C)')
     _chk(_lib.lib().da_bn_apply(_p(x), c, _p(res), c, _p(out), c, w, R * l, c, _p(mean), _p(invstd), _p(gamma),
-                                _p(beta), 1 if relu else 0, _stream()), 'da_bn_apply')
+                                _p(beta), 1 if relu else 0, _p(part), eps, _stream()), 'da_bn_apply')
     return out
 
 
 def bn_bwd(dout, x, R, mean, invstd, gamma, beta, mask_mode, out=None, want_g=False, dx=None,
-           dgamma=None, dbeta=None, accumulate=False):
-    """-> dx, dgamma, dbeta, g (g = masked upstream gradient, only when want_g)."""
+           dgamma=None, dbeta=None, accumulate=False, defer_param_grads=False):
+    """-> dx, dgamma, dbeta, g, ds.  g = masked upstream gradient (only when want_g); ds (2,W,C) holds the
+    per-window totals; with defer_param_grads dgamma/dbeta are not computed (fold ds with bn_param_grad_multi)."""
     _rlc(dout, 'dout')
     _rlc(x, 'x')
     rows, l, c = x.shape
@@ -211,14 +272,29 @@ def bn_bwd(dout, x, R, mean, invstd, gamma, beta, mask_mode, out=None, want_g=Fa
     if dx is None:
         dx = torch.empty_like(x)
     g = torch.empty_like(x) if want_g else None
-    if dgamma is None:
+    if not defer_param_grads and dgamma is None:
         dgamma = torch.empty((c,), device=x.device, dtype=torch.float32)
         dbeta = torch.empty((c,), device=x.device, dtype=torch.float32)
-    scratch = torch.empty((2 * w * c,), device=x.device, dtype=torch.float32)
+    scratch = _bn_ws(w, R * l, c, x.device)
+    ds = torch.empty((2, w, c), device=x.device, dtype=torch.float32)
     _chk(_lib.lib().da_bn_bwd(_p(dout), c, _p(x), c, _p(out), c, _p(dx), c, _p(g), c, w, R * l, c, _p(mean),
-                              _p(invstd), _p(gamma), _p(beta), mask_mode, _p(scratch), _p(dgamma), _p(dbeta),
+                              _p(invstd), _p(gamma), _p(beta), mask_mode, _p(scratch), _p(ds),
+                              None if defer_param_grads else _p(dgamma), None if defer_param_grads else _p(dbeta),
                               1 if accumulate else 0, _stream()), 'da_bn_bwd')
-    return dx, dgamma, dbeta, g
+    return dx, dgamma, dbeta, g, ds
+
+
+def bn_param_grad_multi(items, accumulate=True):
+    """items: (ds (2,W,C), dgamma (C,), dbeta (C,)) -- one launch per 32 BatchNorms."""
+    if not items:
+        return
+    arr = (_lib.BnPgradDesc * len(items))()
+    for d, (ds, dg, db) in zip(arr, items):
+        _, w, c = ds.shape
+        d.s1, d.s2 = ds.data_ptr(), ds.data_ptr() + 4 * w * c
+        d.dgamma, d.dbeta, d.W, d.C = dg.data_ptr(), db.data_ptr(), w, c
+    _chk(_lib.lib().da_bn_param_grad_multi(arr, len(items), 1 if accumulate else 0, _stream()),
+         'da_bn_param_grad_multi')
 
 
 # ------------------------------------------------------------------------------------------------

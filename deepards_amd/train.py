@@ -98,10 +98,12 @@ class HotPathTrainer(object):
 
     # ---- eager pieces ------------------------------------------------------------------------
     def _forward_backward(self, inputs, target):
-        with F_.weight_pack_cache():                     # weights are constant within one step
+        with F_.training_step(self.model):               # weights are constant within one step
             logits = self.model(inputs, None)
+            F_.flush_forward()                           # batched BN running-statistics updates
             loss, dlogits = H.bce_logits(logits.detach(), target, want_grad=True)
             logits.backward(dlogits)
+            F_.flush_backward()                          # batched dgamma/dbeta folds + wgrad slab reductions
         return loss, logits.detach()
 
     def _optimizer_step(self):

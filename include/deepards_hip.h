@@ -52,8 +52,15 @@ int da_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, 
 /* benchmark-only tuning knobs: key 0 = force conv tile id, key 1 = wgrad target blocks (0 = automatic) */
 int da_debug_set(int key, int value);
 
+/* deferred slab reduction: da_conv_wgrad with dw == NULL leaves da_conv_wgrad_splits() slabs in the workspace */
+int da_conv_wgrad_splits(int rows, int Lm, int N, int C, int ntaps);
+typedef struct { const float* slab; float* dw; int splits, ntaps, N, C; } da_wgrad_reduce_desc;
+int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumulate, da_stream_t stream);
+
 /* torch [Co][Ci][K] -> Wf [K][Co][Ci] (forward) and Wd [K][Ci][Co] (data gradient). */
 int da_repack_conv_weight(const float* W, float* Wf, float* Wd, int Co, int Ci, int K, da_stream_t stream);
+typedef struct { const float* W; float* Wf; float* Wd; int Co, Ci, K; } da_repack_desc;
+int da_repack_multi(const da_repack_desc* descs, int n, da_stream_t stream);
 
 /* ---- stem: Conv1d(1, C0, k7, s2, p3)  resnet.py:86-87,142 ; densenet.py:118-119 ----------- */
 int da_stem_conv_fwd(const float* x, const float* w, float* y, int rows, int Lin, int C0, int ldy,
@@ -65,21 +72,33 @@ int da_stem_conv_wgrad(const float* dy, int lddy, const float* x, float* dw, flo
 /* ---- window-grouped train-mode BatchNorm1d (+ReLU, +residual) ------------------------------
  * resnet.py:27-38,143,152 ; densenet.py:23-29,72-74,146 ; per-window statistics because
  * torch_cnn_linear_network.py:108-113 calls breath_block(x[i]) one window at a time. */
-int da_bn_stats(const float* x, int ld, int W, int Wn, int C, float eps, float* mean, float* invstd,
-                da_stream_t stream);
-/* W sequential momentum updates in closed form; num_batches_tracked (int64, may be NULL) += W */
-int da_bn_running_update(const float* mean, const float* invstd, int W, int C, int Wn, float eps, float momentum,
-                         float* running_mean, float* running_var, long long* num_batches_tracked,
-                         da_stream_t stream);
+/* descriptors for the batched small kernels: HOST arrays of these are passed, 32 served per launch */
+typedef struct {
+  const float* mean; const float* invstd; float* running_mean; float* running_var;
+  long long* num_batches_tracked; int W, C, Wn; float eps, momentum;
+} da_bn_running_desc;
+typedef struct { const float* s1; const float* s2; float* dgamma; float* dbeta; int W, C; } da_bn_pgrad_desc;
+
+/* two-stage statistics: P chunks of `chunk` positions per window so that W*C/32*P blocks fill the chip */
+void da_bn_chunks(int W, int Wn, int C, int* P, int* chunk);
+size_t da_bn_workspace(int W, int Wn, int C);      /* bytes of part[w][p][{mean,M2}][C] / backward scratch */
+int da_bn_stats_partial(const float* x, int ld, int W, int Wn, int C, float* part, da_stream_t stream);
+int da_bn_stats_merge(const float* part, int W, int Wn, int C, float eps, float* mean, float* invstd,
+                      da_stream_t stream);
+/* the reference's W sequential momentum-0.1 updates per BatchNorm in closed form; num_batches_tracked += W */
+int da_bn_running_multi(const da_bn_running_desc* descs, int n, da_stream_t stream);
+/* out = act(bn(x) (+res)); with part != NULL the chunk records are merged on the fly and mean/invstd WRITTEN */
 int da_bn_apply(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
-                const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
-                da_stream_t stream);
+                float* mean, float* invstd, const float* gamma, const float* beta, int relu, const float* part,
+                float eps, da_stream_t stream);
 /* mask_mode 0: no ReLU; 1: ReLU, mask recomputed from bn(x); 2: ReLU, mask from `out` (residual).
- * scratch: 2*W*C floats. */
+ * scratch: da_bn_workspace() bytes.  ds: [2][W][C] per-window totals, always written.  dgamma/dbeta NULL:
+ * fold ds later with da_bn_param_grad_multi. */
 int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
               float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd,
-              const float* gamma, const float* beta, int mask_mode, float* scratch, float* dgamma, float* dbeta,
-              int accumulate, da_stream_t stream);
+              const float* gamma, const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma,
+              float* dbeta, int accumulate, da_stream_t stream);
+int da_bn_param_grad_multi(const da_bn_pgrad_desc* descs, int n, int accumulate, da_stream_t stream);
 
 /* ---- pools ------------------------------------------------------------------------------
  * stem BN+ReLU+{Max,Avg}Pool1d(3,2,1): resnet.py:100-104,152-153 ; densenet.py:120-123 */

@@ -91,6 +91,12 @@ def test_conv_fwd_dgrad_wgrad(H, ci, co, k, stride, pad, L, rows):
     dw2 = dw.clone()
     H.conv_wgrad(dyt, xt, k, stride, pad, out=dw2, accumulate=True)
     close(dw2.cpu().numpy(), 2 * dw_ref, tol=3e-6, name='wgrad+acc')
+    # deferred slab reduction (batched) and batched repack
+    dw3 = dw.clone()
+    H.wgrad_reduce_multi([(H.conv_wgrad(dyt, xt, k, stride, pad, defer=True), dw3)], accumulate=True)
+    close(dw3.cpu().numpy(), 2 * dw_ref, tol=3e-6, name='wgrad deferred')
+    (wf2, wd2), = H.repack_multi([wt])
+    assert torch.equal(wf2, wf) and torch.equal(wd2, wd)
 
 
 def test_conv_mfma_layout_identity(H):
@@ -143,24 +149,44 @@ def test_bn_fwd_bwd(H, C, L, R, W):
     # backward, three mask modes
     dout = rng.standard_normal((rows, C, L))
     dt = rlc(dout)
-    for mode, g_ref in ((0, dout), (1, dout * (y_ref > 0)), (2, dout * (out_ref > 0))):
+    for mode, z in ((0, None), (1, y_ref), (2, y_ref + res)):
+        g_ref = dout if z is None else dout * (z > 0)
         dx_ref, dg_ref, db_ref = np_ref.bn_window_bwd(x, gamma, st, g_ref, R)
-        dx, dg, db, g = H.bn_bwd(dt, xt, R, mean, invstd, gt, bt, mode, out=out if mode == 2 else None, want_g=True)
-        # mask decisions can flip for |z| ~ 1e-7; on random data none are that close
-        close(ncl(dx), dx_ref, tol=2e-5, name='bn dx mode %d' % mode)
-        close(ncl(g), g_ref, tol=1e-6, name='bn g mode %d' % mode)
+        dx, dg, db, g, ds = H.bn_bwd(dt, xt, R, mean, invstd, gt, bt, mode, out=out if mode == 2 else None, want_g=True)
+        # the ReLU decision of an element with |z| ~ fp32 rounding is undefined: leave those out (a handful at most)
+        sure = np.ones_like(dout, dtype=bool) if z is None else np.abs(z) > 1e-5
+        assert sure.mean() > 0.9999
+        close(ncl(dx) * sure, dx_ref * sure, tol=2e-5, name='bn dx mode %d' % mode)
+        close(ncl(g) * sure, g_ref * sure, tol=1e-6, name='bn g mode %d' % mode)
+        slack = (np.abs(dout) * ~sure).sum(axis=(0, 2))            # what undecidable elements may contribute
+        assert np.all(np.abs(ds[0].sum(0).cpu().numpy() - db_ref) <= 2e-5 * (1 + np.abs(db_ref).max()) + slack), 'ds1'
         close(dg.cpu().numpy(), dg_ref, tol=2e-5, name='dgamma')
         close(db.cpu().numpy(), db_ref, tol=2e-5, name='dbeta')
     # in-place form used by the block functions: dx aliases dout
     g_ref = dout * (y_ref > 0)
-    dx_ref, _, _ = np_ref.bn_window_bwd(x, gamma, st, g_ref, R)
+    dx_ref, dg_ref, db_ref = np_ref.bn_window_bwd(x, gamma, st, g_ref, R)
+    sure = np.abs(y_ref) > 1e-5
     d2 = dt.clone()
-    H.bn_bwd(d2, xt, R, mean, invstd, gt, bt, 1, dx=d2)
-    close(ncl(d2), dx_ref, tol=2e-5, name='bn dx in-place')
+    _, _, _, _, ds = H.bn_bwd(d2, xt, R, mean, invstd, gt, bt, 1, dx=d2, defer_param_grads=True)
+    close(ncl(d2) * sure, dx_ref * sure, tol=2e-5, name='bn dx in-place')
+    # deferred, batched parameter-gradient fold (accumulating form)
+    dg2, db2 = torch.ones(C, device='cuda'), torch.ones(C, device='cuda')
+    H.bn_param_grad_multi([(ds, dg2, db2)], accumulate=True)
+    close(dg2.cpu().numpy(), dg_ref + 1, tol=2e-5, name='deferred dgamma')
+    close(db2.cpu().numpy(), db_ref + 1, tol=2e-5, name='deferred dbeta')
+    # statistics through the fused consumer: bn_apply merges the chunk records and publishes mean/invstd
+    part = H.bn_stats_partial(xt, R)
+    m2_, i2_ = torch.empty_like(mean), torch.empty_like(invstd)
+    o2 = H.bn_apply(xt, R, m2_, i2_, gt, bt, relu=True, part=part)
+    close(ncl(o2), np.maximum(y_ref, 0), tol=5e-6, name='bn apply(part)')
+    close(m2_.cpu().numpy(), st[0], name='mean via apply')
+    close(i2_.cpu().numpy(), st[1], tol=5e-6, name='invstd via apply')
     # running stats (sequential per-window momentum updates)
     rm0, rv0 = rng.standard_normal(C), rng.uniform(0.5, 2, C)
     rm, rv = cu(rm0), cu(rv0)
-    H.bn_running_update(mean, invstd, R * L, rm, rv)
+    nbt = torch.zeros(1, dtype=torch.int64, device='cuda')
+    H.bn_stats(xt, R, running_mean=rm, running_var=rv, num_batches_tracked=nbt)
+    assert int(nbt) == W
     # oracle closed form starts from given buffers
     m_ref, v_ref = rm0.copy(), rv0.copy()
     var_b = 1.0 / st[1] ** 2 - 1e-5
