@@ -125,24 +125,36 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     }
   }
 
-  // epilogue: lane holds output channel n (column), 16 positions (rows) per 32x32 tile
+  // epilogue: lane holds output channel n (column), 16 positions (rows) per 32x32 tile.
+  // Row offsets first, then (accumulate) ALL the old values in flight before the first add: the
+  // naive per-row load -> wait -> store chain costs 16 dependent round trips.
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    size_t off[16];
+    bool ok[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int mrow = (r & 3) + 8 * (r >> 2) + 4 * fh;
       int m = m_blk + (wm * TM + i) * 32 + mrow;
-      if (m < a.M) {
-        uint32_t row = fdiv((uint32_t)m, a.divLm);
-        int jj = m - (int)row * Lm;
-        size_t off = ((size_t)row * a.Ldst + (size_t)(jj * a.dst_stride + a.dst_off)) * a.ldy;
+      ok[r] = m < a.M;
+      uint32_t row = fdiv((uint32_t)(ok[r] ? m : 0), a.divLm);
+      int jj = (ok[r] ? m : 0) - (int)row * Lm;
+      off[r] = ((size_t)row * a.Ldst + (size_t)(jj * a.dst_stride + a.dst_off)) * a.ldy;
+    }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          int n = n_blk + (wn * TN + j) * 32 + frow;
-          float v = acc[i][j][r];
-          if (a.accumulate) v += a.y[off + n];
-          a.y[off + n] = v;
-        }
+    for (int j = 0; j < TN; ++j) {
+      const int n = n_blk + (wn * TN + j) * 32 + frow;
+      if (a.accumulate) {
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = ok[r] ? a.y[off[r] + n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ok[r]) a.y[off[r] + n] = acc[i][j][r] + old[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ok[r]) a.y[off[r] + n] = acc[i][j][r];
       }
     }
   }
@@ -151,12 +163,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
 // tuning knobs (benchmark use): 0 = automatic
 static int g_force_conv_tile = 0;
 static int g_wgrad_target_blocks = 0;
+static int g_conv_dyn_lds = -1;   // -1: none
 
 template <int TM, int TN, int WGM, int WGN>
 static int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
   constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32;
   dim3 grid((a.M + BM - 1) / BM, a.N / BN);
-  hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, WGM, WGN>), grid, dim3(256), 0, s, a);
+  int dyn = g_conv_dyn_lds >= 0 ? g_conv_dyn_lds : 0;
+  hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, WGM, WGN>), grid, dim3(256), dyn, s, a);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -443,6 +457,7 @@ extern "C" {
 int da_debug_set(int key, int value) {
   if (key == 0) g_force_conv_tile = value;
   else if (key == 1) g_wgrad_target_blocks = value;
+  else if (key == 2) g_conv_dyn_lds = value;
   else return DA_EINVAL;
   return DA_OK;
 }

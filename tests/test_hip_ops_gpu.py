@@ -160,8 +160,10 @@ def test_bn_fwd_bwd(H, C, L, R, W):
         close(ncl(g) * sure, g_ref * sure, tol=1e-6, name='bn g mode %d' % mode)
         slack = (np.abs(dout) * ~sure).sum(axis=(0, 2))            # what undecidable elements may contribute
         assert np.all(np.abs(ds[0].sum(0).cpu().numpy() - db_ref) <= 2e-5 * (1 + np.abs(db_ref).max()) + slack), 'ds1'
-        close(dg.cpu().numpy(), dg_ref, tol=2e-5, name='dgamma')
-        close(db.cpu().numpy(), db_ref, tol=2e-5, name='dbeta')
+        xhat_abs = np.abs((y_ref - beta[None, :, None]) / gamma[None, :, None])
+        slack_g = (np.abs(dout) * ~sure * xhat_abs).sum(axis=(0, 2))
+        assert np.all(np.abs(dg.cpu().numpy() - dg_ref) <= 2e-5 * (1 + np.abs(dg_ref).max()) + slack_g), 'dgamma'
+        assert np.all(np.abs(db.cpu().numpy() - db_ref) <= 2e-5 * (1 + np.abs(db_ref).max()) + slack), 'dbeta' 
     # in-place form used by the block functions: dx aliases dout
     g_ref = dout * (y_ref > 0)
     dx_ref, dg_ref, db_ref = np_ref.bn_window_bwd(x, gamma, st, g_ref, R)
@@ -172,8 +174,11 @@ def test_bn_fwd_bwd(H, C, L, R, W):
     # deferred, batched parameter-gradient fold (accumulating form)
     dg2, db2 = torch.ones(C, device='cuda'), torch.ones(C, device='cuda')
     H.bn_param_grad_multi([(ds, dg2, db2)], accumulate=True)
-    close(dg2.cpu().numpy(), dg_ref + 1, tol=2e-5, name='deferred dgamma')
-    close(db2.cpu().numpy(), db_ref + 1, tol=2e-5, name='deferred dbeta')
+    unsure = ~sure
+    sl_b = (np.abs(dout) * unsure).sum(axis=(0, 2))
+    sl_g = (np.abs(dout) * unsure * np.abs((y_ref - beta[None, :, None]) / gamma[None, :, None])).sum(axis=(0, 2))
+    assert np.all(np.abs(dg2.cpu().numpy() - dg_ref - 1) <= 2e-5 * (1 + np.abs(dg_ref).max()) + sl_g), 'deferred dgamma'
+    assert np.all(np.abs(db2.cpu().numpy() - db_ref - 1) <= 2e-5 * (1 + np.abs(db_ref).max()) + sl_b), 'deferred dbeta' 
     # statistics through the fused consumer: bn_apply merges the chunk records and publishes mean/invstd
     part = H.bn_stats_partial(xt, R)
     m2_, i2_ = torch.empty_like(mean), torch.empty_like(invstd)
