@@ -23,6 +23,15 @@
 // both operands, so each MFMA pairs identical k on A and B).
 #include "common.h"
 
+// XCD-aware block order (MI355X: 8 XCDs, blocks are dealt to them round-robin, each with its own 4 MiB L2):
+// give every XCD a CONTIGUOUS chunk of the linear tile order, so that tiles which share an operand
+// panel run on the same L2 close together in time.  Bijective for any block count; affects speed only.
+__device__ __forceinline__ int xcd_linear_tile(int id, int total) {
+  const int q = total >> 3, r = total & 7;
+  const int xcd = id & 7, s = id >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + s;
+}
+
 struct ConvGemmArgs {
   const float* x;
   const float* w;
@@ -163,14 +172,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
 // tuning knobs (benchmark use): 0 = automatic
 static int g_force_conv_tile = 0;
 static int g_wgrad_target_blocks = 0;
-static int g_conv_dyn_lds = -1;   // -1: none
 
 template <int TM, int TN, int WGM, int WGN>
 static int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
   constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32;
   dim3 grid((a.M + BM - 1) / BM, a.N / BN);
-  int dyn = g_conv_dyn_lds >= 0 ? g_conv_dyn_lds : 0;
-  hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, WGM, WGN>), grid, dim3(256), dyn, s, a);
+  hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, WGM, WGN>), grid, dim3(256), 0, s, a);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -243,11 +250,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int ntn = a.C / BN, ntm = a.N / BM;
-  int bx = blockIdx.x;
+  const int tiles = ntm * ntn * a.ntaps;
+  // tile fastest: the tiles that re-read one position chunk of dY / X are consecutive on one XCD
+  const int lin = xcd_linear_tile(blockIdx.x, gridDim.x);
+  int bx = lin % tiles;
+  const int split = lin / tiles;
   const int t = bx / (ntm * ntn);
   bx -= t * ntm * ntn;
   const int n_blk = (bx / ntn) * BM, c_blk = (bx % ntn) * BN;
-  const int split = blockIdx.y;
   const int so = t == 0 ? a.so0 : (t == 1 ? a.so1 : a.so2);
   const int Lm = (int)a.divLm.d;
   const int k_beg = split * a.kchunk;
@@ -398,7 +408,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgradReduceTabl
 template <int TM, int TN, int WGM, int WGN>
 static int launch_wgrad(const WgradArgs& a, int splits, hipStream_t s) {
   constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32;
-  dim3 grid((a.N / BM) * (a.C / BN) * a.ntaps, splits);
+  dim3 grid((a.N / BM) * (a.C / BN) * a.ntaps * splits);
   hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, WGM, WGN>), grid, dim3(256), 0, s, a);
   DA_CHECK_LAUNCH();
   return DA_OK;
@@ -457,7 +467,6 @@ extern "C" {
 int da_debug_set(int key, int value) {
   if (key == 0) g_force_conv_tile = value;
   else if (key == 1) g_wgrad_target_blocks = value;
-  else if (key == 2) g_conv_dyn_lds = value;
   else return DA_EINVAL;
   return DA_OK;
 }
