@@ -23,6 +23,15 @@
 // both operands, so each MFMA pairs identical k on A and B).
 #include "common.h"
 
+#ifndef WGRAD_GLOAD_AT
+#define WGRAD_GLOAD_AT 8
+#endif
+#ifndef GLOAD_AT
+#define GLOAD_AT 3   // quarter of the K step's MFMAs (0..3; 4 = after them) before which the next step's global
+                     // loads are issued.  Measured on MI355X: issuing them first (0) costs 5-8 % -- the wave's
+                     // vector-memory instructions queue in front of its MFMAs; 3 leaves a quarter step of cover.
+#endif
+
 // XCD-aware block order (MI355X: 8 XCDs, blocks are dealt to them round-robin, each with its own 4 MiB L2):
 // give every XCD a CONTIGUOUS chunk of the linear tile order, so that tiles which share an operand
 // panel run on the same L2 close together in time.  Bijective for any block count; affects speed only.
@@ -114,9 +123,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
 #pragma unroll
     for (int p = 0; p < BP; ++p) *reinterpret_cast<f32x4*>(&Bs[(lr + 32 * p) * PITCH + lq * 4]) = rb[p];
     __syncthreads();
-    if (it + 1 < nk) gload(it + 1);
 #pragma unroll
     for (int c8 = 0; c8 < 4; ++c8) {
+      if (c8 == GLOAD_AT) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < nk) gload(it + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       f32x4 af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -131,6 +144,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (GLOAD_AT >= 4) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + 1 < nk) gload(it + 1);
     }
   }
 
@@ -323,9 +340,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       *reinterpret_cast<f32x4*>(&Xs[(idx / XQ) * BN + (idx % XQ) * 4]) = rx[p];
     }
     __syncthreads();
-    if (k0 + 32 < k_end) gload(k0 + 32);
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
+      if (kk == WGRAD_GLOAD_AT) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 32 < k_end) gload(k0 + 32);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       float af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = Ys[(2 * kk + fh) * BM + (wm * TM + i) * 32 + frow];
