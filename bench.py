@@ -143,6 +143,15 @@ def cpu_baseline(backbone, batch, seconds):
                        (n, b, dt, backbone, torch.__version__, cores))
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None.
+    bench.py cannot run the profiler on itself; the passes are re-collected with the command in the file."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))['hbm_bytes_per_launch']
+    except Exception:
+        return None
+
+
 def say(*a):
     print('[bench]', *a, file=sys.stderr, flush=True)
 
@@ -252,7 +261,7 @@ def main():
         out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_gemm_kernel<*> (da_conv_gemm: conv fwd + dgrad implicit GEMM, '
                                                        'v_mfma_f32_32x32x2_f32)',
                            'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                           'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
                            'launches_per_step': dom['calls'] // nprof, 'avg_launch_us': round(dom['avg_us'], 2),
                            'alg_flops_per_launch': round(dom['flops'] / dom['calls'], 1)}
         tot = sum(v['total_ms'] for v in summ.values())

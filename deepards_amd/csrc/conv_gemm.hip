@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
+  // n-tile fastest, contiguous chunk per XCD: the N/BN tiles that re-read one A panel run back to back on one L2
+  const int ntn = a.N / BN;
+  const int lin = xcd_linear_tile(blockIdx.x, gridDim.x);
+  const int m_blk = (lin / ntn) * BM, n_blk = (lin % ntn) * BN;
   const int lr = tid >> 3, lq = tid & 7;
   const int Lm = (int)a.divLm.d;
 
@@ -193,7 +196,7 @@ static int g_wgrad_target_blocks = 0;
 template <int TM, int TN, int WGM, int WGN>
 static int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
   constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32;
-  dim3 grid((a.M + BM - 1) / BM, a.N / BN);
+  dim3 grid(((a.M + BM - 1) / BM) * (a.N / BN));
   hipLaunchKernelGGL((conv_gemm_kernel<TM, TN, WGM, WGN>), grid, dim3(256), 0, s, a);
   DA_CHECK_LAUNCH();
   return DA_OK;
