@@ -231,3 +231,28 @@ def test_densenet_dropout_active_and_scaled(M):
     assert all(np.isfinite(l))
     loss, logits, pred = tr.test_step(xt, tt)
     assert pred.shape == (2,) and np.isfinite(float(loss))
+
+
+def test_reference_pickled_fixture_windows(M):
+    """BASELINE config C1's inputs: the 20 windows of the reference's own tests/test_dataset.pkl (extracted
+    without unpickling, oracle/extract_fixture.py), normalised like ARDSRawDataset.__getitem__ (float64
+    (x-mu)/std, then .float() as train_ards_detector.py:150-152): logits of all 20 windows and the loss against
+    the numpy oracle within 1e-4, for both backbones; and the argmax predictions of the test epoch."""
+    from deepards_amd.train import HotPathTrainer
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'test_dataset_windows.npz'))
+    x64 = (z['x'] - float(z['mu'])) / float(z['std'])
+    tgt = z['target'].astype(np.float64)
+    for backbone in ('resnet18', 'densenet18'):
+        params = {k: v.astype(np.float64) for k, v in seeded_params(backbone, 3).items()}
+        ref = np_ref.cnn_linear_forward_backward(params, x64.astype(np.float32).astype(np.float64), tgt, backbone=backbone,
+                                                 need_grads=False)
+        model = build(M, backbone, 3)
+        tr = HotPathTrainer(model, use_graph=False)
+        xt = torch.from_numpy(x64).float().cuda()
+        tt = torch.from_numpy(tgt).float().cuda()
+        loss, logits, pred = tr.test_step(xt, tt)
+        err = np.abs(logits.cpu().numpy() - ref['logits']).max()
+        log(backbone, 'reference fixture (20 windows): logits err %.3e loss %.7f vs %.7f' % (err, float(loss), ref['loss']))
+        assert err < 1e-4 and abs(float(loss) - ref['loss']) < 1e-5
+        sure = np.abs(ref['logits'][:, 0] - ref['logits'][:, 1]) > 1e-3
+        assert np.array_equal(pred.cpu().numpy()[sure], ref['logits'].argmax(-1)[sure])

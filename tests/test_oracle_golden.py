@@ -132,3 +132,21 @@ def test_torch_oracle_bitwise_vs_reference_import():
             a = ref.train()(x, None)
             b = torch_ref.cnn_linear(p, x, backbone)
         assert torch.equal(a, b), backbone
+
+
+def test_reference_fixture_windows_through_both_oracles():
+    """The reference's own pickled fixture (deepards/tests/test_dataset.pkl, arrays extracted without
+    unpickling by oracle/extract_fixture.py): z-scored with the fixture's scaling factors exactly as
+    ARDSRawDataset.__getitem__ does (dataset.py:1364,1379), through the numpy and the torch oracle."""
+    import torch
+    from oracle import torch_ref
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'test_dataset_windows.npz'))
+    x = (z['x'] - float(z['mu'])) / float(z['std'])                     # float64, like the reference
+    assert x.shape == (20, 20, 1, 224) and z['target'].sum() == 20 and z['target'][:, 1].sum() == 15
+    xb, tb = x[:4], z['target'][:4].astype(np.float64)
+    for backbone in ('resnet18', 'densenet18'):
+        p64 = {k: v.astype(np.float64) for k, v in seeded_params(backbone, 3).items()}
+        out = np_ref.cnn_linear_forward_backward(p64, xb, tb, backbone=backbone, need_grads=False)
+        pt = {k: torch.from_numpy(v) for k, v in seeded_params(backbone, 3).items()}
+        lt = torch_ref.cnn_linear(pt, torch.from_numpy(xb).float(), backbone).detach().numpy()
+        assert np.abs(lt - out['logits']).max() < 1e-5
