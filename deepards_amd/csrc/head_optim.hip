@@ -241,6 +241,38 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
   }
 }
 
+// Device-resident window store: out[b][:] = float((tiles[idx[b]][:] - mu) / std), the
+// reference's ARDSRawDataset.__getitem__ normalisation (dataset.py:1364,1379: float64 arithmetic) followed by
+// the .float() cast of train_ards_detector.py:150-152 -- fused with the batch gather, bit-identical results.
+__global__ __launch_bounds__(256) void gather_normalize_kernel(const double* __restrict__ tiles,
+                                                               const int64_t* __restrict__ idx, double mu, double stdv,
+                                                               float* __restrict__ out, int tile_elems) {
+  const int b = blockIdx.x;
+  const double* src = tiles + (size_t)idx[b] * tile_elems;
+  float* dst = out + (size_t)b * tile_elems;
+  for (int i = threadIdx.x; i < tile_elems; i += blockDim.x) dst[i] = (float)((src[i] - mu) / stdv);
+}
+
+// one-hot targets gathered the same way (float32 [N][2] -> [B][2])
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, float* __restrict__ out,
+                                   int B, int width) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * width) out[i] = src[(size_t)idx[i / width] * width + i % width];
+}
+
+// Test-epoch reduction on the device: pred[b] = argmax(logits[b]) (first maximum, as
+// torch.argmax: class 0 on a tie) and votes[group[b]][pred[b]] += 1 -- the per-patient vote table the reference
+// builds on the host (train_ards_detector.py:932-936, metrics.py:572-604).  Integer atomics: exact, order-free.
+__global__ void vote_kernel(const float* __restrict__ logits, const int64_t* __restrict__ group, int B, int n_groups,
+                            int* __restrict__ votes, int* __restrict__ pred) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int p = logits[2 * b + 1] > logits[2 * b] ? 1 : 0;
+  if (pred) pred[b] = p;
+  int64_t g = group[b];
+  if (g >= 0 && g < n_groups) atomicAdd(&votes[2 * g + p], 1);
+}
+
 static inline int grid_for(size_t total, int bs, int cap) {
   size_t g = (total + bs - 1) / bs;
   if (g > (size_t)cap) g = cap;
@@ -327,6 +359,37 @@ int da_repack_conv_weight(const float* W, float* Wf, float* Wd, int Co, int Ci, 
   size_t total = (size_t)Co * Ci * K;
   hipLaunchKernelGGL(repack_conv_weight_kernel, dim3(grid_for(total, 256, 2048)), dim3(256), 0, stream, W, Wf, Wd, Co,
                      Ci, K);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// tiles: [N][tile_elems] float64 raw windows; idx: [B] int64 window indices; out: [B][tile_elems] float32.
+int da_gather_normalize(const double* tiles, const int64_t* idx, double mu, double stdv, float* out, int B,
+                        int tile_elems, hipStream_t stream) {
+  DA_ENTER();
+  if (!tiles || !idx || !out || tile_elems < 1 || stdv == 0.0) return DA_EINVAL;
+  if (B == 0) return DA_OK;
+  hipLaunchKernelGGL(gather_normalize_kernel, dim3(B), dim3(256), 0, stream, tiles, idx, mu, stdv, out, tile_elems);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// votes: [n_groups][2] int32, accumulated across calls (zero it at the start of the epoch); pred: [B] int32 or NULL.
+int da_vote_counts(const float* logits, const int64_t* group, int B, int n_groups, int* votes, int* pred,
+                   hipStream_t stream) {
+  DA_ENTER();
+  if (!logits || !group || !votes || n_groups < 1) return DA_EINVAL;
+  if (B == 0) return DA_OK;
+  hipLaunchKernelGGL(vote_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, logits, group, B, n_groups, votes, pred);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+int da_gather_rows(const float* src, const int64_t* idx, float* out, int B, int width, hipStream_t stream) {
+  DA_ENTER();
+  if (!src || !idx || !out || width < 1) return DA_EINVAL;
+  if (B == 0) return DA_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((B * width + 255) / 256), dim3(256), 0, stream, src, idx, out, B, width);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

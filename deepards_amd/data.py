@@ -1,0 +1,55 @@
+"""Device-resident window store.
+
+The reference feeds every step through ``ARDSRawDataset.__getitem__`` (dataset.py:1343-1404: k-fold relative ->
+absolute index, ``(data - mu) / std`` in float64), default_collate, a float64->float32 cast and a synchronous
+H2D copy (train_ards_detector.py:144-152, ``num_workers=0``).  On MI355X the whole dataset fits in HBM many
+times over (a 24 h recording is ~36 KB per window), so the raw float64 windows are uploaded ONCE and a batch is
+one HIP kernel: gather by index fused with the normalisation and the cast -- bit-identical values, no host work
+per step.  Index plumbing (k-fold index lists, oversampling, shuffling) stays plain host/torch code.
+"""
+import torch
+
+from . import hip_ops as H
+
+
+class DeviceTileStore(object):
+    def __init__(self, windows, targets, mu, std, device='cuda'):
+        """windows: (N, NB, 1, L) float64 array-like of RAW (un-normalised) flow windows; targets (N, 2) one-hot;
+        mu, std: this fold's scaling factors (scalars, dataset.py:627-649)."""
+        w = torch.as_tensor(windows, dtype=torch.float64)
+        if w.dim() != 4 or w.shape[2] != 1:
+            raise ValueError('windows must be (N, NB, 1, L)')
+        self.tiles = w.contiguous().to(device)
+        self.targets = torch.as_tensor(targets, dtype=torch.float32).contiguous().to(device)
+        if self.targets.shape != (w.shape[0], 2):
+            raise ValueError('targets must be (N, 2) one-hot')
+        self.mu, self.std = float(mu), float(std)
+        self.kfold_indexes = None                     # absolute indices of the current fold (dataset.py:765-772)
+
+    def __len__(self):
+        return self.tiles.shape[0] if self.kfold_indexes is None else len(self.kfold_indexes)
+
+    def set_kfold_indexes(self, indexes):
+        """Relative -> absolute index map of the current fold (reference: set_kfold_indexes_for_fold)."""
+        self.kfold_indexes = None if indexes is None else torch.as_tensor(indexes, dtype=torch.int64,
+                                                                          device=self.tiles.device)
+
+    def batch(self, rel_idx):
+        """(inputs (B, NB, 1, L) float32, targets (B, 2) float32) for fold-relative indices."""
+        idx = torch.as_tensor(rel_idx, dtype=torch.int64, device=self.tiles.device).contiguous()
+        if self.kfold_indexes is not None:
+            idx = self.kfold_indexes[idx].contiguous()
+        return H.gather_normalize(self.tiles, idx, self.mu, self.std), H.gather_rows(self.targets, idx)
+
+    def epoch(self, batch_size, shuffle=True, generator=None, drop_odd=True):
+        """Iterate one epoch like DataLoader(batch_size, shuffle) + clip_odd_batch_sizes (:146-147,482-494)."""
+        n = len(self)
+        order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
+        for s in range(0, n, batch_size):
+            idx = order[s:s + batch_size]
+            if drop_odd and batch_size != 1 and len(idx) % 2 == 1:
+                idx = idx[:-1]
+            if len(idx) == 0:
+                continue
+            x, t = self.batch(idx)
+            yield idx, x, t

@@ -413,3 +413,45 @@ def dropout(x, seed, salt, p):
     y = torch.empty_like(x)
     _chk(_lib.lib().da_dropout(_p(x), _p(y), x.numel(), _p(seed), salt, p, _stream()), 'da_dropout')
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# device-resident window store
+# ------------------------------------------------------------------------------------------------
+def gather_normalize(tiles, idx, mu, std, out=None):
+    """tiles (N, ...) float64 CUDA raw windows, idx (B,) int64 CUDA -> (B, ...) float32 = float((x-mu)/std)."""
+    if not (tiles.is_cuda and tiles.dtype == torch.float64 and tiles.is_contiguous()):
+        raise ValueError('tiles must be a contiguous float64 CUDA tensor')
+    if not (idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous()):
+        raise ValueError('idx must be a contiguous int64 CUDA tensor')
+    b = idx.numel()
+    elems = tiles[0].numel()
+    if out is None:
+        out = torch.empty((b,) + tuple(tiles.shape[1:]), device=tiles.device, dtype=torch.float32)
+    _chk(_lib.lib().da_gather_normalize(_p(tiles), _p(idx), float(mu), float(std), _p(out), b, elems, _stream()),
+         'da_gather_normalize')
+    return out
+
+
+def gather_rows(src, idx, out=None):
+    """src (N, W) float32 CUDA, idx (B,) int64 CUDA -> (B, W)."""
+    _f32(src, 'src')
+    b, width = idx.numel(), src.shape[1]
+    if out is None:
+        out = torch.empty((b, width), device=src.device, dtype=torch.float32)
+    _chk(_lib.lib().da_gather_rows(_p(src), _p(idx), _p(out), b, width, _stream()), 'da_gather_rows')
+    return out
+
+
+def vote_counts(logits, group, votes, want_pred=True):
+    """logits (B,2) f32, group (B,) int64 patient slot per window, votes (P,2) int32 accumulated in place.
+    -> pred (B,) int32 window predictions (argmax, class 0 on ties)."""
+    _f32(logits, 'logits')
+    if not (group.is_cuda and group.dtype == torch.int64 and votes.is_cuda and votes.dtype == torch.int32
+            and votes.is_contiguous() and votes.shape[1] == 2):
+        raise ValueError('group must be int64 CUDA, votes (P,2) int32 CUDA')
+    b = logits.shape[0]
+    pred = torch.empty((b,), device=logits.device, dtype=torch.int32) if want_pred else None
+    _chk(_lib.lib().da_vote_counts(_p(logits), _p(group.contiguous()), b, votes.shape[0], _p(votes), _p(pred), _stream()),
+         'da_vote_counts')
+    return pred

@@ -224,3 +224,34 @@ def run_train_epoch(trainer, loader, batch_size=None):
         tgt = target[sl].float().to(dev, non_blocking=True)
         losses.append(trainer.train_step(inputs, tgt).clone())
     return losses
+
+
+def run_test_epoch(trainer, store, patient_slot, batch_size=16):
+    """BaseTraining.run_test_epoch (:424-465) + record_final_epoch_testing_results (:519-524) with the reductions on
+    the device: no_grad forward in train mode, BCE loss, window argmax, per-patient vote table.  ``store`` is a
+    DeviceTileStore, ``patient_slot`` an int64 tensor (len(store),) mapping every window to a patient slot
+    0..P-1.  One host sync at the end.  Returns dict(votes (P,2), pred_frac (P,), prediction (P,), window_pred,
+    mean_loss) mirroring metrics.py:572-604: pred_frac = ARDS votes / all votes, prediction = argmax of the votes."""
+    dev = store.tiles.device
+    slot = torch.as_tensor(patient_slot, dtype=torch.int64, device=dev)
+    n_pat = int(slot.max()) + 1
+    votes = torch.zeros((n_pat, 2), dtype=torch.int32, device=dev)
+    preds, losses, order = [], [], []
+    for idx, x, t in store.epoch(batch_size, shuffle=False, drop_odd=trainer_clip_odd_batches(trainer)):
+        loss, logits, _ = trainer.test_step(x, t)
+        gidx = idx.to(dev)
+        if store.kfold_indexes is not None:
+            gidx = store.kfold_indexes[gidx]
+        preds.append(H.vote_counts(logits, slot[gidx], votes))
+        losses.append(loss)
+        order.append(idx)
+    v = votes.cpu().numpy()
+    tot = v.sum(axis=1)
+    return dict(votes=v, pred_frac=v[:, 1] / tot.clip(min=1), prediction=v.argmax(axis=1),
+                window_pred=torch.cat(preds).cpu().numpy(), window_index=torch.cat(order).numpy(),
+                mean_loss=float(torch.cat(losses).mean()))
+
+
+def trainer_clip_odd_batches(trainer):
+    """BaseTraining.clip_odd_batches is False for the cnn_linear model: test batches keep their odd item (:449-450)."""
+    return getattr(trainer, 'clip_odd_batches', False)

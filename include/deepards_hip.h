@@ -132,6 +132,19 @@ int da_clamp_sgd_nesterov(float* p, const float* g, float* buf, size_t n, float 
 int da_clamp_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                   float eps, int step, float clip, float gscale, da_stream_t stream);
 
+/* ---- device-resident window store: batch gather fused with the (x-mu)/std normalisation -------------------
+ * ARDSRawDataset.__getitem__ dataset.py:1343-1404 (index map :1349-1350, normalisation :1364,1379 in float64)
+ * + the .float() cast of train_ards_detector.py:150-152; replaces DataLoader/collate/H2D per step. */
+int da_gather_normalize(const double* tiles, const int64_t* idx, double mu, double stdv, float* out, int B,
+                        int tile_elems, da_stream_t stream);
+int da_gather_rows(const float* src, const int64_t* idx, float* out, int B, int width, da_stream_t stream);
+
+/* ---- test epoch on the device: window predictions + per-patient vote table --------------------------------
+ * CNNLinearModel._process_test_batch_results train_ards_detector.py:932-936 (outputs.argmax) and
+ * DeepARDSResults.perform_patient_predictions metrics.py:572-604 (votes per pathology, pred_frac, majority). */
+int da_vote_counts(const float* logits, const int64_t* group, int B, int n_groups, int* votes, int* pred,
+                   da_stream_t stream);
+
 /* ---- densenet helpers: torch.cat([x, new], 1) and F.dropout  densenet.py:36-40 -------------- */
 int da_concat2(const float* a, int lda, int C1, const float* b, int ldb, int C2, float* out, int ldo, size_t npos,
                da_stream_t stream);

@@ -13,7 +13,7 @@ from oracle import np_ref
 from oracle.weights import seeded_params, seeded_batch, digest, DEAD_RESNET_PARAMS
 
 pytestmark = pytest.mark.gpu
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*.npz')))
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*net18_*.npz')))
 LOG = os.path.join(os.path.dirname(os.path.dirname(__file__)), 'gpurun_out', 'parity_model.log')
 
 
@@ -256,3 +256,42 @@ def test_reference_pickled_fixture_windows(M):
         assert err < 1e-4 and abs(float(loss) - ref['loss']) < 1e-5
         sure = np.abs(ref['logits'][:, 0] - ref['logits'][:, 1]) > 1e-3
         assert np.array_equal(pred.cpu().numpy()[sure], ref['logits'].argmax(-1)[sure])
+
+
+def test_device_tile_store_matches_reference_getitem():
+    """Gather + normalise kernel vs the reference's host path: float64 (x-mu)/std then .float() -- bit-exact;
+    k-fold index map and odd-batch clipping as in dataset.py:765-772 / train_ards_detector.py:482-494."""
+    from deepards_amd.data import DeviceTileStore
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'test_dataset_windows.npz'))
+    store = DeviceTileStore(z['x'], z['target'], float(z['mu']), float(z['std']))
+    ref = ((z['x'] - float(z['mu'])) / float(z['std'])).astype(np.float32)
+    x, t = store.batch([3, 0, 19, 7])
+    assert np.array_equal(x.cpu().numpy(), ref[[3, 0, 19, 7]])
+    assert np.array_equal(t.cpu().numpy(), z['target'][[3, 0, 19, 7]])
+    store.set_kfold_indexes([10, 11, 12, 13, 14])
+    x, t = store.batch([4, 0])
+    assert np.array_equal(x.cpu().numpy(), ref[[14, 10]])
+    sizes = [len(i) for i, _, _ in store.epoch(2, shuffle=True, generator=torch.Generator().manual_seed(0))]
+    assert sizes == [2, 2] and len(store) == 5          # the odd last batch of 1 is clipped away
+
+
+def test_test_epoch_votes_on_device(M):
+    """Window argmax + per-patient vote table (metrics.py:572-604) computed on the device vs numpy."""
+    from deepards_amd.data import DeviceTileStore
+    from deepards_amd.train import HotPathTrainer, run_test_epoch
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'test_dataset_windows.npz'))
+    store = DeviceTileStore(z['x'], z['target'], float(z['mu']), float(z['std']))
+    slot = np.arange(20) % 6                      # 6 synthetic patients (ids are not exported from the fixture)
+    model = build(M, 'densenet18', 3)
+    tr = HotPathTrainer(model, use_graph=False)
+    res = run_test_epoch(tr, store, slot, batch_size=8)
+    with torch.no_grad():
+        x, _ = store.batch(np.arange(20))
+        logits = torch.cat([model(x[i:i + 8], None) for i in range(0, 20, 8)]).cpu().numpy()
+    pred = (logits[:, 1] > logits[:, 0]).astype(int)
+    assert np.array_equal(res['window_pred'], pred)
+    votes = np.zeros((6, 2), dtype=int)
+    np.add.at(votes, (slot, pred), 1)
+    assert np.array_equal(res['votes'], votes)
+    assert np.array_equal(res['prediction'], votes.argmax(1))
+    assert np.allclose(res['pred_frac'], votes[:, 1] / votes.sum(1))

@@ -8,7 +8,7 @@ import pytest
 from oracle import np_ref
 from oracle.weights import seeded_params, digest, DEAD_RESNET_PARAMS
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*.npz')))
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*net18_*.npz')))
 
 
 def _load(path):
