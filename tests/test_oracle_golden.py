@@ -20,7 +20,8 @@ def _load(path):
 def test_np_oracle_matches_reference(path):
     g = _load(path)
     backbone = str(g['backbone'])
-    params = {k: v.astype(np.float64) for k, v in seeded_params(backbone, int(g['seed'])).items()}
+    params = {k: v.astype(np.float64)
+              for k, v in seeded_params(backbone, int(g['seed']), bn_bias_shift=float(g['bn_bias_shift'])).items()}
     out = np_ref.cnn_linear_forward_backward(params, g['x'].astype(np.float64), g['target'].astype(np.float64),
                                              backbone=backbone, first_pool_type=str(g['first_pool_type']))
     np.testing.assert_allclose(out['logits'], g['logits64'], rtol=0, atol=1e-10)
@@ -29,7 +30,7 @@ def test_np_oracle_matches_reference(path):
     for k in g:
         if k.startswith('grad64/'):
             name = k[len('grad64/'):]
-            np.testing.assert_allclose(digest(out['grads'][name]), g[k], rtol=1e-8, atol=1e-11, err_msg=name)
+            np.testing.assert_allclose(digest(out['grads'][name]), g[k], rtol=1e-8, atol=1e-9, err_msg=name)
             checked += 1
     dead = [n for n in DEAD_RESNET_PARAMS if n in params]
     assert checked == len(params) - (len(dead) if backbone == 'resnet18' else 0)
@@ -94,9 +95,10 @@ def test_torch_oracle_matches_reference(path):
     from oracle import torch_ref
     g = _load(path)
     backbone = str(g['backbone'])
-    p = {k: torch.from_numpy(v) for k, v in seeded_params(backbone, int(g['seed'])).items()}
+    p = {k: torch.from_numpy(v)
+         for k, v in seeded_params(backbone, int(g['seed']), bn_bias_shift=float(g['bn_bias_shift'])).items()}
     out = torch_ref.cnn_linear(p, torch.from_numpy(g['x']), backbone, str(g['first_pool_type']))
-    assert np.abs(out.detach().numpy() - g['logits32']).max() < 2e-6
+    assert np.abs(out.detach().numpy() - g['logits32']).max() < 2e-6 * max(1.0, np.abs(g['logits32']).max())
 
 
 def test_torch_oracle_sgd_matches_reference():
