@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--no-extra', action='store_true', help='skip the secondary densenet18 measurement')
     return ap.parse_args()
 
 
@@ -270,6 +271,26 @@ def main():
         if wg:
             out['wgrad_tflops'] = round(wg['flops'] / (wg['total_ms'] * 1e-3) / 1e12, 2)
         out['eager_kernel_ms_per_step'] = round(tot / nprof, 3)
+
+    if world == 1 and not args.no_extra and args.backbone == 'resnet18':
+        # secondary figure: the reference's DEFAULT backbone (defaults.yml:18), same step definition, dropout active
+        torch.manual_seed(0)
+        m2 = M.CNNLinearNetwork(M.densenet18(), 20, 0).to(dev)
+        tr2 = HotPathTrainer(m2, optimizer='sgd', use_graph=not args.no_graph)
+        for _ in range(3):
+            tr2.train_step(x, t)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            tr2.train_step(x, t)
+        torch.cuda.synchronize()
+        d2 = (time.perf_counter() - t1) / args.steps
+        w2 = WORK['densenet18']
+        out['extra'] = {'densenet18': {'value': round(B * 20 / d2, 1), 'ms_per_step': round(1e3 * d2, 4),
+                                       'alg_tflops': round(w2['flops'] * B * 20 / d2 / 1e12, 2),
+                                       'alg_gbs': round((w2['act_bytes'] * B * 20 + 32 * w2['params']) / d2 / 1e9, 1),
+                                       'note': 'cnn_linear+densenet18 (reference default backbone), drop_rate 0.2 active'}}
+        say('densenet18 extra done')
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         say('cpu baseline ...')

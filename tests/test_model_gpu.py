@@ -295,3 +295,28 @@ def test_test_epoch_votes_on_device(M):
     assert np.array_equal(res['votes'], votes)
     assert np.array_equal(res['prediction'], votes.argmax(1))
     assert np.allclose(res['pred_frac'], votes[:, 1] / votes.sum(1))
+
+
+def test_data_parallel_step_structure_on_one_gpu(M):
+    """The world_size > 1 step (graph: zero-grad/forward/backward -> eager all-reduce of the flat bucket ->
+    graph: 1/W scale + clamp + SGD) exercised on ONE GPU with a stand-in all-reduce that sums two identical
+    ranks (g -> 2g): with gscale = 1/2 it must reproduce the single-GPU trajectory bit for bit."""
+    from deepards_amd.train import HotPathTrainer, FlatBucket
+    g = _gold([p for p in GOLD if 'resnet18_b2_randn' in p][0])
+    x = torch.from_numpy(g['x']).cuda()
+    t = torch.from_numpy(g['target']).cuda()
+    ref_model = build(M, 'resnet18', 0)
+    ref_tr = HotPathTrainer(ref_model, use_graph=True)
+    dp_model = build(M, 'resnet18', 0)
+    dp_tr = HotPathTrainer(dp_model, use_graph=True, world_size=2, rank=0)
+    orig = FlatBucket.allreduce
+    FlatBucket.allreduce = lambda self, group=None: self.g.mul_(2.0)      # sum over 2 identical ranks
+    try:
+        for _ in range(4):
+            l_ref = float(ref_tr.train_step(x, t))
+            l_dp = float(dp_tr.train_step(x, t))
+            assert l_ref == l_dp
+    finally:
+        FlatBucket.allreduce = orig
+    for (n, p), (_, q) in zip(ref_model.named_parameters(), dp_model.named_parameters()):
+        assert torch.equal(p, q), n
