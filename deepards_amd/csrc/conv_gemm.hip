@@ -409,23 +409,35 @@ struct WgradReduceTable {
 };
 
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgradReduceTable t, int accumulate) {
+  // block = 256 consecutive slab elements (64 lanes x float4 = 1 KiB contiguous per split) x 4 split slots
   const WgradReduceDesc& d = t.d[blockIdx.y];
-  const int total = d.ntaps * d.N * d.C;
-  if ((int)blockIdx.x * 32 >= total) return;
-  __shared__ float red[8][32];
-  const int i = blockIdx.x * 32 + (threadIdx.x & 31), slot = threadIdx.x >> 5;
-  float s = 0.f;
-  if (i < total)
-    for (int sp = slot; sp < d.splits; sp += 8) s += d.slab[(size_t)sp * total + i];
-  red[slot][threadIdx.x & 31] = s;
+  const int total = d.ntaps * d.N * d.C;          // multiple of 1024 (N, C multiples of 32)
+  if ((int)blockIdx.x * 256 >= total) return;
+  __shared__ f32x4 red[4][64];
+  const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  const int i = blockIdx.x * 256 + lane * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int sp = slot; sp < d.splits; sp += 4) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(d.slab + (size_t)sp * total + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] += v[e];
+  }
+  red[slot][lane] = s;
   __syncthreads();
-  if (threadIdx.x < 32 && i < total) {
-    s = 0.f;
-    for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
-    int tap = i / (d.N * d.C);
-    int rem = i - tap * d.N * d.C;
-    size_t o = (size_t)rem * d.ntaps + tap;
-    d.dw[o] = accumulate ? d.dw[o] + s : s;
+  if (slot == 0) {
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += red[k][lane][e];
+    // slab order [tap][co][ci] -> torch order [co][ci][tap]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int ii = i + e;
+      int tap = ii / (d.N * d.C);
+      int rem = ii - tap * d.N * d.C;
+      size_t o = (size_t)rem * d.ntaps + tap;
+      d.dw[o] = accumulate ? d.dw[o] + s[e] : s[e];
+    }
   }
 }
 
@@ -548,7 +560,7 @@ int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumula
       int tot = s.ntaps * s.N * s.C;
       if (tot > maxtot) maxtot = tot;
     }
-    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((maxtot + 31) / 32, m), dim3(256), 0, stream, t, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((maxtot + 255) / 256, m), dim3(256), 0, stream, t, accumulate);
     DA_CHECK_LAUNCH();
   }
   return DA_OK;
