@@ -202,6 +202,119 @@ static int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
   return DA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3-tap, stride-1 convolution (forward and data gradient of every k3 s1 conv: the bulk of the FLOPs) with
+// the three taps sharing ONE staged A panel: for a channel chunk the 64 output positions need source
+// positions m0-1 .. m0+64 of the flattened [rows*L] sequence axis -- 66 rows staged once, read three times
+// with a row shift; positions whose neighbour belongs to another sequence (j == 0 for the -1 tap, j == L-1 for
+// the +1 tap) are zeroed at fragment-read time.  Per 48 MFMAs a wave issues 9 vector loads instead of 12 and
+// sits through one barrier pair instead of three.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3_halo_kernel(ConvGemmArgs a) {
+  constexpr int BM = 64, BN = 64, PITCH = 36, AROWS = BM + 2;
+  __shared__ float lds[AROWS * PITCH + 3 * BN * PITCH];
+  float* As = lds;
+  float* Bs = lds + AROWS * PITCH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = a.N / BN;
+  const int lin = xcd_linear_tile(blockIdx.x, gridDim.x);
+  const int m_blk = (lin / ntn) * BM, n_blk = (lin % ntn) * BN;
+  const int lr = tid >> 3, lq = tid & 7;
+  const int L = (int)a.divLm.d;
+  const int kc = a.C >> 5;
+
+  // A loader: rows e = lr + 32*p (p = 0,1) and, for the first 16 threads, the two halo-completing rows 64, 65
+  // source position of row e: m_blk - 1 + e on the flattened axis (valid while 0 <= pos < M)
+  f32x4 ra[3], rb[6];
+  auto gload = [&](int kstep) {
+    const int c0 = kstep << 5;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      int e = p < 2 ? lr + 32 * p : 64 + (tid >> 3);
+      int pos = m_blk - 1 + e;
+      bool ok = pos >= 0 && pos < a.M && (p < 2 || tid < 16);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(a.x + (size_t)pos * a.ldx + c0 + lq * 4);
+      ra[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      int t = p >> 1;
+      int wt = t == 0 ? a.wt0 : (t == 1 ? a.wt1 : a.wt2);
+      int n = n_blk + lr + 32 * (p & 1);
+      rb[p] = *reinterpret_cast<const f32x4*>(a.w + ((size_t)wt * a.N + n) * a.C + c0 + lq * 4);
+    }
+  };
+
+  // per-lane edge flags of its fragment row: which taps fall outside the row's own sequence
+  const int frow = lane & 31, fh = lane >> 5;
+  const int m_lane = m_blk + wm * 32 + frow;
+  const uint32_t rowq = fdiv((uint32_t)(m_lane < a.M ? m_lane : 0), a.divLm);
+  const int j_lane = (m_lane < a.M ? m_lane : 0) - (int)rowq * L;
+  const bool at_first = j_lane == 0, at_last = j_lane == L - 1;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  gload(0);
+  for (int ks = 0; ks < kc; ++ks) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(&As[(lr + 32 * p) * PITCH + lq * 4]) = ra[p];
+    if (tid < 16) *reinterpret_cast<f32x4*>(&As[(64 + (tid >> 3)) * PITCH + lq * 4]) = ra[2];
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+      *reinterpret_cast<f32x4*>(&Bs[((p >> 1) * BN + lr + 32 * (p & 1)) * PITCH + lq * 4]) = rb[p];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int so = t == 0 ? a.so0 : (t == 1 ? a.so1 : a.so2);
+      const bool dead = (so < 0 && at_first) || (so > 0 && at_last);
+#pragma unroll
+      for (int c8 = 0; c8 < 4; ++c8) {
+        if (t == 2 && c8 == 1) {   // next chunk's loads late in the MFMA sequence (see GLOAD_AT)
+          __builtin_amdgcn_sched_barrier(0);
+          if (ks + 1 < kc) gload(ks + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 af = *reinterpret_cast<const f32x4*>(&As[(wm * 32 + frow + so + 1) * PITCH + c8 * 8 + fh * 4]);
+        f32x4 bf = *reinterpret_cast<const f32x4*>(&Bs[(t * BN + wn * 32 + frow) * PITCH + c8 * 8 + fh * 4]);
+        if (dead) af = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue (dst position == flattened m: stride-1, same length)
+  size_t off[16];
+  bool ok[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int m = m_blk + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+    ok[r] = m < a.M;
+    off[r] = (size_t)(ok[r] ? m : 0) * a.ldy;
+  }
+  const int n = n_blk + wn * 32 + frow;
+  if (a.accumulate) {
+    float old[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) old[r] = ok[r] ? a.y[off[r] + n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ok[r]) a.y[off[r] + n] = acc[r] + old[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ok[r]) a.y[off[r] + n] = acc[r];
+  }
+}
+
+static int g_use_halo = 1;
+
 // Tile choice.  Measured on MI355X: every tile shape below runs at about the same per-block MFMA
 // efficiency, so the choice is about balance: blocks are work-conserving on a CU, the makespan is
 // max-blocks-per-CU / mean-blocks-per-CU.  Pick the largest tile whose grid keeps that ratio high.
@@ -215,6 +328,16 @@ static int conv_gemm_dispatch(const ConvGemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return DA_OK;
   if (a.C % 32 || a.N % 32 || a.ldx % 4 || a.ntaps < 1 || a.ntaps > 3) return DA_EINVAL;
   if ((uint64_t)a.M * (uint64_t)a.divLm.d >= 0xffffffffull) return DA_EINVAL;
+  // k3 stride-1 (forward / data gradient): shared-panel kernel (+2 % on C >= 128; its 37 KB of LDS cap a CU at 4
+  // blocks, which costs more than it gains on the 2-chunk C = 64 layer).  Needs src and dst on the same flattened axis.
+  if (g_use_halo && a.C >= 128 && a.ntaps == 3 && a.src_stride == 1 && a.dst_stride == 1 && a.dst_off == 0 && a.N % 64 == 0 &&
+      a.Lsrc == (int)a.divLm.d && a.Ldst == (int)a.divLm.d && a.so0 >= -1 && a.so0 <= 1 && a.so1 >= -1 && a.so1 <= 1 &&
+      a.so2 >= -1 && a.so2 <= 1 && !g_force_conv_tile) {
+    dim3 grid(((a.M + 63) / 64) * (a.N / 64));
+    hipLaunchKernelGGL(conv3_halo_kernel, grid, dim3(256), 0, s, a);
+    DA_CHECK_LAUNCH();
+    return DA_OK;
+  }
   // candidates: id, BM, BN, relative per-block efficiency
   struct Cand { int id, bm, bn; double eff; };
   static const Cand cands[] = {{1, 128, 128, 1.00}, {2, 64, 128, 0.99}, {3, 128, 64, 0.97}, {4, 64, 64, 0.93},
@@ -503,6 +626,7 @@ extern "C" {
 int da_debug_set(int key, int value) {
   if (key == 0) g_force_conv_tile = value;
   else if (key == 1) g_wgrad_target_blocks = value;
+  else if (key == 2) g_use_halo = value;
   else return DA_EINVAL;
   return DA_OK;
 }

@@ -8,6 +8,7 @@ from deepards_amd import hip_ops as H
 ROWS = int(os.environ.get('ROWS', 1280))
 from deepards_amd import _lib
 if os.environ.get('TILE'): _lib.lib().da_debug_set(0, int(os.environ['TILE']))
+if os.environ.get('HALO'): _lib.lib().da_debug_set(2, int(os.environ['HALO']))
 if os.environ.get('WGB'): _lib.lib().da_debug_set(1, int(os.environ['WGB']))
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 SHAPES = [  # ci, co, k, stride, L
