@@ -6,9 +6,13 @@ Activation layout "RLC": contiguous ``(rows, L, C)`` float32 CUDA tensors (chann
 BatchNorm window = ``R`` consecutive rows (reference models/torch_cnn_linear_network.py:108-113).
 """
 import ctypes
+import os
+
 import torch
 
 from . import _lib
+
+_DEBUG_SYNC = os.environ.get('DEEPARDS_DEBUG_SYNC') == '1'      # debugging aid: synchronise after every launch
 
 
 class HipError(RuntimeError):
@@ -21,10 +25,6 @@ def _stream():
 
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
-
-
-import os
-_DEBUG_SYNC = os.environ.get('DEEPARDS_DEBUG_SYNC') == '1'
 
 
 def _chk(rc, name):

@@ -9,7 +9,6 @@ containers here: ``forward`` runs the hand-written HIP kernels through
 """
 import math
 
-import torch
 import torch.nn as nn
 
 from .. import functional as F_
