@@ -53,10 +53,10 @@ __global__ __launch_bounds__(256) void kc(float* out, const float* __restrict__ 
       __syncthreads();
     }
     if ((MODE & 2) && !(MODE & 4) && !(MODE & 8)) {
-      size_t o = (base + (size_t)it * 32) % span;
+      size_t o = (base + (size_t)it * 32) & (span - 1);
       for (int p = 0; p < 2; ++p) {
         ra[p] = *reinterpret_cast<const f32x4*>(src + o + p * 2048);
-        rb[p] = *reinterpret_cast<const f32x4*>(src + (o + 4096 + p * 2048) % span);
+        rb[p] = *reinterpret_cast<const f32x4*>(src + ((o + 4096 + p * 2048) & (span - 1)));
       }
     }
 #pragma unroll
@@ -67,53 +67,55 @@ __global__ __launch_bounds__(256) void kc(float* out, const float* __restrict__ 
       for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
     }
     if ((MODE & 2) && (MODE & 4)) {   // loads issued after the MFMAs
-      size_t o = (base + (size_t)it * 32) % span;
+      size_t o = (base + (size_t)it * 32) & (span - 1);
       for (int p = 0; p < 2; ++p) {
         ra[p] = *reinterpret_cast<const f32x4*>(src + o + p * 2048);
-        rb[p] = *reinterpret_cast<const f32x4*>(src + (o + 4096 + p * 2048) % span);
+        rb[p] = *reinterpret_cast<const f32x4*>(src + ((o + 4096 + p * 2048) & (span - 1)));
       }
     }
     if (MODE & 16) {  // second register stage: what was loaded one step ago moves up, new loads go two steps ahead
-      size_t o = (base + (size_t)it * 32) % span;
+      size_t o = (base + (size_t)it * 32) & (span - 1);
       for (int p = 0; p < 2; ++p) {
         ra[p] = ra2[p]; rb[p] = rb2[p];
         ra2[p] = *reinterpret_cast<const f32x4*>(src + o + p * 2048);
-        rb2[p] = *reinterpret_cast<const f32x4*>(src + (o + 4096 + p * 2048) % span);
+        rb2[p] = *reinterpret_cast<const f32x4*>(src + ((o + 4096 + p * 2048) & (span - 1)));
       }
     }
     if (MODE & 8) {   // async global->LDS (no VGPR staging), linear layout, other half of the LDS
-      size_t o = (base + (size_t)it * 32) % span;
+      size_t o = (base + (size_t)it * 32) & (span - 1);
       float* dst = lds + 128 * 36 + wave * 1024;   // wave-uniform base; lane*16B appended by hardware
       for (int p = 0; p < 4; ++p)
-        __builtin_amdgcn_global_load_lds((const void*)(src + (o + p * 2048) % span), (__attribute__((address_space(3))) void*)(dst + p * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(src + ((o + p * 2048) & (span - 1))), (__attribute__((address_space(3))) void*)(dst + p * 256), 16, 0, 0);
     }
   }
   float s = 0; for (int r = 0; r < 16; ++r) s += acc[r];
   out[blockIdx.x * 256 + threadIdx.x] = s + ra[0][0] + rb[1][3] + ra2[0][0] + rb2[1][1];
 }
-// producer/consumer specialisation: wave 4 moves global -> regs -> LDS[(it+1)&1], waves 0-3 only do
+// producer/consumer specialisation: NLOAD loader waves move global -> regs -> LDS[(it+1)&1], waves 0-3 only do
 // LDS reads + MFMA on LDS[it&1]; one barrier per step; consumers never touch vector memory.
-__global__ __launch_bounds__(320) void kspec(float* out, const float* __restrict__ src, int iters, size_t span) {
+template <int NLOAD>
+__global__ __launch_bounds__(256 + 64 * NLOAD) void kspec(float* out, const float* __restrict__ src, int iters, size_t span) {
   __shared__ float lds[2 * 128 * 36];
-  for (int i = threadIdx.x; i < 2 * 128 * 36; i += 320) lds[i] = (float)i * 1e-6f;
+  for (int i = threadIdx.x; i < 2 * 128 * 36; i += blockDim.x) lds[i] = (float)i * 1e-6f;
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   f32x16 acc; for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  f32x4 st[16];
-  for (int p = 0; p < 16; ++p) st[p] = f32x4{1, 2, 3, 4};
+  constexpr int PER = 16 / NLOAD;          // float4 loads per loader lane per step (16 KB per block-step)
+  f32x4 st[PER];
+  for (int p = 0; p < PER; ++p) st[p] = f32x4{1, 2, 3, 4};
   size_t base = ((size_t)blockIdx.x * 64) * 64;
   const int wm = (wave & 3) >> 1, wn = wave & 1;
   for (int it = 0; it < iters; ++it) {
     float* buf = lds + (it & 1) * 128 * 36;
     float* nbuf = lds + ((it + 1) & 1) * 128 * 36;
-    if (wave == 4) {
-      // write what was loaded during the previous step, then issue the loads of the next one
-      for (int p = 0; p < 16; ++p) {
-        int row = p * 8 + (lane >> 3), q = lane & 7;
+    if (wave >= 4) {
+      const int lw = wave - 4;
+      for (int p = 0; p < PER; ++p) {
+        int row = (lw * PER + p) * 8 + (lane >> 3), q = lane & 7;
         *reinterpret_cast<f32x4*>(&nbuf[row * 36 + q * 4]) = st[p];
       }
-      size_t o = (base + (size_t)it * 32) % span;
-      for (int p = 0; p < 16; ++p) st[p] = *reinterpret_cast<const f32x4*>(src + (o + (size_t)p * 512 + lane * 4) % span);
+      size_t o = (base + (size_t)it * 32) & (span - 1);
+      for (int p = 0; p < PER; ++p) st[p] = *reinterpret_cast<const f32x4*>(src + ((o + (size_t)(lw * PER + p) * 512 + lane * 4) & (span - 1)));
     } else {
 #pragma unroll
       for (int c8 = 0; c8 < 4; ++c8) {
@@ -126,20 +128,21 @@ __global__ __launch_bounds__(320) void kspec(float* out, const float* __restrict
     __syncthreads();
   }
   float s = 0; for (int r = 0; r < 16; ++r) s += acc[r];
-  out[blockIdx.x * 320 + threadIdx.x] = s + st[0][0] + st[15][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s + st[0][0] + st[PER - 1][3];
 }
+template <int NLOAD>
 void runspec(int blocks_per_cu, size_t span_floats) {
-  float* out; hipMalloc(&out, 256 * 8 * 320 * 4);
+  float* out; hipMalloc(&out, 256 * 8 * 512 * 4);
   float* src; hipMalloc(&src, span_floats * 4 + (1 << 20)); hipMemset(src, 0, span_floats * 4 + (1 << 20));
-  int iters = 2000, grid = 256 * blocks_per_cu;
+  int iters = 2000, grid = 256 * blocks_per_cu, th = 256 + 64 * NLOAD;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(kspec, dim3(grid), dim3(320), 0, 0, out, src, iters, span_floats);
+  hipLaunchKernelGGL((kspec<NLOAD>), dim3(grid), dim3(th), 0, 0, out, src, iters, span_floats);
   hipEventRecord(e0);
-  hipLaunchKernelGGL(kspec, dim3(grid), dim3(320), 0, 0, out, src, iters, span_floats);
+  hipLaunchKernelGGL((kspec<NLOAD>), dim3(grid), dim3(th), 0, 0, out, src, iters, span_floats);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   double flops = (double)grid * 4 * iters * 16 * 4096.0;
-  printf("%-44s blocks/CU %d: %.3f ms  %.1f TF/s\n", "conv-mimic: SPECIALISED loader wave", blocks_per_cu, ms, flops / ms / 1e9);
+  printf("conv-mimic: SPECIALISED %d loader waves         blocks/CU %d: %.3f ms  %.1f TF/s\n", NLOAD, blocks_per_cu, ms, flops / ms / 1e9);
   hipFree(out); hipFree(src);
 }
 template <int MODE>
@@ -174,7 +177,7 @@ void run(const char* name, int blocks_per_cu) {
 int main() {
   for (int b : {1, 2, 4}) { run<1, 0>("1 acc, regs", b); run<2, 0>("2 acc, regs", b); run<4, 0>("4 acc, regs", b); }
   for (int b : {1, 2, 4}) { run<1, 1>("1 acc, LDS b128 reads", b); run<2, 1>("2 acc, LDS reads", b); run<1, 2>("1 acc, LDS reads + barrier", b); }
-  for (int b : {2, 4}) runspec(b, 1 << 22);
+  for (int b : {2, 4}) { runspec<1>(b, 1 << 22); runspec<2>(b, 1 << 22); runspec<4>(b, 1 << 22); }
   for (int b : {2, 4}) {
     runc<0>("conv-mimic: LDS reads only", b, 1 << 22);
     runc<1>("conv-mimic: + 2 barriers + staging writes", b, 1 << 22);
@@ -182,6 +185,8 @@ int main() {
     runc<7>("conv-mimic: loads AFTER the MFMAs (L2)", b, 1 << 22);
     runc<2>("conv-mimic: loads, no barriers/staging", b, 1 << 22);
     runc<17>("conv-mimic: staging + DISTANCE-2 reg prefetch", b, 1 << 22);
+    runc<8>("conv-mimic: glds x4, no staging, no barrier", b, 1 << 22);
+    runc<9>("conv-mimic: barriers+staging + glds x4 (L2)", b, 1 << 22);
   }
   return 0;
 }
