@@ -62,6 +62,8 @@ class KernelTimer(object):
             return 2.0 * a[3] * a[4] * a[7] * a[10] * a[14]
         if name == 'da_conv_wgrad':      # dy,x,dw,ws,rows,Lm,Ldy,lddy,N,Lx,ldx,C,...,ntaps at index 15
             return 2.0 * a[4] * a[5] * a[8] * a[11] * a[15]
+        if name == 'da_conv_wgrad_multi':   # jobs (host array of da_wgrad_job), n
+            return sum(2.0 * a[0][i].rows * a[0][i].Lm * a[0][i].N * a[0][i].C * a[0][i].ntaps for i in range(a[1]))
         return 0.0
 
     def install(self, names):
@@ -245,7 +247,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         # instrumented EAGER steps: HIP events around every C-ABI launch, on the launch stream
         kt = KernelTimer(lib, torch)
-        names = [n for n in _lib.SIGNATURES if n not in ('da_version', 'da_conv_wgrad_workspace', 'da_stem_wgrad_workspace', 'da_bn_workspace', 'da_debug_set', 'da_bn_chunks', 'da_conv_wgrad_splits',
+        names = [n for n in _lib.SIGNATURES if n not in ('da_version', 'da_conv_wgrad_workspace', 'da_stem_wgrad_workspace', 'da_bn_workspace', 'da_debug_set', 'da_bn_chunks', 'da_conv_wgrad_splits', 'da_conv_wgrad_plan',
                                                           'da_hip_runtime_symbol')]
         tr_e = HotPathTrainer(model, optimizer='sgd', use_graph=False)
         tr_e.bucket, tr_e.state = tr.bucket, tr.state
@@ -267,8 +269,8 @@ def main():
                            'alg_flops_per_launch': round(dom['flops'] / dom['calls'], 1)}
         tot = sum(v['total_ms'] for v in summ.values())
         out['kernel_time_share'] = {k: round(v['total_ms'] / tot, 4) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]['total_ms'])}
-        wg = summ.get('da_conv_wgrad')
-        if wg:
+        wg = summ.get('da_conv_wgrad_multi') or summ.get('da_conv_wgrad')
+        if wg and wg['flops']:
             out['wgrad_tflops'] = round(wg['flops'] / (wg['total_ms'] * 1e-3) / 1e12, 2)
         out['eager_kernel_ms_per_step'] = round(tot / nprof, 3)
 

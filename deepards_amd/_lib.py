@@ -31,6 +31,12 @@ class WgradReduceDesc(ctypes.Structure):
     _fields_ = [('slab', _P), ('dw', _P), ('splits', _I), ('ntaps', _I), ('N', _I), ('C', _I)]
 
 
+class WgradJob(ctypes.Structure):
+    _fields_ = [('dy', _P), ('x', _P), ('workspace', _P)] + [(n, _I) for n in
+               ('rows', 'Lm', 'Ldy', 'lddy', 'N', 'Lx', 'ldx', 'C', 'dy_stride', 'dy_off', 'src_stride', 'ntaps')] + \
+               [('src_off', _I * 3)]
+
+
 class RepackDesc(ctypes.Structure):
     _fields_ = [('W', _P), ('Wf', _P), ('Wd', _P), ('Co', _I), ('Ci', _I), ('K', _I)]
 
@@ -56,6 +62,8 @@ SIGNATURES = {
     'da_bn_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
     'da_bn_param_grad_multi': (_I, [ctypes.POINTER(BnPgradDesc), _I, _I, _P]),
     'da_conv_wgrad_splits': (_I, [_I] * 5),
+    'da_conv_wgrad_plan': (_I, [_I] * 5 + [ctypes.POINTER(_I)]),
+    'da_conv_wgrad_multi': (_I, [ctypes.POINTER(WgradJob), _I, _P]),
     'da_wgrad_reduce_multi': (_I, [ctypes.POINTER(WgradReduceDesc), _I, _I, _P]),
     'da_repack_multi': (_I, [ctypes.POINTER(RepackDesc), _I, _P]),
     'da_bn_relu_pool_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
@@ -116,6 +124,9 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _check_same_runtime(l)
+        for key, env in ((0, 'DA_CONV_TILE'), (1, 'DA_WGRAD_BLOCKS'), (2, 'DA_HALO')):      # tuning knobs (scripts/)
+            if os.environ.get(env):
+                l.da_debug_set(key, int(os.environ[env]))
         _lib = l
     return _lib
 

@@ -22,6 +22,9 @@
 // reads 4 consecutive k of its row, lane half h takes k = 8*c8 + 4*h + e, the same permutation for
 // both operands, so each MFMA pairs identical k on A and B).
 #include "common.h"
+#include <algorithm>
+#include <utility>
+#include <vector>
 
 #ifndef WGRAD_GLOAD_AT
 #define WGRAD_GLOAD_AT 8
@@ -383,10 +386,9 @@ struct WgradArgs {
 // output tile (TM*WGM*32 co) x (TN*WGN*32 ci); K = positions, 32 per step; LDS tiles stored as they
 // sit in HBM ([pos][channel]): lane (i, h) reads T[2*kk + h][i] -- 32 consecutive floats per half.
 template <int TM, int TN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block_id, const int nblocks, float* lds) {
   constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32;
   static_assert(WGM * WGN == 4, "4 waves");
-  __shared__ float lds[32 * (BM + BN)];
   float* Ys = lds;             // [32][BM]
   float* Xs = lds + 32 * BM;   // [32][BN]
 
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int ntn = a.C / BN, ntm = a.N / BM;
   const int tiles = ntm * ntn * a.ntaps;
   // tile fastest: the tiles that re-read one position chunk of dY / X are consecutive on one XCD
-  const int lin = xcd_linear_tile(blockIdx.x, gridDim.x);
+  const int lin = xcd_linear_tile(block_id, nblocks);
   int bx = lin % tiles;
   const int split = lin / tiles;
   const int t = bx / (ntm * ntn);
@@ -497,6 +499,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         int c = c_blk + (wn * TN + j) * 32 + frow;
         out[(size_t)n * a.C + c] = acc[i][j][r];
       }
+}
+
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  __shared__ float lds[32 * (TM * WGM * 32 + TN * WGN * 32)];
+  wgrad_body<TM, TN, WGM, WGN>(a, blockIdx.x, gridDim.x, lds);
+}
+
+// All weight gradients of a step that share a tile shape in ONE launch.  They are independent of each other and of
+// the rest of the backward pass, and each alone has only 1-2 blocks per CU at B = 64 -- too few to hide its own
+// ramp-up and tail (the same kernel runs ~20 % faster with 8 tiles per CU than with 4, scripts/balance_probe.py).
+struct WgradTable {
+  WgradArgs d[24];
+  int first_block[25];
+  int n;
+};
+
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_wgrad_multi_kernel(WgradTable t) {
+  __shared__ float lds[32 * (TM * WGM * 32 + TN * WGN * 32)];
+  int i = 0;
+  while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
+  wgrad_body<TM, TN, WGM, WGN>(t.d[i], blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i], lds);
 }
 
 // dW[co][ci][k] (torch layout) (+)= sum_split slab[split][k][co][ci]
@@ -619,6 +644,58 @@ static WgradPlan wgrad_plan(int M, int N, int C, int ntaps) {
 // =============================================================================================
 // C ABI
 // =============================================================================================
+typedef struct {
+  const float* dy;
+  const float* x;
+  float* workspace;      // da_conv_wgrad_workspace() bytes: receives the split-K slabs
+  int rows, Lm, Ldy, lddy, N, Lx, ldx, C, dy_stride, dy_off, src_stride, ntaps;
+  int src_off[3];
+} da_wgrad_job;
+
+template <int TM, int TN, int WGM, int WGN>
+static int launch_wgrad_group(const da_wgrad_job* jobs, int n, int tn, int tc, hipStream_t s) {
+  constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32;
+  WgradTable t;
+  int cnt = 0, blocks = 0;
+  auto flush = [&]() -> int {
+    if (!cnt) return DA_OK;
+    t.n = cnt;
+    t.first_block[cnt] = blocks;
+    hipLaunchKernelGGL((conv_wgrad_multi_kernel<TM, TN, WGM, WGN>), dim3(blocks), dim3(256), 0, s, t);
+    DA_CHECK_LAUNCH();
+    cnt = 0;
+    blocks = 0;
+    return DA_OK;
+  };
+  // longest blocks first (block time ~ kchunk * taps-independent tile work): short ones fill the launch's tail
+  std::vector<std::pair<int, int>> order;
+  for (int i = 0; i < n; ++i) {
+    WgradPlan pl = wgrad_plan(jobs[i].rows * jobs[i].Lm, jobs[i].N, jobs[i].C, jobs[i].ntaps);
+    if (pl.tn == tn && pl.tc == tc) order.push_back({-pl.kchunk, i});
+  }
+  std::stable_sort(order.begin(), order.end());
+  for (const auto& o : order) {
+    const da_wgrad_job& j = jobs[o.second];
+    WgradPlan pl = wgrad_plan(j.rows * j.Lm, j.N, j.C, j.ntaps);
+    WgradArgs& a = t.d[cnt];
+    a.dy = j.dy; a.x = j.x; a.slab = j.workspace;
+    a.M = j.rows * j.Lm; a.Ldy = j.Ldy; a.lddy = j.lddy; a.N = j.N;
+    a.Lx = j.Lx; a.ldx = j.ldx; a.C = j.C;
+    a.dy_stride = j.dy_stride; a.dy_off = j.dy_off; a.src_stride = j.src_stride;
+    a.ntaps = j.ntaps;
+    a.so0 = j.src_off[0]; a.so1 = j.ntaps > 1 ? j.src_off[1] : 0; a.so2 = j.ntaps > 2 ? j.src_off[2] : 0;
+    a.kchunk = pl.kchunk;
+    a.divLm = make_fastdiv((uint32_t)j.Lm);
+    t.first_block[cnt] = blocks;
+    blocks += (j.N / BM) * (j.C / BN) * j.ntaps * pl.splits;
+    if (++cnt == 24) {
+      int rc = flush();
+      if (rc) return rc;
+    }
+  }
+  return flush();
+}
+
 extern "C" {
 
 // Benchmark-only tuning knobs.  key 0: force the conv GEMM tile (0 auto, 1 128x128, 2 64x128, 3 128x64,
@@ -659,9 +736,40 @@ size_t da_conv_wgrad_workspace(int rows, int Lm, int N, int C, int ntaps) {
   return (size_t)p.splits * ntaps * N * C * sizeof(float);
 }
 
+// Slabs of n weight gradients (jobs: HOST array) with one launch per tile shape; reduce them afterwards with
+// da_wgrad_reduce_multi (da_conv_wgrad_splits() slabs per job).
+int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
+  DA_ENTER();
+  if (n < 0 || (n && !jobs)) return DA_EINVAL;
+  for (int i = 0; i < n; ++i) {
+    const da_wgrad_job& j = jobs[i];
+    if (!j.dy || !j.x || !j.workspace || j.ntaps < 1 || j.ntaps > 3 || j.C % 32 || j.N % 32 || j.lddy % 4 || j.ldx % 4)
+      return DA_EINVAL;
+    if ((uint64_t)j.rows * j.Lm * (uint64_t)j.Lm >= 0xffffffffull) return DA_EINVAL;
+    if (!wgrad_plan(j.rows * j.Lm, j.N, j.C, j.ntaps).tn) return DA_EINVAL;
+  }
+  int rc;
+  if ((rc = launch_wgrad_group<2, 2, 2, 2>(jobs, n, 128, 128, stream))) return rc;
+  if ((rc = launch_wgrad_group<2, 1, 2, 2>(jobs, n, 128, 64, stream))) return rc;
+  if ((rc = launch_wgrad_group<1, 2, 2, 2>(jobs, n, 64, 128, stream))) return rc;
+  if ((rc = launch_wgrad_group<1, 1, 2, 2>(jobs, n, 64, 64, stream))) return rc;
+  if ((rc = launch_wgrad_group<1, 1, 4, 1>(jobs, n, 128, 32, stream))) return rc;
+  if ((rc = launch_wgrad_group<1, 1, 1, 4>(jobs, n, 32, 128, stream))) return rc;
+  return DA_OK;
+}
+
 // number of slabs da_conv_wgrad writes for this shape (workspace = splits * ntaps*N*C floats)
 int da_conv_wgrad_splits(int rows, int Lm, int N, int C, int ntaps) {
   return wgrad_plan(rows * Lm, N, C, ntaps).splits;
+}
+
+// the plan da_conv_wgrad / da_conv_wgrad_multi use for this shape: out = {tile_n, tile_c, splits, kchunk};
+// a job's workspace is splits * ntaps*N*C floats.
+int da_conv_wgrad_plan(int rows, int Lm, int N, int C, int ntaps, int* out) {
+  if (!out || ntaps < 1 || ntaps > 3 || N % 32 || C % 32) return DA_EINVAL;
+  WgradPlan p = wgrad_plan(rows * Lm, N, C, ntaps);
+  out[0] = p.tn; out[1] = p.tc; out[2] = p.splits; out[3] = p.kchunk;
+  return p.tn ? DA_OK : DA_EINVAL;
 }
 
 typedef struct {

@@ -34,12 +34,12 @@ class BNState(object):
 #   * the ~60 tiny per-layer launches -- BN running statistics, BN dgamma/dbeta folds, split-K slab
 #     reductions of the weight gradients -- are queued and served by three batched launches.
 # Outside it (plain autograd use, tests) everything runs immediately.
-_STEP = {'on': False, 'pack': {}, 'running': [], 'pgrad': [], 'wgrad': []}
+_STEP = {'on': False, 'pack': {}, 'running': [], 'pgrad': [], 'wgrad': [], 'wslab': []}
 
 
 @contextlib.contextmanager
 def training_step(model=None):
-    _STEP.update(on=True, pack={}, running=[], pgrad=[], wgrad=[])
+    _STEP.update(on=True, pack={}, running=[], pgrad=[], wgrad=[], wslab=[])
     try:
         if model is not None:
             ws = [m.weight for m in model.modules()
@@ -49,7 +49,7 @@ def training_step(model=None):
                 _STEP['pack'][w.data_ptr()] = e
         yield
     finally:
-        _STEP.update(on=False, pack={}, running=[], pgrad=[], wgrad=[])
+        _STEP.update(on=False, pack={}, running=[], pgrad=[], wgrad=[], wslab=[])
 
 
 def flush_forward():
@@ -61,8 +61,17 @@ def flush_forward():
 def flush_backward():
     """Run the queued parameter-gradient folds (call after the backward, before the optimiser)."""
     H.bn_param_grad_multi(_STEP['pgrad'], accumulate=True)
-    H.wgrad_reduce_multi(_STEP['wgrad'], accumulate=True)
-    _STEP['pgrad'], _STEP['wgrad'] = [], []
+    _launch_wgrads()
+    H.wgrad_reduce_multi(_STEP['wslab'], accumulate=True)
+    _STEP['pgrad'], _STEP['wslab'] = [], []
+
+
+def _launch_wgrads():
+    jobs = _STEP['wgrad']                        # (dy, x, k, stride, pad, target): queued weight-gradient GEMMs, one launch
+    if jobs:
+        slabs = H.conv_wgrad_multi([j[:5] for j in jobs])
+        _STEP['wslab'] += [(sl, j[5]) for sl, j in zip(slabs, jobs)]
+        _STEP['wgrad'] = []
 
 
 def _wf(w):
@@ -160,7 +169,7 @@ def _bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, tg, tb, out=None, dx=No
 
 def _wgrad(dy, x, k, stride, pad, tw):
     if tw is not None and _STEP['on']:
-        _STEP['wgrad'].append((H.conv_wgrad(dy, x, k, stride, pad, defer=True), tw))
+        _STEP['wgrad'].append((dy, x, k, stride, pad, tw))     # launched with all the others by flush_backward()
         return None
     dw = H.conv_wgrad(dy, x, k, stride, pad, out=tw, accumulate=tw is not None)
     return None if tw is not None else dw

@@ -143,6 +143,34 @@ def conv_wgrad(dy, x, k, stride, pad, out=None, accumulate=False, defer=False):
     return out
 
 
+def conv_wgrad_multi(jobs):
+    """jobs: [(dy, x, k, stride, pad)] -> [(slab, splits, k, co, ci)]: every weight-gradient GEMM of the list in
+    one launch per tile shape (slabs only; reduce with wgrad_reduce_multi)."""
+    if not jobs:
+        return []
+    L = _lib.lib()
+    arr = (_lib.WgradJob * len(jobs))()
+    plan = (ctypes.c_int * 4)()
+    outs = []
+    for d, (dy, x, k, stride, pad) in zip(arr, jobs):
+        _rlc(dy, 'dy')
+        _rlc(x, 'x')
+        rows, lo, co = dy.shape
+        rows2, l, ci = x.shape
+        if rows != rows2 or lo != conv_out_len(l, k, stride, pad) or k > 3 or ci % 32 or co % 32:
+            raise ValueError('conv_wgrad_multi: unsupported shape')
+        _chk(L.da_conv_wgrad_plan(rows, lo, co, ci, k, plan), 'da_conv_wgrad_plan')
+        ws = torch.empty((plan[2] * k * co * ci,), device=x.device, dtype=torch.float32)
+        d.dy, d.x, d.workspace = dy.data_ptr(), x.data_ptr(), ws.data_ptr()
+        d.rows, d.Lm, d.Ldy, d.lddy, d.N, d.Lx, d.ldx, d.C = rows, lo, lo, co, co, l, ci, ci
+        d.dy_stride, d.dy_off, d.src_stride, d.ntaps = 1, 0, stride, k
+        for t in range(3):
+            d.src_off[t] = t - pad if t < k else 0
+        outs.append((ws, plan[2], k, co, ci))
+    _chk(L.da_conv_wgrad_multi(arr, len(jobs), _stream()), 'da_conv_wgrad_multi')
+    return outs
+
+
 def wgrad_reduce_multi(items, accumulate=True):
     """items: ((slab, splits, k, co, ci), dw) -- one launch per 32 convolutions."""
     if not items:

@@ -52,8 +52,17 @@ int da_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, 
 /* benchmark-only tuning knobs: key 0 = force conv tile id, key 1 = wgrad target blocks (0 = automatic) */
 int da_debug_set(int key, int value);
 
+/* all weight-gradient GEMMs of a step in one launch per tile shape (jobs: HOST array); slabs only, reduce afterwards */
+typedef struct {
+  const float* dy; const float* x; float* workspace;
+  int rows, Lm, Ldy, lddy, N, Lx, ldx, C, dy_stride, dy_off, src_stride, ntaps; int src_off[3];
+} da_wgrad_job;
+int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, da_stream_t stream);
 /* deferred slab reduction: da_conv_wgrad with dw == NULL leaves da_conv_wgrad_splits() slabs in the workspace */
 int da_conv_wgrad_splits(int rows, int Lm, int N, int C, int ntaps);
+/* host only: out[4] = {tile_n, tile_c, splits, positions per split} the plan of da_conv_wgrad and
+   da_conv_wgrad_multi for this shape; a job's workspace is splits * ntaps*N*C floats */
+int da_conv_wgrad_plan(int rows, int Lm, int N, int C, int ntaps, int* out);
 typedef struct { const float* slab; float* dw; int splits, ntaps, N, C; } da_wgrad_reduce_desc;
 int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumulate, da_stream_t stream);
 

@@ -64,6 +64,30 @@ CONV_CASES = [
 ]
 
 
+def test_conv_wgrad_multi_matches_single_jobs(H):
+    """Every weight gradient of a step in one launch per tile shape (da_conv_wgrad_multi: 30 jobs, so more than one
+    24-entry table) == the oracle, and bit-identical to the one-job launches (same plan, same slabs)."""
+    rng = np.random.default_rng(77)
+    jobs, refs, targets, singles = [], [], [], []
+    for n, (ci, co, k, stride, pad, L, rows) in enumerate(CONV_CASES + CONV_CASES[:12]):
+        x = rng.standard_normal((rows, ci, L))
+        lo = (L + 2 * pad - k) // stride + 1
+        dy = rng.standard_normal((rows, co, lo))
+        w = np.zeros((co, ci, k))
+        refs.append(np_ref.conv1d_bwd(x, w, dy, stride, pad)[1])
+        xt, dyt = rlc(x), rlc(dy)
+        jobs.append((dyt, xt, k, stride, pad))
+        targets.append(torch.zeros(co, ci, k, device='cuda'))
+        singles.append(torch.zeros(co, ci, k, device='cuda'))
+        H.wgrad_reduce_multi([(H.conv_wgrad(dyt, xt, k, stride, pad, defer=True), singles[-1])], accumulate=True)
+    slabs = H.conv_wgrad_multi(jobs)
+    H.wgrad_reduce_multi(list(zip(slabs, targets)), accumulate=True)
+    for n, (t, r, s1) in enumerate(zip(targets, refs, singles)):
+        close(t.cpu().numpy(), r, tol=3e-6, name='job %d' % n)
+        assert torch.equal(t, s1), 'job %d differs from the one-job launch' % n
+    assert H.conv_wgrad_multi([]) == []
+
+
 @pytest.mark.parametrize('ci,co,k,stride,pad,L,rows', CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(H, ci, co, k, stride, pad, L, rows):
     rng = np.random.default_rng(ci * 1000 + co + k + L)
