@@ -14,6 +14,8 @@
 #define CG 32       // channels per block
 #define SLOTS 32    // position slots per block (256 threads / 8 quads)
 
+static int g_bn_two_stage = 0;   // da_bn_debug_two_stage(): force the two-stage kernels (tests compare both paths)
+
 __device__ __forceinline__ void block_fold(float (&v)[4], float* red, int slot, int q, float (&out)[4]) {
   // red: [SLOTS][CG]; returns the per-channel total to every thread that owns those channels
   __syncthreads();
@@ -316,6 +318,204 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Single-pass forms.  For Wn <= FUSED_MAX_WN a (window, 32-channel) slab fits the registers of one
+// block (thread = one channel quad x NPOS positions), so every tensor crosses HBM exactly once:
+//   forward : read x (+res), write out           (two-stage path: x is read by stats AND by apply)
+//   backward: read dout, x (+out), write dx (+g) (two-stage path: both are read by reduce AND apply)
+// block = 8 quads x P position slots, P = ceil(Wn / NPOS) rounded to 8 (whole waves); the fold over
+// slots is 3 wave shuffles + one LDS exchange between the waves, in a fixed order (deterministic).
+// Both kernels read their whole slab before the first store, so out/dx may alias an input.
+// -------------------------------------------------------------------------------------------------
+#define FUSED_NPOS 10
+#define FUSED_MAX_WN (FUSED_NPOS * 128)
+
+template <int NV>
+__device__ __forceinline__ void quad_block_sum(f32x4 (&v)[NV], float* red) {
+  // lanes 8s+q of a wave hold the same channel quad q for 8 slots s
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = v[i][e];
+      t += __shfl_xor(t, 8, 64);
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      v[i][e] = t;
+    }
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6, q = threadIdx.x & 7;
+  __syncthreads();
+  if (lane < 8) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(&red[(wv * NV + i) * CG + lane * 4]) = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nw; ++k) {
+      f32x4 r = *reinterpret_cast<const f32x4*>(&red[(k * NV + i) * CG + q * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] += r[e];
+    }
+    v[i] = t;
+  }
+}
+
+// mean / invstd of the window (two-pass from registers), published, and out = act(bn(x) (+res))
+template <int NPOS>
+__global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ res, int ldr,
+                                                            float* __restrict__ out, int ldo, int Wn, int C,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int relu, float eps,
+                                                            float* __restrict__ mean_out,
+                                                            float* __restrict__ invstd_out) {
+  __shared__ float red[16 * CG];
+  const int w = blockIdx.x, cg = blockIdx.y, P = blockDim.x >> 3;
+  const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  const int c0 = cg * CG + q * 4;
+  const size_t base = (size_t)w * Wn;
+  const float* xb = x + base * ldx + cg * CG;      // wave-uniform bases + 32-bit lane offsets
+  const float* rb = res ? res + base * ldr + cg * CG : nullptr;
+  float* ob = out + base * ldo + cg * CG;
+  f32x4 v[NPOS];
+#pragma unroll
+  for (int k = 0; k < NPOS; ++k) {
+    const int p = slot + k * P;
+    v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p < Wn) v[k] = *reinterpret_cast<const f32x4*>(xb + (uint32_t)(p * ldx + q * 4));
+  }
+  f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int k = 0; k < NPOS; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[0][e] += v[k][e];
+  quad_block_sum<1>(acc, red);
+  const float inv_n = 1.0f / (float)Wn;
+  f32x4 mu;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) mu[e] = acc[0][e] * inv_n;
+  acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NPOS; ++k) {
+    if (slot + k * P < Wn) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float d = v[k][e] - mu[e];
+        acc[0][e] += d * d;
+      }
+    }
+  }
+  quad_block_sum<1>(acc, red);
+  f32x4 is;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) is[e] = 1.0f / sqrtf(acc[0][e] * inv_n + eps);
+  if (slot == 0) {
+    *reinterpret_cast<f32x4*>(mean_out + (size_t)w * C + c0) = mu;
+    *reinterpret_cast<f32x4*>(invstd_out + (size_t)w * C + c0) = is;
+  }
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c0);
+#pragma unroll
+  for (int k = 0; k < NPOS; ++k) {
+    const int p = slot + k * P;
+    if (p < Wn) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mu[e]) * is[e] * ga[e] + be[e];
+      if (rb) {
+        f32x4 r = *reinterpret_cast<const f32x4*>(rb + (uint32_t)(p * ldr + q * 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += r[e];
+      }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(ob + (uint32_t)(p * ldo + q * 4)) = o;
+    }
+  }
+}
+
+// same arithmetic as bn_bwd_reduce_kernel + bn_bwd_apply_kernel with the slab held in registers
+template <int NPOS>
+__global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restrict__ dout, int ldd,
+                                                            const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ outp, int ldo,
+                                                            float* __restrict__ dx, int lddx, float* __restrict__ gout,
+                                                            int ldg, int Wn, int C, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int mask_mode,
+                                                            float* __restrict__ ds1, float* __restrict__ ds2) {
+  __shared__ float red[16 * 2 * CG];
+  const int w = blockIdx.x, cg = blockIdx.y, P = blockDim.x >> 3;
+  const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  const int c0 = cg * CG + q * 4;
+  // wave-uniform slab bases + 32-bit lane offsets (one SGPR pair + one VGPR per access instead of a 64-bit VGPR pair)
+  const size_t base = (size_t)w * Wn;
+  const float* db = dout + base * ldd + cg * CG;
+  const float* xb = x + base * ldx + cg * CG;
+  const float* ob = outp ? outp + base * ldo + cg * CG : nullptr;
+  float* dxb = dx + base * lddx + cg * CG;
+  float* gb = gout ? gout + base * ldg + cg * CG : nullptr;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
+  const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * C + c0);
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c0);
+  f32x4 g[NPOS], xh[NPOS];
+#pragma unroll
+  for (int k = 0; k < NPOS; ++k) {
+    const int p = slot + k * P;
+    g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    xh[k] = mu;
+    if (p < Wn) {
+      g[k] = *reinterpret_cast<const f32x4*>(db + (uint32_t)(p * ldd + q * 4));
+      xh[k] = *reinterpret_cast<const f32x4*>(xb + (uint32_t)(p * ldx + q * 4));
+    }
+  }
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int k = 0; k < NPOS; ++k) {
+    const int p = slot + k * P;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xh[k][e] = (xh[k][e] - mu[e]) * is[e];
+    if (p < Wn) g[k] = bn_masked_g(g[k], xh[k], ga, be, mask_mode, ob, (uint32_t)(p * ldo + q * 4));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[0][e] += g[k][e];
+      acc[1][e] += g[k][e] * xh[k][e];
+    }
+  }
+  quad_block_sum<2>(acc, red);
+  if (slot == 0) {
+    *reinterpret_cast<f32x4*>(ds1 + (size_t)w * C + c0) = acc[0];
+    *reinterpret_cast<f32x4*>(ds2 + (size_t)w * C + c0) = acc[1];
+  }
+  const float inv_n = 1.0f / (float)Wn;
+#pragma unroll
+  for (int k = 0; k < NPOS; ++k) {
+    const int p = slot + k * P;
+    if (p < Wn) {
+      f32x4 d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        d[e] = ga[e] * is[e] * (g[k][e] - acc[0][e] * inv_n - xh[k][e] * acc[1][e] * inv_n);
+      *reinterpret_cast<f32x4*>(dxb + (uint32_t)(p * lddx + q * 4)) = d;
+      if (gb) *reinterpret_cast<f32x4*>(gb + (uint32_t)(p * ldg + q * 4)) = g[k];
+    }
+  }
+}
+
+// block size of the single-pass kernels for a window of Wn positions (0: does not fit, use the two-stage path)
+static int bn_fused_threads(int Wn) {
+  if (Wn < 1 || Wn > FUSED_MAX_WN || g_bn_two_stage) return 0;
+  int P = (Wn + FUSED_NPOS - 1) / FUSED_NPOS;
+  P = (P + 7) / 8 * 8;
+  return 8 * P;
+}
+
 // dbeta[c] (+)= sum_w s1[w][c];  dgamma[c] (+)= sum_w s2[w][c] for up to 32 BatchNorms in one launch
 // (blockIdx.y = which BN); block = 32 channels x 8 window slots, fixed order (deterministic).
 struct BnPgradDesc {
@@ -482,6 +682,34 @@ int da_bn_apply(const float* x, int ldx, const float* res, int ldr, float* out, 
   return DA_OK;
 }
 
+// Statistics + normalisation in one call: mean/invstd [W][C] are OUTPUTS, out = act(bn(x) (+res)).
+// One single-pass kernel when a window slab fits a block's registers (Wn <= 1280), otherwise
+// da_bn_stats_partial + da_bn_apply.  scratch: da_bn_workspace() bytes.
+int da_bn_fwd(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
+              float* mean, float* invstd, const float* gamma, const float* beta, int relu, float eps, float* scratch,
+              hipStream_t stream) {
+  DA_ENTER();
+  if (!x || !out || !mean || !invstd || !gamma || !beta || !scratch || C % CG || ldx % 4 || ldo % 4 ||
+      (res && ldr % 4) || Wn < 1)
+    return DA_EINVAL;
+  if (W == 0) return DA_OK;
+  if (int threads = bn_fused_threads(Wn)) {
+    hipLaunchKernelGGL((bn_fwd_fused_kernel<FUSED_NPOS>), dim3(W, C / CG), dim3(threads), 0, stream, x, ldx, res, ldr,
+                       out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd);
+    DA_CHECK_LAUNCH();
+    return DA_OK;
+  }
+  int rc = da_bn_stats_partial(x, ldx, W, Wn, C, scratch, stream);
+  if (rc) return rc;
+  return da_bn_apply(x, ldx, res, ldr, out, ldo, W, Wn, C, mean, invstd, gamma, beta, relu, scratch, eps, stream);
+}
+
+// tests: 1 = always take the two-stage kernels (so both paths are checked against the oracle)
+int da_bn_debug_two_stage(int on) {
+  g_bn_two_stage = on;
+  return DA_OK;
+}
+
 // scratch: da_bn_workspace() bytes.  ds: [2][W][C] per-window totals (sum g, sum g*xhat), always written.
 // dgamma/dbeta: [C]; when both are non-NULL they are computed here (accumulated when accumulate != 0),
 // when NULL the caller folds ds later with da_bn_param_grad_multi.
@@ -500,12 +728,18 @@ int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* 
   bn_chunks(W, Wn, C, &P, &chunk);
   float* s1 = ds;
   float* s2 = ds + (size_t)W * C;
+  if (int threads = bn_fused_threads(Wn)) {
+    hipLaunchKernelGGL((bn_bwd_fused_kernel<FUSED_NPOS>), dim3(W, C / CG), dim3(threads), 0, stream, dout, ldd, x, ldx,
+                       out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2);
+    DA_CHECK_LAUNCH();
+  } else {
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(W, C / CG, P), dim3(256), 0, stream, dout, ldd, x, ldx, out, ldo, Wn, C,
                      chunk, mean, invstd, gamma, beta, mask_mode, scratch);
   DA_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(W, C / CG, P), dim3(256), 0, stream, dout, ldd, x, ldx, out, ldo, dx,
                      lddx, gout, ldg, Wn, C, chunk, mean, invstd, gamma, beta, mask_mode, scratch, s1, s2);
   DA_CHECK_LAUNCH();
+  }
   if (dgamma) {
     BnPgradTable t;
     t.d[0] = {s1, s2, dgamma, dbeta, W, C};

@@ -96,22 +96,18 @@ def _tgt(*params):
 
 
 class _Stats(object):
-    """Per-window statistics of one BatchNorm input: chunk records now, mean/invstd once a consumer ran."""
-    __slots__ = ('part', 'mean', 'invstd')
+    """Per-window statistics of one BatchNorm input (filled by the BatchNorm's consumer, _bn_apply)."""
+    __slots__ = ('mean', 'invstd')
 
 
 def _stats(x, R, st):
-    s = _Stats()
-    s.part = H.bn_stats_partial(x, R)
-    w = x.shape[0] // R
-    s.mean = torch.empty((w, x.shape[2]), device=x.device, dtype=torch.float32)
-    s.invstd = torch.empty_like(s.mean)
-    return s
+    return _Stats()
 
 
 def _bn_apply(x, R, s, st, gamma, beta, relu, res=None):
-    """act(bn(x)(+res)); merges the chunk records (fills s.mean / s.invstd) and books the running update."""
-    out = H.bn_apply(x, R, s.mean, s.invstd, gamma, beta, relu=relu, res=res, part=s.part, eps=st.eps)
+    """act(bn(x)(+res)): statistics and normalisation in one call; fills s.mean / s.invstd and books the running
+    update."""
+    out, s.mean, s.invstd = H.bn_fwd(x, R, gamma, beta, relu=relu, res=res, eps=st.eps)
     _running(x, R, s, st)
     return out
 

@@ -289,6 +289,30 @@ def bn_apply(x, R, mean, invstd, gamma, beta, relu=True, res=None, out=None, par
     return out
 
 
+def bn_fwd(x, R, gamma, beta, relu=True, res=None, eps=1e-5, out=None):
+    """-> out, mean, invstd: per-window statistics and out = act(bn(x) (+res)) in one call (single pass over x when
+    a window slab fits a block's registers)."""
+    _rlc(x, 'x')
+    rows, l, c = x.shape
+    if rows % R:
+        raise ValueError('rows %d not a multiple of rows_per_window %d' % (rows, R))
+    w = rows // R
+    if out is None:
+        out = torch.empty_like(x)
+    if res is not None and tuple(res.shape) != tuple(x.shape):
+        raise ValueError('residual shape mismatch')
+    mean = torch.empty((w, c), device=x.device, dtype=torch.float32)
+    invstd = torch.empty((w, c), device=x.device, dtype=torch.float32)
+    scratch = _bn_ws(w, R * l, c, x.device)
+    _chk(_lib.lib().da_bn_fwd(_p(x), c, _p(res), c, _p(out), c, w, R * l, c, _p(mean), _p(invstd), _p(gamma), _p(beta),
+                              1 if relu else 0, eps, _p(scratch), _stream()), 'da_bn_fwd')
+    return out, mean, invstd
+
+
+def bn_debug_two_stage(on):
+    _chk(_lib.lib().da_bn_debug_two_stage(1 if on else 0), 'da_bn_debug_two_stage')
+
+
 def bn_bwd(dout, x, R, mean, invstd, gamma, beta, mask_mode, out=None, want_g=False, dx=None,
            dgamma=None, dbeta=None, accumulate=False, defer_param_grads=False):
     """-> dx, dgamma, dbeta, g, ds.  g = masked upstream gradient (only when want_g); ds (2,W,C) holds the

@@ -100,6 +100,14 @@ int da_bn_running_multi(const da_bn_running_desc* descs, int n, da_stream_t stre
 int da_bn_apply(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
                 float* mean, float* invstd, const float* gamma, const float* beta, int relu, const float* part,
                 float eps, da_stream_t stream);
+/* statistics + normalisation in one call (mean/invstd [W][C] are OUTPUTS): one single-pass kernel when a window
+   slab fits a block's registers (Wn <= 1280), else da_bn_stats_partial + da_bn_apply.  scratch: da_bn_workspace().
+   replaces nn.BatchNorm1d(+ReLU)(+residual) forward, reference models/resnet.py:27-38, models/densenet.py:23-29 */
+int da_bn_fwd(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
+              float* mean, float* invstd, const float* gamma, const float* beta, int relu, float eps, float* scratch,
+              da_stream_t stream);
+/* tests: on != 0 forces the two-stage kernels in da_bn_fwd / da_bn_bwd (both paths are checked against the oracle) */
+int da_bn_debug_two_stage(int on);
 /* mask_mode 0: no ReLU; 1: ReLU, mask recomputed from bn(x); 2: ReLU, mask from `out` (residual).
  * scratch: da_bn_workspace() bytes.  ds: [2][W][C] per-window totals, always written.  dgamma/dbeta NULL:
  * fold ds later with da_bn_param_grad_multi. */

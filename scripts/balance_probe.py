@@ -9,7 +9,7 @@ def timeit(fn, reps=30):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for rows, L in ((1024, 8), (1152, 8), (1280, 7), (1280, 8), (2048, 8), (2304, 8)):
+for rows, L in ((1024, 8), (1152, 8), (1170, 7), (1280, 7), (1280, 8), (1463, 7), (1536, 8), (2048, 8), (2304, 8)):
     for ci, co in ((512, 512), (256, 256)):
         x = torch.randn(rows, L, ci, device='cuda'); w = torch.randn(co, ci, 3, device='cuda') * 0.05
         wf, _ = H.repack_weight(w, True, True)

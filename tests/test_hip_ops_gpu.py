@@ -151,8 +151,19 @@ def test_stem_conv(H, rows, L):
 
 
 @pytest.mark.parametrize('C,L,R,W', [(64, 56, 20, 3), (128, 28, 20, 2), (512, 7, 20, 2), (96, 56, 20, 1),
-                                     (64, 112, 20, 2), (32, 5, 3, 4)])
-def test_bn_fwd_bwd(H, C, L, R, W):
+                                     (64, 112, 20, 2), (32, 5, 3, 4), (256, 14, 20, 2), (32, 64, 20, 1)])
+@pytest.mark.parametrize('two_stage', [False, True])
+def test_bn_fwd_bwd(H, C, L, R, W, two_stage):
+    """da_bn_fwd / da_bn_bwd take a single-pass register-resident kernel for Wn <= 1280 and the two-stage kernels
+    above that; two_stage forces the latter so that both are checked on every shape."""
+    H.bn_debug_two_stage(two_stage)
+    try:
+        _bn_fwd_bwd(H, C, L, R, W)
+    finally:
+        H.bn_debug_two_stage(False)
+
+
+def _bn_fwd_bwd(H, C, L, R, W):
     rng = np.random.default_rng(C + L + R)
     rows = W * R
     x = rng.standard_normal((rows, C, L)) * rng.uniform(0.2, 3, (1, C, 1)) + rng.uniform(-4, 4, (1, C, 1))
@@ -203,6 +214,12 @@ def test_bn_fwd_bwd(H, C, L, R, W):
     sl_g = (np.abs(dout) * unsure * np.abs((y_ref - beta[None, :, None]) / gamma[None, :, None])).sum(axis=(0, 2))
     assert np.all(np.abs(dg2.cpu().numpy() - dg_ref - 1) <= 2e-5 * (1 + np.abs(dg_ref).max()) + sl_g), 'deferred dgamma'
     assert np.all(np.abs(db2.cpu().numpy() - db_ref - 1) <= 2e-5 * (1 + np.abs(db_ref).max()) + sl_b), 'deferred dbeta' 
+    # statistics + normalisation in one call
+    for relu_, res_, ref_ in ((False, None, y_ref), (True, None, np.maximum(y_ref, 0)), (True, res, out_ref)):
+        o3, m3, i3 = H.bn_fwd(xt, R, gt, bt, relu=relu_, res=None if res_ is None else rlc(res_))
+        close(ncl(o3), ref_, tol=5e-6, name='bn_fwd out')
+        close(m3.cpu().numpy(), st[0], name='bn_fwd mean')
+        close(i3.cpu().numpy(), st[1], tol=5e-6, name='bn_fwd invstd')
     # statistics through the fused consumer: bn_apply merges the chunk records and publishes mean/invstd
     part = H.bn_stats_partial(xt, R)
     m2_, i2_ = torch.empty_like(mean), torch.empty_like(invstd)
