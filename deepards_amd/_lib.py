@@ -126,7 +126,7 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _check_same_runtime(l)
-        for key, env in ((0, 'DA_CONV_TILE'), (1, 'DA_WGRAD_BLOCKS'), (2, 'DA_HALO')):      # tuning knobs (scripts/)
+        for key, env in ((0, 'DA_CONV_TILE'), (1, 'DA_WGRAD_BLOCKS'), (2, 'DA_HALO'), (3, 'DA_TAIL')):      # tuning knobs (scripts/)
             if os.environ.get(env):
                 l.da_debug_set(key, int(os.environ[env]))
         _lib = l

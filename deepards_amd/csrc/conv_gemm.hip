@@ -57,10 +57,9 @@ struct ConvGemmArgs {
 };
 
 template <int TM, int TN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
+__device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs& a, const int block_id, const int nblocks, float* lds) {
   constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32, PITCH = 36;
   static_assert(WGM * WGN == 4, "4 waves");
-  __shared__ float lds[(BM + BN) * PITCH];
   float* As = lds;
   float* Bs = lds + BM * PITCH;
 
@@ -68,7 +67,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
   const int wm = wave / WGN, wn = wave % WGN;
   // n-tile fastest, contiguous chunk per XCD: the N/BN tiles that re-read one A panel run back to back on one L2
   const int ntn = a.N / BN;
-  const int lin = xcd_linear_tile(blockIdx.x, gridDim.x);
+  const int lin = xcd_linear_tile(block_id, nblocks);
   const int m_blk = (lin / ntn) * BM, n_blk = (lin % ntn) * BN;
   const int lr = tid >> 3, lq = tid & 7;
   const int Lm = (int)a.divLm.d;
@@ -192,6 +191,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
   }
 }
 
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
+  __shared__ float lds[(TM * WGM * 32 + TN * WGN * 32) * 36];
+  conv_gemm_body<TM, TN, WGM, WGN>(a, blockIdx.x, gridDim.x, lds);
+}
+
 // tuning knobs (benchmark use): 0 = automatic
 static int g_force_conv_tile = 0;
 static int g_wgrad_target_blocks = 0;
@@ -213,16 +218,15 @@ static int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t s) {
 // the +1 tap) are zeroed at fragment-read time.  Per 48 MFMAs a wave issues 9 vector loads instead of 12 and
 // sits through one barrier pair instead of three.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv3_halo_kernel(ConvGemmArgs a) {
+__device__ __forceinline__ void conv3_halo_body(const ConvGemmArgs& a, const int block_id, const int nblocks, float* lds) {
   constexpr int BM = 64, BN = 64, PITCH = 36, AROWS = BM + 2;
-  __shared__ float lds[AROWS * PITCH + 3 * BN * PITCH];
   float* As = lds;
   float* Bs = lds + AROWS * PITCH;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ntn = a.N / BN;
-  const int lin = xcd_linear_tile(blockIdx.x, gridDim.x);
+  const int lin = xcd_linear_tile(block_id, nblocks);
   const int m_blk = (lin / ntn) * BM, n_blk = (lin % ntn) * BN;
   const int lr = tid >> 3, lq = tid & 7;
   const int L = (int)a.divLm.d;
@@ -316,7 +320,162 @@ __global__ __launch_bounds__(256) void conv3_halo_kernel(ConvGemmArgs a) {
   }
 }
 
+#define HALO_LDS_FLOATS ((64 + 2) * 36 + 3 * 64 * 36)
+__global__ __launch_bounds__(256) void conv3_halo_kernel(ConvGemmArgs a) {
+  __shared__ float lds[HALO_LDS_FLOATS];
+  conv3_halo_body(a, blockIdx.x, gridDim.x, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tail tiles.  A grid of T 64x64 tiles runs as rounds of 256 (one per CU and slot); the R = T % 256 tiles of the
+// last, partly filled round cost a whole round (at the bench batch every layer has T = 1120: 4.375 rounds paid as 5).
+// Those R tiles are cut into 2R half tiles -- 32 positions x 64 channels -- whose 4 waves also split every
+// 64-channel K step in two (wave = (channel half wn, k half ks)); the two partial accumulators meet in LDS.
+// A half tile occupies a CU for a quarter of a full tile's MFMA time, so the partial round costs ~0.5 instead of 1.
+// They are the first blocks of the same launch (padded to a multiple of 8 so that block id % 8 stays the XCD of the
+// full tiles) and share the CUs with the full tiles from the start.
+// ---------------------------------------------------------------------------------------------
+#define TAIL_LDS_FLOATS ((2 * 32 + 2 * 64) * 36)
+__device__ __forceinline__ void conv_tail_body(const ConvGemmArgs& a, const int mini_id, const int first_tile, float* lds) {
+  constexpr int PITCH = 36;
+  float* As = lds;                     // [2 k halves][32][PITCH]
+  float* Bs = lds + 2 * 32 * PITCH;    // [2 k halves][64][PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, ks = wave >> 1;
+  const int ntn = a.N >> 6;
+  const int lin = first_tile + (mini_id >> 1);
+  const int m_blk = (lin / ntn) * 64 + 32 * (mini_id & 1), n_blk = (lin % ntn) * 64;
+  const int lr = tid >> 3, lq = tid & 7;
+  const int Lm = (int)a.divLm.d;
+
+  const int m_a = m_blk + lr;
+  const bool a_ok = m_a < a.M;
+  const uint32_t row_a = fdiv((uint32_t)(a_ok ? m_a : 0), a.divLm);
+  const int a_rowoff = (int)row_a * a.Lsrc;
+  const int a_j = ((a_ok ? m_a : 0) - (int)row_a * Lm) * a.src_stride;
+
+  const int kc = a.C >> 6;
+  const int nk = a.ntaps * kc;
+  f32x4 ra[2], rb[4];
+  auto gload = [&](int it) {
+    const int t = it / kc;
+    const int c0 = (it - t * kc) << 6;
+    const int so = t == 0 ? a.so0 : (t == 1 ? a.so1 : a.so2);
+    const int wt = t == 0 ? a.wt0 : (t == 1 ? a.wt1 : a.wt2);
+    const int ls = a_j + so;
+    const bool ok = a_ok && ls >= 0 && ls < a.Lsrc;
+    const float* src = a.x + (size_t)(a_rowoff + (ok ? ls : 0)) * a.ldx + c0 + lq * 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(src + 32 * h);
+      ra[h] = v;
+    }
+    const float* wtp = a.w + (size_t)wt * a.N * a.C + c0 + lq * 4;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        rb[2 * p + h] = *reinterpret_cast<const f32x4*>(wtp + (size_t)(n_blk + lr + 32 * p) * a.C + 32 * h);
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int frow = lane & 31, fh = lane >> 5;
+  gload(0);
+  for (int it = 0; it < nk; ++it) {
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4*>(&As[(h * 32 + lr) * PITCH + lq * 4]) = ra[h];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        *reinterpret_cast<f32x4*>(&Bs[(h * 64 + lr + 32 * p) * PITCH + lq * 4]) = rb[2 * p + h];
+    __syncthreads();
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8) {
+      if (c8 == 3) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < nk) gload(it + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const f32x4 af = *reinterpret_cast<const f32x4*>(&As[(ks * 32 + frow) * PITCH + c8 * 8 + fh * 4]);
+      const f32x4 bf = *reinterpret_cast<const f32x4*>(&Bs[(ks * 64 + wn * 32 + frow) * PITCH + c8 * 8 + fh * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
+    }
+  }
+
+  // k half 1 hands its partial sums to k half 0 (fixed order: deterministic)
+  __syncthreads();
+  float* red = lds;                    // [2 channel halves][16][64 lanes]
+  if (ks == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wn * 16 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (ks == 1) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += red[(wn * 16 + r) * 64 + lane];
+
+  size_t off[16];
+  bool ok[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m_blk + (r & 3) + 8 * (r >> 2) + 4 * fh;
+    ok[r] = m < a.M;
+    const uint32_t row = fdiv((uint32_t)(ok[r] ? m : 0), a.divLm);
+    const int jj = (ok[r] ? m : 0) - (int)row * Lm;
+    off[r] = ((size_t)row * a.Ldst + (size_t)(jj * a.dst_stride + a.dst_off)) * a.ldy;
+  }
+  const int n = n_blk + wn * 32 + frow;
+  if (a.accumulate) {
+    float old[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) old[r] = ok[r] ? a.y[off[r] + n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ok[r]) a.y[off[r] + n] = acc[r] + old[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ok[r]) a.y[off[r] + n] = acc[r];
+  }
+}
+
+// full 64x64 tiles [0, full) + the half tiles of tiles [full, full + nmini / 2) in one launch
+template <bool HALO>
+__global__ __launch_bounds__(256) void conv_gemm_tailed_kernel(ConvGemmArgs a, int nmini, int nmini_pad, int full) {
+  __shared__ float lds[HALO ? HALO_LDS_FLOATS : TAIL_LDS_FLOATS];
+  if ((int)blockIdx.x < nmini_pad) {
+    if ((int)blockIdx.x < nmini) conv_tail_body(a, blockIdx.x, full, lds);
+    return;
+  }
+  if (HALO) conv3_halo_body(a, blockIdx.x - nmini_pad, full, lds);
+  else conv_gemm_body<1, 1, 2, 2>(a, blockIdx.x - nmini_pad, full, lds);
+}
+
 static int g_use_halo = 1;
+static int g_use_tail = 1;
+
+// launch T = tiles 64x64 tiles, the partly filled last round of 256 as half tiles when that pays (see above)
+template <bool HALO>
+static int launch_conv64(const ConvGemmArgs& a, hipStream_t s) {
+  const int tiles = ((a.M + 63) / 64) * (a.N / 64);
+  const int R = tiles % 256;
+  if (g_use_tail && a.C % 64 == 0 && tiles > 256 && R >= 1 && R <= 128) {
+    const int full = tiles - R, nmini = 2 * R, nmini_pad = (nmini + 7) / 8 * 8;
+    hipLaunchKernelGGL((conv_gemm_tailed_kernel<HALO>), dim3(nmini_pad + full), dim3(256), 0, s, a, nmini, nmini_pad, full);
+  } else if (HALO) {
+    hipLaunchKernelGGL(conv3_halo_kernel, dim3(tiles), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((conv_gemm_kernel<1, 1, 2, 2>), dim3(tiles), dim3(256), 0, s, a);
+  }
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
 
 // Tile choice.  Measured on MI355X: every tile shape below runs at about the same per-block MFMA
 // efficiency, so the choice is about balance: blocks are work-conserving on a CU, the makespan is
@@ -336,10 +495,7 @@ static int conv_gemm_dispatch(const ConvGemmArgs& a, hipStream_t s) {
   if (g_use_halo && a.C >= 128 && a.ntaps == 3 && a.src_stride == 1 && a.dst_stride == 1 && a.dst_off == 0 && a.N % 64 == 0 &&
       a.Lsrc == (int)a.divLm.d && a.Ldst == (int)a.divLm.d && a.so0 >= -1 && a.so0 <= 1 && a.so1 >= -1 && a.so1 <= 1 &&
       a.so2 >= -1 && a.so2 <= 1 && !g_force_conv_tile) {
-    dim3 grid(((a.M + 63) / 64) * (a.N / 64));
-    hipLaunchKernelGGL(conv3_halo_kernel, grid, dim3(256), 0, s, a);
-    DA_CHECK_LAUNCH();
-    return DA_OK;
+    return launch_conv64<true>(a, s);
   }
   // candidates: id, BM, BN, relative per-block efficiency
   struct Cand { int id, bm, bn; double eff; };
@@ -361,7 +517,7 @@ static int conv_gemm_dispatch(const ConvGemmArgs& a, hipStream_t s) {
     case 1: return launch_conv_gemm<2, 2, 2, 2>(a, s);
     case 2: return launch_conv_gemm<1, 2, 2, 2>(a, s);
     case 3: return launch_conv_gemm<1, 2, 4, 1>(a, s);
-    case 4: return launch_conv_gemm<1, 1, 2, 2>(a, s);
+    case 4: return launch_conv64<false>(a, s);
     case 5: return launch_conv_gemm<1, 1, 4, 1>(a, s);
     case 6: return launch_conv_gemm<1, 1, 1, 4>(a, s);
     default: return DA_EINVAL;
@@ -704,6 +860,7 @@ int da_debug_set(int key, int value) {
   if (key == 0) g_force_conv_tile = value;
   else if (key == 1) g_wgrad_target_blocks = value;
   else if (key == 2) g_use_halo = value;
+  else if (key == 3) g_use_tail = value;
   else return DA_EINVAL;
   return DA_OK;
 }

@@ -61,6 +61,12 @@ CONV_CASES = [
     (128, 32, 3, 1, 1, 7, 40),
     (128, 128, 3, 1, 1, 28, 40),
     (128, 64, 1, 1, 0, 56, 40),
+    # more than 256 64x64 tiles with a partly filled last round: the tail runs as split-K half tiles
+    (64, 64, 3, 1, 1, 56, 300),
+    (128, 128, 3, 1, 1, 28, 300),
+    (64, 128, 3, 2, 1, 56, 300),
+    (128, 64, 1, 1, 0, 14, 1200),
+    (256, 256, 3, 1, 1, 14, 150),
 ]
 
 
