@@ -261,8 +261,8 @@ def main():
         say('roofline pass done')
         dom = summ['da_conv_gemm']
         ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_gemm_kernel<*> (da_conv_gemm: conv fwd + dgrad implicit GEMM, '
-                                                       'v_mfma_f32_32x32x2_f32)',
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_gemm_tailed_kernel<*> / conv_gemm_kernel<*> (da_conv_gemm: conv fwd + dgrad '
+                                                       'implicit GEMM, v_mfma_f32_32x32x2_f32)',
                            'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
                            'launches_per_step': dom['calls'] // nprof, 'avg_launch_us': round(dom['avg_us'], 2),

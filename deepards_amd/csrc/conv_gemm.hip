@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void conv_gemm_tailed_kernel(ConvGemmArgs a, i
   else conv_gemm_body<1, 1, 2, 2>(a, blockIdx.x - nmini_pad, full, lds);
 }
 
-static int g_use_halo = 1;
+static int g_use_halo = 128;   // smallest channel count that takes the shared-panel kernel (0: never)
 static int g_use_tail = 1;
 
 // launch T = tiles 64x64 tiles, the partly filled last round of 256 as half tiles when that pays (see above)
@@ -492,7 +492,7 @@ static int conv_gemm_dispatch(const ConvGemmArgs& a, hipStream_t s) {
   if ((uint64_t)a.M * (uint64_t)a.divLm.d >= 0xffffffffull) return DA_EINVAL;
   // k3 stride-1 (forward / data gradient): shared-panel kernel (+2 % on C >= 128; its 37 KB of LDS cap a CU at 4
   // blocks, which costs more than it gains on the 2-chunk C = 64 layer).  Needs src and dst on the same flattened axis.
-  if (g_use_halo && a.C >= 128 && a.ntaps == 3 && a.src_stride == 1 && a.dst_stride == 1 && a.dst_off == 0 && a.N % 64 == 0 &&
+  if (g_use_halo && a.C >= g_use_halo && a.ntaps == 3 && a.src_stride == 1 && a.dst_stride == 1 && a.dst_off == 0 && a.N % 64 == 0 &&
       a.Lsrc == (int)a.divLm.d && a.Ldst == (int)a.divLm.d && a.so0 >= -1 && a.so0 <= 1 && a.so1 >= -1 && a.so1 <= 1 &&
       a.so2 >= -1 && a.so2 <= 1 && !g_force_conv_tile) {
     return launch_conv64<true>(a, s);
