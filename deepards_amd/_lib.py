@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libdeepards_hip.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'deepards_hip.h')
-SOURCES = ['conv_gemm.hip', 'bn.hip', 'stem_pool.hip', 'head_optim.hip']
+SOURCES = ['conv_gemm.hip', 'conv_wino.hip', 'bn.hip', 'stem_pool.hip', 'head_optim.hip']
 
 _P, _I, _F, _Z, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_uint
 _IP = ctypes.POINTER(ctypes.c_int)
@@ -38,7 +38,7 @@ class WgradJob(ctypes.Structure):
 
 
 class RepackDesc(ctypes.Structure):
-    _fields_ = [('W', _P), ('Wf', _P), ('Wd', _P), ('Co', _I), ('Ci', _I), ('K', _I)]
+    _fields_ = [('W', _P), ('Wf', _P), ('Wd', _P), ('Uf', _P), ('Ud', _P), ('Co', _I), ('Ci', _I), ('K', _I)]
 
 
 # name -> (restype, argtypes); must list exactly the symbols the header declares (tests check it)
@@ -65,6 +65,8 @@ SIGNATURES = {
     'da_bn_param_grad_multi': (_I, [ctypes.POINTER(BnPgradDesc), _I, _I, _P]),
     'da_conv_wgrad_splits': (_I, [_I] * 5),
     'da_conv_wgrad_plan': (_I, [_I] * 5 + [ctypes.POINTER(_I)]),
+    'da_conv3_winograd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'da_wino_weights': (_I, [_P, _P, _I, _I, _I, _P]),
     'da_conv_wgrad_multi': (_I, [ctypes.POINTER(WgradJob), _I, _P]),
     'da_wgrad_reduce_multi': (_I, [ctypes.POINTER(WgradReduceDesc), _I, _I, _P]),
     'da_repack_multi': (_I, [ctypes.POINTER(RepackDesc), _I, _P]),

@@ -167,6 +167,8 @@ struct RepackDesc {
   const float* W;
   float* Wf;
   float* Wd;
+  float* Uf;   // K == 3 only: Winograd F(2,3) taps [4][Co][Ci] (forward) ...
+  float* Ud;   // ... and [4][Ci][Co] (data gradient), same arithmetic as wino_weight_kernel (conv_wino.hip)
   int Co, Ci, K;
 };
 struct RepackTable {
@@ -182,6 +184,24 @@ __global__ __launch_bounds__(256) void repack_multi_kernel(RepackTable t) {
     float v = d.W[i];
     if (d.Wf) d.Wf[((size_t)k * d.Co + co) * d.Ci + ci] = v;
     if (d.Wd) d.Wd[((size_t)k * d.Ci + ci) * d.Co + co] = v;
+    if (k == 0 && d.K == 3 && (d.Uf || d.Ud)) {
+      const float w0 = v, w1 = d.W[i + 1], w2 = d.W[i + 2];
+      const size_t tot = (size_t)d.Co * d.Ci;
+      if (d.Uf) {
+        const size_t o = (size_t)co * d.Ci + ci;
+        d.Uf[o] = w0;
+        d.Uf[tot + o] = (w0 + w1 + w2) * 0.5f;
+        d.Uf[2 * tot + o] = (w0 - w1 + w2) * 0.5f;
+        d.Uf[3 * tot + o] = w2;
+      }
+      if (d.Ud) {                              // taps reversed: g_t = w[..][2 - t]
+        const size_t o = (size_t)ci * d.Co + co;
+        d.Ud[o] = w2;
+        d.Ud[tot + o] = (w2 + w1 + w0) * 0.5f;
+        d.Ud[2 * tot + o] = (w2 - w1 + w0) * 0.5f;
+        d.Ud[3 * tot + o] = w0;
+      }
+    }
   }
 }
 
@@ -398,6 +418,8 @@ typedef struct {
   const float* W;
   float* Wf;
   float* Wd;
+  float* Uf;
+  float* Ud;
   int Co, Ci, K;
 } da_repack_desc;
 
@@ -410,8 +432,8 @@ int da_repack_multi(const da_repack_desc* descs, int n, hipStream_t stream) {
     int m = n - base < 32 ? n - base : 32;
     for (int i = 0; i < m; ++i) {
       const da_repack_desc& s = descs[base + i];
-      if (!s.W || (!s.Wf && !s.Wd)) return DA_EINVAL;
-      t.d[i] = {s.W, s.Wf, s.Wd, s.Co, s.Ci, s.K};
+      if (!s.W || (!s.Wf && !s.Wd && !s.Uf && !s.Ud) || ((s.Uf || s.Ud) && s.K != 3)) return DA_EINVAL;
+      t.d[i] = {s.W, s.Wf, s.Wd, s.Uf, s.Ud, s.Co, s.Ci, s.K};
     }
     hipLaunchKernelGGL(repack_multi_kernel, dim3(256, m), dim3(256), 0, stream, t);
     DA_CHECK_LAUNCH();

@@ -7,6 +7,7 @@ Every unit is a single autograd node with explicit gradient accumulation inside,
 graph of a model is a plain chain and no PyTorch arithmetic kernel runs on the hot path.
 """
 import contextlib
+import os
 
 import torch
 from torch.autograd import Function
@@ -42,10 +43,12 @@ def training_step(model=None):
     _STEP.update(on=True, pack={}, running=[], pgrad=[], wgrad=[], wslab=[])
     try:
         if model is not None:
-            ws = [m.weight for m in model.modules()
+            ms = [m for m in model.modules()
                   if isinstance(m, torch.nn.Conv1d) and m.kernel_size[0] <= 3 and m.in_channels % 32 == 0
                   and m.weight.is_cuda]
-            for w, e in zip(ws, H.repack_multi(ws)):
+            ws = [m.weight for m in ms]
+            wino = [_is_wino(m.weight, m.stride[0], m.padding[0]) for m in ms]
+            for w, e in zip(ws, H.repack_multi(ws, wino)):
                 _STEP['pack'][w.data_ptr()] = e
         yield
     finally:
@@ -74,18 +77,34 @@ def _launch_wgrads():
         _STEP['wgrad'] = []
 
 
-def _wf(w):
-    if _STEP['on']:
-        e = _STEP['pack'].get(w.data_ptr())
-        if e is None:
-            e = _STEP['pack'][w.data_ptr()] = H.repack_weight(w, True, True)
-        return e[0]
-    return H.repack_weight(w, True, False)[0]
+_WINOGRAD = os.environ.get('DA_WINOGRAD', '1') != '0'
 
 
-def _wd(w):
+def _is_wino(w, stride, pad):
+    """k3 s1 p1 convs run as Winograd F(2,3) (2/3 of the direct conv's MFMAs, fp32 throughout)."""
+    return _WINOGRAD and w.shape[2] == 3 and stride == 1 and pad == 1 and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0
+
+
+def _pack(w, wino):
+    """(wf, wd, uf, ud) of a conv weight: direct packs or Winograd taps, repacked once per step."""
     e = _STEP['pack'].get(w.data_ptr()) if _STEP['on'] else None
-    return e[1] if e is not None else H.repack_weight(w, False, True)[1]
+    if e is None or (e[2] is None if wino else e[0] is None):
+        e = H.repack_multi([w], [wino])[0]
+        if _STEP['on']:
+            _STEP['pack'][w.data_ptr()] = e
+    return e
+
+
+def _conv_fwd(x, w, stride, pad):
+    if _is_wino(w, stride, pad):
+        return H.conv3_winograd(x, _pack(w, True)[2])
+    return H.conv_fwd(x, _pack(w, False)[0], stride, pad)
+
+
+def _conv_dgrad(dy, w, stride, pad, l_in, out=None, accumulate=False):
+    if _is_wino(w, stride, pad):
+        return H.conv3_winograd(dy, _pack(w, True)[3], out=out, accumulate=accumulate)
+    return H.conv_dgrad(dy, _pack(w, False)[1], stride, pad, l_in, out=out, accumulate=accumulate)
 
 
 def _tgt(*params):
@@ -177,13 +196,13 @@ class BasicBlockFunction(Function):
 
     @staticmethod
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, R, st1, st2, std):
-        y1 = H.conv_fwd(x, _wf(w1), stride, 1)
+        y1 = _conv_fwd(x, w1, stride, 1)
         s1 = _stats(y1, R, st1)
         h1 = _bn_apply(y1, R, s1, st1, g1, b1, True)
-        y2 = H.conv_fwd(h1, _wf(w2), 1, 1)
+        y2 = _conv_fwd(h1, w2, 1, 1)
         s2 = _stats(y2, R, st2)
         if wd is not None:
-            yd = H.conv_fwd(x, _wf(wd), stride, 0)
+            yd = _conv_fwd(x, wd, stride, 0)
             sd = _stats(yd, R, std)
             res = _bn_apply(yd, R, sd, std, gd, bd, False)
             md, idd = sd.mean, sd.invstd
@@ -212,18 +231,18 @@ class BasicBlockFunction(Function):
         # relu + residual add + bn2
         dy2, dg2, db2, g = _bn_bwd(dout, y2, R, m2, i2, g2, b2, 2, tg2, tb2, out=out, want_g=True)
         dw2 = _wgrad(dy2, h1, 3, 1, 1, tw2)
-        dh1 = H.conv_dgrad(dy2, _wd(w2), 1, 1, h1.shape[1])
+        dh1 = _conv_dgrad(dy2, w2, 1, 1, h1.shape[1])
         dy1, dg1, db1 = _bn_bwd(dh1, y1, R, m1, i1, g1, b1, 1, tg1, tb1, dx=dh1)
         dw1 = _wgrad(dy1, x, 3, stride, 1, tw1)
         if ctx.has_ds:
             wd, gd, bd, yd, md, idd = s[15:]
             dyd, dgd, dbd = _bn_bwd(g, yd, R, md, idd, gd, bd, 0, tgd, tbd, dx=g)
             dwd = _wgrad(dyd, x, 1, stride, 0, twd)
-            dx = H.conv_dgrad(dy1, _wd(w1), stride, 1, lin)
-            H.conv_dgrad(dyd, _wd(wd), stride, 0, lin, out=dx, accumulate=True)
+            dx = _conv_dgrad(dy1, w1, stride, 1, lin)
+            _conv_dgrad(dyd, wd, stride, 0, lin, out=dx, accumulate=True)
         else:
             dwd = dgd = dbd = None
-            dx = H.conv_dgrad(dy1, _wd(w1), stride, 1, lin, out=g, accumulate=True)   # identity grad + conv path
+            dx = _conv_dgrad(dy1, w1, stride, 1, lin, out=g, accumulate=True)   # identity grad + conv path
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None
 
 
@@ -235,11 +254,11 @@ class DenseLayerFunction(Function):
     def forward(ctx, x, g1, b1, w1, g2, b2, w2, R, st1, st2, drop_p, seed, salt):
         s1 = _stats(x, R, st1)
         h = _bn_apply(x, R, s1, st1, g1, b1, True)
-        y1 = H.conv_fwd(h, _wf(w1), 1, 0)
+        y1 = _conv_fwd(h, w1, 1, 0)
         s2 = _stats(y1, R, st2)
         h2 = _bn_apply(y1, R, s2, st2, g2, b2, True)
         m1, i1, m2, i2 = s1.mean, s1.invstd, s2.mean, s2.invstd
-        new = H.conv_fwd(h2, _wf(w2), 1, 1)
+        new = _conv_fwd(h2, w2, 1, 1)
         if drop_p > 0:
             new = H.dropout(new, seed, salt, drop_p)
         out = H.concat2(x, new)
@@ -259,10 +278,10 @@ class DenseLayerFunction(Function):
         if ctx.drop_p > 0:
             dnew = H.dropout(dnew, seed, ctx.salt, ctx.drop_p)
         dw2 = _wgrad(dnew, h2, 3, 1, 1, tw2)
-        dh2 = H.conv_dgrad(dnew, _wd(w2), 1, 1, h2.shape[1])
+        dh2 = _conv_dgrad(dnew, w2, 1, 1, h2.shape[1])
         dy1, dg2, db2 = _bn_bwd(dh2, y1, R, m2, i2, g2, b2, 1, tg2, tb2, dx=dh2)
         dw1 = _wgrad(dy1, h, 1, 1, 0, tw1)
-        dh = H.conv_dgrad(dy1, _wd(w1), 1, 0, h.shape[1])
+        dh = _conv_dgrad(dy1, w1, 1, 0, h.shape[1])
         dx, dg1, db1 = _bn_bwd(dh, x, R, m1, i1, g1, b1, 1, tg1, tb1, dx=dh)
         H.slice_channels(dout, 0, cin, out=dx, accumulate=True)                     # pass-through half of the cat
         return dx, dg1, db1, dw1, dg2, db2, dw2, None, None, None, None, None, None
@@ -276,7 +295,7 @@ class TransitionFunction(Function):
         s_ = _stats(x, R, st)
         h = _bn_apply(x, R, s_, st, g, b, True)
         m, i = s_.mean, s_.invstd
-        y = H.conv_fwd(h, _wf(w), 1, 0)
+        y = _conv_fwd(h, w, 1, 0)
         out = H.avgpool_fwd(y, 2)
         ctx.R = R
         ctx.gt = _tgt(g, b, w)
@@ -289,7 +308,7 @@ class TransitionFunction(Function):
         tg, tb, tw = ctx.gt
         dy = H.avgpool_bwd(dout.contiguous(), x.shape[1], 2)
         dw = _wgrad(dy, h, 1, 1, 0, tw)
-        dh = H.conv_dgrad(dy, _wd(w), 1, 0, h.shape[1])
+        dh = _conv_dgrad(dy, w, 1, 0, h.shape[1])
         dx, dg, db = _bn_bwd(dh, x, ctx.R, m, i, g, b, 1, tg, tb, dx=dh)
         return dx, dg, db, dw, None, None
 

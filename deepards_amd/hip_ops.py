@@ -87,6 +87,35 @@ def conv_fwd(x, wf, stride, pad, out=None):
     return out
 
 
+def wino_weights(w, transpose=False):
+    """Winograd F(2,3) taps of a (Co, Ci, 3) conv weight: (4, Co, Ci) for the forward, (4, Ci, Co) (transpose) for the
+    data gradient."""
+    co, ci, k = w.shape
+    if k != 3 or not w.is_contiguous():
+        raise ValueError('wino_weights: (Co, Ci, 3) contiguous weight expected')
+    u = torch.empty((4, ci, co) if transpose else (4, co, ci), device=w.device, dtype=torch.float32)
+    _chk(_lib.lib().da_wino_weights(_p(w), _p(u), co, ci, 1 if transpose else 0, _stream()), 'da_wino_weights')
+    return u
+
+
+def conv3_winograd(x, u, out=None, accumulate=False):
+    """k3 s1 p1 conv of x (rows, L, C) with taps u (4, N, C) from wino_weights -> (rows, L, N)."""
+    _rlc(x, 'x')
+    rows, l, c = x.shape
+    four, n, c2 = u.shape
+    if four != 4 or c2 != c or c % 32 or n % 32:
+        raise ValueError('conv3_winograd: unsupported shape x%s u%s' % (tuple(x.shape), tuple(u.shape)))
+    if out is None:
+        if accumulate:
+            raise ValueError('accumulate needs out')
+        out = torch.empty((rows, l, n), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (rows, l, n):
+        raise ValueError('conv3_winograd: bad out shape')
+    _chk(_lib.lib().da_conv3_winograd(_p(x), _p(u), _p(out), rows, l, c, c, n, n, 1 if accumulate else 0, _stream()),
+         'da_conv3_winograd')
+    return out
+
+
 def conv_dgrad(dy, wd, stride, pad, l_in, out=None, accumulate=False):
     """dy (rows,Lo,Co), wd packed (K,Ci,Co) -> dx (rows,l_in,Ci).  With accumulate the result is
     added into `out`; positions no tap reaches are left untouched (accumulate) or zeroed."""
@@ -183,17 +212,23 @@ def wgrad_reduce_multi(items, accumulate=True):
     _chk(_lib.lib().da_wgrad_reduce_multi(arr, len(items), 1 if accumulate else 0, _stream()), 'da_wgrad_reduce_multi')
 
 
-def repack_multi(weights):
-    """[(Co,Ci,K) weights] -> [(wf, wd)] with one launch per 32 weights."""
+def repack_multi(weights, winograd=None):
+    """[(Co,Ci,K) weights] -> [(wf, wd, uf, ud)] with one launch per 32 weights.  winograd[i] (K == 3): emit the
+    Winograd taps uf (4,Co,Ci) / ud (4,Ci,Co) INSTEAD of the direct packs wf / wd (None in the tuple)."""
     outs = []
     arr = (_lib.RepackDesc * len(weights))()
-    for d, w in zip(arr, weights):
+    for n, (d, w) in enumerate(zip(arr, weights)):
         _f32(w, 'w')
         co, ci, k = w.shape
-        wf = torch.empty((k, co, ci), device=w.device, dtype=torch.float32)
-        wd = torch.empty((k, ci, co), device=w.device, dtype=torch.float32)
-        d.W, d.Wf, d.Wd, d.Co, d.Ci, d.K = w.data_ptr(), wf.data_ptr(), wd.data_ptr(), co, ci, k
-        outs.append((wf, wd))
+        wino = bool(winograd[n]) if winograd is not None else False
+        if wino and k != 3:
+            raise ValueError('winograd taps need a 3-tap weight')
+        mk = lambda *shape: torch.empty(shape, device=w.device, dtype=torch.float32)
+        wf, wd = (None, None) if wino else (mk(k, co, ci), mk(k, ci, co))
+        uf, ud = (mk(4, co, ci), mk(4, ci, co)) if wino else (None, None)
+        d.W, d.Wf, d.Wd, d.Uf, d.Ud = w.data_ptr(), _p(wf), _p(wd), _p(uf), _p(ud)
+        d.Co, d.Ci, d.K = co, ci, k
+        outs.append((wf, wd, uf, ud))
     if weights:
         _chk(_lib.lib().da_repack_multi(arr, len(weights), _stream()), 'da_repack_multi')
     return outs

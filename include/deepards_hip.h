@@ -52,6 +52,13 @@ int da_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, 
 /* benchmark-only tuning knobs: key 0 = force conv tile id, key 1 = wgrad target blocks (0 = automatic) */
 int da_debug_set(int key, int value);
 
+/* k3 stride-1 pad-1 conv (forward, or data gradient with the transposed taps) as Winograd F(2,3): y (+)= conv(x);
+   u = da_wino_weights() taps [4][N][C].  x: [rows][L][ldx] (C channels), y: [rows][L][ldy] (N channels).
+   replaces nn.Conv1d(k=3, s=1, p=1) forward / input-grad, reference models/resnet.py:5-8,27-38, models/densenet.py:25-32 */
+int da_conv3_winograd(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
+                      int accumulate, da_stream_t stream);
+/* u[4][co][ci] (transpose = 0, forward) or u[4][ci][co] (transpose = 1, data gradient) from w[co][ci][3] */
+int da_wino_weights(const float* w, float* u, int co, int ci, int transpose, da_stream_t stream);
 /* all weight-gradient GEMMs of a step in one launch per tile shape (jobs: HOST array); slabs only, reduce afterwards */
 typedef struct {
   const float* dy; const float* x; float* workspace;
@@ -68,7 +75,8 @@ int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumula
 
 /* torch [Co][Ci][K] -> Wf [K][Co][Ci] (forward) and Wd [K][Ci][Co] (data gradient). */
 int da_repack_conv_weight(const float* W, float* Wf, float* Wd, int Co, int Ci, int K, da_stream_t stream);
-typedef struct { const float* W; float* Wf; float* Wd; int Co, Ci, K; } da_repack_desc;
+/* Uf / Ud (K == 3 only, may be NULL): the Winograd taps of da_wino_weights for the forward / data gradient */
+typedef struct { const float* W; float* Wf; float* Wd; float* Uf; float* Ud; int Co, Ci, K; } da_repack_desc;
 int da_repack_multi(const da_repack_desc* descs, int n, da_stream_t stream);
 
 /* ---- stem: Conv1d(1, C0, k7, s2, p3)  resnet.py:86-87,142 ; densenet.py:118-119 ----------- */

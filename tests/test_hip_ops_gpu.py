@@ -125,8 +125,35 @@ def test_conv_fwd_dgrad_wgrad(H, ci, co, k, stride, pad, L, rows):
     dw3 = dw.clone()
     H.wgrad_reduce_multi([(H.conv_wgrad(dyt, xt, k, stride, pad, defer=True), dw3)], accumulate=True)
     close(dw3.cpu().numpy(), 2 * dw_ref, tol=3e-6, name='wgrad deferred')
-    (wf2, wd2), = H.repack_multi([wt])
-    assert torch.equal(wf2, wf) and torch.equal(wd2, wd)
+    (wf2, wd2, uf2, ud2), = H.repack_multi([wt])
+    assert torch.equal(wf2, wf) and torch.equal(wd2, wd) and uf2 is None and ud2 is None
+
+
+@pytest.mark.parametrize('ci,co,L,rows', [(64, 64, 56, 40), (128, 128, 28, 23), (256, 256, 14, 40), (512, 512, 7, 40),
+                                          (128, 32, 56, 20), (64, 64, 56, 1), (128, 32, 9, 5), (32, 32, 1, 7),
+                                          (64, 64, 56, 300), (32, 64, 2, 33)])
+def test_conv3_winograd(H, ci, co, L, rows):
+    """Winograd F(2,3) k3 s1 p1 conv: forward, data gradient (transposed taps) and accumulate form vs the oracle."""
+    rng = np.random.default_rng(ci + co + L + rows)
+    x = rng.standard_normal((rows, ci, L))
+    w = rng.standard_normal((co, ci, 3)) * np.sqrt(2.0 / (3 * co))
+    y_ref = np_ref.conv1d_fwd(x, w, 1, 1)
+    dy = rng.standard_normal(y_ref.shape)
+    dx_ref, _ = np_ref.conv1d_bwd(x, w, dy, 1, 1)
+    xt, wt, dyt = rlc(x), cu(w), rlc(dy)
+    uf, ud = H.wino_weights(wt), H.wino_weights(wt, transpose=True)
+    g = w.astype(np.float32).astype(np.float64)
+    u_ref = np.stack([g[:, :, 0], (g[:, :, 0] + g[:, :, 1] + g[:, :, 2]) / 2, (g[:, :, 0] - g[:, :, 1] + g[:, :, 2]) / 2, g[:, :, 2]])
+    close(uf.cpu().numpy(), u_ref, tol=1e-6, name='taps fwd')
+    close(ud.cpu().numpy(), np.stack([g[:, :, 2].T, u_ref[1].T, u_ref[2].T, g[:, :, 0].T]), tol=1e-6, name='taps dgrad')
+    (wf2, wd2, uf2, ud2), = H.repack_multi([wt], [True])          # the batched repack emits the same taps
+    assert wf2 is None and wd2 is None and torch.equal(uf2, uf) and torch.equal(ud2, ud)
+    close(ncl(H.conv3_winograd(xt, uf)), y_ref, tol=4e-6, name='winograd fwd')
+    close(ncl(H.conv3_winograd(dyt, ud)), dx_ref, tol=4e-6, name='winograd dgrad')
+    base = rng.standard_normal(dx_ref.shape)
+    bt = rlc(base)
+    H.conv3_winograd(dyt, ud, out=bt, accumulate=True)
+    close(ncl(bt), base + dx_ref, tol=4e-6, name='winograd dgrad+acc')
 
 
 def test_conv_mfma_layout_identity(H):
