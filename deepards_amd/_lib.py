@@ -66,6 +66,7 @@ SIGNATURES = {
     'da_conv_wgrad_splits': (_I, [_I] * 5),
     'da_conv_wgrad_plan': (_I, [_I] * 5 + [ctypes.POINTER(_I)]),
     'da_conv3_winograd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'da_wino_debug_tail': (_I, [_I]),
     'da_wino_weights': (_I, [_P, _P, _I, _I, _I, _P]),
     'da_conv_wgrad_multi': (_I, [ctypes.POINTER(WgradJob), _I, _P]),
     'da_wgrad_reduce_multi': (_I, [ctypes.POINTER(WgradReduceDesc), _I, _I, _P]),
@@ -131,6 +132,8 @@ def lib():
         for key, env in ((0, 'DA_CONV_TILE'), (1, 'DA_WGRAD_BLOCKS'), (2, 'DA_HALO'), (3, 'DA_TAIL')):      # tuning knobs (scripts/)
             if os.environ.get(env):
                 l.da_debug_set(key, int(os.environ[env]))
+        if os.environ.get('DA_WINO_TAIL'):
+            l.da_wino_debug_tail(int(os.environ['DA_WINO_TAIL']))
         _lib = l
     return _lib
 

@@ -39,28 +39,34 @@ __device__ __forceinline__ int xcd_chunked(int id, int total) {   // same block 
 #define WINO_AROWS 66
 #define WINO_LDS_FLOATS (2 * WINO_AROWS * WINO_PITCH + 4 * 32 * WINO_PITCH)
 
-__device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int block_id, const int nblocks, float* lds) {
-  constexpr int PITCH = WINO_PITCH, AR = WINO_AROWS;
-  float* Es = lds;                      // [66][PITCH] even positions of pairs P0-1 .. P0+64
-  float* Os = lds + AR * PITCH;         // [66][PITCH] odd positions
+// MINI = false: the 64 pairs x 32 channels tile `tile`, wave = 16 pairs, whole K.
+// MINI = true : half such a tile (32 pairs), wave = (16 pairs, one 16-channel half of every K step); the two partial
+//               accumulator sets meet in LDS (fixed order).  Used for the partly filled last round of tiles, see
+//               conv_gemm.hip "Tail tiles": a half tile holds its CU for a quarter of a full tile's time.
+template <bool MINI>
+__device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int tile, const int sub, float* lds) {
+  constexpr int PITCH = WINO_PITCH, PAIRS = MINI ? 32 : 64, AR = PAIRS + 2;
+  float* Es = lds;                      // [AR][PITCH] even positions of pairs P0-1 .. P0+PAIRS
+  float* Os = lds + AR * PITCH;         // [AR][PITCH] odd positions
   float* Us = lds + 2 * AR * PITCH;     // [4][32][PITCH]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntn = a.N >> 5;
-  const int lin = xcd_chunked(block_id, nblocks);
-  const int P0 = (lin / ntn) * 64, n_blk = (lin % ntn) * 32;
+  const int P0 = (tile / ntn) * 64 + (MINI ? 32 * sub : 0), n_blk = (tile % ntn) * 32;
   const int lr = tid >> 3, lq = tid & 7;
   const int PL = a.PL;
 
-  // loader: rows e = lr, lr + 32 of both panels (p = 0..3), rows 64 / 65 by the first 32 threads (p = 4)
-  int aoff[5];
-  bool aok[5];
+  // loader: panel rows lr (+32) of both panels, the two rows past PAIRS by the first 32 threads (last slot)
+  constexpr int NA = MINI ? 3 : 5;
+  int aoff[NA];
+  bool aok[NA];
 #pragma unroll
-  for (int p = 0; p < 5; ++p) {
-    const int e = p < 4 ? lr + 32 * (p & 1) : 64 + (tid >> 4);
-    const int odd = p < 4 ? (p >> 1) : ((tid >> 3) & 1);
+  for (int p = 0; p < NA; ++p) {
+    const bool extra = p == NA - 1;
+    const int e = extra ? PAIRS + (tid >> 4) : (MINI ? lr : lr + 32 * (p & 1));
+    const int odd = extra ? ((tid >> 3) & 1) : (MINI ? p : (p >> 1));
     const int P = P0 - 1 + e;
-    bool ok = P >= 0 && P < a.MP && (p < 4 || tid < 32);
+    bool ok = P >= 0 && P < a.MP && (!extra || tid < 32);
     const uint32_t r = fdiv((uint32_t)(ok ? P : 0), a.divPL);
     const int i = (ok ? P : 0) - (int)r * PL;
     const int pos = 2 * i + odd;
@@ -71,11 +77,11 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int blo
   const float* ub = a.u + (size_t)(n_blk + lr) * a.C + lq * 4;
   const size_t ustride = (size_t)a.N * a.C;
 
-  f32x4 ra[5], rb[4];
+  f32x4 ra[NA], rb[4];
   auto gload = [&](int ks) {
     const int c0 = ks << 5;
 #pragma unroll
-    for (int p = 0; p < 5; ++p) {
+    for (int p = 0; p < NA; ++p) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (aok[p]) v = *reinterpret_cast<const f32x4*>(a.x + aoff[p] + c0);
       ra[p] = v;
@@ -86,8 +92,9 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int blo
 
   // fragment geometry (16x16x4: lane = (row l%16, k group l/16))
   const int prow = lane & 15, g = lane >> 4;
-  const int pr = wave * 16 + prow + 1;                  // panel row of this lane's pair
-  const int P_lane = P0 + wave * 16 + prow;
+  const int wp = MINI ? (wave & 1) : wave, khalf = wave >> 1;
+  const int pr = wp * 16 + prow + 1;                    // panel row of this lane's pair
+  const int P_lane = P0 + wp * 16 + prow;
   const int Pc = P_lane < a.MP ? P_lane : 0;
   const int i_lane = Pc - (int)fdiv((uint32_t)Pc, a.divPL) * PL;
   const bool at_first = i_lane == 0, at_last = i_lane == PL - 1;
@@ -103,9 +110,13 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int blo
   for (int ks = 0; ks < kc; ++ks) {
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-      *reinterpret_cast<f32x4*>(&((p >> 1) ? Os : Es)[(lr + 32 * (p & 1)) * PITCH + lq * 4]) = ra[p];
-    if (tid < 32) *reinterpret_cast<f32x4*>(&(((tid >> 3) & 1) ? Os : Es)[(64 + (tid >> 4)) * PITCH + lq * 4]) = ra[4];
+    for (int p = 0; p < NA - 1; ++p) {
+      const int e = MINI ? lr : lr + 32 * (p & 1);
+      const int odd = MINI ? p : (p >> 1);
+      *reinterpret_cast<f32x4*>(&(odd ? Os : Es)[e * PITCH + lq * 4]) = ra[p];
+    }
+    if (tid < 32)
+      *reinterpret_cast<f32x4*>(&(((tid >> 3) & 1) ? Os : Es)[(PAIRS + (tid >> 4)) * PITCH + lq * 4]) = ra[NA - 1];
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&Us[(j * 32 + lr) * PITCH + lq * 4]) = rb[j];
     __syncthreads();
@@ -117,6 +128,7 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int blo
         if (ks + 1 < kc) gload(ks + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (MINI && half != khalf) continue;
       f32x4 d0 = *reinterpret_cast<const f32x4*>(&Os[(pr - 1) * PITCH + col]);
       const f32x4 d1 = *reinterpret_cast<const f32x4*>(&Es[pr * PITCH + col]);
       const f32x4 d2 = *reinterpret_cast<const f32x4*>(&Os[pr * PITCH + col]);
@@ -143,10 +155,31 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int blo
     }
   }
 
+  if (MINI) {   // k half 1 hands its partial sums to k half 0
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(lds);          // [2 pair halves][8 tiles][64 lanes]
+    if (khalf == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) red[((wp * 4 + j) * 2 + nt) * 64 + lane] = acc[j][nt];
+    }
+    __syncthreads();
+    if (khalf == 1) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 o = red[((wp * 4 + j) * 2 + nt) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][nt][e] += o[e];
+      }
+  }
+
   // output transform + store: lane holds channel n = nt*16 + l%16 of pairs 4*(l/16) + r
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int P = P0 + wave * 16 + g * 4 + r;
+    const int P = P0 + wp * 16 + g * 4 + r;
     if (P >= a.MP) continue;
     const uint32_t rr = fdiv((uint32_t)P, a.divPL);
     const int i = P - (int)rr * PL;
@@ -167,10 +200,18 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int blo
   }
 }
 
-__global__ __launch_bounds__(256) void conv3_wino_kernel(WinoArgs a) {
+// tiles [0, full) as whole tiles; with nmini > 0 the tiles [full, full + nmini / 2) as half tiles in the first
+// blocks of the launch (padded to a multiple of 8: block id % 8 stays the XCD of the full tiles)
+__global__ __launch_bounds__(256) void conv3_wino_kernel(WinoArgs a, int nmini, int nmini_pad, int full) {
   __shared__ float lds[WINO_LDS_FLOATS];
-  conv3_wino_body(a, blockIdx.x, gridDim.x, lds);
+  if ((int)blockIdx.x < nmini_pad) {
+    if ((int)blockIdx.x < nmini) conv3_wino_body<true>(a, full + ((int)blockIdx.x >> 1), blockIdx.x & 1, lds);
+    return;
+  }
+  conv3_wino_body<false>(a, xcd_chunked(blockIdx.x - nmini_pad, full), 0, lds);
 }
+
+static int g_wino_tail = 1;
 
 // U[4][N][C] from torch-layout weights w[co][ci][3]:
 //   forward  (transpose = 0): N = co, C = ci, taps g_t = w[n][c][t]
@@ -208,8 +249,21 @@ int da_conv3_winograd(const float* x, const float* u, float* y, int rows, int L,
   a.divPL = make_fastdiv((uint32_t)a.PL);
   if ((uint64_t)a.MP * (uint64_t)a.PL >= 0xffffffffull) return DA_EINVAL;
   const int tiles = ((a.MP + 63) / 64) * (N / 32);
-  hipLaunchKernelGGL(conv3_wino_kernel, dim3(tiles), dim3(256), 0, stream, a);
+  const int R = tiles % 256;
+  int nmini = 0, full = tiles;
+  if (g_wino_tail && tiles > 256 && R >= 1 && R <= 128) {
+    nmini = 2 * R;
+    full = tiles - R;
+  }
+  const int nmini_pad = (nmini + 7) / 8 * 8;
+  hipLaunchKernelGGL(conv3_wino_kernel, dim3(nmini_pad + full), dim3(256), 0, stream, a, nmini, nmini_pad, full);
   DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// tuning / tests: 0 = no half tiles for the last round
+int da_wino_debug_tail(int on) {
+  g_wino_tail = on;
   return DA_OK;
 }
 

@@ -57,6 +57,8 @@ int da_debug_set(int key, int value);
    replaces nn.Conv1d(k=3, s=1, p=1) forward / input-grad, reference models/resnet.py:5-8,27-38, models/densenet.py:25-32 */
 int da_conv3_winograd(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
                       int accumulate, da_stream_t stream);
+/* tuning / tests: 0 = the partly filled last round of tiles is NOT cut into split-K half tiles */
+int da_wino_debug_tail(int on);
 /* u[4][co][ci] (transpose = 0, forward) or u[4][ci][co] (transpose = 1, data gradient) from w[co][ci][3] */
 int da_wino_weights(const float* w, float* u, int co, int ci, int transpose, da_stream_t stream);
 /* all weight-gradient GEMMs of a step in one launch per tile shape (jobs: HOST array); slabs only, reduce afterwards */

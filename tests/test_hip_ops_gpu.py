@@ -131,9 +131,11 @@ def test_conv_fwd_dgrad_wgrad(H, ci, co, k, stride, pad, L, rows):
 
 @pytest.mark.parametrize('ci,co,L,rows', [(64, 64, 56, 40), (128, 128, 28, 23), (256, 256, 14, 40), (512, 512, 7, 40),
                                           (128, 32, 56, 20), (64, 64, 56, 1), (128, 32, 9, 5), (32, 32, 1, 7),
-                                          (64, 64, 56, 300), (32, 64, 2, 33)])
+                                          (64, 64, 56, 300), (32, 64, 2, 33), (128, 128, 28, 300), (64, 64, 57, 300),
+                                          (64, 128, 7, 1040)])
 def test_conv3_winograd(H, ci, co, L, rows):
-    """Winograd F(2,3) k3 s1 p1 conv: forward, data gradient (transposed taps) and accumulate form vs the oracle."""
+    """Winograd F(2,3) k3 s1 p1 conv: forward, data gradient (transposed taps) and accumulate form vs the oracle
+    (the 300 / 150 / 1290-row cases have more than 256 tiles: their last round runs as split-K half tiles)."""
     rng = np.random.default_rng(ci + co + L + rows)
     x = rng.standard_normal((rows, ci, L))
     w = rng.standard_normal((co, ci, 3)) * np.sqrt(2.0 / (3 * co))
