@@ -247,7 +247,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         # instrumented EAGER steps: HIP events around every C-ABI launch, on the launch stream
         kt = KernelTimer(lib, torch)
-        names = [n for n in _lib.SIGNATURES if n not in ('da_version', 'da_conv_wgrad_workspace', 'da_stem_wgrad_workspace', 'da_bn_workspace', 'da_debug_set', 'da_bn_chunks', 'da_conv_wgrad_splits', 'da_conv_wgrad_plan', 'da_bn_debug_two_stage', 'da_wino_debug_tail', 'da_wino_weights',
+        names = [n for n in _lib.SIGNATURES if n not in ('da_version', 'da_conv_wgrad_workspace', 'da_stem_wgrad_workspace', 'da_bn_workspace', 'da_debug_set', 'da_bn_chunks', 'da_conv_wgrad_splits', 'da_conv_wgrad_plan', 'da_bn_debug_two_stage', 'da_wino_debug_tail', 'da_wino_debug_pchunk', 'da_wino_weights',
                                                           'da_hip_runtime_symbol')]
         tr_e = HotPathTrainer(model, optimizer='sgd', use_graph=False)
         tr_e.bucket, tr_e.state = tr.bucket, tr.state

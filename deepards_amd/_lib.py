@@ -34,7 +34,7 @@ class WgradReduceDesc(ctypes.Structure):
 class WgradJob(ctypes.Structure):
     _fields_ = [('dy', _P), ('x', _P), ('workspace', _P)] + [(n, _I) for n in
                ('rows', 'Lm', 'Ldy', 'lddy', 'N', 'Lx', 'ldx', 'C', 'dy_stride', 'dy_off', 'src_stride', 'ntaps')] + \
-               [('src_off', _I * 3)]
+               [('src_off', _I * 3), ('winograd', _I)]
 
 
 class RepackDesc(ctypes.Structure):
@@ -64,9 +64,10 @@ SIGNATURES = {
     'da_bn_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
     'da_bn_param_grad_multi': (_I, [ctypes.POINTER(BnPgradDesc), _I, _I, _P]),
     'da_conv_wgrad_splits': (_I, [_I] * 5),
-    'da_conv_wgrad_plan': (_I, [_I] * 5 + [ctypes.POINTER(_I)]),
+    'da_conv_wgrad_plan': (_I, [_I] * 6 + [ctypes.POINTER(_I)]),
     'da_conv3_winograd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'da_wino_debug_tail': (_I, [_I]),
+    'da_wino_debug_pchunk': (_I, [_I]),
     'da_wino_weights': (_I, [_P, _P, _I, _I, _I, _P]),
     'da_conv_wgrad_multi': (_I, [ctypes.POINTER(WgradJob), _I, _P]),
     'da_wgrad_reduce_multi': (_I, [ctypes.POINTER(WgradReduceDesc), _I, _I, _P]),
@@ -134,6 +135,8 @@ def lib():
                 l.da_debug_set(key, int(os.environ[env]))
         if os.environ.get('DA_WINO_TAIL'):
             l.da_wino_debug_tail(int(os.environ['DA_WINO_TAIL']))
+        if os.environ.get('DA_WINO_PCHUNK'):
+            l.da_wino_debug_pchunk(int(os.environ['DA_WINO_PCHUNK']))
         _lib = l
     return _lib
 

@@ -46,3 +46,18 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// One weight-gradient GEMM of da_conv_wgrad_multi (include/deepards_hip.h); shared by conv_gemm.hip and conv_wino.hip.
+typedef struct {
+  const float* dy;
+  const float* x;
+  float* workspace;      // splits * ntaps*N*C floats: receives the split-K slabs
+  int rows, Lm, Ldy, lddy, N, Lx, ldx, C, dy_stride, dy_off, src_stride, ntaps;
+  int src_off[3];
+  int winograd;          // != 0 (k3 s1 p1, N and C multiples of 64): Winograd F(2,3) form, da_conv_wgrad_plan(winograd = 1)
+} da_wgrad_job;
+
+// conv_wino.hip
+bool wino_wgrad_eligible(const da_wgrad_job& j);
+void wino_wgrad_plan(int rows, int L, int* splits, int* pchunk);
+int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream);

@@ -800,13 +800,6 @@ static WgradPlan wgrad_plan(int M, int N, int C, int ntaps) {
 // =============================================================================================
 // C ABI
 // =============================================================================================
-typedef struct {
-  const float* dy;
-  const float* x;
-  float* workspace;      // da_conv_wgrad_workspace() bytes: receives the split-K slabs
-  int rows, Lm, Ldy, lddy, N, Lx, ldx, C, dy_stride, dy_off, src_stride, ntaps;
-  int src_off[3];
-} da_wgrad_job;
 
 template <int TM, int TN, int WGM, int WGN>
 static int launch_wgrad_group(const da_wgrad_job* jobs, int n, int tn, int tc, hipStream_t s) {
@@ -826,6 +819,7 @@ static int launch_wgrad_group(const da_wgrad_job* jobs, int n, int tn, int tc, h
   // longest blocks first (block time ~ kchunk * taps-independent tile work): short ones fill the launch's tail
   std::vector<std::pair<int, int>> order;
   for (int i = 0; i < n; ++i) {
+    if (jobs[i].winograd) continue;                       // conv_wino.hip
     WgradPlan pl = wgrad_plan(jobs[i].rows * jobs[i].Lm, jobs[i].N, jobs[i].C, jobs[i].ntaps);
     if (pl.tn == tn && pl.tc == tc) order.push_back({-pl.kchunk, i});
   }
@@ -903,9 +897,10 @@ int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
     if (!j.dy || !j.x || !j.workspace || j.ntaps < 1 || j.ntaps > 3 || j.C % 32 || j.N % 32 || j.lddy % 4 || j.ldx % 4)
       return DA_EINVAL;
     if ((uint64_t)j.rows * j.Lm * (uint64_t)j.Lm >= 0xffffffffull) return DA_EINVAL;
-    if (!wgrad_plan(j.rows * j.Lm, j.N, j.C, j.ntaps).tn) return DA_EINVAL;
+    if (j.winograd ? !wino_wgrad_eligible(j) : !wgrad_plan(j.rows * j.Lm, j.N, j.C, j.ntaps).tn) return DA_EINVAL;
   }
   int rc;
+  if ((rc = wino_wgrad_launch(jobs, n, stream))) return rc;   // the heaviest blocks first
   if ((rc = launch_wgrad_group<2, 2, 2, 2>(jobs, n, 128, 128, stream))) return rc;
   if ((rc = launch_wgrad_group<2, 1, 2, 2>(jobs, n, 128, 64, stream))) return rc;
   if ((rc = launch_wgrad_group<1, 2, 2, 2>(jobs, n, 64, 128, stream))) return rc;
@@ -921,9 +916,16 @@ int da_conv_wgrad_splits(int rows, int Lm, int N, int C, int ntaps) {
 }
 
 // the plan da_conv_wgrad / da_conv_wgrad_multi use for this shape: out = {tile_n, tile_c, splits, kchunk};
-// a job's workspace is splits * ntaps*N*C floats.
-int da_conv_wgrad_plan(int rows, int Lm, int N, int C, int ntaps, int* out) {
+// a job's workspace is splits * ntaps*N*C floats.  winograd != 0: the plan of a job with that flag set (k3 s1 p1;
+// kchunk counts output PAIRS).
+int da_conv_wgrad_plan(int rows, int Lm, int N, int C, int ntaps, int winograd, int* out) {
   if (!out || ntaps < 1 || ntaps > 3 || N % 32 || C % 32) return DA_EINVAL;
+  if (winograd) {
+    if (ntaps != 3 || N % 64 || C % 64) return DA_EINVAL;
+    out[0] = 64; out[1] = 64;
+    wino_wgrad_plan(rows, Lm, &out[2], &out[3]);
+    return DA_OK;
+  }
   WgradPlan p = wgrad_plan(rows * Lm, N, C, ntaps);
   out[0] = p.tn; out[1] = p.tc; out[2] = p.splits; out[3] = p.kchunk;
   return p.tn ? DA_OK : DA_EINVAL;

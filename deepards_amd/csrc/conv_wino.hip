@@ -213,6 +213,198 @@ __global__ __launch_bounds__(256) void conv3_wino_kernel(WinoArgs a, int nmini, 
 
 static int g_wino_tail = 1;
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of the same convolution, Winograd form.  With dm = A dy = (dy0, dy0 + dy1, dy0 - dy1, -dy1) per
+// output pair and D = B^T d as in the forward,
+//     M_j[n][c] = sum over pairs  dm_j[n] * D_j[c]                 (4 contractions over PAIRS instead of 3 over positions)
+//     dW0 = M0 + (M1 + M2)/2     dW1 = (M1 - M2)/2     dW2 = (M1 + M2)/2 + M3
+// Block = 64 co x 64 ci, 4 waves of 32 x 32 with the four M_j accumulators (v_mfma_f32_32x32x2_f32, K = pairs);
+// K step = 32 pairs: dY and X staged in pair-indexed even / odd panels ([pair][channel], as they sit in HBM),
+// transforms at fragment-read time; sequence edges (d0 of a first pair, d3 of a last pair) from two 32-bit masks
+// per K step.  The combination to dW happens on the accumulators, so the slabs have the direct kernel's layout
+// [split][3][N][C] and share its reduction.
+// ---------------------------------------------------------------------------------------------
+struct WinoWgradArgs {
+  const float* dy;
+  const float* x;
+  float* slab;
+  int MP, L, PL, lddy, N, ldx, C, pchunk;
+  FastDiv divPL;
+};
+
+#define WW_LDS_FLOATS ((2 * 32 + 2 * 34) * 64)
+
+__device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& a, const int block_id, const int nblocks, float* lds) {
+  float* YE = lds;                 // [32][64] dY at the even position of pairs k0 .. k0+31
+  float* YO = lds + 32 * 64;       // [32][64] odd position (0 past the sequence end)
+  float* XE = lds + 64 * 64;       // [34][64] X even, pairs k0-1 .. k0+32
+  float* XO = XE + 34 * 64;        // [34][64] X odd
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntc = a.C >> 6, tiles = (a.N >> 6) * ntc;
+  const int lin = xcd_chunked(block_id, nblocks);      // tile fastest: one pair chunk's readers share an XCD
+  const int bx = lin % tiles, split = lin / tiles;
+  const int n_blk = (bx / ntc) * 64, c_blk = (bx % ntc) * 64;
+  const int PL = a.PL;
+  const int k_beg = split * a.pchunk, k_end = min(a.MP, k_beg + a.pchunk);
+
+  const int lrow = tid >> 4, lq = tid & 15;             // loader: 16 pair rows x 16 channel quads per pass
+  f32x4 ry[4], rx[5];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int P = k0 + lrow + 16 * rb;
+      const bool ok = P < a.MP;
+      const uint32_t r = fdiv((uint32_t)(ok ? P : 0), a.divPL);
+      const int i = (ok ? P : 0) - (int)r * PL;
+      const size_t pos = (size_t)r * a.L + 2 * i;
+      const bool ok1 = ok && 2 * i + 1 < a.L;
+      const bool okk = ok && P < k_end;                 // dY only inside this split's pairs; X neighbours beyond it are real
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      ry[2 * rb] = okk ? *reinterpret_cast<const f32x4*>(a.dy + pos * a.lddy + n_blk + lq * 4) : z;
+      ry[2 * rb + 1] = (okk && ok1) ? *reinterpret_cast<const f32x4*>(a.dy + (pos + 1) * a.lddy + n_blk + lq * 4) : z;
+      rx[2 * rb] = ok ? *reinterpret_cast<const f32x4*>(a.x + pos * a.ldx + c_blk + lq * 4) : z;
+      rx[2 * rb + 1] = ok1 ? *reinterpret_cast<const f32x4*>(a.x + (pos + 1) * a.ldx + c_blk + lq * 4) : z;
+    }
+    if (tid < 32) {                                     // halo: odd of pair k0-1 (tid < 16), even of pair k0+32
+      const int P = tid < 16 ? k0 - 1 : k0 + 32;
+      const bool ok = P >= 0 && P < a.MP;
+      const uint32_t r = fdiv((uint32_t)(ok ? P : 0), a.divPL);
+      const int i = (ok ? P : 0) - (int)r * PL;
+      const int pp = 2 * i + (tid < 16 ? 1 : 0);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok && pp < a.L) v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)r * a.L + pp) * a.ldx + c_blk + lq * 4);
+      rx[4] = v;
+    }
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int frow = lane & 31, fh = lane >> 5;
+  if (k_beg < k_end) gload(k_beg);
+  for (int k0 = k_beg; k0 < k_end; k0 += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int row = lrow + 16 * rb;
+      *reinterpret_cast<f32x4*>(&YE[row * 64 + lq * 4]) = ry[2 * rb];
+      *reinterpret_cast<f32x4*>(&YO[row * 64 + lq * 4]) = ry[2 * rb + 1];
+      *reinterpret_cast<f32x4*>(&XE[(row + 1) * 64 + lq * 4]) = rx[2 * rb];
+      *reinterpret_cast<f32x4*>(&XO[(row + 1) * 64 + lq * 4]) = rx[2 * rb + 1];
+    }
+    if (tid < 16) *reinterpret_cast<f32x4*>(&XO[lq * 4]) = rx[4];
+    else if (tid < 32) *reinterpret_cast<f32x4*>(&XE[33 * 64 + lq * 4]) = rx[4];
+    // sequence-edge masks of this step's 32 pairs (bit p: pair k0+p is the first / last of its sequence)
+    const int Pm = k0 + (lane & 31);
+    const int im = Pm - (int)fdiv((uint32_t)(Pm < a.MP ? Pm : 0), a.divPL) * PL;
+    const uint32_t fmask = (uint32_t)__ballot(Pm < a.MP && im == 0);
+    const uint32_t lmask = (uint32_t)__ballot(Pm < a.MP && im == PL - 1);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      if (kk == 8) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 32 < k_end) gload(k0 + 32);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int p = 2 * kk + fh;
+      const float y0 = YE[p * 64 + wm * 32 + frow], y1 = YO[p * 64 + wm * 32 + frow];
+      float d0 = XO[p * 64 + wn * 32 + frow];
+      const float d1 = XE[(p + 1) * 64 + wn * 32 + frow], d2 = XO[(p + 1) * 64 + wn * 32 + frow];
+      float d3 = XE[(p + 2) * 64 + wn * 32 + frow];
+      if ((fmask >> p) & 1) d0 = 0.f;
+      if ((lmask >> p) & 1) d3 = 0.f;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, d0 - d2, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0 + y1, d1 + d2, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0 - y1, d2 - d1, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(y1, d1 - d3, acc[3], 0, 0, 0);     // = -M3
+    }
+  }
+
+  float* out = a.slab + (size_t)split * 3 * a.N * a.C;
+  const size_t plane = (size_t)a.N * a.C;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n_blk + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+    const int c = c_blk + wn * 32 + frow;
+    const float h = 0.5f * (acc[1][r] + acc[2][r]);
+    float* o = out + (size_t)n * a.C + c;
+    o[0] = acc[0][r] + h;
+    o[plane] = 0.5f * (acc[1][r] - acc[2][r]);
+    o[2 * plane] = h - acc[3][r];
+  }
+}
+
+struct WinoWgradTable {
+  WinoWgradArgs d[24];
+  int first_block[25];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void wino_wgrad_multi_kernel(WinoWgradTable t) {
+  __shared__ float lds[WW_LDS_FLOATS];
+  int i = 0;
+  while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
+  wino_wgrad_body(t.d[i], blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i], lds);
+}
+
+bool wino_wgrad_eligible(const da_wgrad_job& j) {
+  return j.ntaps == 3 && j.dy_stride == 1 && j.dy_off == 0 && j.src_stride == 1 && j.src_off[0] == -1 &&
+         j.src_off[1] == 0 && j.src_off[2] == 1 && j.Lm == j.Ldy && j.Lm == j.Lx && j.N % 64 == 0 && j.C % 64 == 0 &&
+         j.N >= 64 && j.C >= 64;
+}
+
+static int g_ww_pchunk = 512;
+
+// pairs per split: every block of every job carries the same work (16 K steps), slab traffic 48 KB per block
+void wino_wgrad_plan(int rows, int L, int* splits, int* pchunk) {
+  const int MP = rows * ((L + 1) / 2);
+  int sp = (MP + g_ww_pchunk - 1) / g_ww_pchunk;
+  if (sp < 1) sp = 1;
+  int pc = ((MP + sp - 1) / sp + 31) / 32 * 32;
+  if (pc < 32) pc = 32;
+  *splits = (MP + pc - 1) / pc > 0 ? (MP + pc - 1) / pc : 1;
+  *pchunk = pc;
+}
+
+int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s) {
+  WinoWgradTable t;
+  int cnt = 0, blocks = 0;
+  auto flush = [&]() -> int {
+    if (!cnt) return DA_OK;
+    t.n = cnt;
+    t.first_block[cnt] = blocks;
+    hipLaunchKernelGGL(wino_wgrad_multi_kernel, dim3(blocks), dim3(256), 0, s, t);
+    DA_CHECK_LAUNCH();
+    cnt = 0;
+    blocks = 0;
+    return DA_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    const da_wgrad_job& j = jobs[i];
+    if (!j.winograd) continue;
+    int splits, pchunk;
+    wino_wgrad_plan(j.rows, j.Lm, &splits, &pchunk);
+    WinoWgradArgs& a = t.d[cnt];
+    a.dy = j.dy; a.x = j.x; a.slab = j.workspace;
+    a.L = j.Lm; a.PL = (j.Lm + 1) / 2; a.MP = j.rows * a.PL;
+    a.lddy = j.lddy; a.N = j.N; a.ldx = j.ldx; a.C = j.C; a.pchunk = pchunk;
+    a.divPL = make_fastdiv((uint32_t)a.PL);
+    t.first_block[cnt] = blocks;
+    blocks += (j.N / 64) * (j.C / 64) * splits;
+    if (++cnt == 24) {
+      int rc = flush();
+      if (rc) return rc;
+    }
+  }
+  return flush();
+}
+
 // U[4][N][C] from torch-layout weights w[co][ci][3]:
 //   forward  (transpose = 0): N = co, C = ci, taps g_t = w[n][c][t]
 //   dgrad    (transpose = 1): N = ci, C = co, taps g_t = w[c][n][2 - t]   (dx[m] = sum_t dy[m + t - 1] w[..][2 - t])
@@ -261,9 +453,13 @@ int da_conv3_winograd(const float* x, const float* u, float* y, int rows, int L,
   return DA_OK;
 }
 
-// tuning / tests: 0 = no half tiles for the last round
+// tuning / tests: 0 = no half tiles for the last round; pchunk > 0: pairs per weight-gradient split
 int da_wino_debug_tail(int on) {
   g_wino_tail = on;
+  return DA_OK;
+}
+int da_wino_debug_pchunk(int pchunk) {
+  if (pchunk > 0) g_ww_pchunk = pchunk;
   return DA_OK;
 }
 

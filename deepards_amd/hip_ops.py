@@ -172,9 +172,13 @@ def conv_wgrad(dy, x, k, stride, pad, out=None, accumulate=False, defer=False):
     return out
 
 
+WINOGRAD_WGRAD = os.environ.get('DA_WINOGRAD_WGRAD', '1') != '0'
+
+
 def conv_wgrad_multi(jobs):
     """jobs: [(dy, x, k, stride, pad)] -> [(slab, splits, k, co, ci)]: every weight-gradient GEMM of the list in
-    one launch per tile shape (slabs only; reduce with wgrad_reduce_multi)."""
+    one launch per tile shape (slabs only; reduce with wgrad_reduce_multi).  k3 s1 p1 jobs with 64-multiple
+    channel counts take the Winograd F(2,3) form."""
     if not jobs:
         return []
     L = _lib.lib()
@@ -188,11 +192,13 @@ def conv_wgrad_multi(jobs):
         rows2, l, ci = x.shape
         if rows != rows2 or lo != conv_out_len(l, k, stride, pad) or k > 3 or ci % 32 or co % 32:
             raise ValueError('conv_wgrad_multi: unsupported shape')
-        _chk(L.da_conv_wgrad_plan(rows, lo, co, ci, k, plan), 'da_conv_wgrad_plan')
+        wino = 1 if (WINOGRAD_WGRAD and k == 3 and stride == 1 and pad == 1 and co % 64 == 0 and ci % 64 == 0) else 0
+        _chk(L.da_conv_wgrad_plan(rows, lo, co, ci, k, wino, plan), 'da_conv_wgrad_plan')
         ws = torch.empty((plan[2] * k * co * ci,), device=x.device, dtype=torch.float32)
         d.dy, d.x, d.workspace = dy.data_ptr(), x.data_ptr(), ws.data_ptr()
         d.rows, d.Lm, d.Ldy, d.lddy, d.N, d.Lx, d.ldx, d.C = rows, lo, lo, co, co, l, ci, ci
         d.dy_stride, d.dy_off, d.src_stride, d.ntaps = 1, 0, stride, k
+        d.winograd = wino
         for t in range(3):
             d.src_off[t] = t - pad if t < k else 0
         outs.append((ws, plan[2], k, co, ci))

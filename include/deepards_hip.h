@@ -59,19 +59,21 @@ int da_conv3_winograd(const float* x, const float* u, float* y, int rows, int L,
                       int accumulate, da_stream_t stream);
 /* tuning / tests: 0 = the partly filled last round of tiles is NOT cut into split-K half tiles */
 int da_wino_debug_tail(int on);
+int da_wino_debug_pchunk(int pchunk);
 /* u[4][co][ci] (transpose = 0, forward) or u[4][ci][co] (transpose = 1, data gradient) from w[co][ci][3] */
 int da_wino_weights(const float* w, float* u, int co, int ci, int transpose, da_stream_t stream);
 /* all weight-gradient GEMMs of a step in one launch per tile shape (jobs: HOST array); slabs only, reduce afterwards */
 typedef struct {
   const float* dy; const float* x; float* workspace;
   int rows, Lm, Ldy, lddy, N, Lx, ldx, C, dy_stride, dy_off, src_stride, ntaps; int src_off[3];
+  int winograd;   /* != 0: k3 s1 p1 job (N, C multiples of 64) in Winograd F(2,3) form; plan with winograd = 1 */
 } da_wgrad_job;
 int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, da_stream_t stream);
 /* deferred slab reduction: da_conv_wgrad with dw == NULL leaves da_conv_wgrad_splits() slabs in the workspace */
 int da_conv_wgrad_splits(int rows, int Lm, int N, int C, int ntaps);
 /* host only: out[4] = {tile_n, tile_c, splits, positions per split} the plan of da_conv_wgrad and
    da_conv_wgrad_multi for this shape; a job's workspace is splits * ntaps*N*C floats */
-int da_conv_wgrad_plan(int rows, int Lm, int N, int C, int ntaps, int* out);
+int da_conv_wgrad_plan(int rows, int Lm, int N, int C, int ntaps, int winograd, int* out);
 typedef struct { const float* slab; float* dw; int splits, ntaps, N, C; } da_wgrad_reduce_desc;
 int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumulate, da_stream_t stream);
 

@@ -71,8 +71,9 @@ CONV_CASES = [
 
 
 def test_conv_wgrad_multi_matches_single_jobs(H):
-    """Every weight gradient of a step in one launch per tile shape (da_conv_wgrad_multi: 30 jobs, so more than one
-    24-entry table) == the oracle, and bit-identical to the one-job launches (same plan, same slabs)."""
+    """Every weight gradient of a step in one launch per tile shape (da_conv_wgrad_multi: more jobs than one 24-entry
+    table holds) == the oracle; direct jobs are bit-identical to the one-job launches (same plan, same slabs), the
+    k3 s1 p1 jobs with 64-multiple channels run in Winograd F(2,3) form (even and odd L, 1 row, > 256 tiles)."""
     rng = np.random.default_rng(77)
     jobs, refs, targets, singles = [], [], [], []
     for n, (ci, co, k, stride, pad, L, rows) in enumerate(CONV_CASES + CONV_CASES[:12]):
@@ -88,9 +89,14 @@ def test_conv_wgrad_multi_matches_single_jobs(H):
         H.wgrad_reduce_multi([(H.conv_wgrad(dyt, xt, k, stride, pad, defer=True), singles[-1])], accumulate=True)
     slabs = H.conv_wgrad_multi(jobs)
     H.wgrad_reduce_multi(list(zip(slabs, targets)), accumulate=True)
-    for n, (t, r, s1) in enumerate(zip(targets, refs, singles)):
+    nw = 0
+    for n, (t, r, s1, (dyt, xt, k, stride, pad)) in enumerate(zip(targets, refs, singles, jobs)):
         close(t.cpu().numpy(), r, tol=3e-6, name='job %d' % n)
-        assert torch.equal(t, s1), 'job %d differs from the one-job launch' % n
+        wino = H.WINOGRAD_WGRAD and k == 3 and stride == 1 and pad == 1 and dyt.shape[2] % 64 == 0 and xt.shape[2] % 64 == 0
+        nw += bool(wino)
+        if not wino:        # same plan, same slabs as the one-job launch; the Winograd form is a different summation
+            assert torch.equal(t, s1), 'job %d differs from the one-job launch' % n
+    assert nw >= 8 or not H.WINOGRAD_WGRAD
     assert H.conv_wgrad_multi([]) == []
 
 
