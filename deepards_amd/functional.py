@@ -35,12 +35,12 @@ class BNState(object):
 #   * the ~60 tiny per-layer launches -- BN running statistics, BN dgamma/dbeta folds, split-K slab
 #     reductions of the weight gradients -- are queued and served by three batched launches.
 # Outside it (plain autograd use, tests) everything runs immediately.
-_STEP = {'on': False, 'pack': {}, 'running': [], 'pgrad': [], 'wgrad': [], 'wslab': []}
+_STEP = {'on': False, 'pack': {}, 'running': [], 'pgrad': [], 'wgrad': [], 'wslab': [], 'forked': False, 'keep': []}
 
 
 @contextlib.contextmanager
 def training_step(model=None):
-    _STEP.update(on=True, pack={}, running=[], pgrad=[], wgrad=[], wslab=[])
+    _STEP.update(on=True, pack={}, running=[], pgrad=[], wgrad=[], wslab=[], forked=False, keep=[])
     try:
         if model is not None:
             ms = [m for m in model.modules()
@@ -52,7 +52,7 @@ def training_step(model=None):
                 _STEP['pack'][w.data_ptr()] = e
         yield
     finally:
-        _STEP.update(on=False, pack={}, running=[], pgrad=[], wgrad=[], wslab=[])
+        _STEP.update(on=False, pack={}, running=[], pgrad=[], wgrad=[], wslab=[], forked=False, keep=[])
 
 
 def flush_forward():
@@ -65,16 +65,43 @@ def flush_backward():
     """Run the queued parameter-gradient folds (call after the backward, before the optimiser)."""
     H.bn_param_grad_multi(_STEP['pgrad'], accumulate=True)
     _launch_wgrads()
+    if _STEP.get('forked'):
+        torch.cuda.current_stream().wait_stream(_side_stream())        # join the weight-gradient branch
+        _STEP['forked'], _STEP['keep'] = False, []
     H.wgrad_reduce_multi(_STEP['wslab'], accumulate=True)
     _STEP['pgrad'], _STEP['wslab'] = [], []
 
 
-def _launch_wgrads():
-    jobs = _STEP['wgrad']                        # (dy, x, k, stride, pad, target): queued weight-gradient GEMMs, one launch
-    if jobs:
+_OVERLAP_STEM = os.environ.get('DA_WGRAD_OVERLAP', '1') != '0'
+_SIDE = {}
+
+
+def _side_stream():
+    dev = torch.cuda.current_device()
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream()
+    return _SIDE[dev]
+
+
+def _launch_wgrads(side=False):
+    """Launch the queued weight-gradient GEMMs ((dy, x, k, stride, pad, target) jobs), all in one batched call.
+    side: on a forked stream (joined by flush_backward) -- used when the stem's backward starts: every residual
+    block has queued its jobs by then, and the stem's bandwidth-bound backward chain (pool, BatchNorm, k7 weight
+    gradient) runs beside the MFMA-bound weight gradients instead of in front of them."""
+    jobs = _STEP['wgrad']
+    if not jobs:
+        return
+    if side:
+        s = _side_stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            slabs = H.conv_wgrad_multi([j[:5] for j in jobs])
+        _STEP['forked'] = True
+        _STEP['keep'] = jobs                     # dy / x stay alive until the join
+    else:
         slabs = H.conv_wgrad_multi([j[:5] for j in jobs])
-        _STEP['wslab'] += [(sl, j[5]) for sl, j in zip(slabs, jobs)]
-        _STEP['wgrad'] = []
+    _STEP['wslab'] += [(sl, j[5]) for sl, j in zip(slabs, jobs)]
+    _STEP['wgrad'] = []
 
 
 _WINOGRAD = os.environ.get('DA_WINOGRAD', '1') != '0'
@@ -163,6 +190,8 @@ class StemFunction(Function):
     def backward(ctx, dout):
         x2d, y0, mean, invstd, gamma, beta = ctx.saved_tensors
         tw, tg, tb = ctx.gt
+        if _STEP['on'] and _OVERLAP_STEM:
+            _launch_wgrads(side=True)
         dz = H.pool_bwd(dout.contiguous(), y0, ctx.R, mean, invstd, gamma, beta, ctx.pool_mode)
         dy0, dgamma, dbeta = _bn_bwd(dz, y0, ctx.R, mean, invstd, gamma, beta, 1, tg, tb, dx=dz)
         dw = H.stem_conv_wgrad(dy0, x2d, out=tw, accumulate=tw is not None)

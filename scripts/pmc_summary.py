@@ -6,5 +6,5 @@ for d in sys.argv[1:]:
         for r in csv.DictReader(open(f)):
             acc[r['Kernel_Name'].split('(')[0][:50]][r['Counter_Name']].append(float(r['Counter_Value']))
         for k, c in acc.items():
-            if 'conv' not in k and 'bn_' not in k: continue
+            if 'conv' not in k and 'bn_' not in k and 'wino' not in k: continue
             print(k, {n: round(sum(v) / len(v)) for n, v in c.items()})
