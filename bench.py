@@ -62,6 +62,8 @@ class KernelTimer(object):
             return 2.0 * a[3] * a[4] * a[7] * a[10] * a[14]
         if name == 'da_conv_wgrad':      # dy,x,dw,ws,rows,Lm,Ldy,lddy,N,Lx,ldx,C,...,ntaps at index 15
             return 2.0 * a[4] * a[5] * a[8] * a[11] * a[15]
+        if name == 'da_conv3_winograd':  # x,u,y,rows,L,ldx,C,ldy,N,...: ALGORITHMIC flops = those of the direct 3-tap conv
+            return 2.0 * a[3] * a[4] * a[6] * a[8] * 3
         if name == 'da_conv_wgrad_multi':   # jobs (host array of da_wgrad_job), n
             return sum(2.0 * a[0][i].rows * a[0][i].Lm * a[0][i].N * a[0][i].C * a[0][i].ntaps for i in range(a[1]))
         return 0.0
@@ -146,11 +148,12 @@ def cpu_baseline(backbone, batch, seconds):
                        (n, b, dt, backbone, torch.__version__, cores))
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None.
-    bench.py cannot run the profiler on itself; the passes are re-collected with the command in the file."""
+def pmc_traffic(entry):
+    """HBM bytes per launch of the dominant kernel (C-ABI entry point `entry`) from the committed rocprofv3 PMC passes
+    (profiles/), or None.  bench.py cannot run the profiler on itself; scripts/profile_round.sh re-collects them."""
     try:
-        return json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))['hbm_bytes_per_launch']
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
+        return d['hbm_bytes_per_launch'] if d.get('entry') == entry else None
     except Exception:
         return None
 
@@ -259,12 +262,16 @@ def main():
         summ = kt.summary()
         kt.remove()
         say('roofline pass done')
-        dom = summ['da_conv_gemm']
+        KERNELS = {'da_conv3_winograd': 'conv3_wino_kernel (da_conv3_winograd: k3 s1 conv forward + data gradient, Winograd '
+                                        'F(2,3) on v_mfma_f32_16x16x4_f32; algorithmic = direct-conv FLOPs, 2/3 of them executed)',
+                   'da_conv_gemm': 'conv_gemm_tailed_kernel<*> / conv_gemm_kernel<*> (da_conv_gemm: conv fwd + dgrad implicit '
+                                   'GEMM, v_mfma_f32_32x32x2_f32)'}
+        dname = max(KERNELS, key=lambda k: summ[k]['total_ms'] if k in summ else -1.0)      # the dominant kernel family
+        dom = summ[dname]
         ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_gemm_tailed_kernel<*> / conv_gemm_kernel<*> (da_conv_gemm: conv fwd + dgrad '
-                                                       'implicit GEMM, v_mfma_f32_32x32x2_f32)',
+        out['roofline'] = {'bound': 'mfma', 'kernel': KERNELS[dname],
                            'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
+                           'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(dname),
                            'launches_per_step': dom['calls'] // nprof, 'avg_launch_us': round(dom['avg_us'], 2),
                            'alg_flops_per_launch': round(dom['flops'] / dom['calls'], 1)}
         tot = sum(v['total_ms'] for v in summ.values())

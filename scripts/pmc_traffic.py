@@ -4,7 +4,7 @@ WRITE_SIZE is taken as reported; both are in KiB."""
 import csv, glob, json, sys, collections
 
 tag, fdir, wdir = sys.argv[1], sys.argv[2], sys.argv[3]
-FAMILY = ('conv_gemm_tailed_kernel', 'conv3_halo_kernel', 'conv_gemm_kernel')     # da_conv_gemm: conv forward + data gradient
+FAMILY = ('conv3_wino_kernel',)     # da_conv3_winograd: k3 s1 conv forward + data gradient (the dominant kernel)
 
 
 def per_kernel(d, counter):
@@ -27,7 +27,7 @@ for counter, d in (('FETCH_SIZE', fdir), ('WRITE_SIZE', wdir)):
     out[counter] = (len(fam), sum(fam) / max(1, len(fam)))
 n, fetch = out['FETCH_SIZE']
 _, write = out['WRITE_SIZE']
-res = {'kernel': 'conv_gemm_tailed_kernel<*> / conv3_halo_kernel / conv_gemm_kernel<*> (da_conv_gemm)', 'launches': n,
+res = {'kernel': 'conv3_wino_kernel', 'entry': 'da_conv3_winograd', 'launches': n,
        'fetch_size_kb_raw_per_launch': round(fetch, 1), 'write_size_kb_per_launch': round(write, 1),
        'hbm_bytes_per_launch': int((2 * fetch + write) * 1024),
        'how': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 '

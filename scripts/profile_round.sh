@@ -3,7 +3,7 @@
 #   1. the default bench line                               -> gpurun_out/<tag>_bench.json
 #   2. rocprofv3 --kernel-trace --stats of `bench.py --no-extra --no-cpu-baseline` (the resnet18 workload only, so the
 #      per-kernel averages are those of the bench line's roofline kernel) -> gpurun_out/<tag>_bench_kernel_stats.csv,
-#      the line it printed, and <tag>_conv_gemm_family.json (launch-weighted average of the da_conv_gemm kernels)
+#      the line it printed, and <tag>_dominant_kernel.json (rocprof average of the dominant kernel next to the bench's HIP-event average)
 #   3. PMC passes FETCH_SIZE / WRITE_SIZE (separate runs)   -> gpurun_out/<tag>_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv, <tag>_traffic.json
 # Copy what should be judged from gpurun_out/ into profiles/.
 set -o pipefail
@@ -15,7 +15,7 @@ timeout -k 10 500 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_stats -- python3 $R/bench.py --no-extra --no-cpu-baseline > $out/${tag}_bench_under_rocprof.json 2> $out/prof_stats.err || { tail -5 $out/prof_stats.err; exit 1; }
 cp $(find $out/prof_stats -name '*kernel_stats.csv' | head -1) $out/${tag}_bench_kernel_stats.csv
-python $R/scripts/stats_family.py $out/${tag}_bench_kernel_stats.csv $out/${tag}_bench_under_rocprof.json > $out/${tag}_conv_gemm_family.json
+python $R/scripts/stats_family.py $out/${tag}_bench_kernel_stats.csv $out/${tag}_bench_under_rocprof.json > $out/${tag}_dominant_kernel.json
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/prof_$c -- python3 $R/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-extra --no-roofline > $out/prof_$c.log 2>&1 || { tail -5 $out/prof_$c.log; exit 1; }
 done

@@ -1,7 +1,7 @@
-"""Launch-weighted average duration of the da_conv_gemm kernels in a rocprofv3 --stats CSV, next to the
-avg_launch_us the bench line measured with HIP events in the same process."""
+"""Launch-weighted average duration of the dominant kernel (conv3_wino_kernel = da_conv3_winograd) in a rocprofv3
+--stats CSV, next to the avg_launch_us the bench line measured with HIP events in the same process."""
 import csv, json, sys
-FAMILY = ('void conv_gemm_tailed_kernel', 'conv3_halo_kernel', 'void conv_gemm_kernel')
+FAMILY = ('conv3_wino_kernel',)
 tot = calls = 0
 for r in csv.DictReader(open(sys.argv[1])):
     if r['Name'].startswith(FAMILY):
