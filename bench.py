@@ -281,6 +281,21 @@ def main():
             out['wgrad_tflops'] = round(wg['flops'] / (wg['total_ms'] * 1e-3) / 1e12, 2)
         out['eager_kernel_ms_per_step'] = round(tot / nprof, 3)
 
+    if world == 1 and not args.no_extra:
+        # forward-only (run_test_epoch step: no_grad train-mode forward + loss + argmax), same batch, graph replayed
+        for _ in range(3):
+            tr.test_step(x, t)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.test_step(x, t)
+        torch.cuda.synchronize()
+        d1 = (time.perf_counter() - t1) / args.steps
+        out.setdefault('extra', {})['inference'] = {'value': round(B * 20 / d1, 1), 'unit': 'breath-sequences/s',
+                                                     'ms_per_step': round(1e3 * d1, 4),
+                                                     'note': 'forward-only test step of %s, B=%d' % (args.backbone, B)}
+        say('inference extra done')
+
     if world == 1 and not args.no_extra and args.backbone == 'resnet18':
         # secondary figure: the reference's DEFAULT backbone (defaults.yml:18), same step definition, dropout active
         torch.manual_seed(0)
@@ -295,10 +310,11 @@ def main():
         torch.cuda.synchronize()
         d2 = (time.perf_counter() - t1) / args.steps
         w2 = WORK['densenet18']
-        out['extra'] = {'densenet18': {'value': round(B * 20 / d2, 1), 'ms_per_step': round(1e3 * d2, 4),
-                                       'alg_tflops': round(w2['flops'] * B * 20 / d2 / 1e12, 2),
-                                       'alg_gbs': round((w2['act_bytes'] * B * 20 + 32 * w2['params']) / d2 / 1e9, 1),
-                                       'note': 'cnn_linear+densenet18 (reference default backbone), drop_rate 0.2 active'}}
+        out.setdefault('extra', {})['densenet18'] = {
+            'value': round(B * 20 / d2, 1), 'ms_per_step': round(1e3 * d2, 4),
+            'alg_tflops': round(w2['flops'] * B * 20 / d2 / 1e12, 2),
+            'alg_gbs': round((w2['act_bytes'] * B * 20 + 32 * w2['params']) / d2 / 1e9, 1),
+            'note': 'cnn_linear+densenet18 (reference default backbone), drop_rate 0.2 active'}
         say('densenet18 extra done')
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

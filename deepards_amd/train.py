@@ -93,6 +93,7 @@ class HotPathTrainer(object):
         self.steps = 0
         self._graph = None
         self._static = None
+        self._test_graphs = {}
         self.last_loss = None
         self.last_logits = None
 
@@ -200,13 +201,43 @@ class HotPathTrainer(object):
         self.last_loss, self.last_logits = loss, logits
         return loss
 
-    def test_step(self, inputs, target):
-        """run_test_epoch body: no_grad forward with train-mode modules, loss, argmax predictions."""
-        self.model.train()
-        with torch.no_grad():
+    def _test_forward(self, inputs, target):
+        with torch.no_grad(), F_.training_step(self.model):      # packs / Winograd taps once, batched small kernels
             logits = self.model(inputs, None)
+            F_.flush_forward()                                   # train-mode forward: BN running statistics do move
             loss, _ = H.bce_logits(logits, target, want_grad=False)
         return loss, logits, logits.argmax(dim=-1)
+
+    def test_step(self, inputs, target):
+        """run_test_epoch body: no_grad forward with train-mode modules, loss, argmax predictions.  With use_graph
+        the step is captured once per batch shape and replayed (outputs are static buffers: consume or clone them
+        before the next call)."""
+        if not inputs.is_cuda:
+            raise RuntimeError('HotPathTrainer needs CUDA (MI355X) tensors; there is no CPU fallback')
+        self.model.train()
+        if not self.use_graph:
+            return self._test_forward(inputs, target)
+        key = (tuple(inputs.shape), tuple(target.shape))
+        ent = self._test_graphs.get(key)
+        if ent is None:
+            static = (inputs.clone(), target.clone())
+            saved = [b.clone() for b in self.model.buffers()]
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):                           # allocator warm-up, side effects rolled back
+                self._test_forward(*static)
+                for b, c in zip(self.model.buffers(), saved):
+                    b.copy_(c)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._test_forward(*static)
+            ent = self._test_graphs[key] = (g, static, out)
+        g, static, out = ent
+        static[0].copy_(inputs)
+        static[1].copy_(target)
+        g.replay()
+        return out
 
 
 def run_train_epoch(trainer, loader, batch_size=None):
@@ -243,7 +274,7 @@ def run_test_epoch(trainer, store, patient_slot, batch_size=16):
         if store.kfold_indexes is not None:
             gidx = store.kfold_indexes[gidx]
         preds.append(H.vote_counts(logits, slot[gidx], votes))
-        losses.append(loss)
+        losses.append(loss.reshape(1).clone())      # static graph output: copy before the next replay
         order.append(idx)
     v = votes.cpu().numpy()
     tot = v.sum(axis=1)

@@ -275,6 +275,27 @@ def test_device_tile_store_matches_reference_getitem():
     assert sizes == [2, 2] and len(store) == 5          # the odd last batch of 1 is clipped away
 
 
+def test_test_step_graph_replay_matches_eager(M):
+    """test_step captured per batch shape (packs once per step, batched small kernels) == the eager form, bit for
+    bit, including the BatchNorm running statistics a train-mode forward moves (run_test_epoch never calls eval())."""
+    from deepards_amd.train import HotPathTrainer
+    x, t = seeded_batch(4, 20, 5)
+    xt, tt = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    ma, mb = build(M, 'resnet18', 1), build(M, 'resnet18', 1)
+    ta, tb = HotPathTrainer(ma, use_graph=True), HotPathTrainer(mb, use_graph=False)
+    for rep in range(3):
+        la, ga, pa = ta.test_step(xt + rep, tt)
+        lb, gb, pb = tb.test_step(xt + rep, tt)
+        assert torch.equal(ga, gb) and torch.equal(pa, pb) and torch.equal(la, lb)
+    sa, sb = ma.state_dict(), mb.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert int(sa['breath_block.bn1.num_batches_tracked']) == 3 * 4
+    la, ga, pa = ta.test_step(xt[:2], tt[:2])            # another shape: second graph
+    lb, gb, pb = tb.test_step(xt[:2], tt[:2])
+    assert torch.equal(ga, gb)
+
+
 def test_test_epoch_votes_on_device(M):
     """Window argmax + per-patient vote table (metrics.py:572-604) computed on the device vs numpy."""
     from deepards_amd.data import DeviceTileStore
