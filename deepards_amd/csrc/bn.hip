@@ -319,33 +319,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // -------------------------------------------------------------------------------------------------
-// Single-pass forms.  For Wn <= FUSED_MAX_WN a (window, 32-channel) slab fits the registers of one
-// block (thread = one channel quad x NPOS positions), so every tensor crosses HBM exactly once:
+// Single-pass forms.  A (window, 32- or 16-channel) slab fits the registers of one block (thread = one channel
+// quad x NPOS positions; Wn <= 1280 positions with 32 channels per block, <= 2560 with 16), so every tensor crosses
+// HBM exactly once:
 //   forward : read x (+res), write out           (two-stage path: x is read by stats AND by apply)
 //   backward: read dout, x (+out), write dx (+g) (two-stage path: both are read by reduce AND apply)
-// block = 8 quads x P position slots, P = ceil(Wn / NPOS) rounded to 8 (whole waves); the fold over
-// slots is 3 wave shuffles + one LDS exchange between the waves, in a fixed order (deterministic).
+// block = NQ quads x P position slots, P = ceil(Wn / NPOS) rounded to whole waves; the fold over slots is wave
+// shuffles + one LDS exchange between the waves, in a fixed order (deterministic).  16 channels per block are used
+// when 32 would leave CUs without a block (the 64-channel layers at B = 64: the two halves of a 128-B line are read
+// by blocks of the same window, which share an XCD and its L2) or the window is too long for one block.
 // Both kernels read their whole slab before the first store, so out/dx may alias an input.
 // -------------------------------------------------------------------------------------------------
 #define FUSED_NPOS 10
-#define FUSED_MAX_WN (FUSED_NPOS * 128)
 
-template <int NV>
+template <int NV, int NQ>
 __device__ __forceinline__ void quad_block_sum(f32x4 (&v)[NV], float* red) {
-  // lanes 8s+q of a wave hold the same channel quad q for 8 slots s
+  // lanes NQ*s+q of a wave hold the same channel quad q for 64/NQ slots s
 #pragma unroll
   for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float t = v[i][e];
-      t += __shfl_xor(t, 8, 64);
-      t += __shfl_xor(t, 16, 64);
-      t += __shfl_xor(t, 32, 64);
+#pragma unroll
+      for (int o = NQ; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
       v[i][e] = t;
     }
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6, q = threadIdx.x & 7;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6, q = threadIdx.x & (NQ - 1);
   __syncthreads();
-  if (lane < 8) {
+  if (lane < NQ) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(&red[(wv * NV + i) * CG + lane * 4]) = v[i];
   }
@@ -363,7 +364,7 @@ __device__ __forceinline__ void quad_block_sum(f32x4 (&v)[NV], float* red) {
 }
 
 // mean / invstd of the window (two-pass from registers), published, and out = act(bn(x) (+res))
-template <int NPOS>
+template <int NPOS, int QB>
 __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const float* __restrict__ x, int ldx,
                                                             const float* __restrict__ res, int ldr,
                                                             float* __restrict__ out, int ldo, int Wn, int C,
@@ -372,13 +373,14 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const float* __restr
                                                             float* __restrict__ mean_out,
                                                             float* __restrict__ invstd_out) {
   __shared__ float red[16 * CG];
-  const int w = blockIdx.x, cg = blockIdx.y, P = blockDim.x >> 3;
-  const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
-  const int c0 = cg * CG + q * 4;
+  constexpr int NQ = 1 << QB, CGB = 4 * NQ;            // channel quads / channels per block (32 or 16)
+  const int w = blockIdx.x, cg = blockIdx.y, P = blockDim.x >> QB;
+  const int q = threadIdx.x & (NQ - 1), slot = threadIdx.x >> QB;
+  const int c0 = cg * CGB + q * 4;
   const size_t base = (size_t)w * Wn;
-  const float* xb = x + base * ldx + cg * CG;      // wave-uniform bases + 32-bit lane offsets
-  const float* rb = res ? res + base * ldr + cg * CG : nullptr;
-  float* ob = out + base * ldo + cg * CG;
+  const float* xb = x + base * ldx + cg * CGB;      // wave-uniform bases + 32-bit lane offsets
+  const float* rb = res ? res + base * ldr + cg * CGB : nullptr;
+  float* ob = out + base * ldo + cg * CGB;
   f32x4 v[NPOS];
 #pragma unroll
   for (int k = 0; k < NPOS; ++k) {
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const float* __restr
   for (int k = 0; k < NPOS; ++k)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[0][e] += v[k][e];
-  quad_block_sum<1>(acc, red);
+  quad_block_sum<1, NQ>(acc, red);
   const float inv_n = 1.0f / (float)Wn;
   f32x4 mu;
 #pragma unroll
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const float* __restr
       }
     }
   }
-  quad_block_sum<1>(acc, red);
+  quad_block_sum<1, NQ>(acc, red);
   f32x4 is;
 #pragma unroll
   for (int e = 0; e < 4; ++e) is[e] = 1.0f / sqrtf(acc[0][e] * inv_n + eps);
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const float* __restr
 }
 
 // same arithmetic as bn_bwd_reduce_kernel + bn_bwd_apply_kernel with the slab held in registers
-template <int NPOS>
+template <int NPOS, int QB>
 __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restrict__ dout, int ldd,
                                                             const float* __restrict__ x, int ldx,
                                                             const float* __restrict__ outp, int ldo,
@@ -450,16 +452,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restr
                                                             const float* __restrict__ beta, int mask_mode,
                                                             float* __restrict__ ds1, float* __restrict__ ds2) {
   __shared__ float red[16 * 2 * CG];
-  const int w = blockIdx.x, cg = blockIdx.y, P = blockDim.x >> 3;
-  const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
-  const int c0 = cg * CG + q * 4;
+  constexpr int NQ = 1 << QB, CGB = 4 * NQ;            // channel quads / channels per block (32 or 16)
+  const int w = blockIdx.x, cg = blockIdx.y, P = blockDim.x >> QB;
+  const int q = threadIdx.x & (NQ - 1), slot = threadIdx.x >> QB;
+  const int c0 = cg * CGB + q * 4;
   // wave-uniform slab bases + 32-bit lane offsets (one SGPR pair + one VGPR per access instead of a 64-bit VGPR pair)
   const size_t base = (size_t)w * Wn;
-  const float* db = dout + base * ldd + cg * CG;
-  const float* xb = x + base * ldx + cg * CG;
-  const float* ob = outp ? outp + base * ldo + cg * CG : nullptr;
-  float* dxb = dx + base * lddx + cg * CG;
-  float* gb = gout ? gout + base * ldg + cg * CG : nullptr;
+  const float* db = dout + base * ldd + cg * CGB;
+  const float* xb = x + base * ldx + cg * CGB;
+  const float* ob = outp ? outp + base * ldo + cg * CGB : nullptr;
+  float* dxb = dx + base * lddx + cg * CGB;
+  float* gb = gout ? gout + base * ldg + cg * CGB : nullptr;
   const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
   const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * C + c0);
   const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restr
       acc[1][e] += g[k][e] * xh[k][e];
     }
   }
-  quad_block_sum<2>(acc, red);
+  quad_block_sum<2, NQ>(acc, red);
   if (slot == 0) {
     *reinterpret_cast<f32x4*>(ds1 + (size_t)w * C + c0) = acc[0];
     *reinterpret_cast<f32x4*>(ds2 + (size_t)w * C + c0) = acc[1];
@@ -508,12 +511,19 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restr
   }
 }
 
-// block size of the single-pass kernels for a window of Wn positions (0: does not fit, use the two-stage path)
-static int bn_fused_threads(int Wn) {
-  if (Wn < 1 || Wn > FUSED_MAX_WN || g_bn_two_stage) return 0;
+// geometry of the single-pass kernels for W windows of Wn positions: channels per block (32, or 16 when 32 would
+// leave CUs without a block or the window too long for one block) and block size; 0: use the two-stage path
+static int bn_fused_geometry(int W, int Wn, int C, int* cgb) {
+  if (Wn < 1 || g_bn_two_stage) return 0;
+  const int max32 = FUSED_NPOS * 128, max16 = FUSED_NPOS * 256;
+  int nq = 8;
+  if (Wn > max32 || (long)W * (C / 32) < 256) nq = 4;
+  if (Wn > (nq == 8 ? max32 : max16)) return 0;
+  const int mult = 64 / nq;                                  // whole waves
   int P = (Wn + FUSED_NPOS - 1) / FUSED_NPOS;
-  P = (P + 7) / 8 * 8;
-  return 8 * P;
+  P = (P + mult - 1) / mult * mult;
+  *cgb = 4 * nq;
+  return nq * P;
 }
 
 // dbeta[c] (+)= sum_w s1[w][c];  dgamma[c] (+)= sum_w s2[w][c] for up to 32 BatchNorms in one launch
@@ -693,9 +703,14 @@ int da_bn_fwd(const float* x, int ldx, const float* res, int ldr, float* out, in
       (res && ldr % 4) || Wn < 1)
     return DA_EINVAL;
   if (W == 0) return DA_OK;
-  if (int threads = bn_fused_threads(Wn)) {
-    hipLaunchKernelGGL((bn_fwd_fused_kernel<FUSED_NPOS>), dim3(W, C / CG), dim3(threads), 0, stream, x, ldx, res, ldr,
-                       out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd);
+  int cgb = 0;
+  if (int threads = bn_fused_geometry(W, Wn, C, &cgb)) {
+    if (cgb == 32)
+      hipLaunchKernelGGL((bn_fwd_fused_kernel<FUSED_NPOS, 3>), dim3(W, C / 32), dim3(threads), 0, stream, x, ldx, res,
+                         ldr, out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd);
+    else
+      hipLaunchKernelGGL((bn_fwd_fused_kernel<FUSED_NPOS, 2>), dim3(W, C / 16), dim3(threads), 0, stream, x, ldx, res,
+                         ldr, out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd);
     DA_CHECK_LAUNCH();
     return DA_OK;
   }
@@ -728,9 +743,14 @@ int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* 
   bn_chunks(W, Wn, C, &P, &chunk);
   float* s1 = ds;
   float* s2 = ds + (size_t)W * C;
-  if (int threads = bn_fused_threads(Wn)) {
-    hipLaunchKernelGGL((bn_bwd_fused_kernel<FUSED_NPOS>), dim3(W, C / CG), dim3(threads), 0, stream, dout, ldd, x, ldx,
-                       out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2);
+  int cgb = 0;
+  if (int threads = bn_fused_geometry(W, Wn, C, &cgb)) {
+    if (cgb == 32)
+      hipLaunchKernelGGL((bn_bwd_fused_kernel<FUSED_NPOS, 3>), dim3(W, C / 32), dim3(threads), 0, stream, dout, ldd, x,
+                         ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2);
+    else
+      hipLaunchKernelGGL((bn_bwd_fused_kernel<FUSED_NPOS, 2>), dim3(W, C / 16), dim3(threads), 0, stream, dout, ldd, x,
+                         ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2);
     DA_CHECK_LAUNCH();
   } else {
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(W, C / CG, P), dim3(256), 0, stream, dout, ldd, x, ldx, out, ldo, Wn, C,

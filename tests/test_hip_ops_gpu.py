@@ -192,7 +192,8 @@ def test_stem_conv(H, rows, L):
 
 
 @pytest.mark.parametrize('C,L,R,W', [(64, 56, 20, 3), (128, 28, 20, 2), (512, 7, 20, 2), (96, 56, 20, 1),
-                                     (64, 112, 20, 2), (32, 5, 3, 4), (256, 14, 20, 2), (32, 64, 20, 1)])
+                                     (64, 112, 20, 2), (32, 5, 3, 4), (256, 14, 20, 2), (32, 64, 20, 1),
+                                     (512, 7, 20, 16), (64, 150, 20, 1)])
 @pytest.mark.parametrize('two_stage', [False, True])
 def test_bn_fwd_bwd(H, C, L, R, W, two_stage):
     """da_bn_fwd / da_bn_bwd take a single-pass register-resident kernel for Wn <= 1280 and the two-stage kernels
