@@ -300,6 +300,39 @@ static inline int grid_for(size_t total, int bs, int cap) {
   return (int)g;
 }
 
+// Lower median over the NB breath rows of every window (torch.median(outputs, dim=1)[0] of CNNLinearComprToRF,
+// reference models/torch_cnn_linear_network.py:47): out[b][f] = the ((NB-1)/2)-th smallest of feat[b*NB + r][f],
+// idx[b][f] = its row r (ties: the earliest row, a stable order).  One thread per (window, feature), NB <= 64.
+__global__ __launch_bounds__(256) void window_median_fwd_kernel(const float* __restrict__ x, int ld, int B, int NB, int F,
+                                                               float* __restrict__ out, int* __restrict__ idx) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * F) return;
+  const int b = t / F, f = t - b * F;
+  const float* col = x + (size_t)b * NB * ld + f;
+  float v[64];
+  for (int r = 0; r < NB; ++r) v[r] = col[(size_t)r * ld];
+  const int k = (NB - 1) >> 1;
+  int sel = 0;
+  for (int i = 0; i < NB; ++i) {
+    int rank = 0;
+    for (int j = 0; j < NB; ++j) rank += (v[j] < v[i]) || (v[j] == v[i] && j < i);
+    if (rank == k) sel = i;
+  }
+  out[t] = v[sel];
+  idx[t] = sel;
+}
+
+// dfeat[b*NB + r][f] = (r == idx[b][f]) ? dout[b][f] : 0
+__global__ __launch_bounds__(256) void window_median_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ idx,
+                                                               int B, int NB, int F, float* __restrict__ dx, int ld) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)B * NB * F) return;
+  const int f = (int)(t % F);
+  const size_t row = t / F;
+  const int b = (int)(row / NB), r = (int)(row - (size_t)b * NB);
+  dx[row * ld + f] = idx[(size_t)b * F + f] == r ? dout[(size_t)b * F + f] : 0.f;
+}
+
 extern "C" {
 
 int da_version(void) { return 100; }
@@ -401,6 +434,29 @@ int da_vote_counts(const float* logits, const int64_t* group, int B, int n_group
   if (!logits || !group || !votes || n_groups < 1) return DA_EINVAL;
   if (B == 0) return DA_OK;
   hipLaunchKernelGGL(vote_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, logits, group, B, n_groups, votes, pred);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// CNNLinearComprToRF head: lower median over the NB rows of each of the B windows (torch_cnn_linear_network.py:47).
+// x: [B*NB][ld] (F features used), out: [B][F], idx: [B][F] selected row (kept for the backward).  NB <= 64.
+int da_window_median_fwd(const float* x, int ld, int B, int NB, int F, float* out, int* idx, hipStream_t stream) {
+  DA_ENTER();
+  if (!x || !out || !idx || NB < 1 || NB > 64 || F < 1 || ld < F) return DA_EINVAL;
+  if (B == 0) return DA_OK;
+  hipLaunchKernelGGL(window_median_fwd_kernel, dim3((B * F + 255) / 256), dim3(256), 0, stream, x, ld, B, NB, F, out, idx);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// dx [B*NB][ld] = the median's gradient: dout[b][f] at row idx[b][f] of window b, 0 elsewhere.
+int da_window_median_bwd(const float* dout, const int* idx, int B, int NB, int F, float* dx, int ld, hipStream_t stream) {
+  DA_ENTER();
+  if (!dout || !idx || !dx || NB < 1 || NB > 64 || F < 1 || ld < F) return DA_EINVAL;
+  if (B == 0) return DA_OK;
+  const size_t total = (size_t)B * NB * F;
+  hipLaunchKernelGGL(window_median_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dout, idx, B,
+                     NB, F, dx, ld);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

@@ -397,6 +397,40 @@ class Linear2Function(Function):
         return dflat, None if direct else dw, None if direct else dbias
 
 
+class WindowMeanFunction(Function):
+    """torch.mean(outputs, dim=1) over the NB breaths of every window (CNNLinearToMean,
+    models/torch_cnn_linear_network.py:25): (B*NB, F) -> (B, F)."""
+
+    @staticmethod
+    def forward(ctx, feat, nb):
+        ctx.nb = nb
+        b = feat.shape[0] // nb
+        return H.avgpool_fwd(feat.view(b, nb, feat.shape[1]), nb).view(b, feat.shape[1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        d = dout.contiguous().view(dout.shape[0], 1, dout.shape[1])
+        dx = H.avgpool_bwd(d, ctx.nb, ctx.nb)                       # (B, NB, F)
+        return dx.view(dout.shape[0] * ctx.nb, dout.shape[1]), None
+
+
+class WindowMedianFunction(Function):
+    """torch.median(outputs, dim=1)[0] (the lower median) over the NB breaths (CNNLinearComprToRF,
+    models/torch_cnn_linear_network.py:47): (B*NB, F) -> (B, F); the gradient goes to the selected breath."""
+
+    @staticmethod
+    def forward(ctx, feat, nb):
+        out, idx = H.window_median_fwd(feat.contiguous(), nb)
+        ctx.save_for_backward(idx)
+        ctx.nb = nb
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        return H.window_median_bwd(dout.contiguous(), idx, ctx.nb), None
+
+
 class BCEWithLogitsFunction(Function):
     """torch.nn.BCEWithLogitsLoss() (mean) -- train_ards_detector.py:530,929-930."""
 

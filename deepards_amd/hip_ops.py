@@ -536,6 +536,27 @@ def gather_rows(src, idx, out=None):
     return out
 
 
+def window_median_fwd(feat, nb):
+    """feat (B*NB, F) -> (median (B, F), idx (B, F) int32): lower median over the NB rows of every window."""
+    _f32(feat, 'feat')
+    rows, f = feat.shape
+    if rows % nb or nb > 64:
+        raise ValueError('window_median: rows %d not a multiple of NB %d (<= 64)' % (rows, nb))
+    b = rows // nb
+    out = torch.empty((b, f), device=feat.device, dtype=torch.float32)
+    idx = torch.empty((b, f), device=feat.device, dtype=torch.int32)
+    _chk(_lib.lib().da_window_median_fwd(_p(feat), f, b, nb, f, _p(out), _p(idx), _stream()), 'da_window_median_fwd')
+    return out, idx
+
+
+def window_median_bwd(dout, idx, nb):
+    _f32(dout, 'dout')
+    b, f = dout.shape
+    dx = torch.empty((b * nb, f), device=dout.device, dtype=torch.float32)
+    _chk(_lib.lib().da_window_median_bwd(_p(dout), _p(idx), b, nb, f, _p(dx), f, _stream()), 'da_window_median_bwd')
+    return dx
+
+
 def vote_counts(logits, group, votes, want_pred=True):
     """logits (B,2) f32, group (B,) int64 patient slot per window, votes (P,2) int32 accumulated in place.
     -> pred (B,) int32 window predictions (argmax, class 0 on ties)."""

@@ -1,10 +1,16 @@
-"""CNNLinearNetwork on MI355X.
+"""CNNLinearNetwork and its sibling heads on MI355X.
 
-Operator surface of reference ``deepards/models/torch_cnn_linear_network.py:92-113``: same
-constructor, ``breath_block`` / ``linear_final`` / ``seq_size`` attributes, same exception for a
-wrong sequence length, same output ``(B, 2)``.  Instead of looping over the batch in Python and
-``torch.cat``-ing the per-window logits, all B windows go through the breath block in one batched
-pass (BatchNorm statistics still per window) and one head kernel.
+Operator surface of reference ``deepards/models/torch_cnn_linear_network.py``: same constructors,
+``breath_block`` / ``linear_final`` (/ ``linear_intermediate``) / ``seq_size`` attributes, same exception for a
+wrong sequence length, same output shapes.  Instead of looping over the batch in Python and ``torch.cat``-ing
+the per-window results, all B windows go through the breath block in one batched pass (BatchNorm statistics
+still per window) and one head kernel.
+
+    CNNLinearNetwork              :92-113   Linear(F*NB, 2) on the flattened (NB, F) block        -> (B, 2)
+    CNNLinearToMean               :7-26     Linear(F, 2) on the mean over the NB breaths          -> (B, 2)
+    CNNLinearComprToRF            :29-47    Linear(F, 2) on the (lower) median over the breaths   -> (B, 2)
+    CNNSingleBreathLinearNetwork  :50-67    Linear(F, 2) per breath                               -> (B, NB, 2)
+    CNNDoubleLinearNetwork        :70-89    Linear(2*NB, 2) on the flattened per-breath Linear(F, 2) -> (B, 2)
 """
 import torch.nn as nn
 
@@ -32,3 +38,67 @@ class CNNLinearNetwork(nn.Module):
         feat = self.breath_block.forward_windows(x.reshape(b * nb, c, l), nb)        # (B*NB, F)
         flat = feat.view(b, nb * feat.shape[1])                                     # == view(-1) per window
         return F_.Linear2Function.apply(flat, self.linear_final.weight, self.linear_final.bias)
+
+
+def _windows(model, x):
+    # input should be in shape: (batches, breaths in seq, chans, 224)
+    if x.shape[-1] != 224:
+        raise Exception('input breaths must have sequence length of 224')
+    b, nb, c, l = x.shape
+    return b, nb, model.breath_block.forward_windows(x.reshape(b * nb, c, l), nb)    # (B*NB, F)
+
+
+class CNNLinearToMean(nn.Module):
+    def __init__(self, breath_block):
+        super(CNNLinearToMean, self).__init__()
+        self.seq_size = 224
+        self.breath_block = breath_block
+        self.linear_final = nn.Linear(self.breath_block.n_out_filters, 2)
+
+    def forward(self, x, metadata):
+        b, nb, feat = _windows(self, x)
+        return F_.Linear2Function.apply(F_.WindowMeanFunction.apply(feat, nb), self.linear_final.weight,
+                                        self.linear_final.bias)
+
+
+class CNNLinearComprToRF(nn.Module):
+    def __init__(self, breath_block):
+        super(CNNLinearComprToRF, self).__init__()
+        self.seq_size = 224
+        self.breath_block = breath_block
+        self.linear_final = nn.Linear(self.breath_block.n_out_filters, 2)
+
+    def forward(self, x, metadata):
+        b, nb, feat = _windows(self, x)
+        return F_.Linear2Function.apply(F_.WindowMedianFunction.apply(feat, nb), self.linear_final.weight,
+                                        self.linear_final.bias)
+
+
+class CNNSingleBreathLinearNetwork(nn.Module):
+    def __init__(self, breath_block):
+        super(CNNSingleBreathLinearNetwork, self).__init__()
+        self.seq_size = 224
+        self.breath_block = breath_block
+        self.linear_final = nn.Linear(self.breath_block.n_out_filters, 2)
+
+    def forward(self, x, metadata):
+        b, nb, feat = _windows(self, x)
+        return F_.Linear2Function.apply(feat, self.linear_final.weight, self.linear_final.bias).view(b, nb, 2)
+
+
+class CNNDoubleLinearNetwork(nn.Module):
+    def __init__(self, breath_block, sequence_size, metadata_features):
+        super(CNNDoubleLinearNetwork, self).__init__()
+        self.seq_size = 224
+        self.breath_block = breath_block
+        self.metadata_features = metadata_features
+        self.linear_intermediate = nn.Linear(self.breath_block.n_out_filters, 2)
+        self.linear_final = nn.Linear(2 * sequence_size + metadata_features, 2)
+
+    def forward(self, x, metadata):
+        if self.metadata_features:
+            raise NotImplementedError('metadata_features > 0 is not runnable in the reference either '
+                                      '(SURVEY.md finding 8)')
+        b, nb, feat = _windows(self, x)
+        inter = F_.Linear2Function.apply(feat, self.linear_intermediate.weight, self.linear_intermediate.bias)
+        return F_.Linear2Function.apply(inter.view(b, nb * 2), self.linear_final.weight, self.linear_final.bias)

@@ -41,6 +41,14 @@ def shard_windows(n_windows, world_size, rank):
     return slice(rank * per, (rank + 1) * per)
 
 
+def _loss_operands(logits, target):
+    """(logits, target) as (n, 2) pairs for the BCE kernel.  Per-breath outputs (B, NB, 2) repeat the window target
+    over the breaths (PerBreathClassifierMixin.calc_loss, train_ards_detector.py:540-543)."""
+    if logits.dim() == 3:
+        target = target.unsqueeze(1).expand(-1, logits.shape[1], -1)
+    return logits.reshape(-1, 2).contiguous(), target.reshape(-1, 2).contiguous()
+
+
 class FlatBucket(object):
     """Flat fp32 views over the live parameters: p (weights), g (gradients)."""
 
@@ -102,8 +110,9 @@ class HotPathTrainer(object):
         with F_.training_step(self.model):               # weights are constant within one step
             logits = self.model(inputs, None)
             F_.flush_forward()                           # batched BN running-statistics updates
-            loss, dlogits = H.bce_logits(logits.detach(), target, want_grad=True)
-            logits.backward(dlogits)
+            lg, tg = _loss_operands(logits.detach(), target)
+            loss, dlogits = H.bce_logits(lg, tg, want_grad=True)
+            logits.backward(dlogits.view(logits.shape))
             F_.flush_backward()                          # batched dgamma/dbeta folds + wgrad slab reductions
         return loss, logits.detach()
 
@@ -205,7 +214,7 @@ class HotPathTrainer(object):
         with torch.no_grad(), F_.training_step(self.model):      # packs / Winograd taps once, batched small kernels
             logits = self.model(inputs, None)
             F_.flush_forward()                                   # train-mode forward: BN running statistics do move
-            loss, _ = H.bce_logits(logits, target, want_grad=False)
+            loss, _ = H.bce_logits(*_loss_operands(logits, target), want_grad=False)
         return loss, logits, logits.argmax(dim=-1)
 
     def test_step(self, inputs, target):

@@ -166,6 +166,13 @@ int da_clamp_adam(float* p, const float* g, float* m, float* v, size_t n, float 
  * + the .float() cast of train_ards_detector.py:150-152; replaces DataLoader/collate/H2D per step. */
 int da_gather_normalize(const double* tiles, const int64_t* idx, double mu, double stdv, float* out, int B,
                         int tile_elems, da_stream_t stream);
+/* ---- sibling heads of CNNLinearNetwork (torch_cnn_linear_network.py:7-89) ---------------------- */
+/* CNNLinearComprToRF: lower median over the NB breath rows of each window (torch.median(outputs, dim=1)[0], :47);
+   x [B*NB][ld], out [B][F], idx [B][F] = selected row (for the backward); NB <= 64.  The mean of CNNLinearToMean
+   (:25) is da_avgpool_fwd over the breath axis; the per-breath / double linear heads (:67,:87) are da_linear2_*. */
+int da_window_median_fwd(const float* x, int ld, int B, int NB, int F, float* out, int* idx, da_stream_t stream);
+int da_window_median_bwd(const float* dout, const int* idx, int B, int NB, int F, float* dx, int ld, da_stream_t stream);
+
 int da_gather_rows(const float* src, const int64_t* idx, float* out, int B, int width, da_stream_t stream);
 
 /* ---- test epoch on the device: window predictions + per-patient vote table --------------------------------

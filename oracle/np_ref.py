@@ -346,14 +346,27 @@ def densenet18_features(t, x, prefix='breath_block.', drop_masks=None):
     return out, bwd
 
 
+HEADS = ('linear', 'to_mean', 'compr_to_rf', 'single_breath', 'double_linear')
+
+
 def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_batches=20,
-                                first_pool_type='max', drop_masks=None, need_grads=True):
+                                first_pool_type='max', drop_masks=None, need_grads=True, head='linear'):
     """CNNLinearNetwork.forward over a batch (torch_cnn_linear_network.py:104-113) + BCE loss
     (train_ards_detector.py:929-930) + backward.  x (B,NB,C,224); target (B,2) one-hot.
     params: dict name -> ndarray with the reference's state_dict keys.
-    Returns dict(logits, loss, grads{name}, feat, stats)."""
+    Returns dict(logits, loss, grads{name}, feat, stats).
+
+    head selects the sibling networks on the same breath block (torch_cnn_linear_network.py:7-89):
+      'to_mean'        CNNLinearToMean:              Linear(F,2)(mean over the NB breaths)              -> (B,2)
+      'compr_to_rf'    CNNLinearComprToRF:           Linear(F,2)(torch.median over NB = LOWER median)   -> (B,2)
+      'single_breath'  CNNSingleBreathLinearNetwork: Linear(F,2) per breath                             -> (B,NB,2)
+      'double_linear'  CNNDoubleLinearNetwork:       Linear(2 NB,2)(flatten(Linear(F,2) per breath))    -> (B,2)
+    The loss of a (B,NB,2) output repeats the window target over the breaths (PerBreathClassifierMixin.calc_loss,
+    train_ards_detector.py:540-543)."""
     if x.shape[-1] != 224:
         raise Exception('input breaths must have sequence length of 224')
+    if head not in HEADS:
+        raise ValueError(head)
     b, nb, c, l = x.shape
     t = _Tape(params, nb)
     rows = x.reshape(b * nb, c, l)
@@ -363,17 +376,52 @@ def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_ba
         feat, fbwd = densenet18_features(t, rows, drop_masks=drop_masks)
     else:
         raise ValueError(backbone)
-    flat = feat.reshape(b, -1)                                       # view(-1) of (NB,F) per window
     w, bias = params['linear_final.weight'], params['linear_final.bias']
+    f3 = feat.reshape(b, nb, -1)
+    med_idx = None
+    if head == 'linear':
+        flat = feat.reshape(b, -1)                                   # view(-1) of (NB,F) per window
+    elif head == 'to_mean':
+        flat = f3.mean(axis=1)
+    elif head == 'compr_to_rf':
+        med_idx = np.argsort(f3, axis=1, kind='stable')[:, (nb - 1) // 2, :]        # lower median (torch.median)
+        flat = np.take_along_axis(f3, med_idx[:, None, :], axis=1)[:, 0, :]
+    elif head == 'single_breath':
+        flat = feat                                                  # (B*NB, F)
+    else:
+        wi, bi = params['linear_intermediate.weight'], params['linear_intermediate.bias']
+        inter = linear_fwd(feat, wi, bi)                             # (B*NB, 2)
+        flat = inter.reshape(b, -1)                                  # .view(-1): breath-major, class-minor
     logits = linear_fwd(flat, w, bias)
+    if head == 'single_breath':
+        logits = logits.reshape(b, nb, 2)
     out = dict(logits=logits, feat=feat, stats=t.stats)
     if target is None:
         return out
-    loss, dlogits = bce_with_logits(logits, target)
+    if head == 'single_breath':
+        loss, dl = bce_with_logits(logits.reshape(b * nb, 2), np.repeat(target, nb, axis=0))
+    else:
+        loss, dl = bce_with_logits(logits, target)
     out['loss'] = loss
     if need_grads:
-        t.acc('linear_final.weight', dlogits.T @ flat)
-        t.acc('linear_final.bias', dlogits.sum(axis=0))
-        fbwd((dlogits @ w).reshape(feat.shape))
+        t.acc('linear_final.weight', dl.T @ flat)
+        t.acc('linear_final.bias', dl.sum(axis=0))
+        dflat = dl @ w
+        if head == 'linear':
+            dfeat = dflat.reshape(feat.shape)
+        elif head == 'to_mean':
+            dfeat = np.repeat(dflat[:, None, :] / nb, nb, axis=1).reshape(feat.shape)
+        elif head == 'compr_to_rf':
+            d3 = np.zeros_like(f3)
+            np.put_along_axis(d3, med_idx[:, None, :], dflat[:, None, :], axis=1)
+            dfeat = d3.reshape(feat.shape)
+        elif head == 'single_breath':
+            dfeat = dflat
+        else:
+            dinter = dflat.reshape(b * nb, 2)
+            t.acc('linear_intermediate.weight', dinter.T @ feat)
+            t.acc('linear_intermediate.bias', dinter.sum(axis=0))
+            dfeat = dinter @ wi
+        fbwd(dfeat)
         out['grads'] = t.g
     return out

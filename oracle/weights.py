@@ -11,7 +11,7 @@ import zlib
 import numpy as np
 
 
-def param_spec(backbone, n_sub_batches=20, in_ch=1, n_meta=0):
+def param_spec(backbone, n_sub_batches=20, in_ch=1, n_meta=0, head='linear'):
     """-> list of (name, shape, kind) with kind in {'conv','bn_w','bn_b','lin_w','lin_b'},
     in the reference's ``named_parameters()`` order."""
     out = []
@@ -66,7 +66,18 @@ def param_spec(backbone, n_sub_batches=20, in_ch=1, n_meta=0):
         feat = nf
     else:
         raise ValueError(backbone)
-    out.append(('linear_final.weight', (2, feat * n_sub_batches + n_meta), 'lin_w'))
+    # heads of torch_cnn_linear_network.py: 'linear' (CNNLinearNetwork :92-103), 'to_mean' / 'compr_to_rf' /
+    # 'single_breath' (Linear(F, 2), :7-67), 'double_linear' (Linear(F, 2) then Linear(2 NB + meta, 2), :70-89)
+    if head == 'linear':
+        out.append(('linear_final.weight', (2, feat * n_sub_batches + n_meta), 'lin_w'))
+    elif head in ('to_mean', 'compr_to_rf', 'single_breath'):
+        out.append(('linear_final.weight', (2, feat), 'lin_w'))
+    elif head == 'double_linear':
+        out.append(('linear_intermediate.weight', (2, feat), 'lin_w'))
+        out.append(('linear_intermediate.bias', (2,), 'lin_b'))
+        out.append(('linear_final.weight', (2, 2 * n_sub_batches + n_meta), 'lin_w'))
+    else:
+        raise ValueError(head)
     out.append(('linear_final.bias', (2,), 'lin_b'))
     return out
 
@@ -75,7 +86,7 @@ DEAD_RESNET_PARAMS = ('breath_block.conv1_alt.weight', 'breath_block.conv2.weigh
                       'breath_block.bn2.weight', 'breath_block.bn2.bias')
 
 
-def seeded_params(backbone, seed=0, n_sub_batches=20, dtype=np.float32, bn_bias_shift=0.0):
+def seeded_params(backbone, seed=0, n_sub_batches=20, dtype=np.float32, bn_bias_shift=0.0, head='linear'):
     """Deterministic weights: conv ~ N(0, sqrt(2/(k*C_out))) as the reference's init
     (resnet.py:115-118, densenet.py:154-157); BN gamma ~ U(.5,1.5), beta ~ N(0,.1) (NOT the
     reference's 1/0 -- randomised so that parity tests see gamma/beta); linear ~ U(+-1/sqrt(in)).
@@ -83,7 +94,7 @@ def seeded_params(backbone, seed=0, n_sub_batches=20, dtype=np.float32, bn_bias_
     no activation decisions an fp32 rounding could flip, which makes whole-model GRADIENT parity a
     well-posed 1e-4 comparison (see tests/test_model_gpu.py)."""
     params = {}
-    for name, shape, kind in param_spec(backbone, n_sub_batches):
+    for name, shape, kind in param_spec(backbone, n_sub_batches, head=head):
         rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
         if kind == 'conv':
             std = np.sqrt(2.0 / (shape[2] * shape[0]))

@@ -404,6 +404,28 @@ def test_concat_slice_dropout(H):
     assert torch.allclose(y1[y1 > 0], torch.tensor(1.25, device='cuda'))
 
 
+@pytest.mark.parametrize('B,NB,F', [(3, 20, 128), (64, 20, 512), (2, 7, 32), (5, 1, 64), (4, 64, 16)])
+def test_window_median(H, B, NB, F):
+    """Lower median over the NB breath rows (torch.median semantics, models/torch_cnn_linear_network.py:47) and its
+    gradient; ties (post-ReLU zeros) go to the earliest row."""
+    rng = np.random.default_rng(B + NB + F)
+    x = np.maximum(rng.standard_normal((B, NB, F)), -0.3).astype(np.float32)
+    x[x == -0.3] = 0.0                                              # plenty of exact ties
+    xt = cu(x.reshape(B * NB, F))
+    med, idx = H.window_median_fwd(xt, NB)
+    order = np.argsort(x, axis=1, kind='stable')[:, (NB - 1) // 2, :]
+    ref = np.take_along_axis(x, order[:, None, :], axis=1)[:, 0, :]
+    assert np.array_equal(med.cpu().numpy(), ref)
+    assert np.array_equal(idx.cpu().numpy(), order)
+    tm = torch.median(torch.from_numpy(x), dim=1)[0].numpy()
+    assert np.array_equal(med.cpu().numpy(), tm)
+    dout = rng.standard_normal((B, F)).astype(np.float32)
+    dx = H.window_median_bwd(cu(dout), idx, NB).cpu().numpy().reshape(B, NB, F)
+    dref = np.zeros_like(x)
+    np.put_along_axis(dref, order[:, None, :], dout[:, None, :], axis=1)
+    assert np.array_equal(dx, dref)
+
+
 def test_bad_arguments_are_refused(H):
     x = torch.zeros(4, 8, 48, device='cuda')               # C = 48 is not a multiple of 32
     with pytest.raises(ValueError):

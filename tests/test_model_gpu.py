@@ -13,7 +13,9 @@ from oracle import np_ref
 from oracle.weights import seeded_params, seeded_batch, digest, DEAD_RESNET_PARAMS
 
 pytestmark = pytest.mark.gpu
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*net18_*.npz')))
+GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*net18_*.npz'))
+              if not os.path.basename(p).startswith('head_'))
+HEAD_GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'head_*.npz')))
 LOG = os.path.join(os.path.dirname(os.path.dirname(__file__)), 'gpurun_out', 'parity_model.log')
 
 
@@ -104,6 +106,65 @@ def test_logits_and_grads_match_reference_golden(M, path):
             bad.append((n, abs_err, rl2))
     log('   worst grad abs err %.3e' % worst)
     assert not bad, bad
+
+
+def build_head(M, head, backbone, seed, first_pool_type='max', shift=0.0):
+    bb = M.resnet18(first_pool_type=first_pool_type) if backbone == 'resnet18' else M.densenet18(drop_rate=0.0)
+    model = {'to_mean': lambda: M.CNNLinearToMean(bb), 'compr_to_rf': lambda: M.CNNLinearComprToRF(bb),
+             'single_breath': lambda: M.CNNSingleBreathLinearNetwork(bb),
+             'double_linear': lambda: M.CNNDoubleLinearNetwork(bb, 20, 0)}[head]()
+    sd = {k: torch.from_numpy(v) for k, v in seeded_params(backbone, seed, bn_bias_shift=shift, head=head).items()}
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys
+    return model.cuda().train()
+
+
+@pytest.mark.parametrize('path', HEAD_GOLD, ids=[os.path.basename(p)[:-4] for p in HEAD_GOLD])
+def test_sibling_heads_match_reference_golden(M, path):
+    """CNNLinearToMean / CNNLinearComprToRF / CNNSingleBreathLinearNetwork / CNNDoubleLinearNetwork
+    (reference models/torch_cnn_linear_network.py:7-89; goldens from the reference classes,
+    oracle/make_golden_heads.py): logits 1e-4 absolute; gradients strict on the '_active' goldens, flip-tolerant on
+    the others (same criteria as test_logits_and_grads_match_reference_golden); one trainer step runs."""
+    from deepards_amd.functional import bce_with_logits
+    from deepards_amd.train import HotPathTrainer, _loss_operands
+    g = _gold(path)
+    backbone, head, shift = str(g['backbone']), str(g['head']), float(g['bn_bias_shift'])
+    strict = shift > 0
+    model = build_head(M, head, backbone, int(g['seed']), str(g['first_pool_type']), shift)
+    x = torch.from_numpy(g['x']).cuda()
+    t = torch.from_numpy(g['target']).cuda()
+    out = model(x, None)
+    assert tuple(out.shape) == g['logits64'].shape
+    loss = bce_with_logits(*[o.view(-1, 2) if i == 0 else o for i, o in enumerate(_loss_operands(out, t))])
+    loss.backward()
+    err = np.abs(out.detach().cpu().numpy().astype(np.float64) - g['logits64']).max()
+    log(os.path.basename(path), 'logits max|hip-ref64| %.3e loss %.8f vs %.8f' % (err, float(loss), float(g['loss64'])))
+    assert err < 1e-4 and abs(float(loss) - float(g['loss64'])) < 1e-5
+    bad = []
+    for n, p in model.named_parameters():
+        key = 'grad64/' + n
+        if key not in g:
+            assert p.grad is None, n
+            continue
+        d = digest(p.grad.cpu().numpy())
+        body = slice(None) if p.numel() <= 1024 else slice(0, -3)
+        abs_err = np.abs(d - g[key])[body].max()
+        rl2 = rel_l2(d[body], g[key][body])
+        scale = max(1.0, np.abs(g[key][body]).max())
+        if strict:
+            # the median head keeps ONE decision even here: which breath is the median (ties in fp32 vs fp64 order)
+            ok = abs_err <= 1e-4 * scale or (head == 'compr_to_rf' and rl2 <= 5e-2)
+        else:
+            ok = rl2 <= 5e-2 or abs_err <= 1e-4 * scale
+        if not ok:
+            bad.append((n, abs_err, rl2))
+    assert not bad, bad
+    if strict and backbone == 'resnet18':                 # the trainer drives every head (per-breath loss included)
+        tr = HotPathTrainer(model, use_graph=True)
+        l = [float(tr.train_step(x, t)) for _ in range(3)]
+        assert all(np.isfinite(l)) and abs(l[0] - float(g['loss64'])) < 1e-4
+        lt, lg, pred = tr.test_step(x, t)
+        assert pred.shape == tuple(g['logits64'].shape[:-1])
 
 
 def test_window_independence_and_breath_block_call(M):

@@ -8,7 +8,9 @@ import pytest
 from oracle import np_ref
 from oracle.weights import seeded_params, digest, DEAD_RESNET_PARAMS
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*net18_*.npz')))
+GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*net18_*.npz'))
+              if not os.path.basename(p).startswith('head_'))
+HEAD_GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'head_*.npz')))
 
 
 def _load(path):
@@ -36,6 +38,30 @@ def test_np_oracle_matches_reference(path):
     assert checked == len(params) - (len(dead) if backbone == 'resnet18' else 0)
     # the fp32 reference sits within 1e-5 of the fp64 one: the 1e-4 parity budget is meaningful
     assert np.abs(g['logits32'] - g['logits64']).max() < 1e-5
+
+
+@pytest.mark.parametrize('path', HEAD_GOLD, ids=[os.path.basename(p)[:-4] for p in HEAD_GOLD])
+def test_np_oracle_sibling_heads_match_reference(path):
+    """CNNLinearToMean / CNNLinearComprToRF / CNNSingleBreathLinearNetwork / CNNDoubleLinearNetwork
+    (torch_cnn_linear_network.py:7-89) restated in the oracle vs the reference classes (oracle/make_golden_heads.py)."""
+    g = _load(path)
+    backbone, head = str(g['backbone']), str(g['head'])
+    params = {k: v.astype(np.float64) for k, v in
+              seeded_params(backbone, int(g['seed']), bn_bias_shift=float(g['bn_bias_shift']), head=head).items()}
+    out = np_ref.cnn_linear_forward_backward(params, g['x'].astype(np.float64), g['target'].astype(np.float64),
+                                             backbone=backbone, first_pool_type=str(g['first_pool_type']), head=head)
+    assert out['logits'].shape == g['logits64'].shape
+    np.testing.assert_allclose(out['logits'], g['logits64'], rtol=0, atol=1e-10)
+    assert abs(out['loss'] - float(g['loss64'])) < 1e-12
+    checked = 0
+    for k in g:
+        if k.startswith('grad64/'):
+            name = k[len('grad64/'):]
+            np.testing.assert_allclose(digest(out['grads'][name]), g[k], rtol=1e-8, atol=1e-9, err_msg=name)
+            checked += 1
+    assert checked >= 60 and 'linear_final.weight' in out['grads']
+    if head == 'double_linear':
+        assert 'linear_intermediate.weight' in out['grads']
 
 
 def test_np_oracle_sgd_trajectory():
