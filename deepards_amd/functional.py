@@ -343,14 +343,15 @@ class TransitionFunction(Function):
 
 
 class NormReluFunction(Function):
-    """BN -> ReLU (densenet norm5 + F.relu, models/densenet.py:146,181-182)."""
+    """BN -> ReLU (densenet norm5 + F.relu, models/densenet.py:146,181-182); relu=False: the bare norm5 output
+    that ``features(x)`` returns to the explainers (gradcam.py:45)."""
 
     @staticmethod
-    def forward(ctx, x, g, b, R, st):
+    def forward(ctx, x, g, b, R, st, relu=True):
         s_ = _stats(x, R, st)
-        out = _bn_apply(x, R, s_, st, g, b, True)
+        out = _bn_apply(x, R, s_, st, g, b, relu)
         m, i = s_.mean, s_.invstd
-        ctx.R = R
+        ctx.R, ctx.relu = R, relu
         ctx.gt = _tgt(g, b)
         ctx.save_for_backward(x, g, b, m, i)
         return out
@@ -359,8 +360,8 @@ class NormReluFunction(Function):
     def backward(ctx, dout):
         x, g, b, m, i = ctx.saved_tensors
         tg, tb = ctx.gt
-        dx, dg, db = _bn_bwd(dout.contiguous(), x, ctx.R, m, i, g, b, 1, tg, tb)
-        return dx, dg, db, None, None
+        dx, dg, db = _bn_bwd(dout.contiguous(), x, ctx.R, m, i, g, b, 1 if ctx.relu else 0, tg, tb)
+        return dx, dg, db, None, None, None
 
 
 class GlobalAvgPoolFunction(Function):

@@ -81,6 +81,39 @@ class _Transition(nn.Sequential):
                                            F_.BNState(self.norm))
 
 
+class _Features(nn.Sequential):
+    """``DenseNet.features``: the reference's Sequential (same child names / state_dict keys); calling it runs the
+    HIP pipeline and returns the norm5 output in the reference's (N, C, L) layout WITHOUT the final ReLU, as
+    ``nn.Sequential.__call__`` does there -- what gradcam.py:45 hooks."""
+    drop_rate = 0.0
+
+    def forward_rlc(self, x, R, relu):
+        _require_cuda(x, 'DenseNet')
+        if x.dim() != 3 or x.shape[1] != 1:
+            raise ValueError('expected (rows, 1, L) input, got %s' % (tuple(x.shape),))
+        rows, _, l = x.shape
+        if rows % R:
+            raise ValueError('rows not a multiple of rows_per_window')
+        x2d = x.contiguous().float().view(rows, l)
+        h = F_.StemFunction.apply(x2d, self.conv0.weight, self.norm0.weight, self.norm0.bias, R, F_.POOL_MAX,
+                                  F_.BNState(self.norm0))
+        use_drop = self.training and self.drop_rate > 0
+        if use_drop:
+            self._drop_seed.add_(0x9E3779B97F4A7C15 >> 1)
+        salt = 0
+        for name, mod in self.named_children():
+            if isinstance(mod, _DenseBlock):
+                for layer in mod.children():
+                    salt += 1
+                    h = layer.forward_rlc(h, R, self._drop_seed, salt)
+            elif isinstance(mod, _Transition):
+                h = mod.forward_rlc(h, R)
+        return F_.NormReluFunction.apply(h, self.norm5.weight, self.norm5.bias, R, F_.BNState(self.norm5), relu)
+
+    def forward(self, x):
+        return self.forward_rlc(x, x.shape[0], False).permute(0, 2, 1)
+
+
 class DenseNet(nn.Module):
     def __init__(self, growth_rate=32, block_config=(6, 12, 24, 16), num_init_features=64, bn_size=4,
                  drop_rate=0.2, num_classes=1000, with_fft=False, only_fft=False, fft_real_only=False):
@@ -94,7 +127,7 @@ class DenseNet(nn.Module):
         self.inplanes = num_init_features
         self.drop_rate = drop_rate
         track_running_stats = False
-        self.features = nn.Sequential(OrderedDict([
+        self.features = _Features(OrderedDict([
             ('conv0', nn.Conv1d(1, num_init_features, kernel_size=7, stride=2, padding=3, bias=False)),
             ('norm0', nn.BatchNorm1d(num_init_features, track_running_stats=track_running_stats)),
             ('relu0', nn.ReLU(inplace=True)),
@@ -130,7 +163,8 @@ class DenseNet(nn.Module):
         self.avgpool = nn.AvgPool1d(7, stride=1)
         # device-resident dropout seed: bumped on the device each forward so a captured graph replays
         # with fresh masks
-        self.register_buffer('_drop_seed', torch.zeros(1, dtype=torch.int64), persistent=False)
+        self.features.drop_rate = drop_rate
+        self.features.register_buffer('_drop_seed', torch.zeros(1, dtype=torch.int64), persistent=False)
 
     def update_conv_info(self, obj):
         bks, bs, bp = obj.conv_info()
@@ -143,28 +177,7 @@ class DenseNet(nn.Module):
         return self.kernel_sizes, self.strides, self.paddings
 
     def _features_rlc(self, x, R):
-        _require_cuda(x, 'DenseNet')
-        if x.dim() != 3 or x.shape[1] != 1:
-            raise ValueError('expected (rows, 1, L) input, got %s' % (tuple(x.shape),))
-        rows, _, l = x.shape
-        if rows % R:
-            raise ValueError('rows not a multiple of rows_per_window')
-        f = self.features
-        x2d = x.contiguous().float().view(rows, l)
-        h = F_.StemFunction.apply(x2d, f.conv0.weight, f.norm0.weight, f.norm0.bias, R, F_.POOL_MAX,
-                                  F_.BNState(f.norm0))
-        use_drop = self.training and self.drop_rate > 0
-        if use_drop:
-            self._drop_seed.add_(0x9E3779B97F4A7C15 >> 1)
-        salt = 0
-        for name, mod in f.named_children():
-            if isinstance(mod, _DenseBlock):
-                for layer in mod.children():
-                    salt += 1
-                    h = layer.forward_rlc(h, R, self._drop_seed, salt)
-            elif isinstance(mod, _Transition):
-                h = mod.forward_rlc(h, R)
-        return F_.NormReluFunction.apply(h, f.norm5.weight, f.norm5.bias, R, F_.BNState(f.norm5))
+        return self.features.forward_rlc(x, R, True)
 
     def forward_windows(self, x, rows_per_window):
         h = self._features_rlc(x, rows_per_window)

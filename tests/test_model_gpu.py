@@ -357,6 +357,47 @@ def test_test_step_graph_replay_matches_eager(M):
     assert torch.equal(ga, gb)
 
 
+def test_gradcam_surface_on_densenet(M):
+    """The explainer surface of SURVEY 8f row 4: gradcam.py:38-108 calls ``model.breath_block.features(x)`` (norm5
+    output, (N, C, L), no ReLU), hooks its gradient, then relu -> ``breath_block.avgpool`` -> view(-1) ->
+    ``linear_final`` and backpropagates the one-hot class score.  Same calls on this build vs the reference modules
+    (oracle/make_golden_gradcam.py); a whole-module torch.save / torch.load round trip keeps working too."""
+    import io
+    import torch.nn.functional as Fn
+    g = _gold(os.path.join(os.path.dirname(__file__), 'golden', 'gradcam_densenet18.npz'))
+    model = build(M, 'densenet18', int(g['seed']))
+    buf = io.BytesIO()
+    torch.save(model, buf)                                   # train_ards_detector.py:364,374 pickles whole modules
+    buf.seek(0)
+    model = torch.load(buf, weights_only=False)
+    x = torch.from_numpy(g['x']).float().cuda()
+    grads = {}
+    conv = model.breath_block.features(x)
+    conv.register_hook(lambda gr: grads.__setitem__('g', gr))
+    h = Fn.relu(conv)
+    h = model.breath_block.avgpool(h).view(-1)
+    out = model.linear_final(h).unsqueeze(0)
+    target = int(out.argmax())
+    assert target == int(g['target64'])
+    one_hot = torch.zeros((1, 2), device='cuda')
+    one_hot[0, target] = 1
+    model.zero_grad()
+    torch.sum(one_hot * out).backward()
+    assert tuple(conv.shape) == g['conv64'].shape == (20, 128, 7)
+    e_conv = np.abs(conv.detach().cpu().numpy() - g['conv64']).max()
+    e_out = np.abs(out.detach().cpu().numpy() - g['out64']).max()
+    gr = grads['g'].cpu().numpy()
+    e_grad = np.abs(gr - g['grad64']).max()
+    log('gradcam surface: conv err %.3e out err %.3e guided-gradient err %.3e (scale %.3e)' %
+        (e_conv, e_out, e_grad, np.abs(g['grad64']).max()))
+    assert e_conv < 1e-4 * max(1.0, np.abs(g['conv64']).max()) and e_out < 1e-4
+    assert e_grad < 1e-4 * np.abs(g['grad64']).max()
+    # the pooled path the training step uses is the same function
+    feat = model.breath_block(x)
+    ref = model.breath_block.avgpool(Fn.relu(model.breath_block.features(x))).view(20, -1)
+    assert torch.allclose(feat, ref, atol=1e-6)
+
+
 def test_test_epoch_votes_on_device(M):
     """Window argmax + per-patient vote table (metrics.py:572-604) computed on the device vs numpy."""
     from deepards_amd.data import DeviceTileStore
