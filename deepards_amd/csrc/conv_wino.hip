@@ -243,6 +243,10 @@ struct WinoWgradArgs {
 };
 
 #define WW_LDS_FLOATS ((2 * 32 + 2 * 34) * 64)
+#ifndef WW_MIN_WAVES
+#define WW_MIN_WAVES 4
+#define WW_UNROLL 8
+#endif
 
 __device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& a, const int block_id, const int nblocks, float* lds) {
   float* YE = lds;                 // [32][64] dY at the even position of pairs k0 .. k0+31
@@ -315,7 +319,7 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& a, const in
     const uint32_t fmask = (uint32_t)__ballot(Pm < a.MP && im == 0);
     const uint32_t lmask = (uint32_t)__ballot(Pm < a.MP && im == PL - 1);
     __syncthreads();
-#pragma unroll
+#pragma unroll WW_UNROLL
     for (int kk = 0; kk < 16; ++kk) {
       if (kk == 8) {
         __builtin_amdgcn_sched_barrier(0);
@@ -356,7 +360,7 @@ struct WinoWgradTable {
   int n;
 };
 
-__global__ __launch_bounds__(256) void wino_wgrad_multi_kernel(WinoWgradTable t) {
+__global__ __launch_bounds__(256, WW_MIN_WAVES) void wino_wgrad_multi_kernel(WinoWgradTable t) {
   __shared__ float lds[WW_LDS_FLOATS];
   int i = 0;
   while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
