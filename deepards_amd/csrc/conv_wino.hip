@@ -40,6 +40,9 @@ __device__ __forceinline__ int wino_row(int i) {
   return (i >= 4 && i < 12) ? 2 * (i - 4) : (i < 4 ? 2 * i + 1 : 2 * (i - 12) + 9);
 }
 
+#ifndef WINO_SPLIT_GLOAD
+#define WINO_SPLIT_GLOAD 1   // tap loads in the first half of the MFMAs, activation loads in the second (+2..5 %)
+#endif
 #define WINO_PITCH 36
 #define WINO_AROWS 66
 #define WINO_LDS_FLOATS (2 * WINO_AROWS * WINO_PITCH + 4 * 32 * WINO_PITCH)
@@ -83,7 +86,7 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int til
   const size_t ustride = (size_t)a.N * a.C;
 
   f32x4 ra[NA], rb[4];
-  auto gload = [&](int ks) {
+  auto gload_a = [&](int ks) {
     const int c0 = ks << 5;
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
@@ -91,8 +94,15 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int til
       if (aok[p]) v = *reinterpret_cast<const f32x4*>(a.x + aoff[p] + c0);
       ra[p] = v;
     }
+  };
+  auto gload_b = [&](int ks) {
+    const int c0 = ks << 5;
 #pragma unroll
     for (int j = 0; j < 4; ++j) rb[j] = *reinterpret_cast<const f32x4*>(ub + j * ustride + c0);
+  };
+  auto gload = [&](int ks) {
+    gload_a(ks);
+    gload_b(ks);
   };
 
   // fragment geometry (16x16x4: lane = (row l%16, k group l/16)).  ds_read_b128 is served in the lane groups
@@ -133,11 +143,20 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int til
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int col = (2 * g + half) * 4;
+#if WINO_SPLIT_GLOAD
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < kc) {
+        if (half == 0) gload_b(ks + 1);
+        else gload_a(ks + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#else
       if (half == 1) {                    // next chunk's loads late in the MFMA sequence (see GLOAD_AT in conv_gemm.hip)
         __builtin_amdgcn_sched_barrier(0);
         if (ks + 1 < kc) gload(ks + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
       if (MINI && half != khalf) continue;
       f32x4 d0 = *reinterpret_cast<const f32x4*>(&Os[(pr - 1) * PITCH + col]);
       const f32x4 d1 = *reinterpret_cast<const f32x4*>(&Es[pr * PITCH + col]);
