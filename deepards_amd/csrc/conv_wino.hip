@@ -20,6 +20,7 @@
 // Block = 64 pairs x 32 output channels, 4 waves of 16 pairs x 32 channels each: v_mfma_f32_16x16x4_f32 (same rate
 // as 32x32x2), 8 accumulator tiles (4 products x 2 channel halves) = 32 VGPRs.  K step = 32 channels; LDS pitch 36.
 #include "common.h"
+#include <type_traits>
 
 struct WinoArgs {
   const float* x;   // [rows][L][ldx]
@@ -262,6 +263,9 @@ struct WinoWgradArgs {
 };
 
 #define WW_LDS_FLOATS ((2 * 32 + 2 * 34) * 64)
+#ifndef WW_SPLIT_GLOAD
+#define WW_SPLIT_GLOAD 0   // 1: half the loads in each half of the MFMAs -- measured slower (spills at 128 registers)
+#endif
 #ifndef WW_MIN_WAVES
 #define WW_MIN_WAVES 4
 #define WW_UNROLL 8
@@ -284,9 +288,9 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& a, const in
 
   const int lrow = tid >> 4, lq = tid & 15;             // loader: 16 pair rows x 16 channel quads per pass
   f32x4 ry[4], rx[5];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+  auto gload_part = [&](int k0, auto rbc) {              // rb: pair rows 16 rb .. 16 rb + 15 (+ the halo rows with rb = 1)
+    constexpr int rb = decltype(rbc)::value;
+    {
       const int P = k0 + lrow + 16 * rb;
       const bool ok = P < a.MP;
       const uint32_t r = fdiv((uint32_t)(ok ? P : 0), a.divPL);
@@ -300,7 +304,7 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& a, const in
       rx[2 * rb] = ok ? *reinterpret_cast<const f32x4*>(a.x + pos * a.ldx + c_blk + lq * 4) : z;
       rx[2 * rb + 1] = ok1 ? *reinterpret_cast<const f32x4*>(a.x + (pos + 1) * a.ldx + c_blk + lq * 4) : z;
     }
-    if (tid < 32) {                                     // halo: odd of pair k0-1 (tid < 16), even of pair k0+32
+    if (rb == 1 && tid < 32) {                          // halo: odd of pair k0-1 (tid < 16), even of pair k0+32
       const int P = tid < 16 ? k0 - 1 : k0 + 32;
       const bool ok = P >= 0 && P < a.MP;
       const uint32_t r = fdiv((uint32_t)(ok ? P : 0), a.divPL);
@@ -310,6 +314,10 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& a, const in
       if (ok && pp < a.L) v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)r * a.L + pp) * a.ldx + c_blk + lq * 4);
       rx[4] = v;
     }
+  };
+  auto gload = [&](int k0) {
+    gload_part(k0, std::integral_constant<int, 0>());
+    gload_part(k0, std::integral_constant<int, 1>());
   };
 
   f32x16 acc[4];
@@ -340,11 +348,22 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& a, const in
     __syncthreads();
 #pragma unroll WW_UNROLL
     for (int kk = 0; kk < 16; ++kk) {
+#if WW_SPLIT_GLOAD
+      if ((kk & 7) == 4) {                // half of the next step's loads in each half of the MFMA sequence
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 32 < k_end) {
+          if (kk < 8) gload_part(k0 + 32, std::integral_constant<int, 0>());
+          else gload_part(k0 + 32, std::integral_constant<int, 1>());
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
       if (kk == 8) {
         __builtin_amdgcn_sched_barrier(0);
         if (k0 + 32 < k_end) gload(k0 + 32);
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
       const int p = 2 * kk + fh;
       const float y0 = YE[p * 64 + wm * 32 + frow], y1 = YO[p * 64 + wm * 32 + frow];
       float d0 = XO[p * 64 + wn * 32 + frow];
