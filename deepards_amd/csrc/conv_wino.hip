@@ -249,7 +249,7 @@ static int g_wino_tail = 1;
 //     M_j[n][c] = sum over pairs  dm_j[n] * D_j[c]                 (4 contractions over PAIRS instead of 3 over positions)
 //     dW0 = M0 + (M1 + M2)/2     dW1 = (M1 - M2)/2     dW2 = (M1 + M2)/2 + M3
 // Block = 64 co x 64 ci, 4 waves of 32 x 32 with the four M_j accumulators (v_mfma_f32_32x32x2_f32, K = pairs);
-// K step = 32 pairs: dY and X staged in pair-indexed even / odd panels ([pair][channel], as they sit in HBM),
+// K step = WW_KP pairs: dY and X staged in pair-indexed even / odd panels ([pair][channel], as they sit in HBM),
 // transforms at fragment-read time; sequence edges (d0 of a first pair, d3 of a last pair) from two 32-bit masks
 // per K step.  The combination to dW happens on the accumulators, so the slabs have the direct kernel's layout
 // [split][3][N][C] and share its reduction.
@@ -262,20 +262,21 @@ struct WinoWgradArgs {
   FastDiv divPL;
 };
 
-#define WW_LDS_FLOATS ((2 * 32 + 2 * 34) * 64)
-#ifndef WW_SPLIT_GLOAD
-#define WW_SPLIT_GLOAD 0   // 1: half the loads in each half of the MFMAs -- measured slower (spills at 128 registers)
+#ifndef WW_KP
+#define WW_KP 32          // pairs per K step (32 or 16)
 #endif
 #ifndef WW_MIN_WAVES
-#define WW_MIN_WAVES 4
+#define WW_MIN_WAVES 4    // waves per SIMD the register allocation must allow
 #define WW_UNROLL 8
 #endif
+#define WW_LDS_FLOATS ((2 * WW_KP + 2 * (WW_KP + 2)) * 64)
 
 __device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& a, const int block_id, const int nblocks, float* lds) {
-  float* YE = lds;                 // [32][64] dY at the even position of pairs k0 .. k0+31
-  float* YO = lds + 32 * 64;       // [32][64] odd position (0 past the sequence end)
-  float* XE = lds + 64 * 64;       // [34][64] X even, pairs k0-1 .. k0+32
-  float* XO = XE + 34 * 64;        // [34][64] X odd
+  constexpr int KP = WW_KP, NRB = KP / 16;
+  float* YE = lds;                     // [KP][64]   dY at the even position of pairs k0 .. k0+KP-1
+  float* YO = lds + KP * 64;           // [KP][64]   odd position (0 past the sequence end)
+  float* XE = lds + 2 * KP * 64;       // [KP+2][64] X even, pairs k0-1 .. k0+KP
+  float* XO = XE + (KP + 2) * 64;      // [KP+2][64] X odd
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -287,10 +288,10 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& a, const in
   const int k_beg = split * a.pchunk, k_end = min(a.MP, k_beg + a.pchunk);
 
   const int lrow = tid >> 4, lq = tid & 15;             // loader: 16 pair rows x 16 channel quads per pass
-  f32x4 ry[4], rx[5];
-  auto gload_part = [&](int k0, auto rbc) {              // rb: pair rows 16 rb .. 16 rb + 15 (+ the halo rows with rb = 1)
-    constexpr int rb = decltype(rbc)::value;
-    {
+  f32x4 ry[2 * NRB], rx[2 * NRB + 1];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
       const int P = k0 + lrow + 16 * rb;
       const bool ok = P < a.MP;
       const uint32_t r = fdiv((uint32_t)(ok ? P : 0), a.divPL);
@@ -304,20 +305,16 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& a, const in
       rx[2 * rb] = ok ? *reinterpret_cast<const f32x4*>(a.x + pos * a.ldx + c_blk + lq * 4) : z;
       rx[2 * rb + 1] = ok1 ? *reinterpret_cast<const f32x4*>(a.x + (pos + 1) * a.ldx + c_blk + lq * 4) : z;
     }
-    if (rb == 1 && tid < 32) {                          // halo: odd of pair k0-1 (tid < 16), even of pair k0+32
-      const int P = tid < 16 ? k0 - 1 : k0 + 32;
+    if (tid < 32) {                                     // halo: odd of pair k0-1 (tid < 16), even of pair k0+KP
+      const int P = tid < 16 ? k0 - 1 : k0 + KP;
       const bool ok = P >= 0 && P < a.MP;
       const uint32_t r = fdiv((uint32_t)(ok ? P : 0), a.divPL);
       const int i = (ok ? P : 0) - (int)r * PL;
       const int pp = 2 * i + (tid < 16 ? 1 : 0);
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (ok && pp < a.L) v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)r * a.L + pp) * a.ldx + c_blk + lq * 4);
-      rx[4] = v;
+      rx[2 * NRB] = v;
     }
-  };
-  auto gload = [&](int k0) {
-    gload_part(k0, std::integral_constant<int, 0>());
-    gload_part(k0, std::integral_constant<int, 1>());
   };
 
   f32x16 acc[4];
@@ -328,42 +325,31 @@ __device__ __forceinline__ void wino_wgrad_body(const WinoWgradArgs& a, const in
 
   const int frow = lane & 31, fh = lane >> 5;
   if (k_beg < k_end) gload(k_beg);
-  for (int k0 = k_beg; k0 < k_end; k0 += 32) {
+  for (int k0 = k_beg; k0 < k_end; k0 += KP) {
     __syncthreads();
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+    for (int rb = 0; rb < NRB; ++rb) {
       const int row = lrow + 16 * rb;
       *reinterpret_cast<f32x4*>(&YE[row * 64 + lq * 4]) = ry[2 * rb];
       *reinterpret_cast<f32x4*>(&YO[row * 64 + lq * 4]) = ry[2 * rb + 1];
       *reinterpret_cast<f32x4*>(&XE[(row + 1) * 64 + lq * 4]) = rx[2 * rb];
       *reinterpret_cast<f32x4*>(&XO[(row + 1) * 64 + lq * 4]) = rx[2 * rb + 1];
     }
-    if (tid < 16) *reinterpret_cast<f32x4*>(&XO[lq * 4]) = rx[4];
-    else if (tid < 32) *reinterpret_cast<f32x4*>(&XE[33 * 64 + lq * 4]) = rx[4];
-    // sequence-edge masks of this step's 32 pairs (bit p: pair k0+p is the first / last of its sequence)
+    if (tid < 16) *reinterpret_cast<f32x4*>(&XO[lq * 4]) = rx[2 * NRB];
+    else if (tid < 32) *reinterpret_cast<f32x4*>(&XE[(KP + 1) * 64 + lq * 4]) = rx[2 * NRB];
+    // sequence-edge masks of this step's pairs (bit p: pair k0+p is the first / last of its sequence)
     const int Pm = k0 + (lane & 31);
     const int im = Pm - (int)fdiv((uint32_t)(Pm < a.MP ? Pm : 0), a.divPL) * PL;
     const uint32_t fmask = (uint32_t)__ballot(Pm < a.MP && im == 0);
     const uint32_t lmask = (uint32_t)__ballot(Pm < a.MP && im == PL - 1);
     __syncthreads();
 #pragma unroll WW_UNROLL
-    for (int kk = 0; kk < 16; ++kk) {
-#if WW_SPLIT_GLOAD
-      if ((kk & 7) == 4) {                // half of the next step's loads in each half of the MFMA sequence
+    for (int kk = 0; kk < KP / 2; ++kk) {
+      if (kk == KP / 4) {
         __builtin_amdgcn_sched_barrier(0);
-        if (k0 + 32 < k_end) {
-          if (kk < 8) gload_part(k0 + 32, std::integral_constant<int, 0>());
-          else gload_part(k0 + 32, std::integral_constant<int, 1>());
-        }
+        if (k0 + KP < k_end) gload(k0 + KP);
         __builtin_amdgcn_sched_barrier(0);
       }
-#else
-      if (kk == 8) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (k0 + 32 < k_end) gload(k0 + 32);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#endif
       const int p = 2 * kk + fh;
       const float y0 = YE[p * 64 + wm * 32 + frow], y1 = YO[p * 64 + wm * 32 + frow];
       float d0 = XO[p * 64 + wn * 32 + frow];
