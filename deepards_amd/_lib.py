@@ -37,6 +37,12 @@ class WgradJob(ctypes.Structure):
                [('src_off', _I * 3), ('winograd', _I)]
 
 
+class ConvJob(ctypes.Structure):
+    _fields_ = [('x', _P), ('w', _P), ('y', _P)] + [(n, _I) for n in
+               ('rows', 'Lm', 'Lsrc', 'ldx', 'C', 'Ldst', 'ldy', 'N', 'dst_stride', 'dst_off', 'src_stride', 'ntaps')] + \
+               [('src_off', _I * 3), ('wtap', _I * 3), ('accumulate', _I)]
+
+
 class RepackDesc(ctypes.Structure):
     _fields_ = [('W', _P), ('Wf', _P), ('Wd', _P), ('Uf', _P), ('Ud', _P), ('Co', _I), ('Ci', _I), ('K', _I)]
 
@@ -65,6 +71,7 @@ SIGNATURES = {
     'da_bn_param_grad_multi': (_I, [ctypes.POINTER(BnPgradDesc), _I, _I, _P]),
     'da_conv_wgrad_splits': (_I, [_I] * 5),
     'da_conv_wgrad_plan': (_I, [_I] * 6 + [ctypes.POINTER(_I)]),
+    'da_conv_gemm_multi': (_I, [ctypes.POINTER(ConvJob), _I, _P]),
     'da_conv3_winograd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'da_wino_debug_tail': (_I, [_I]),
     'da_wino_debug_pchunk': (_I, [_I]),

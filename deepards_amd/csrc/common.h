@@ -61,3 +61,14 @@ typedef struct {
 bool wino_wgrad_eligible(const da_wgrad_job& j);
 void wino_wgrad_plan(int rows, int L, int* splits, int* pchunk);
 int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream);
+
+// One problem of da_conv_gemm_multi: the arguments of da_conv_gemm (include/deepards_hip.h).
+typedef struct {
+  const float* x;
+  const float* w;
+  float* y;
+  int rows, Lm, Lsrc, ldx, C, Ldst, ldy, N, dst_stride, dst_off, src_stride, ntaps;
+  int src_off[3];
+  int wtap[3];
+  int accumulate;
+} da_conv_job;

@@ -57,7 +57,7 @@ struct ConvGemmArgs {
 };
 
 template <int TM, int TN, int WGM, int WGN>
-__device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs& a, const int block_id, const int nblocks, float* lds) {
+__device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs& a, const int lin, float* lds) {
   constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32, PITCH = 36;
   static_assert(WGM * WGN == 4, "4 waves");
   float* As = lds;
@@ -67,7 +67,6 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs& a, const int 
   const int wm = wave / WGN, wn = wave % WGN;
   // n-tile fastest, contiguous chunk per XCD: the N/BN tiles that re-read one A panel run back to back on one L2
   const int ntn = a.N / BN;
-  const int lin = xcd_linear_tile(block_id, nblocks);
   const int m_blk = (lin / ntn) * BM, n_blk = (lin % ntn) * BN;
   const int lr = tid >> 3, lq = tid & 7;
   const int Lm = (int)a.divLm.d;
@@ -194,7 +193,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs& a, const int 
 template <int TM, int TN, int WGM, int WGN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
   __shared__ float lds[(TM * WGM * 32 + TN * WGN * 32) * 36];
-  conv_gemm_body<TM, TN, WGM, WGN>(a, blockIdx.x, gridDim.x, lds);
+  conv_gemm_body<TM, TN, WGM, WGN>(a, xcd_linear_tile(blockIdx.x, gridDim.x), lds);
 }
 
 // tuning knobs (benchmark use): 0 = automatic
@@ -336,15 +335,14 @@ __global__ __launch_bounds__(256) void conv3_halo_kernel(ConvGemmArgs a) {
 // full tiles) and share the CUs with the full tiles from the start.
 // ---------------------------------------------------------------------------------------------
 #define TAIL_LDS_FLOATS ((2 * 32 + 2 * 64) * 36)
-__device__ __forceinline__ void conv_tail_body(const ConvGemmArgs& a, const int mini_id, const int first_tile, float* lds) {
+__device__ __forceinline__ void conv_tail_body(const ConvGemmArgs& a, const int lin, const int half, float* lds) {
   constexpr int PITCH = 36;
   float* As = lds;                     // [2 k halves][32][PITCH]
   float* Bs = lds + 2 * 32 * PITCH;    // [2 k halves][64][PITCH]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, ks = wave >> 1;
   const int ntn = a.N >> 6;
-  const int lin = first_tile + (mini_id >> 1);
-  const int m_blk = (lin / ntn) * 64 + 32 * (mini_id & 1), n_blk = (lin % ntn) * 64;
+  const int m_blk = (lin / ntn) * 64 + 32 * half, n_blk = (lin % ntn) * 64;
   const int lr = tid >> 3, lq = tid & 7;
   const int Lm = (int)a.divLm.d;
 
@@ -450,11 +448,11 @@ template <bool HALO>
 __global__ __launch_bounds__(256) void conv_gemm_tailed_kernel(ConvGemmArgs a, int nmini, int nmini_pad, int full) {
   __shared__ float lds[HALO ? HALO_LDS_FLOATS : TAIL_LDS_FLOATS];
   if ((int)blockIdx.x < nmini_pad) {
-    if ((int)blockIdx.x < nmini) conv_tail_body(a, blockIdx.x, full, lds);
+    if ((int)blockIdx.x < nmini) conv_tail_body(a, full + ((int)blockIdx.x >> 1), blockIdx.x & 1, lds);
     return;
   }
   if (HALO) conv3_halo_body(a, blockIdx.x - nmini_pad, full, lds);
-  else conv_gemm_body<1, 1, 2, 2>(a, blockIdx.x - nmini_pad, full, lds);
+  else conv_gemm_body<1, 1, 2, 2>(a, xcd_linear_tile(blockIdx.x - nmini_pad, full), lds);
 }
 
 static int g_use_halo = 128;   // smallest channel count that takes the shared-panel kernel (0: never)
@@ -484,6 +482,54 @@ static double balance(long blocks) {
   double per = (double)blocks / 256.0;
   double mx = (double)((blocks + 255) / 256);
   return per / mx;
+}
+
+// Several independent conv GEMMs (64x64 tiles, generic kernel) in ONE launch: the stride-2 conv and the 1x1
+// downsample of a block read the same input, the even / odd position sub-problems of a stride-2 data gradient write
+// disjoint outputs -- alone each has only 2-4 tiles per CU.  Tiles of all problems form one sequence; its partly
+// filled last round runs as half tiles like a single problem's.
+struct ConvGemmTable {
+  ConvGemmArgs d[4];
+  int first_block[5];     // cumulative count of the problems' full-tile blocks
+  int n;
+  int tail_first;         // first tile (of the LAST problem) that runs as two half tiles
+};
+
+__global__ __launch_bounds__(256) void conv_gemm_multi_kernel(ConvGemmTable t, int nmini, int nmini_pad) {
+  __shared__ float lds[TAIL_LDS_FLOATS];
+  if ((int)blockIdx.x < nmini_pad) {
+    if ((int)blockIdx.x < nmini) conv_tail_body(t.d[t.n - 1], t.tail_first + ((int)blockIdx.x >> 1), blockIdx.x & 1, lds);
+    return;
+  }
+  const int g = blockIdx.x - nmini_pad;
+  int i = 0;
+  while (i + 1 < t.n && g >= t.first_block[i + 1]) ++i;      // wave-uniform
+  // every problem spreads over all XCDs (a contiguous chunk of ITS tiles per XCD): problems differ in work per tile
+  conv_gemm_body<1, 1, 2, 2>(t.d[i], xcd_linear_tile(g - t.first_block[i], t.first_block[i + 1] - t.first_block[i]), lds);
+}
+
+static int launch_conv_multi(const ConvGemmArgs* a, int n, hipStream_t s) {
+  ConvGemmTable t;
+  int tiles = 0, last = 0;
+  bool tail_ok = g_use_tail != 0;
+  for (int i = 0; i < n; ++i) {
+    t.d[i] = a[i];
+    t.first_block[i] = tiles;
+    last = ((a[i].M + 63) / 64) * (a[i].N / 64);
+    tiles += last;
+    tail_ok = tail_ok && a[i].C % 64 == 0;
+  }
+  t.n = n;
+  if (tiles == 0) return DA_OK;
+  const int R = tiles % 256;
+  int nmini = 0;
+  if (tail_ok && tiles > 256 && R >= 1 && R <= 128 && R < last) nmini = 2 * R;   // the tail comes out of the last problem
+  t.first_block[n] = tiles - nmini / 2;
+  t.tail_first = last - nmini / 2;
+  const int nmini_pad = (nmini + 7) / 8 * 8;
+  hipLaunchKernelGGL(conv_gemm_multi_kernel, dim3(nmini_pad + t.first_block[n]), dim3(256), 0, s, t, nmini, nmini_pad);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
 }
 
 static int conv_gemm_dispatch(const ConvGemmArgs& a, hipStream_t s) {
@@ -879,6 +925,31 @@ int da_conv_gemm(const float* x, const float* w, float* y, int rows, int Lm, int
   a.accumulate = accumulate;
   a.divLm = make_fastdiv((uint32_t)Lm);
   return conv_gemm_dispatch(a, stream);
+}
+
+// n <= 4 independent problems of da_conv_gemm (jobs: HOST array) in one launch of the 64x64-tile kernel (N % 64 == 0).
+// The problems must not write the same output elements.
+int da_conv_gemm_multi(const da_conv_job* jobs, int n, hipStream_t stream) {
+  DA_ENTER();
+  if (n < 1 || n > 4 || !jobs) return DA_EINVAL;
+  ConvGemmArgs a[4];
+  for (int i = 0; i < n; ++i) {
+    const da_conv_job& j = jobs[i];
+    if (!j.x || !j.w || !j.y || j.rows < 0 || j.Lm < 1 || j.ntaps < 1 || j.ntaps > 3 || j.C % 32 || j.N % 64 || j.ldx % 4)
+      return DA_EINVAL;
+    if ((uint64_t)j.rows * j.Lm * (uint64_t)j.Lm >= 0xffffffffull) return DA_EINVAL;
+    ConvGemmArgs& g = a[i];
+    g.x = j.x; g.w = j.w; g.y = j.y;
+    g.M = j.rows * j.Lm; g.Lsrc = j.Lsrc; g.ldx = j.ldx; g.C = j.C;
+    g.Ldst = j.Ldst; g.ldy = j.ldy; g.N = j.N;
+    g.dst_stride = j.dst_stride; g.dst_off = j.dst_off; g.src_stride = j.src_stride;
+    g.ntaps = j.ntaps;
+    g.so0 = j.src_off[0]; g.so1 = j.ntaps > 1 ? j.src_off[1] : 0; g.so2 = j.ntaps > 2 ? j.src_off[2] : 0;
+    g.wt0 = j.wtap[0]; g.wt1 = j.ntaps > 1 ? j.wtap[1] : 0; g.wt2 = j.ntaps > 2 ? j.wtap[2] : 0;
+    g.accumulate = j.accumulate;
+    g.divLm = make_fastdiv((uint32_t)j.Lm);
+  }
+  return launch_conv_multi(a, n, stream);
 }
 
 // Bytes of slab workspace da_conv_wgrad needs for this shape.

@@ -105,6 +105,7 @@ def _launch_wgrads(side=False):
 
 
 _WINOGRAD = os.environ.get('DA_WINOGRAD', '1') != '0'
+_PAIR_S2 = os.environ.get('DA_PAIR_S2', '1') != '0'      # stride-2 block heads: conv + downsample GEMMs share launches
 
 
 def _is_wino(w, stride, pad):
@@ -225,13 +226,18 @@ class BasicBlockFunction(Function):
 
     @staticmethod
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, R, st1, st2, std):
-        y1 = _conv_fwd(x, w1, stride, 1)
+        pair = wd is not None and stride == 2 and _PAIR_S2 and not _is_wino(w1, stride, 1)
+        if pair:      # the stride-2 conv and the 1x1 downsample read the same input: one launch
+            y1, yd = H.conv_fwd_multi([(x, _pack(w1, False)[0], stride, 1), (x, _pack(wd, False)[0], stride, 0)])
+        else:
+            y1 = _conv_fwd(x, w1, stride, 1)
         s1 = _stats(y1, R, st1)
         h1 = _bn_apply(y1, R, s1, st1, g1, b1, True)
         y2 = _conv_fwd(h1, w2, 1, 1)
         s2 = _stats(y2, R, st2)
         if wd is not None:
-            yd = _conv_fwd(x, wd, stride, 0)
+            if not pair:
+                yd = _conv_fwd(x, wd, stride, 0)
             sd = _stats(yd, R, std)
             res = _bn_apply(yd, R, sd, std, gd, bd, False)
             md, idd = sd.mean, sd.invstd
@@ -267,8 +273,11 @@ class BasicBlockFunction(Function):
             wd, gd, bd, yd, md, idd = s[15:]
             dyd, dgd, dbd = _bn_bwd(g, yd, R, md, idd, gd, bd, 0, tgd, tbd, dx=g)
             dwd = _wgrad(dyd, x, 1, stride, 0, twd)
-            dx = _conv_dgrad(dy1, w1, stride, 1, lin)
-            _conv_dgrad(dyd, wd, stride, 0, lin, out=dx, accumulate=True)
+            if stride == 2 and _PAIR_S2 and not _is_wino(w1, stride, 1):
+                dx = H.conv_dgrad_s2_pair(dy1, _pack(w1, False)[1], dyd, _pack(wd, False)[1], lin)
+            else:
+                dx = _conv_dgrad(dy1, w1, stride, 1, lin)
+                _conv_dgrad(dyd, wd, stride, 0, lin, out=dx, accumulate=True)
         else:
             dwd = dgd = dbd = None
             dx = _conv_dgrad(dy1, w1, stride, 1, lin, out=g, accumulate=True)   # identity grad + conv path

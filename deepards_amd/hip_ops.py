@@ -146,6 +146,62 @@ def conv_dgrad(dy, wd, stride, pad, l_in, out=None, accumulate=False):
     return out
 
 
+def _conv_job(d, x, w, y, rows, lm, lsrc, ldx, c, ldst, ldy, n, dst_stride, dst_off, src_stride, so, wt, accumulate):
+    d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    d.rows, d.Lm, d.Lsrc, d.ldx, d.C, d.Ldst, d.ldy, d.N = rows, lm, lsrc, ldx, c, ldst, ldy, n
+    d.dst_stride, d.dst_off, d.src_stride, d.ntaps = dst_stride, dst_off, src_stride, len(so)
+    for t in range(3):
+        d.src_off[t] = so[t] if t < len(so) else 0
+        d.wtap[t] = wt[t] if t < len(wt) else 0
+    d.accumulate = 1 if accumulate else 0
+
+
+def conv_fwd_multi(problems):
+    """[(x, wf, stride, pad)] (<= 4, Co % 64 == 0) -> [y]: independent forward convs in ONE launch (a block's stride-2
+    conv and its 1x1 downsample read the same input; alone each has 2-4 tiles per CU)."""
+    if len(problems) > 4 or any(wf.shape[1] % 64 for _, wf, _, _ in problems):
+        return [conv_fwd(x, wf, s_, p_) for x, wf, s_, p_ in problems]
+    arr = (_lib.ConvJob * len(problems))()
+    outs = []
+    for d, (x, wf, stride, pad) in zip(arr, problems):
+        _rlc(x, 'x')
+        k, co, ci = wf.shape
+        rows, l, c = x.shape
+        if c != ci or k > 3 or ci % 32:
+            raise ValueError('conv_fwd_multi: unsupported shape x%s wf%s' % (tuple(x.shape), tuple(wf.shape)))
+        lo = conv_out_len(l, k, stride, pad)
+        y = torch.empty((rows, lo, co), device=x.device, dtype=torch.float32)
+        _conv_job(d, x, wf, y, rows, lo, l, c, ci, lo, co, co, 1, 0, stride, [t - pad for t in range(k)], list(range(k)), False)
+        outs.append(y)
+    _chk(_lib.lib().da_conv_gemm_multi(arr, len(problems), _stream()), 'da_conv_gemm_multi(fwd)')
+    return outs
+
+
+def conv_dgrad_s2_pair(dy1, wd1, dyd, wdd, l_in):
+    """dx = dgrad(k3 s2 p1 conv, dy1) + dgrad(k1 s2 p0 downsample, dyd) of one block in two launches instead of three:
+    {conv odd positions, downsample even positions} (disjoint writes) then {conv even positions} accumulating."""
+    _rlc(dy1, 'dy1')
+    _rlc(dyd, 'dyd')
+    k1, ci, co = wd1.shape
+    kd, ci2, co2 = wdd.shape
+    rows, lo, c = dy1.shape
+    if (k1, kd) != (3, 1) or ci != ci2 or co != co2 or c != co or tuple(dyd.shape) != tuple(dy1.shape) or ci % 64 or l_in % 2:
+        dx = conv_dgrad(dy1, wd1, 2, 1, l_in)
+        return conv_dgrad(dyd, wdd, 2, 0, l_in, out=dx, accumulate=True)
+    dx = torch.empty((rows, l_in, ci), device=dy1.device, dtype=torch.float32)
+    lm = l_in // 2
+    a = (_lib.ConvJob * 2)()
+    # odd input positions 2j+1: taps t = 0, 2 of the k3 conv, source positions (1 + 1 - t) / 2 + j
+    _conv_job(a[0], dy1, wd1, dx, rows, lm, lo, co, co, l_in, ci, ci, 2, 1, 1, [1, 0], [0, 2], False)
+    # even input positions 2j: the downsample's only tap
+    _conv_job(a[1], dyd, wdd, dx, rows, lm, lo, co, co, l_in, ci, ci, 2, 0, 1, [0], [0], False)
+    _chk(_lib.lib().da_conv_gemm_multi(a, 2, _stream()), 'da_conv_gemm_multi(dgrad)')
+    b = (_lib.ConvJob * 1)()
+    _conv_job(b[0], dy1, wd1, dx, rows, lm, lo, co, co, l_in, ci, ci, 2, 0, 1, [0], [1], True)   # even: tap 1, accumulate
+    _chk(_lib.lib().da_conv_gemm_multi(b, 1, _stream()), 'da_conv_gemm_multi(dgrad even)')
+    return dx
+
+
 def conv_wgrad(dy, x, k, stride, pad, out=None, accumulate=False, defer=False):
     """dW (Co,Ci,K) torch layout = sum_positions dy (x) x.  defer=True: only the split-K slabs are produced;
     returns (slab, splits, k, co, ci) for wgrad_reduce_multi."""

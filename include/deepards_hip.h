@@ -52,6 +52,14 @@ int da_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, 
 /* benchmark-only tuning knobs: key 0 = force conv tile id, key 1 = wgrad target blocks (0 = automatic) */
 int da_debug_set(int key, int value);
 
+/* n <= 4 independent da_conv_gemm problems (jobs: HOST array, N % 64 == 0, disjoint outputs) in ONE launch: the
+   stride-2 conv + 1x1 downsample of a block (same input), the even / odd sub-problems of a stride-2 data gradient */
+typedef struct {
+  const float* x; const float* w; float* y;
+  int rows, Lm, Lsrc, ldx, C, Ldst, ldy, N, dst_stride, dst_off, src_stride, ntaps; int src_off[3]; int wtap[3];
+  int accumulate;
+} da_conv_job;
+int da_conv_gemm_multi(const da_conv_job* jobs, int n, da_stream_t stream);
 /* k3 stride-1 pad-1 conv (forward, or data gradient with the transposed taps) as Winograd F(2,3): y (+)= conv(x);
    u = da_wino_weights() taps [4][N][C].  x: [rows][L][ldx] (C channels), y: [rows][L][ldy] (N channels).
    replaces nn.Conv1d(k=3, s=1, p=1) forward / input-grad, reference models/resnet.py:5-8,27-38, models/densenet.py:25-32 */

@@ -164,6 +164,32 @@ def test_conv3_winograd(H, ci, co, L, rows):
     close(ncl(bt), base + dx_ref, tol=4e-6, name='winograd dgrad+acc')
 
 
+@pytest.mark.parametrize('ci,co,L,rows', [(64, 128, 56, 40), (128, 256, 28, 23), (256, 512, 14, 300), (64, 128, 56, 300)])
+def test_stride2_block_head_shared_launches(H, ci, co, L, rows):
+    """The k3 s2 p1 conv and the k1 s2 downsample of a block: forward pair in one launch (da_conv_gemm_multi), the
+    data gradient of both in two (odd positions + downsample's even positions, then the conv's even positions) ==
+    the oracle and the one-problem launches (the last round's split-K half tiles fall on different tiles)."""
+    rng = np.random.default_rng(ci + co + L + rows)
+    x = rng.standard_normal((rows, ci, L))
+    w1 = rng.standard_normal((co, ci, 3)) * np.sqrt(2.0 / (3 * co))
+    wd = rng.standard_normal((co, ci, 1)) * np.sqrt(2.0 / co)
+    y1_ref, yd_ref = np_ref.conv1d_fwd(x, w1, 2, 1), np_ref.conv1d_fwd(x, wd, 2, 0)
+    dy1, dyd = rng.standard_normal(y1_ref.shape), rng.standard_normal(yd_ref.shape)
+    dx_ref = np_ref.conv1d_bwd(x, w1, dy1, 2, 1)[0] + np_ref.conv1d_bwd(x, wd, dyd, 2, 0)[0]
+    xt = rlc(x)
+    wf1, wd1 = H.repack_weight(cu(w1), True, True)
+    wfd, wdd = H.repack_weight(cu(wd), True, True)
+    y1, yd = H.conv_fwd_multi([(xt, wf1, 2, 1), (xt, wfd, 2, 0)])
+    close(ncl(y1), y1_ref, name='pair fwd conv')
+    close(ncl(yd), yd_ref, name='pair fwd downsample')
+    close(ncl(y1), ncl(H.conv_fwd(xt, wf1, 2, 1)).astype(np.float64), tol=1e-6, name='pair vs single fwd')
+    dx = H.conv_dgrad_s2_pair(rlc(dy1), wd1, rlc(dyd), wdd, L)
+    close(ncl(dx), dx_ref, name='pair dgrad')
+    one = H.conv_dgrad(rlc(dy1), wd1, 2, 1, L)
+    H.conv_dgrad(rlc(dyd), wdd, 2, 0, L, out=one, accumulate=True)
+    close(ncl(dx), ncl(one).astype(np.float64), tol=1e-6, name='pair vs sequential')
+
+
 def test_conv_mfma_layout_identity(H):
     """A = identity-like input with an ASYMMETRIC weight: catches a transposed C/D or A/B map."""
     ci = co = 32
