@@ -40,7 +40,7 @@ class WgradJob(ctypes.Structure):
 class ConvJob(ctypes.Structure):
     _fields_ = [('x', _P), ('w', _P), ('y', _P)] + [(n, _I) for n in
                ('rows', 'Lm', 'Lsrc', 'ldx', 'C', 'Ldst', 'ldy', 'N', 'dst_stride', 'dst_off', 'src_stride', 'ntaps')] + \
-               [('src_off', _I * 3), ('wtap', _I * 3), ('accumulate', _I)]
+               [('src_off', _I * 3), ('wtap', _I * 3), ('accumulate', _I), ('x2', _P), ('w2', _P), ('tap_split', _I)]
 
 
 class RepackDesc(ctypes.Structure):

@@ -71,4 +71,7 @@ typedef struct {
   int src_off[3];
   int wtap[3];
   int accumulate;
+  const float* x2;       // optional second (source, weights) pair for the taps >= tap_split (NULL: one source)
+  const float* w2;
+  int tap_split;
 } da_conv_job;

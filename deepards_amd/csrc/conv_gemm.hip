@@ -47,6 +47,9 @@ __device__ __forceinline__ int xcd_linear_tile(int id, int total) {
 struct ConvGemmArgs {
   const float* x;
   const float* w;
+  const float* x2;  // taps >= tap_split read source x2 / weights w2 (same shapes and pitches): two convolutions that
+  const float* w2;  // add into one output as ONE contraction (generic 64x64 kernel and half tiles only)
+  int tap_split;
   float* y;
   int M, Lsrc, ldx, C;
   int Ldst, ldy, N;
@@ -97,12 +100,12 @@ __device__ __forceinline__ void conv_gemm_body(const ConvGemmArgs& a, const int 
     for (int p = 0; p < AP; ++p) {
       int ls = a_j[p] + so;
       bool ok = a_ok[p] && ls >= 0 && ls < a.Lsrc;
-      const float* src = a.x + (size_t)(a_rowoff[p] + (ok ? ls : 0)) * a.ldx + c0 + lq * 4;
+      const float* src = (t < a.tap_split ? a.x : a.x2) + (size_t)(a_rowoff[p] + (ok ? ls : 0)) * a.ldx + c0 + lq * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (ok) v = *reinterpret_cast<const f32x4*>(src);
       ra[p] = v;
     }
-    const float* wtp = a.w + (size_t)wt * a.N * a.C;
+    const float* wtp = (t < a.tap_split ? a.w : a.w2) + (size_t)wt * a.N * a.C;
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
       int n = n_blk + lr + 32 * p;
@@ -362,14 +365,14 @@ __device__ __forceinline__ void conv_tail_body(const ConvGemmArgs& a, const int 
     const int wt = t == 0 ? a.wt0 : (t == 1 ? a.wt1 : a.wt2);
     const int ls = a_j + so;
     const bool ok = a_ok && ls >= 0 && ls < a.Lsrc;
-    const float* src = a.x + (size_t)(a_rowoff + (ok ? ls : 0)) * a.ldx + c0 + lq * 4;
+    const float* src = (t < a.tap_split ? a.x : a.x2) + (size_t)(a_rowoff + (ok ? ls : 0)) * a.ldx + c0 + lq * 4;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (ok) v = *reinterpret_cast<const f32x4*>(src + 32 * h);
       ra[h] = v;
     }
-    const float* wtp = a.w + (size_t)wt * a.N * a.C + c0 + lq * 4;
+    const float* wtp = (t < a.tap_split ? a.w : a.w2) + (size_t)wt * a.N * a.C + c0 + lq * 4;
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -916,6 +919,7 @@ int da_conv_gemm(const float* x, const float* w, float* y, int rows, int Lm, int
   if (!x || !w || !y || rows < 0 || Lm < 1 || ntaps < 1 || ntaps > 3) return DA_EINVAL;
   ConvGemmArgs a;
   a.x = x; a.w = w; a.y = y;
+  a.x2 = x; a.w2 = w; a.tap_split = 3;
   a.M = rows * Lm; a.Lsrc = Lsrc; a.ldx = ldx; a.C = C;
   a.Ldst = Ldst; a.ldy = ldy; a.N = N;
   a.dst_stride = dst_stride; a.dst_off = dst_off; a.src_stride = src_stride;
@@ -940,6 +944,8 @@ int da_conv_gemm_multi(const da_conv_job* jobs, int n, hipStream_t stream) {
     if ((uint64_t)j.rows * j.Lm * (uint64_t)j.Lm >= 0xffffffffull) return DA_EINVAL;
     ConvGemmArgs& g = a[i];
     g.x = j.x; g.w = j.w; g.y = j.y;
+    g.x2 = j.x2 ? j.x2 : j.x; g.w2 = j.w2 ? j.w2 : j.w; g.tap_split = j.x2 ? j.tap_split : 3;
+    if (j.x2 && (!j.w2 || j.tap_split < 1 || j.tap_split >= j.ntaps)) return DA_EINVAL;
     g.M = j.rows * j.Lm; g.Lsrc = j.Lsrc; g.ldx = j.ldx; g.C = j.C;
     g.Ldst = j.Ldst; g.ldy = j.ldy; g.N = j.N;
     g.dst_stride = j.dst_stride; g.dst_off = j.dst_off; g.src_stride = j.src_stride;

@@ -146,8 +146,10 @@ def conv_dgrad(dy, wd, stride, pad, l_in, out=None, accumulate=False):
     return out
 
 
-def _conv_job(d, x, w, y, rows, lm, lsrc, ldx, c, ldst, ldy, n, dst_stride, dst_off, src_stride, so, wt, accumulate):
+def _conv_job(d, x, w, y, rows, lm, lsrc, ldx, c, ldst, ldy, n, dst_stride, dst_off, src_stride, so, wt, accumulate,
+              x2=None, w2=None, tap_split=0):
     d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    d.x2, d.w2, d.tap_split = _p(x2), _p(w2), tap_split
     d.rows, d.Lm, d.Lsrc, d.ldx, d.C, d.Ldst, d.ldy, d.N = rows, lm, lsrc, ldx, c, ldst, ldy, n
     d.dst_stride, d.dst_off, d.src_stride, d.ntaps = dst_stride, dst_off, src_stride, len(so)
     for t in range(3):
@@ -178,8 +180,9 @@ def conv_fwd_multi(problems):
 
 
 def conv_dgrad_s2_pair(dy1, wd1, dyd, wdd, l_in):
-    """dx = dgrad(k3 s2 p1 conv, dy1) + dgrad(k1 s2 p0 downsample, dyd) of one block in two launches instead of three:
-    {conv odd positions, downsample even positions} (disjoint writes) then {conv even positions} accumulating."""
+    """dx = dgrad(k3 s2 p1 conv, dy1) + dgrad(k1 s2 p0 downsample, dyd) of one block in ONE launch instead of three:
+    the odd input positions (the conv's taps 0 and 2) and the even ones (the conv's tap 1 and the downsample's tap as
+    one contraction over two sources) are two problems with the same work per tile."""
     _rlc(dy1, 'dy1')
     _rlc(dyd, 'dyd')
     k1, ci, co = wd1.shape
@@ -193,12 +196,10 @@ def conv_dgrad_s2_pair(dy1, wd1, dyd, wdd, l_in):
     a = (_lib.ConvJob * 2)()
     # odd input positions 2j+1: taps t = 0, 2 of the k3 conv, source positions (1 + 1 - t) / 2 + j
     _conv_job(a[0], dy1, wd1, dx, rows, lm, lo, co, co, l_in, ci, ci, 2, 1, 1, [1, 0], [0, 2], False)
-    # even input positions 2j: the downsample's only tap
-    _conv_job(a[1], dyd, wdd, dx, rows, lm, lo, co, co, l_in, ci, ci, 2, 0, 1, [0], [0], False)
+    # even input positions 2j: tap 1 of the k3 conv from dy1 AND the downsample's only tap from dyd, one contraction
+    _conv_job(a[1], dy1, wd1, dx, rows, lm, lo, co, co, l_in, ci, ci, 2, 0, 1, [0, 0], [1, 0], False,
+              x2=dyd, w2=wdd, tap_split=1)
     _chk(_lib.lib().da_conv_gemm_multi(a, 2, _stream()), 'da_conv_gemm_multi(dgrad)')
-    b = (_lib.ConvJob * 1)()
-    _conv_job(b[0], dy1, wd1, dx, rows, lm, lo, co, co, l_in, ci, ci, 2, 0, 1, [0], [1], True)   # even: tap 1, accumulate
-    _chk(_lib.lib().da_conv_gemm_multi(b, 1, _stream()), 'da_conv_gemm_multi(dgrad even)')
     return dx
 
 

@@ -58,6 +58,8 @@ typedef struct {
   const float* x; const float* w; float* y;
   int rows, Lm, Lsrc, ldx, C, Ldst, ldy, N, dst_stride, dst_off, src_stride, ntaps; int src_off[3]; int wtap[3];
   int accumulate;
+  const float* x2; const float* w2; int tap_split;   /* optional: taps >= tap_split read x2 / w2 (same shapes): two
+                                                        convolutions adding into one output as one contraction */
 } da_conv_job;
 int da_conv_gemm_multi(const da_conv_job* jobs, int n, da_stream_t stream);
 /* k3 stride-1 pad-1 conv (forward, or data gradient with the transposed taps) as Winograd F(2,3): y (+)= conv(x);
