@@ -96,6 +96,8 @@ SIGNATURES = {
     'da_concat2': (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _Z, _P]),
     'da_slice_copy': (_I, [_P, _I, _I, _P, _I, _I, _Z, _I, _P]),
     'da_dropout': (_I, [_P, _P, _Z, _P, _U, _F, _P]),
+    'da_concat2_dropout': (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _Z, _P, _U, _F, _P]),
+    'da_slice_dropout': (_I, [_P, _I, _I, _P, _I, _I, _Z, _P, _U, _F, _P]),
 }
 
 

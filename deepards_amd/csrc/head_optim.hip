@@ -261,6 +261,58 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
   }
 }
 
+__device__ __forceinline__ float drop_keep(uint32_t key, size_t i, uint32_t thr, float scale, float v) {
+  const uint32_t h = mix32(key, (uint32_t)i ^ (uint32_t)(i >> 32) * 0x27d4eb2fu);      // == dropout_kernel's mask of element i
+  return h >= thr ? v * scale : 0.f;
+}
+
+// out[pos][0:C1] = a[pos][0:C1]; out[pos][C1:C1+C2] = dropout(b)[pos][0:C2]   (_DenseLayer: dropout then torch.cat,
+// reference models/densenet.py:38-41) -- the mask is that of da_dropout on the contiguous [npos][C2] tensor b
+__global__ __launch_bounds__(256) void concat2_dropout_kernel(const float* __restrict__ a, int lda, int C1,
+                                                              const float* __restrict__ b, int ldb, int C2,
+                                                              float* __restrict__ out, int ldo, size_t npos,
+                                                              const int64_t* __restrict__ seed_ptr, uint32_t salt, float p) {
+  const uint32_t seed = (uint32_t)seed_ptr[0] ^ (uint32_t)(seed_ptr[0] >> 32);
+  const uint32_t key = mix32(seed, salt), thr = (uint32_t)(p * 4294967296.0);
+  const float scale = 1.0f / (1.0f - p);
+  const int nq = (C1 + C2) >> 2;
+  const size_t total = npos * nq;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % nq);
+    const size_t pos = idx / nq;
+    const int c = q * 4;
+    f32x4 v;
+    if (c < C1) {
+      v = *reinterpret_cast<const f32x4*>(a + pos * lda + c);
+    } else {
+      v = *reinterpret_cast<const f32x4*>(b + pos * ldb + (c - C1));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = drop_keep(key, pos * C2 + (c - C1) + e, thr, scale, v[e]);
+    }
+    *reinterpret_cast<f32x4*>(out + pos * ldo + c) = v;
+  }
+}
+
+// dst[pos][0:C] = dropout(src[pos][off:off+C]) with the mask of da_dropout on the contiguous [npos][C] tensor
+// (backward of the above: the slice of the concatenated gradient that belongs to the new features)
+__global__ __launch_bounds__(256) void slice_dropout_kernel(const float* __restrict__ src, int lds, int off,
+                                                            float* __restrict__ dst, int ldd, int C, size_t npos,
+                                                            const int64_t* __restrict__ seed_ptr, uint32_t salt, float p) {
+  const uint32_t seed = (uint32_t)seed_ptr[0] ^ (uint32_t)(seed_ptr[0] >> 32);
+  const uint32_t key = mix32(seed, salt), thr = (uint32_t)(p * 4294967296.0);
+  const float scale = 1.0f / (1.0f - p);
+  const int nq = C >> 2;
+  const size_t total = npos * nq;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % nq);
+    const size_t pos = idx / nq;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src + pos * lds + off + q * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = drop_keep(key, pos * C + q * 4 + e, thr, scale, v[e]);
+    *reinterpret_cast<f32x4*>(dst + pos * ldd + q * 4) = v;
+  }
+}
+
 // Device-resident window store: out[b][:] = float((tiles[idx[b]][:] - mu) / std), the
 // reference's ARDSRawDataset.__getitem__ normalisation (dataset.py:1364,1379: float64 arithmetic) followed by
 // the .float() cast of train_ards_detector.py:150-152 -- fused with the batch gather, bit-identical results.
@@ -515,6 +567,30 @@ int da_slice_copy(const float* src, int lds, int off, float* dst, int ldd, int C
   if (npos == 0) return DA_OK;
   hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(npos * (C / 4), 256, 8192)), dim3(256), 0, stream, src, lds, off,
                      dst, ldd, C, npos, accumulate);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// da_concat2 with dropout (keep-prob 1-p, mask of da_dropout on b) applied to the b half on the way.
+int da_concat2_dropout(const float* a, int lda, int C1, const float* b, int ldb, int C2, float* out, int ldo, size_t npos,
+                       const int64_t* seed, unsigned salt, float p, hipStream_t stream) {
+  DA_ENTER();
+  if (!a || !b || !out || !seed || C1 % 4 || C2 % 4 || lda % 4 || ldb % 4 || ldo % 4 || p < 0.f || p >= 1.f) return DA_EINVAL;
+  if (npos == 0) return DA_OK;
+  hipLaunchKernelGGL(concat2_dropout_kernel, dim3(grid_for(npos * ((C1 + C2) / 4), 256, 8192)), dim3(256), 0, stream, a, lda,
+                     C1, b, ldb, C2, out, ldo, npos, seed, salt, p);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// dst = dropout(src[:, off:off+C]) with the mask of da_dropout on a contiguous [npos][C] tensor.
+int da_slice_dropout(const float* src, int lds, int off, float* dst, int ldd, int C, size_t npos, const int64_t* seed,
+                     unsigned salt, float p, hipStream_t stream) {
+  DA_ENTER();
+  if (!src || !dst || !seed || C % 4 || lds % 4 || ldd % 4 || off % 4 || p < 0.f || p >= 1.f) return DA_EINVAL;
+  if (npos == 0) return DA_OK;
+  hipLaunchKernelGGL(slice_dropout_kernel, dim3(grid_for(npos * (C / 4), 256, 8192)), dim3(256), 0, stream, src, lds, off,
+                     dst, ldd, C, npos, seed, salt, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

@@ -297,9 +297,7 @@ class DenseLayerFunction(Function):
         h2 = _bn_apply(y1, R, s2, st2, g2, b2, True)
         m1, i1, m2, i2 = s1.mean, s1.invstd, s2.mean, s2.invstd
         new = _conv_fwd(h2, w2, 1, 1)
-        if drop_p > 0:
-            new = H.dropout(new, seed, salt, drop_p)
-        out = H.concat2(x, new)
+        out = H.concat2(x, new, drop=(seed, salt, drop_p) if drop_p > 0 else None)      # dropout rides on the concat
         ctx.R, ctx.drop_p, ctx.salt = R, drop_p, salt
         ctx.gt = _tgt(g1, b1, w1, g2, b2, w2)
         ctx.save_for_backward(x, g1, b1, w1, g2, b2, w2, m1, i1, h, y1, m2, i2, h2, seed)
@@ -312,9 +310,7 @@ class DenseLayerFunction(Function):
         R = ctx.R
         cin = x.shape[2]
         dout = dout.contiguous()
-        dnew = H.slice_channels(dout, cin, w2.shape[0])
-        if ctx.drop_p > 0:
-            dnew = H.dropout(dnew, seed, ctx.salt, ctx.drop_p)
+        dnew = H.slice_channels(dout, cin, w2.shape[0], drop=(seed, ctx.salt, ctx.drop_p) if ctx.drop_p > 0 else None)
         dw2 = _wgrad(dnew, h2, 3, 1, 1, tw2)
         dh2 = _conv_dgrad(dnew, w2, 1, 1, h2.shape[1])
         dy1, dg2, db2 = _bn_bwd(dh2, y1, R, m2, i2, g2, b2, 1, tg2, tb2, dx=dh2)

@@ -537,24 +537,38 @@ def clamp_adam_(p, g, m, v, lr, step, clip, beta1=0.9, beta2=0.999, eps=1e-8, gs
                                   clip if clip else 0.0, gscale, _stream()), 'da_clamp_adam')
 
 
-def concat2(a, b):
+def concat2(a, b, drop=None):
+    """cat([a, b], channels); drop = (seed, salt, p): dropout (the mask of dropout(b, ...)) on the b half on the way."""
     _rlc(a, 'a')
     _rlc(b, 'b')
     rows, l, c1 = a.shape
     c2 = b.shape[2]
     out = torch.empty((rows, l, c1 + c2), device=a.device, dtype=torch.float32)
-    _chk(_lib.lib().da_concat2(_p(a), c1, c1, _p(b), c2, c2, _p(out), c1 + c2, rows * l, _stream()), 'da_concat2')
+    if drop is None:
+        _chk(_lib.lib().da_concat2(_p(a), c1, c1, _p(b), c2, c2, _p(out), c1 + c2, rows * l, _stream()), 'da_concat2')
+    else:
+        seed, salt, p = drop
+        _chk(_lib.lib().da_concat2_dropout(_p(a), c1, c1, _p(b), c2, c2, _p(out), c1 + c2, rows * l, _p(seed), salt, p,
+                                           _stream()), 'da_concat2_dropout')
     return out
 
 
-def slice_channels(src, off, c, out=None, accumulate=False):
-    """out (rows,L,c) (+)= src[:, :, off:off+c]"""
+def slice_channels(src, off, c, out=None, accumulate=False, drop=None):
+    """out (rows,L,c) (+)= src[:, :, off:off+c]; drop = (seed, salt, p): out = dropout(slice) with the mask of
+    dropout() on a contiguous (rows,L,c) tensor (not with accumulate)."""
     _rlc(src, 'src')
     rows, l, cs = src.shape
     if out is None:
         out = torch.empty((rows, l, c), device=src.device, dtype=torch.float32)
-    _chk(_lib.lib().da_slice_copy(_p(src), cs, off, _p(out), c, c, rows * l, 1 if accumulate else 0, _stream()),
-         'da_slice_copy')
+    if drop is None:
+        _chk(_lib.lib().da_slice_copy(_p(src), cs, off, _p(out), c, c, rows * l, 1 if accumulate else 0, _stream()),
+             'da_slice_copy')
+    else:
+        if accumulate:
+            raise ValueError('slice_channels: drop and accumulate are exclusive')
+        seed, salt, p = drop
+        _chk(_lib.lib().da_slice_dropout(_p(src), cs, off, _p(out), c, c, rows * l, _p(seed), salt, p, _stream()),
+             'da_slice_dropout')
     return out
 
 

@@ -191,6 +191,12 @@ int da_gather_rows(const float* src, const int64_t* idx, float* out, int B, int 
 int da_vote_counts(const float* logits, const int64_t* group, int B, int n_groups, int* votes, int* pred,
                    da_stream_t stream);
 
+/* _DenseLayer's dropout fused into its neighbours (densenet.py:38-41): concat with dropout on the new features, and
+   the backward's slice of the concatenated gradient with the same mask (that of da_dropout on a contiguous tensor) */
+int da_concat2_dropout(const float* a, int lda, int C1, const float* b, int ldb, int C2, float* out, int ldo, size_t npos,
+                       const int64_t* seed, unsigned salt, float p, da_stream_t stream);
+int da_slice_dropout(const float* src, int lds, int off, float* dst, int ldd, int C, size_t npos, const int64_t* seed,
+                     unsigned salt, float p, da_stream_t stream);
 /* ---- densenet helpers: torch.cat([x, new], 1) and F.dropout  densenet.py:36-40 -------------- */
 int da_concat2(const float* a, int lda, int C1, const float* b, int ldb, int C2, float* out, int ldo, size_t npos,
                da_stream_t stream);

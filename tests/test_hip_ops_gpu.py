@@ -428,6 +428,12 @@ def test_concat_slice_dropout(H):
     keep = (y1 > 0).float().mean().item()
     assert abs(keep - 0.8) < 0.005
     assert torch.allclose(y1[y1 > 0], torch.tensor(1.25, device='cuda'))
+    # the fused forms carry exactly the mask of dropout() on the contiguous new-feature tensor
+    bt = rlc(b)
+    catd = H.concat2(rlc(a), bt, drop=(seed, 7, 0.2))
+    assert torch.equal(catd[:, :, :64], rlc(a)) and torch.equal(catd[:, :, 64:], H.dropout(bt, seed, 7, 0.2))
+    sd = H.slice_channels(cat, 64, 32, drop=(seed, 7, 0.2))
+    assert torch.equal(sd, H.dropout(bt, seed, 7, 0.2))
 
 
 @pytest.mark.parametrize('B,NB,F', [(3, 20, 128), (64, 20, 512), (2, 7, 32), (5, 1, 64), (4, 64, 16)])
