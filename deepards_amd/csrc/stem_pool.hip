@@ -69,18 +69,21 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   }
 }
 
+// dw[i] (+)= sum over the nblk partial blocks; block = 8 outputs x 32 partial slots, folded through LDS in a fixed
+// order (448 outputs: 56 blocks -- the 14-block form took 19 us alone and 80-120 us beside other kernels)
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int n,
                                                                 float* __restrict__ dw, int accumulate) {
-  __shared__ float red[8][32];
-  const int i = blockIdx.x * 32 + (threadIdx.x & 31), slot = threadIdx.x >> 5;
+  __shared__ float red[32][8];
+  const int o = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + o;
   float s = 0.f;
   if (i < n)
-    for (int b = slot; b < nblk; b += 8) s += partial[(size_t)b * n + i];
-  red[slot][threadIdx.x & 31] = s;
+    for (int b = slot; b < nblk; b += 32) s += partial[(size_t)b * n + i];
+  red[slot][o] = s;
   __syncthreads();
-  if (threadIdx.x < 32 && i < n) {
+  if (threadIdx.x < 8 && i < n) {
     s = 0.f;
-    for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+    for (int k = 0; k < 32; ++k) s += red[k][threadIdx.x];
     dw[i] = accumulate ? dw[i] + s : s;
   }
 }
@@ -269,7 +272,7 @@ int da_stem_conv_wgrad(const float* dy, int lddy, const float* x, float* dw, flo
                      C0);
   DA_CHECK_LAUNCH();
   int n = C0 * 7;
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, stream, workspace, nblk, n, dw,
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((n + 7) / 8), dim3(256), 0, stream, workspace, nblk, n, dw,
                      accumulate);
   DA_CHECK_LAUNCH();
   return DA_OK;
