@@ -91,6 +91,9 @@ SIGNATURES = {
     'da_gather_normalize': (_I, [_P, _P, ctypes.c_double, ctypes.c_double, _P, _I, _I, _P]),
     'da_window_median_fwd': (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     'da_window_median_bwd': (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
+    'da_lstm_fwd': (_I, [_P] * 11 + [_I, _I, _I, _P]),
+    'da_lstm_bwd': (_I, [_P] * 9 + [_I, _I, _I, _P]),
+    'da_reduce_rows': (_I, [_P, _I, _I, _P, _I, _P]),
     'da_gather_rows': (_I, [_P, _P, _P, _I, _I, _P]),
     'da_vote_counts': (_I, [_P, _P, _I, _I, _P, _P, _P]),
     'da_concat2': (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _Z, _P]),

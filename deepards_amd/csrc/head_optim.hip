@@ -385,6 +385,116 @@ __global__ __launch_bounds__(256) void window_median_bwd_kernel(const float* __r
   dx[row * ld + f] = idx[(size_t)b * F + f] == r ? dout[(size_t)b * F + f] : 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// LSTM head (CNNLSTMNetwork, reference models/torch_cnn_lstm_combo.py:6-50: nn.LSTM(F, H, 1 layer, batch_first) over
+// the NB breath features of a window).  The input projection x W_ih^T for all time steps and the weight / input
+// gradients are 1x1-conv GEMMs (da_conv_gemm / da_conv_wgrad); these two kernels run the recurrence: one block per
+// window, one thread per gate unit (4H <= 1024), T steps inside the kernel.  Gate order i, f, g, o.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(1024) void lstm_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ whh,
+                                                        const float* __restrict__ bih, const float* __restrict__ bhh,
+                                                        const float* __restrict__ h0, const float* __restrict__ c0,
+                                                        float* __restrict__ hs, float* __restrict__ cs,
+                                                        float* __restrict__ gates, float* __restrict__ hT,
+                                                        float* __restrict__ cT, int T, int H) {
+  __shared__ float hsm[256], zs[1024];
+  const int b = blockIdx.x, j = threadIdx.x, G = 4 * H;
+  float c = 0.f;
+  if (j < H) {
+    hsm[j] = h0 ? h0[(size_t)b * H + j] : 0.f;
+    c = c0 ? c0[(size_t)b * H + j] : 0.f;
+  }
+  const float bias = bih[j] + bhh[j];
+  const float* wrow = whh + (size_t)j * H;
+  const bool is_g = j >= 2 * H && j < 3 * H;
+  for (int t = 0; t < T; ++t) {
+    __syncthreads();
+    float z = gx[((size_t)b * T + t) * G + j] + bias;
+    for (int k = 0; k < H; ++k) z = fmaf(wrow[k], hsm[k], z);
+    const float a = is_g ? tanhf(z) : sigmoidf_(z);
+    zs[j] = a;
+    gates[((size_t)b * T + t) * G + j] = a;
+    __syncthreads();
+    if (j < H) {
+      c = zs[H + j] * c + zs[j] * zs[2 * H + j];
+      const float h = zs[3 * H + j] * tanhf(c);
+      hsm[j] = h;
+      hs[((size_t)b * T + t) * H + j] = h;
+      cs[((size_t)b * T + t) * H + j] = c;
+    }
+  }
+  if (j < H) {
+    hT[(size_t)b * H + j] = hsm[j];
+    cT[(size_t)b * H + j] = c;
+  }
+}
+
+// backward through time: dgates [B][T][4H] (pre-activation gradients) and this window's dW_hh [4H][H] (summed over
+// the windows afterwards, fixed order).  No gradient into the initial state (the reference detaches it).  H <= 64.
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ dh_all, const float* __restrict__ whh,
+                                                       const float* __restrict__ hs, const float* __restrict__ cs,
+                                                       const float* __restrict__ gates, const float* __restrict__ h0,
+                                                       const float* __restrict__ c0, float* __restrict__ dgates,
+                                                       float* __restrict__ dwhh_part, int T, int H) {
+  __shared__ float dz[256], dhrec[64], hprev[64];
+  const int b = blockIdx.x, j = threadIdx.x, G = 4 * H;
+  float acc[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) acc[k] = 0.f;
+  float dc_next = 0.f;
+  if (j < H) dhrec[j] = 0.f;
+  for (int t = T - 1; t >= 0; --t) {
+    __syncthreads();
+    const size_t bt = (size_t)b * T + t;
+    if (j < H) {
+      const float* ga = gates + bt * G;
+      const float i = ga[j], f = ga[H + j], g = ga[2 * H + j], o = ga[3 * H + j];
+      const float c = cs[bt * H + j], tc = tanhf(c);
+      const float c_prev = t > 0 ? cs[(bt - 1) * H + j] : (c0 ? c0[(size_t)b * H + j] : 0.f);
+      const float dh = dh_all[bt * H + j] + dhrec[j];
+      const float dc = dh * o * (1.f - tc * tc) + dc_next;
+      dz[j] = dc * g * i * (1.f - i);
+      dz[H + j] = dc * c_prev * f * (1.f - f);
+      dz[2 * H + j] = dc * i * (1.f - g * g);
+      dz[3 * H + j] = dh * tc * o * (1.f - o);
+      dc_next = dc * f;
+      hprev[j] = t > 0 ? hs[(bt - 1) * H + j] : (h0 ? h0[(size_t)b * H + j] : 0.f);
+    }
+    __syncthreads();
+    const float d = dz[j];
+    dgates[bt * G + j] = d;
+#pragma unroll
+    for (int k = 0; k < 64; ++k)
+      if (k < H) acc[k] = fmaf(d, hprev[k], acc[k]);
+    float r = 0.f;
+    if (j < H)
+      for (int q = 0; q < G; ++q) r = fmaf(whh[(size_t)q * H + j], dz[q], r);
+    __syncthreads();
+    if (j < H) dhrec[j] = r;
+  }
+  for (int k = 0; k < H; ++k) dwhh_part[((size_t)b * G + j) * H + k] = acc[k];
+}
+
+// out[i] (+)= sum over the rows r of m[r][i] (fixed order): bias gradients and the fold of per-window partials
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ m, int rows, int n, float* __restrict__ out,
+                                                          int accumulate) {
+  __shared__ float red[32][8];
+  const int o = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + o;
+  float s = 0.f;
+  if (i < n)
+    for (int r = slot; r < rows; r += 32) s += m[(size_t)r * n + i];
+  red[slot][o] = s;
+  __syncthreads();
+  if (threadIdx.x < 8 && i < n) {
+    s = 0.f;
+    for (int k = 0; k < 32; ++k) s += red[k][threadIdx.x];
+    out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
 extern "C" {
 
 int da_version(void) { return 100; }
@@ -509,6 +619,42 @@ int da_window_median_bwd(const float* dout, const int* idx, int B, int NB, int F
   const size_t total = (size_t)B * NB * F;
   hipLaunchKernelGGL(window_median_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dout, idx, B,
                      NB, F, dx, ld);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// LSTM recurrence of CNNLSTMNetwork (torch_cnn_lstm_combo.py:17,46): gx [B][T][4H] = x W_ih^T (da_conv_gemm), whh [4H][H],
+// bih / bhh [4H], h0 / c0 [B][H] or NULL (zeros).  Outputs hs, cs [B][T][H], gates [B][T][4H] (activated i,f,g,o; kept
+// for the backward), hT, cT [B][H].  H % 8 == 0, H <= 256.
+int da_lstm_fwd(const float* gx, const float* whh, const float* bih, const float* bhh, const float* h0, const float* c0,
+                float* hs, float* cs, float* gates, float* hT, float* cT, int B, int T, int H, hipStream_t stream) {
+  DA_ENTER();
+  if (!gx || !whh || !bih || !bhh || !hs || !cs || !gates || !hT || !cT || T < 1 || H < 8 || H % 8 || H > 256)
+    return DA_EINVAL;
+  if (B == 0) return DA_OK;
+  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(B), dim3(4 * H), 0, stream, gx, whh, bih, bhh, h0, c0, hs, cs, gates, hT, cT, T, H);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// dh_all [B][T][H] -> dgates [B][T][4H] and dwhh_part [B][4H][H] (fold with da_reduce_rows).  H <= 64.
+int da_lstm_bwd(const float* dh_all, const float* whh, const float* hs, const float* cs, const float* gates,
+                const float* h0, const float* c0, float* dgates, float* dwhh_part, int B, int T, int H,
+                hipStream_t stream) {
+  DA_ENTER();
+  if (!dh_all || !whh || !hs || !cs || !gates || !dgates || !dwhh_part || T < 1 || H < 8 || H % 8 || H > 64) return DA_EINVAL;
+  if (B == 0) return DA_OK;
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(B), dim3(4 * H), 0, stream, dh_all, whh, hs, cs, gates, h0, c0, dgates, dwhh_part,
+                     T, H);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// out[n] (+)= column sums of m [rows][n], fixed order.
+int da_reduce_rows(const float* m, int rows, int n, float* out, int accumulate, hipStream_t stream) {
+  DA_ENTER();
+  if (!m || !out || rows < 0 || n < 1) return DA_EINVAL;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + 7) / 8), dim3(256), 0, stream, m, rows, n, out, accumulate);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

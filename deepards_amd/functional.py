@@ -437,6 +437,48 @@ class WindowMedianFunction(Function):
         return H.window_median_bwd(dout.contiguous(), idx, ctx.nb), None
 
 
+class LSTMFunction(Function):
+    """nn.LSTM(F, H, num_layers=1, batch_first=True) over the NB breath features of every window
+    (CNNLSTMNetwork, models/torch_cnn_lstm_combo.py:17,46).  feat (B*T, F) -> hs (B, T, H), hT, cT (1, B, H).
+    The input projection and the weight / input gradients run on the conv GEMM kernels (1x1 conv = GEMM), the
+    recurrence in da_lstm_fwd / da_lstm_bwd.  The initial state gets no gradient (the reference detaches it,
+    train_ards_detector.py:848)."""
+
+    @staticmethod
+    def forward(ctx, feat, w_ih, w_hh, b_ih, b_hh, T, h0, c0):
+        rows, f = feat.shape
+        b, g4 = rows // T, w_ih.shape[0]
+        x3 = feat.contiguous().view(rows, 1, f)
+        gx = H.conv_fwd(x3, w_ih.view(1, g4, f), 1, 0)                      # W_ih is already the forward pack
+        hs, cs, gates, ht, ct = H.lstm_fwd(gx.view(b, T, g4), w_hh, b_ih, b_hh, h0, c0)
+        ctx.T = T
+        ctx.gt = _tgt(w_ih, w_hh, b_ih, b_hh)
+        ctx.save_for_backward(x3, w_ih, w_hh, hs, cs, gates, h0 if h0 is not None else hs.new_empty(0),
+                              c0 if c0 is not None else hs.new_empty(0))
+        ctx.mark_non_differentiable(ht, ct)
+        return hs, ht.view(1, b, -1), ct.view(1, b, -1)
+
+    @staticmethod
+    def backward(ctx, dhs, _dht, _dct):
+        x3, w_ih, w_hh, hs, cs, gates, h0, c0 = ctx.saved_tensors
+        h0 = h0 if h0.numel() else None
+        c0 = c0 if c0.numel() else None
+        tih, thh, tbi, tbh = ctx.gt
+        rows, _, f = x3.shape
+        g4 = w_ih.shape[0]
+        dgates, part = H.lstm_bwd(dhs.contiguous(), w_hh, hs, cs, gates, h0, c0)
+        dg3 = dgates.view(rows, 1, g4)
+        dfeat = H.conv_dgrad(dg3, H.repack_weight(w_ih.view(g4, f, 1), False, True)[1], 1, 0, 1)
+        direct = tih is not None
+        dw_ih = H.conv_wgrad(dg3, x3, 1, 1, 0, out=tih.view(g4, f, 1) if direct else None, accumulate=direct)
+        dw_hh = H.reduce_rows(part, out=thh if direct else None, accumulate=direct)
+        db = H.reduce_rows(dgates.view(rows, g4), out=tbi if direct else None, accumulate=direct)
+        if direct:
+            H.reduce_rows(dgates.view(rows, g4), out=tbh, accumulate=True)
+            return dfeat.view(rows, f), None, None, None, None, None, None, None
+        return dfeat.view(rows, f), dw_ih.view(g4, f), dw_hh, db, db.clone(), None, None, None
+
+
 class BCEWithLogitsFunction(Function):
     """torch.nn.BCEWithLogitsLoss() (mean) -- train_ards_detector.py:530,929-930."""
 

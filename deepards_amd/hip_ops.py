@@ -628,6 +628,40 @@ def window_median_bwd(dout, idx, nb):
     return dx
 
 
+def lstm_fwd(gx, whh, bih, bhh, h0=None, c0=None):
+    """gx (B,T,4H) = x W_ih^T -> hs, cs (B,T,H), gates (B,T,4H), hT, cT (B,H): the recurrence of nn.LSTM (1 layer)."""
+    _f32(gx, 'gx')
+    b, t, g4 = gx.shape
+    h = g4 // 4
+    mk = lambda *shape: torch.empty(shape, device=gx.device, dtype=torch.float32)
+    hs, cs, gates, ht, ct = mk(b, t, h), mk(b, t, h), mk(b, t, g4), mk(b, h), mk(b, h)
+    _chk(_lib.lib().da_lstm_fwd(_p(gx), _p(whh), _p(bih), _p(bhh), _p(h0), _p(c0), _p(hs), _p(cs), _p(gates), _p(ht), _p(ct),
+                                b, t, h, _stream()), 'da_lstm_fwd')
+    return hs, cs, gates, ht, ct
+
+
+def lstm_bwd(dh_all, whh, hs, cs, gates, h0=None, c0=None):
+    """-> dgates (B,T,4H), dwhh_part (B,4H,H)."""
+    _f32(dh_all, 'dh_all')
+    b, t, h = dh_all.shape
+    dgates = torch.empty((b, t, 4 * h), device=dh_all.device, dtype=torch.float32)
+    part = torch.empty((b, 4 * h, h), device=dh_all.device, dtype=torch.float32)
+    _chk(_lib.lib().da_lstm_bwd(_p(dh_all), _p(whh), _p(hs), _p(cs), _p(gates), _p(h0), _p(c0), _p(dgates), _p(part),
+                                b, t, h, _stream()), 'da_lstm_bwd')
+    return dgates, part
+
+
+def reduce_rows(m, out=None, accumulate=False):
+    """column sums of m (rows, ...) -> (...), fixed order; accumulate adds into out."""
+    _f32(m, 'm')
+    rows = m.shape[0]
+    n = m.numel() // max(rows, 1)
+    if out is None:
+        out = torch.empty(m.shape[1:], device=m.device, dtype=torch.float32)
+    _chk(_lib.lib().da_reduce_rows(_p(m), rows, n, _p(out), 1 if accumulate else 0, _stream()), 'da_reduce_rows')
+    return out
+
+
 def vote_counts(logits, group, votes, want_pred=True):
     """logits (B,2) f32, group (B,) int64 patient slot per window, votes (P,2) int32 accumulated in place.
     -> pred (B,) int32 window predictions (argmax, class 0 on ties)."""

@@ -3,6 +3,6 @@ hot path: same constructors, attributes and ``state_dict`` keys (SURVEY.md secti
 from .resnet import ResNet, BasicBlock, resnet18            # noqa: F401
 from .densenet import DenseNet, densenet18                  # noqa: F401
 from .torch_cnn_linear_network import (CNNLinearNetwork, CNNLinearToMean, CNNLinearComprToRF,      # noqa: F401
-                                       CNNSingleBreathLinearNetwork, CNNDoubleLinearNetwork)
+                                       CNNSingleBreathLinearNetwork, CNNDoubleLinearNetwork, CNNLSTMNetwork)
 
 base_networks = {'resnet18': resnet18, 'densenet18': densenet18}

@@ -102,3 +102,35 @@ class CNNDoubleLinearNetwork(nn.Module):
         b, nb, feat = _windows(self, x)
         inter = F_.Linear2Function.apply(feat, self.linear_intermediate.weight, self.linear_intermediate.bias)
         return F_.Linear2Function.apply(inter.view(b, nb * 2), self.linear_final.weight, self.linear_final.bias)
+
+
+class CNNLSTMNetwork(nn.Module):
+    """reference models/torch_cnn_lstm_combo.py:6-50: breath block -> nn.LSTM over the NB breaths -> Linear(H, 2) per
+    breath; returns (logits (B, NB, 2), (hx, cx)).  Metadata features are not on the accelerated path (NaN metadata =
+    none, as the reference's default run)."""
+
+    def __init__(self, breath_block, metadata_features, bm_to_linear, lstm_hidden_units):
+        super(CNNLSTMNetwork, self).__init__()
+        if metadata_features:
+            raise NotImplementedError('metadata features are outside the accelerated path')
+        if lstm_hidden_units % 8 or not 8 <= lstm_hidden_units <= 64:
+            raise NotImplementedError('lstm_hidden_units must be a multiple of 8 in [8, 64] (defaults.yml: 16)')
+        self.seq_size = 224
+        self.breath_block = breath_block
+        self.lstm_hidden_units = lstm_hidden_units
+        self.lstm_layers = 1
+        self.bm_to_linear = bm_to_linear
+        self.lstm = nn.LSTM(breath_block.n_out_filters, lstm_hidden_units, num_layers=1, batch_first=True)
+        self.linear_final = nn.Linear(lstm_hidden_units, 2)
+
+    def forward(self, x, metadata, hx_cx=None):
+        b, nb, feat = _windows(self, x)
+        h0 = c0 = None
+        if hx_cx is not None:
+            h0 = hx_cx[0].detach().reshape(b, -1).contiguous()
+            c0 = hx_cx[1].detach().reshape(b, -1).contiguous()
+        lstm = self.lstm
+        hs, hx, cx = F_.LSTMFunction.apply(feat, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
+                                           nb, h0, c0)
+        out = F_.Linear2Function.apply(hs.view(b * nb, -1), self.linear_final.weight, self.linear_final.bias)
+        return out.view(b, nb, 2), (hx, cx)

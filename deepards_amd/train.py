@@ -41,6 +41,12 @@ def shard_windows(n_windows, world_size, rank):
     return slice(rank * per, (rank + 1) * per)
 
 
+def _logits(out):
+    """CNNLSTMNetwork returns (logits, (hx, cx)); every batch starts from a zero state here (the reference's stateful
+    per-patient carry, train_ards_detector.py:845-849, is the caller's loop: pass hx_cx to the model yourself)."""
+    return out[0] if isinstance(out, tuple) else out
+
+
 def _loss_operands(logits, target):
     """(logits, target) as (n, 2) pairs for the BCE kernel.  Per-breath outputs (B, NB, 2) repeat the window target
     over the breaths (PerBreathClassifierMixin.calc_loss, train_ards_detector.py:540-543)."""
@@ -108,7 +114,7 @@ class HotPathTrainer(object):
     # ---- eager pieces ------------------------------------------------------------------------
     def _forward_backward(self, inputs, target):
         with F_.training_step(self.model):               # weights are constant within one step
-            logits = self.model(inputs, None)
+            logits = _logits(self.model(inputs, None))
             F_.flush_forward()                           # batched BN running-statistics updates
             lg, tg = _loss_operands(logits.detach(), target)
             loss, dlogits = H.bce_logits(lg, tg, want_grad=True)
@@ -212,7 +218,7 @@ class HotPathTrainer(object):
 
     def _test_forward(self, inputs, target):
         with torch.no_grad(), F_.training_step(self.model):      # packs / Winograd taps once, batched small kernels
-            logits = self.model(inputs, None)
+            logits = _logits(self.model(inputs, None))
             F_.flush_forward()                                   # train-mode forward: BN running statistics do move
             loss, _ = H.bce_logits(*_loss_operands(logits, target), want_grad=False)
         return loss, logits, logits.argmax(dim=-1)

@@ -183,6 +183,16 @@ int da_gather_normalize(const double* tiles, const int64_t* idx, double mu, doub
 int da_window_median_fwd(const float* x, int ld, int B, int NB, int F, float* out, int* idx, da_stream_t stream);
 int da_window_median_bwd(const float* dout, const int* idx, int B, int NB, int F, float* dx, int ld, da_stream_t stream);
 
+/* ---- LSTM head of CNNLSTMNetwork (torch_cnn_lstm_combo.py:6-50): nn.LSTM(F, H, 1 layer, batch_first), gates i,f,g,o ---
+   the recurrence only: the input projection gx = x W_ih^T and the weight / input gradients are 1x1-conv GEMMs */
+int da_lstm_fwd(const float* gx, const float* whh, const float* bih, const float* bhh, const float* h0, const float* c0,
+                float* hs, float* cs, float* gates, float* hT, float* cT, int B, int T, int H, da_stream_t stream);
+int da_lstm_bwd(const float* dh_all, const float* whh, const float* hs, const float* cs, const float* gates,
+                const float* h0, const float* c0, float* dgates, float* dwhh_part, int B, int T, int H,
+                da_stream_t stream);
+/* out[n] (+)= column sums of m [rows][n] in a fixed order */
+int da_reduce_rows(const float* m, int rows, int n, float* out, int accumulate, da_stream_t stream);
+
 int da_gather_rows(const float* src, const int64_t* idx, float* out, int B, int width, da_stream_t stream);
 
 /* ---- test epoch on the device: window predictions + per-patient vote table --------------------------------

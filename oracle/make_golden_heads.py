@@ -20,11 +20,13 @@ from oracle.weights import param_spec, seeded_params, seeded_batch, digest as sa
 from deepards.models.resnet import resnet18                                                 # noqa: E402
 from deepards.models.densenet import densenet18                                             # noqa: E402
 from deepards.models import torch_cnn_linear_network as ref                                 # noqa: E402
+from deepards.models.torch_cnn_lstm_combo import CNNLSTMNetwork                             # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
 HEADS = {'to_mean': lambda bb: ref.CNNLinearToMean(bb), 'compr_to_rf': lambda bb: ref.CNNLinearComprToRF(bb),
          'single_breath': lambda bb: ref.CNNSingleBreathLinearNetwork(bb),
-         'double_linear': lambda bb: ref.CNNDoubleLinearNetwork(bb, 20, 0)}
+         'double_linear': lambda bb: ref.CNNDoubleLinearNetwork(bb, 20, 0),
+         'lstm': lambda bb: CNNLSTMNetwork(bb, 0, False, 16)}       # defaults.yml:35 time_series_hidden_units = 16
 
 
 def build(head, backbone, seed, dtype, shift):
@@ -49,7 +51,12 @@ def main():
                 for dt, sfx in ((torch.float64, '64'), (torch.float32, '32')):
                     model = build(head, backbone, seed, dt, shift)
                     xt, tt = torch.from_numpy(x).to(dt), torch.from_numpy(tgt).to(dt)
-                    out = model(xt, None)
+                    if head == 'lstm':       # zero initial state, NaN metadata (= none), train_ards_detector.py:846-847
+                        out, (hx, cx) = model(xt, torch.full((b,), float('nan'), dtype=dt), None)
+                        rec['hx' + sfx] = hx.detach().numpy().astype(np.float64)
+                        rec['cx' + sfx] = cx.detach().numpy().astype(np.float64)
+                    else:
+                        out = model(xt, None)
                     tl = tt.unsqueeze(1).repeat((1, out.shape[1], 1)) if out.dim() == 3 else tt
                     loss = torch.nn.BCEWithLogitsLoss()(out, tl)
                     loss.backward()

@@ -346,7 +346,56 @@ def densenet18_features(t, x, prefix='breath_block.', drop_masks=None):
     return out, bwd
 
 
-HEADS = ('linear', 'to_mean', 'compr_to_rf', 'single_breath', 'double_linear')
+HEADS = ('linear', 'to_mean', 'compr_to_rf', 'single_breath', 'double_linear', 'lstm')
+
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def lstm_fwd(x, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None):
+    """nn.LSTM(F, H, num_layers=1, batch_first=True): x (B,T,F) -> h (B,T,H), (hT, cT), tape.  Gate order i, f, g, o."""
+    b, t, _ = x.shape
+    hd = w_hh.shape[1]
+    h = np.zeros((b, hd)) if h0 is None else h0
+    c = np.zeros((b, hd)) if c0 is None else c0
+    hs, tape = [], []
+    for s in range(t):
+        z = x[:, s] @ w_ih.T + b_ih + h @ w_hh.T + b_hh
+        i, f, g, o = _sigmoid(z[:, :hd]), _sigmoid(z[:, hd:2 * hd]), np.tanh(z[:, 2 * hd:3 * hd]), _sigmoid(z[:, 3 * hd:])
+        c_new = f * c + i * g
+        tc = np.tanh(c_new)
+        h_new = o * tc
+        tape.append((h, c, i, f, g, o, tc))
+        h, c = h_new, c_new
+        hs.append(h)
+    return np.stack(hs, axis=1), (h, c), tape
+
+
+def lstm_bwd(x, w_ih, w_hh, tape, dh_all):
+    """-> dx (B,T,F), dw_ih, dw_hh, db (= db_ih = db_hh); no gradient into the initial state (the reference detaches it,
+    train_ards_detector.py:848)."""
+    b, t, _ = x.shape
+    hd = w_hh.shape[1]
+    dx = np.zeros_like(x)
+    dw_ih, dw_hh, db = np.zeros_like(w_ih), np.zeros_like(w_hh), np.zeros(4 * hd)
+    dh_next, dc_next = np.zeros((b, hd)), np.zeros((b, hd))
+    for s in range(t - 1, -1, -1):
+        h_prev, c_prev, i, f, g, o, tc = tape[s]
+        dh = dh_all[:, s] + dh_next
+        do = dh * tc * o * (1 - o)
+        dc = dh * o * (1 - tc * tc) + dc_next
+        di = dc * g * i * (1 - i)
+        df = dc * c_prev * f * (1 - f)
+        dg = dc * i * (1 - g * g)
+        dz = np.concatenate([di, df, dg, do], axis=1)
+        dx[:, s] = dz @ w_ih
+        dw_ih += dz.T @ x[:, s]
+        dw_hh += dz.T @ h_prev
+        db += dz.sum(axis=0)
+        dh_next = dz @ w_hh
+        dc_next = dc * f
+    return dx, dw_ih, dw_hh, db
 
 
 def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_batches=20,
@@ -361,6 +410,8 @@ def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_ba
       'compr_to_rf'    CNNLinearComprToRF:           Linear(F,2)(torch.median over NB = LOWER median)   -> (B,2)
       'single_breath'  CNNSingleBreathLinearNetwork: Linear(F,2) per breath                             -> (B,NB,2)
       'double_linear'  CNNDoubleLinearNetwork:       Linear(2 NB,2)(flatten(Linear(F,2) per breath))    -> (B,2)
+      'lstm'           CNNLSTMNetwork (torch_cnn_lstm_combo.py:6-50, zero initial state, no metadata):
+                                                     Linear(H,2)(LSTM over the NB breath features)       -> (B,NB,2)
     The loss of a (B,NB,2) output repeats the window target over the breaths (PerBreathClassifierMixin.calc_loss,
     train_ards_detector.py:540-543)."""
     if x.shape[-1] != 224:
@@ -388,17 +439,23 @@ def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_ba
         flat = np.take_along_axis(f3, med_idx[:, None, :], axis=1)[:, 0, :]
     elif head == 'single_breath':
         flat = feat                                                  # (B*NB, F)
+    elif head == 'lstm':
+        lw = [params['lstm.' + k] for k in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0')]
+        hseq, (h_t, c_t), ltape = lstm_fwd(f3, *lw)
+        flat = hseq.reshape(b * nb, -1)
     else:
         wi, bi = params['linear_intermediate.weight'], params['linear_intermediate.bias']
         inter = linear_fwd(feat, wi, bi)                             # (B*NB, 2)
         flat = inter.reshape(b, -1)                                  # .view(-1): breath-major, class-minor
     logits = linear_fwd(flat, w, bias)
-    if head == 'single_breath':
+    if head in ('single_breath', 'lstm'):
         logits = logits.reshape(b, nb, 2)
     out = dict(logits=logits, feat=feat, stats=t.stats)
+    if head == 'lstm':
+        out['hx'], out['cx'] = h_t, c_t
     if target is None:
         return out
-    if head == 'single_breath':
+    if head in ('single_breath', 'lstm'):
         loss, dl = bce_with_logits(logits.reshape(b * nb, 2), np.repeat(target, nb, axis=0))
     else:
         loss, dl = bce_with_logits(logits, target)
@@ -417,6 +474,13 @@ def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_ba
             dfeat = d3.reshape(feat.shape)
         elif head == 'single_breath':
             dfeat = dflat
+        elif head == 'lstm':
+            dx3, dwi, dwh, dbb = lstm_bwd(f3, lw[0], lw[1], ltape, dflat.reshape(b, nb, -1))
+            t.acc('lstm.weight_ih_l0', dwi)
+            t.acc('lstm.weight_hh_l0', dwh)
+            t.acc('lstm.bias_ih_l0', dbb)
+            t.acc('lstm.bias_hh_l0', dbb)
+            dfeat = dx3.reshape(feat.shape)
         else:
             dinter = dflat.reshape(b * nb, 2)
             t.acc('linear_intermediate.weight', dinter.T @ feat)

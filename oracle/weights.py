@@ -11,7 +11,7 @@ import zlib
 import numpy as np
 
 
-def param_spec(backbone, n_sub_batches=20, in_ch=1, n_meta=0, head='linear'):
+def param_spec(backbone, n_sub_batches=20, in_ch=1, n_meta=0, head='linear', lstm_hidden=16):
     """-> list of (name, shape, kind) with kind in {'conv','bn_w','bn_b','lin_w','lin_b'},
     in the reference's ``named_parameters()`` order."""
     out = []
@@ -72,6 +72,13 @@ def param_spec(backbone, n_sub_batches=20, in_ch=1, n_meta=0, head='linear'):
         out.append(('linear_final.weight', (2, feat * n_sub_batches + n_meta), 'lin_w'))
     elif head in ('to_mean', 'compr_to_rf', 'single_breath'):
         out.append(('linear_final.weight', (2, feat), 'lin_w'))
+    elif head == 'lstm':          # CNNLSTMNetwork (torch_cnn_lstm_combo.py:6-50), no metadata: nn.LSTM(F, H) + Linear(H, 2)
+        hdim = lstm_hidden
+        out.append(('lstm.weight_ih_l0', (4 * hdim, feat), 'lin_w'))
+        out.append(('lstm.weight_hh_l0', (4 * hdim, hdim), 'lin_w'))
+        out.append(('lstm.bias_ih_l0', (4 * hdim,), 'lin_b'))
+        out.append(('lstm.bias_hh_l0', (4 * hdim,), 'lin_b'))
+        out.append(('linear_final.weight', (2, hdim), 'lin_w'))
     elif head == 'double_linear':
         out.append(('linear_intermediate.weight', (2, feat), 'lin_w'))
         out.append(('linear_intermediate.bias', (2,), 'lin_b'))
@@ -86,7 +93,7 @@ DEAD_RESNET_PARAMS = ('breath_block.conv1_alt.weight', 'breath_block.conv2.weigh
                       'breath_block.bn2.weight', 'breath_block.bn2.bias')
 
 
-def seeded_params(backbone, seed=0, n_sub_batches=20, dtype=np.float32, bn_bias_shift=0.0, head='linear'):
+def seeded_params(backbone, seed=0, n_sub_batches=20, dtype=np.float32, bn_bias_shift=0.0, head='linear', lstm_hidden=16):
     """Deterministic weights: conv ~ N(0, sqrt(2/(k*C_out))) as the reference's init
     (resnet.py:115-118, densenet.py:154-157); BN gamma ~ U(.5,1.5), beta ~ N(0,.1) (NOT the
     reference's 1/0 -- randomised so that parity tests see gamma/beta); linear ~ U(+-1/sqrt(in)).
@@ -94,7 +101,7 @@ def seeded_params(backbone, seed=0, n_sub_batches=20, dtype=np.float32, bn_bias_
     no activation decisions an fp32 rounding could flip, which makes whole-model GRADIENT parity a
     well-posed 1e-4 comparison (see tests/test_model_gpu.py)."""
     params = {}
-    for name, shape, kind in param_spec(backbone, n_sub_batches, head=head):
+    for name, shape, kind in param_spec(backbone, n_sub_batches, head=head, lstm_hidden=lstm_hidden):
         rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
         if kind == 'conv':
             std = np.sqrt(2.0 / (shape[2] * shape[0]))

@@ -458,6 +458,37 @@ def test_window_median(H, B, NB, F):
     assert np.array_equal(dx, dref)
 
 
+@pytest.mark.parametrize('B,T,F,Hd', [(3, 20, 128, 16), (64, 20, 512, 16), (2, 5, 128, 8), (4, 7, 64, 64)])
+def test_lstm_recurrence(H, B, T, F, Hd):
+    """da_lstm_fwd / da_lstm_bwd (+ the GEMMs around them, as LSTMFunction composes them) vs the numpy LSTM of the
+    oracle (pinned to nn.LSTM through the reference goldens): states, outputs, all gradients; with and without an
+    initial state."""
+    from deepards_amd.functional import LSTMFunction
+    rng = np.random.default_rng(B + T + F + Hd)
+    x = rng.standard_normal((B, T, F))
+    k = 1.0 / np.sqrt(Hd)
+    w_ih, w_hh = rng.uniform(-k, k, (4 * Hd, F)), rng.uniform(-k, k, (4 * Hd, Hd))
+    b_ih, b_hh = rng.uniform(-k, k, 4 * Hd), rng.uniform(-k, k, 4 * Hd)
+    dh = rng.standard_normal((B, T, Hd))
+    for init in (False, True):
+        h0 = rng.standard_normal((B, Hd)) if init else None
+        c0 = rng.standard_normal((B, Hd)) if init else None
+        hs_ref, (ht_ref, ct_ref), tape = np_ref.lstm_fwd(x, w_ih, w_hh, b_ih, b_hh, h0, c0)
+        dx_ref, dwi_ref, dwh_ref, db_ref = np_ref.lstm_bwd(x, w_ih, w_hh, tape, dh)
+        feat = cu(x.reshape(B * T, F)).requires_grad_(True)
+        ps = [cu(a).requires_grad_(True) for a in (w_ih, w_hh, b_ih, b_hh)]
+        hs, ht, ct = LSTMFunction.apply(feat, *ps, T, None if h0 is None else cu(h0), None if c0 is None else cu(c0))
+        close(hs.detach().cpu().numpy(), hs_ref, tol=3e-6, name='lstm hs')
+        close(ht.detach().cpu().numpy()[0], ht_ref, tol=3e-6, name='lstm hT')
+        close(ct.detach().cpu().numpy()[0], ct_ref, tol=3e-6, name='lstm cT')
+        hs.backward(cu(dh))
+        close(feat.grad.cpu().numpy().reshape(B, T, F), dx_ref, tol=5e-6, name='lstm dx')
+        close(ps[0].grad.cpu().numpy(), dwi_ref, tol=5e-6, name='lstm dW_ih')
+        close(ps[1].grad.cpu().numpy(), dwh_ref, tol=5e-6, name='lstm dW_hh')
+        close(ps[2].grad.cpu().numpy(), db_ref, tol=5e-6, name='lstm db_ih')
+        close(ps[3].grad.cpu().numpy(), db_ref, tol=5e-6, name='lstm db_hh')
+
+
 def test_bad_arguments_are_refused(H):
     x = torch.zeros(4, 8, 48, device='cuda')               # C = 48 is not a multiple of 32
     with pytest.raises(ValueError):

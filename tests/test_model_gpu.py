@@ -112,7 +112,8 @@ def build_head(M, head, backbone, seed, first_pool_type='max', shift=0.0):
     bb = M.resnet18(first_pool_type=first_pool_type) if backbone == 'resnet18' else M.densenet18(drop_rate=0.0)
     model = {'to_mean': lambda: M.CNNLinearToMean(bb), 'compr_to_rf': lambda: M.CNNLinearComprToRF(bb),
              'single_breath': lambda: M.CNNSingleBreathLinearNetwork(bb),
-             'double_linear': lambda: M.CNNDoubleLinearNetwork(bb, 20, 0)}[head]()
+             'double_linear': lambda: M.CNNDoubleLinearNetwork(bb, 20, 0),
+             'lstm': lambda: M.CNNLSTMNetwork(bb, 0, False, 16)}[head]()
     sd = {k: torch.from_numpy(v) for k, v in seeded_params(backbone, seed, bn_bias_shift=shift, head=head).items()}
     missing = model.load_state_dict(sd, strict=False)
     assert not missing.unexpected_keys
@@ -122,7 +123,8 @@ def build_head(M, head, backbone, seed, first_pool_type='max', shift=0.0):
 @pytest.mark.parametrize('path', HEAD_GOLD, ids=[os.path.basename(p)[:-4] for p in HEAD_GOLD])
 def test_sibling_heads_match_reference_golden(M, path):
     """CNNLinearToMean / CNNLinearComprToRF / CNNSingleBreathLinearNetwork / CNNDoubleLinearNetwork
-    (reference models/torch_cnn_linear_network.py:7-89; goldens from the reference classes,
+    (reference models/torch_cnn_linear_network.py:7-89) and CNNLSTMNetwork (torch_cnn_lstm_combo.py:6-50; goldens from
+    the reference classes,
     oracle/make_golden_heads.py): logits 1e-4 absolute; gradients strict on the '_active' goldens, flip-tolerant on
     the others (same criteria as test_logits_and_grads_match_reference_golden); one trainer step runs."""
     from deepards_amd.functional import bce_with_logits
@@ -134,6 +136,10 @@ def test_sibling_heads_match_reference_golden(M, path):
     x = torch.from_numpy(g['x']).cuda()
     t = torch.from_numpy(g['target']).cuda()
     out = model(x, None)
+    if head == 'lstm':                                   # (logits, (hx, cx)), zero initial state
+        out, (hx, cx) = out
+        assert np.abs(hx.detach().cpu().numpy() - g['hx64']).max() < 1e-5
+        assert np.abs(cx.detach().cpu().numpy() - g['cx64']).max() < 1e-5
     assert tuple(out.shape) == g['logits64'].shape
     loss = bce_with_logits(*[o.view(-1, 2) if i == 0 else o for i, o in enumerate(_loss_operands(out, t))])
     loss.backward()

@@ -62,6 +62,10 @@ def test_np_oracle_sibling_heads_match_reference(path):
     assert checked >= 60 and 'linear_final.weight' in out['grads']
     if head == 'double_linear':
         assert 'linear_intermediate.weight' in out['grads']
+    if head == 'lstm':
+        np.testing.assert_allclose(out['hx'], g['hx64'][0], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(out['cx'], g['cx64'][0], rtol=0, atol=1e-12)
+        assert 'lstm.weight_hh_l0' in out['grads']
 
 
 def test_np_oracle_sgd_trajectory():
