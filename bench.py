@@ -209,6 +209,13 @@ def main():
     for i in range(2):                                   # setup (not warm-up): eager first step, then the graph capture
         tr.train_step(x, t)
         torch.cuda.synchronize()
+    if tr.static_batch() is not None:
+        # the batch lives in the buffers the captured step reads (a DeviceTileStore fills them in place in training):
+        # no per-step device copy of the inputs
+        xs, ts = tr.static_batch()
+        xs.copy_(x)
+        ts.copy_(t)
+        x, t = xs, ts
     say('captured; warmup')
     for i in range(args.warmup):                         # W untimed steps of exactly what is timed (graph replays)
         tr.train_step(x, t)

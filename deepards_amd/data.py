@@ -34,12 +34,14 @@ class DeviceTileStore(object):
         self.kfold_indexes = None if indexes is None else torch.as_tensor(indexes, dtype=torch.int64,
                                                                           device=self.tiles.device)
 
-    def batch(self, rel_idx):
-        """(inputs (B, NB, 1, L) float32, targets (B, 2) float32) for fold-relative indices."""
+    def batch(self, rel_idx, out=None):
+        """(inputs (B, NB, 1, L) float32, targets (B, 2) float32) for fold-relative indices; out = (x, t) buffers to
+        fill in place (HotPathTrainer.static_batch(): the captured step then needs no input copies)."""
         idx = torch.as_tensor(rel_idx, dtype=torch.int64, device=self.tiles.device).contiguous()
         if self.kfold_indexes is not None:
             idx = self.kfold_indexes[idx].contiguous()
-        return H.gather_normalize(self.tiles, idx, self.mu, self.std), H.gather_rows(self.targets, idx)
+        ox, ot = out if out is not None else (None, None)
+        return H.gather_normalize(self.tiles, idx, self.mu, self.std, out=ox), H.gather_rows(self.targets, idx, out=ot)
 
     def epoch(self, batch_size, shuffle=True, generator=None, drop_odd=True):
         """Iterate one epoch like DataLoader(batch_size, shuffle) + clip_odd_batch_sizes (:146-147,482-494)."""

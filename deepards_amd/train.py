@@ -205,8 +205,10 @@ class HotPathTrainer(object):
             if self._graph is None or self._static[0].shape != inputs.shape:
                 # one eager warm step already happened (_first_step); capture now
                 self._capture(inputs, target)
-            self._static[0].copy_(inputs)
-            self._static[1].copy_(target)
+            if inputs is not self._static[0]:            # batches built in place (static_batch()) skip the copies
+                self._static[0].copy_(inputs)
+            if target is not self._static[1]:
+                self._static[1].copy_(target)
             self._graph.replay()
             if self.world_size > 1:
                 self.bucket.allreduce(self.group)
@@ -215,6 +217,12 @@ class HotPathTrainer(object):
         self.steps += 1
         self.last_loss, self.last_logits = loss, logits
         return loss
+
+    def static_batch(self):
+        """(inputs, target) buffers the captured training step reads (None before the capture).  A producer that writes
+        the next batch into them (DeviceTileStore.batch(..., out=...)) and passes them to train_step saves the two
+        device copies per step."""
+        return self._static
 
     def _test_forward(self, inputs, target):
         with torch.no_grad(), F_.training_step(self.model):      # packs / Winograd taps once, batched small kernels

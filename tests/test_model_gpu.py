@@ -404,6 +404,29 @@ def test_gradcam_surface_on_densenet(M):
     assert torch.allclose(feat, ref, atol=1e-6)
 
 
+def test_in_place_batches_skip_the_input_copies(M):
+    """DeviceTileStore.batch(out=trainer.static_batch()) + train_step on those buffers == train_step on fresh tensors."""
+    from deepards_amd.data import DeviceTileStore
+    from deepards_amd.train import HotPathTrainer
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'test_dataset_windows.npz'))
+    store = DeviceTileStore(z['x'], z['target'], float(z['mu']), float(z['std']))
+    ma, mb = build(M, 'resnet18', 2), build(M, 'resnet18', 2)
+    ta, tb = HotPathTrainer(ma, use_graph=True), HotPathTrainer(mb, use_graph=True)
+    order = [np.arange(0, 8), np.arange(8, 16), np.arange(4, 12), np.arange(12, 20)]
+    for n, idx in enumerate(order):
+        x, t = store.batch(idx)
+        la = float(ta.train_step(x, t))
+        if tb.static_batch() is None:
+            lb = float(tb.train_step(x, t))
+        else:
+            xs, ts = store.batch(idx, out=tb.static_batch())
+            assert xs is tb.static_batch()[0] and ts is tb.static_batch()[1]
+            lb = float(tb.train_step(xs, ts))
+        assert la == lb, (n, la, lb)
+    for (k, a), (_, b) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 def test_test_epoch_votes_on_device(M):
     """Window argmax + per-patient vote table (metrics.py:572-604) computed on the device vs numpy."""
     from deepards_amd.data import DeviceTileStore
