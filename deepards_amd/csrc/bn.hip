@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int mask_mode,
                                                            const float* __restrict__ part, float* __restrict__ ds1,
-                                                           float* __restrict__ ds2) {
+                                                           float* __restrict__ ds2, const float* __restrict__ add,
+                                                           int ldadd) {
   const int w = blockIdx.x, cg = blockIdx.y, pc = blockIdx.z, P = gridDim.z;
   const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
   const int c0 = cg * CG + q * 4;
@@ -313,6 +314,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     g = bn_masked_g(g, xh, ga, be, mask_mode, outp, pos * ldo + c0);
 #pragma unroll
     for (int e = 0; e < 4; ++e) d[e] = ga[e] * is[e] * (g[e] - t1[e] * inv_n - xh[e] * t2[e] * inv_n);
+    if (add) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(add + pos * ldadd + c0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] += av[e];
+    }
     *reinterpret_cast<f32x4*>(dx + pos * lddx + c0) = d;
     if (gout) *reinterpret_cast<f32x4*>(gout + pos * ldg + c0) = g;
   }
@@ -450,7 +456,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restr
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int mask_mode,
-                                                            float* __restrict__ ds1, float* __restrict__ ds2) {
+                                                            float* __restrict__ ds1, float* __restrict__ ds2,
+                                                            const float* __restrict__ add, int ldadd) {
   __shared__ float red[16 * 2 * CG];
   constexpr int NQ = 1 << QB, CGB = 4 * NQ;            // channel quads / channels per block (32 or 16)
   const int w = blockIdx.x, cg = blockIdx.y, P = blockDim.x >> QB;
@@ -463,6 +470,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restr
   const float* ob = outp ? outp + base * ldo + cg * CGB : nullptr;
   float* dxb = dx + base * lddx + cg * CGB;
   float* gb = gout ? gout + base * ldg + cg * CGB : nullptr;
+  const float* ab = add ? add + base * ldadd + cg * CGB : nullptr;       // dx = bn_bwd(...) + add (pass-through gradient)
   const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
   const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * C + c0);
   const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
@@ -505,6 +513,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restr
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         d[e] = ga[e] * is[e] * (g[k][e] - acc[0][e] * inv_n - xh[k][e] * acc[1][e] * inv_n);
+      if (ab) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ab + (uint32_t)(p * ldadd + q * 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] += av[e];
+      }
       *reinterpret_cast<f32x4*>(dxb + (uint32_t)(p * lddx + q * 4)) = d;
       if (gb) *reinterpret_cast<f32x4*>(gb + (uint32_t)(p * ldg + q * 4)) = g[k];
     }
@@ -728,12 +741,13 @@ int da_bn_debug_two_stage(int on) {
 // scratch: da_bn_workspace() bytes.  ds: [2][W][C] per-window totals (sum g, sum g*xhat), always written.
 // dgamma/dbeta: [C]; when both are non-NULL they are computed here (accumulated when accumulate != 0),
 // when NULL the caller folds ds later with da_bn_param_grad_multi.
-int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
-              float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd, const float* gamma,
-              const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma, float* dbeta, int accumulate,
-              hipStream_t stream) {
+static int bn_bwd_impl(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
+                       float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd,
+                       const float* gamma, const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma,
+                       float* dbeta, int accumulate, const float* add, int ldadd, hipStream_t stream) {
   DA_ENTER();
   if (!dout || !x || !dx || !mean || !invstd || !gamma || !beta || !scratch || !ds) return DA_EINVAL;
+  if (add && ldadd % 4) return DA_EINVAL;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return DA_EINVAL;
   if (C % CG || ldd % 4 || ldx % 4 || lddx % 4 || (gout && ldg % 4) || mask_mode < 0 || mask_mode > 2)
     return DA_EINVAL;
@@ -747,17 +761,17 @@ int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* 
   if (int threads = bn_fused_geometry(W, Wn, C, &cgb)) {
     if (cgb == 32)
       hipLaunchKernelGGL((bn_bwd_fused_kernel<FUSED_NPOS, 3>), dim3(W, C / 32), dim3(threads), 0, stream, dout, ldd, x,
-                         ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2);
+                         ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2, add, ldadd);
     else
       hipLaunchKernelGGL((bn_bwd_fused_kernel<FUSED_NPOS, 2>), dim3(W, C / 16), dim3(threads), 0, stream, dout, ldd, x,
-                         ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2);
+                         ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2, add, ldadd);
     DA_CHECK_LAUNCH();
   } else {
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(W, C / CG, P), dim3(256), 0, stream, dout, ldd, x, ldx, out, ldo, Wn, C,
                      chunk, mean, invstd, gamma, beta, mask_mode, scratch);
   DA_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(W, C / CG, P), dim3(256), 0, stream, dout, ldd, x, ldx, out, ldo, dx,
-                     lddx, gout, ldg, Wn, C, chunk, mean, invstd, gamma, beta, mask_mode, scratch, s1, s2);
+                     lddx, gout, ldg, Wn, C, chunk, mean, invstd, gamma, beta, mask_mode, scratch, s1, s2, add, ldadd);
   DA_CHECK_LAUNCH();
   }
   if (dgamma) {
@@ -767,6 +781,25 @@ int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* 
     DA_CHECK_LAUNCH();
   }
   return DA_OK;
+}
+
+int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
+              float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd, const float* gamma,
+              const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma, float* dbeta, int accumulate,
+              hipStream_t stream) {
+  return bn_bwd_impl(dout, ldd, x, ldx, out, ldo, dx, lddx, gout, ldg, W, Wn, C, mean, invstd, gamma, beta, mask_mode,
+                     scratch, ds, dgamma, dbeta, accumulate, nullptr, 0, stream);
+}
+
+// da_bn_bwd with dx = (BatchNorm input gradient) + add[pos][0:C] (pitch ldadd): the pass-through gradient of a
+// concatenation (densenet.py:41 torch.cat) joins in the same pass instead of a separate add kernel.
+int da_bn_bwd_add(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
+                  float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd, const float* gamma,
+                  const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma, float* dbeta,
+                  int accumulate, const float* add, int ldadd, hipStream_t stream) {
+  if (!add) return DA_EINVAL;
+  return bn_bwd_impl(dout, ldd, x, ldx, out, ldo, dx, lddx, gout, ldg, W, Wn, C, mean, invstd, gamma, beta, mask_mode,
+                     scratch, ds, dgamma, dbeta, accumulate, add, ldadd, stream);
 }
 
 }  // extern "C"

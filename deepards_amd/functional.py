@@ -199,13 +199,14 @@ class StemFunction(Function):
         return None, None if tw is not None else dw, dgamma, dbeta, None, None, None
 
 
-def _bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, tg, tb, out=None, dx=None, want_g=False):
-    """bn_bwd with optional direct gradient destinations; returns (dx, dgamma|None, dbeta|None[, g])."""
+def _bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, tg, tb, out=None, dx=None, want_g=False, add=None):
+    """bn_bwd with optional direct gradient destinations; returns (dx, dgamma|None, dbeta|None[, g]).
+    add = (tensor, channel offset): that slice is added to dx in the same pass (a concatenation's pass-through)."""
     direct = tg is not None and tb is not None
     defer = direct and _STEP['on']
     dx, dg, db, g, ds = H.bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, out=out, want_g=want_g, dx=dx,
                                  dgamma=tg if direct else None, dbeta=tb if direct else None, accumulate=direct,
-                                 defer_param_grads=defer)
+                                 defer_param_grads=defer, add=add)
     if defer:
         _STEP['pgrad'].append((ds, tg, tb))
     res = (dx, None if direct else dg, None if direct else db)
@@ -316,8 +317,7 @@ class DenseLayerFunction(Function):
         dy1, dg2, db2 = _bn_bwd(dh2, y1, R, m2, i2, g2, b2, 1, tg2, tb2, dx=dh2)
         dw1 = _wgrad(dy1, h, 1, 1, 0, tw1)
         dh = _conv_dgrad(dy1, w1, 1, 0, h.shape[1])
-        dx, dg1, db1 = _bn_bwd(dh, x, R, m1, i1, g1, b1, 1, tg1, tb1, dx=dh)
-        H.slice_channels(dout, 0, cin, out=dx, accumulate=True)                     # pass-through half of the cat
+        dx, dg1, db1 = _bn_bwd(dh, x, R, m1, i1, g1, b1, 1, tg1, tb1, dx=dh, add=(dout, 0))     # + pass-through half of the cat
         return dx, dg1, db1, dw1, dg2, db2, dw2, None, None, None, None, None, None
 
 

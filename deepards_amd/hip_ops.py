@@ -412,9 +412,10 @@ def bn_debug_two_stage(on):
 
 
 def bn_bwd(dout, x, R, mean, invstd, gamma, beta, mask_mode, out=None, want_g=False, dx=None,
-           dgamma=None, dbeta=None, accumulate=False, defer_param_grads=False):
+           dgamma=None, dbeta=None, accumulate=False, defer_param_grads=False, add=None):
     """-> dx, dgamma, dbeta, g, ds.  g = masked upstream gradient (only when want_g); ds (2,W,C) holds the
-    per-window totals; with defer_param_grads dgamma/dbeta are not computed (fold ds with bn_param_grad_multi)."""
+    per-window totals; with defer_param_grads dgamma/dbeta are not computed (fold ds with bn_param_grad_multi).
+    add = (tensor (rows, L, Ca >= C), channel offset): dx += tensor[:, :, off:off+C] in the same pass."""
     _rlc(dout, 'dout')
     _rlc(x, 'x')
     rows, l, c = x.shape
@@ -427,10 +428,19 @@ def bn_bwd(dout, x, R, mean, invstd, gamma, beta, mask_mode, out=None, want_g=Fa
         dbeta = torch.empty((c,), device=x.device, dtype=torch.float32)
     scratch = _bn_ws(w, R * l, c, x.device)
     ds = torch.empty((2, w, c), device=x.device, dtype=torch.float32)
-    _chk(_lib.lib().da_bn_bwd(_p(dout), c, _p(x), c, _p(out), c, _p(dx), c, _p(g), c, w, R * l, c, _p(mean),
-                              _p(invstd), _p(gamma), _p(beta), mask_mode, _p(scratch), _p(ds),
-                              None if defer_param_grads else _p(dgamma), None if defer_param_grads else _p(dbeta),
-                              1 if accumulate else 0, _stream()), 'da_bn_bwd')
+    args = (_p(dout), c, _p(x), c, _p(out), c, _p(dx), c, _p(g), c, w, R * l, c, _p(mean),
+            _p(invstd), _p(gamma), _p(beta), mask_mode, _p(scratch), _p(ds),
+            None if defer_param_grads else _p(dgamma), None if defer_param_grads else _p(dbeta),
+            1 if accumulate else 0)
+    if add is None:
+        _chk(_lib.lib().da_bn_bwd(*args, _stream()), 'da_bn_bwd')
+    else:
+        at, off = add
+        _rlc(at, 'add')
+        if tuple(at.shape[:2]) != (rows, l) or off % 4 or off + c > at.shape[2]:
+            raise ValueError('bn_bwd: bad add operand')
+        ap = ctypes.c_void_p(at.data_ptr() + 4 * off)
+        _chk(_lib.lib().da_bn_bwd_add(*args, ap, at.shape[2], _stream()), 'da_bn_bwd_add')
     return dx, dgamma, dbeta, g, ds
 
 

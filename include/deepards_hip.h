@@ -137,6 +137,12 @@ int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* 
               float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd,
               const float* gamma, const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma,
               float* dbeta, int accumulate, da_stream_t stream);
+/* da_bn_bwd with dx = input gradient + add[pos][0:C] (pitch ldadd): a concatenation's pass-through gradient
+   (densenet.py:41) joins in the same pass */
+int da_bn_bwd_add(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
+                  float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd, const float* gamma,
+                  const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma, float* dbeta,
+                  int accumulate, const float* add, int ldadd, da_stream_t stream);
 int da_bn_param_grad_multi(const da_bn_pgrad_desc* descs, int n, int accumulate, da_stream_t stream);
 
 /* ---- pools ------------------------------------------------------------------------------

@@ -267,6 +267,14 @@ def _bn_fwd_bwd(H, C, L, R, W):
         slack_g = (np.abs(dout) * ~sure * xhat_abs).sum(axis=(0, 2))
         assert np.all(np.abs(dg.cpu().numpy() - dg_ref) <= 2e-5 * (1 + np.abs(dg_ref).max()) + slack_g), 'dgamma'
         assert np.all(np.abs(db.cpu().numpy() - db_ref) <= 2e-5 * (1 + np.abs(db_ref).max()) + slack), 'dbeta' 
+    # pass-through gradient added in the same pass (a concatenation's backward, densenet.py:41)
+    extra = rng.standard_normal((rows, C + 32, L))
+    et = rlc(extra)
+    dxa, _, _, _, _ = H.bn_bwd(dt, xt, R, mean, invstd, gt, bt, 1, defer_param_grads=True, add=(et, 32))
+    g1_ref = dout * (y_ref > 0)
+    dx1_ref = np_ref.bn_window_bwd(x, gamma, st, g1_ref, R)[0]
+    s1 = np.abs(y_ref) > 1e-5
+    close(ncl(dxa) * s1, (dx1_ref + extra[:, 32:32 + C]) * s1, tol=2e-5, name='bn dx + add')
     # in-place form used by the block functions: dx aliases dout
     g_ref = dout * (y_ref > 0)
     dx_ref, dg_ref, db_ref = np_ref.bn_window_bwd(x, gamma, st, g_ref, R)
