@@ -78,26 +78,43 @@ __global__ __launch_bounds__(256) void linear2_bwd_input_kernel(const float* __r
   *reinterpret_cast<f32x4*>(dflat + (size_t)b * K + i) = o;
 }
 
-// dW[o][i] (+)= sum_b dl[b][o] flat[b][i];  dbias[o] (+)= sum_b dl[b][o]   (b in order: deterministic)
+// dW[o][i] (+)= sum_b dl[b][o] flat[b][i];  dbias[o] (+)= sum_b dl[b][o].  Block = 64 columns (16 float4 lanes) x 16 row
+// slots folded through LDS in a fixed order (deterministic); rows = windows for cnn_linear, window*breath rows for the
+// per-breath heads (1280 at B = 64: the one-thread-per-column loop over all rows took hundreds of microseconds there).
 __global__ __launch_bounds__(256) void linear2_bwd_weight_kernel(const float* __restrict__ dl,
                                                                  const float* __restrict__ flat, float* __restrict__ dW,
                                                                  float* __restrict__ dbias, int B, int K,
                                                                  int accumulate) {
-  int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  __shared__ f32x4 red[2][16][16];
+  const int kq = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  const int i = (blockIdx.x * 16 + kq) * 4;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
   if (i < K) {
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < B; ++b) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(flat + (size_t)b * K + i);
-      float d0 = dl[b * 2], d1 = dl[b * 2 + 1];
+    for (int b = slot; b < B; b += 16) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(flat + (size_t)b * K + i);
+      const float d0 = dl[b * 2], d1 = dl[b * 2 + 1];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         a0[e] = fmaf(d0, v[e], a0[e]);
         a1[e] = fmaf(d1, v[e], a1[e]);
       }
     }
+  }
+  red[0][slot][kq] = a0;
+  red[1][slot][kq] = a1;
+  __syncthreads();
+  if (slot == 0 && i < K) {
+    for (int k = 1; k < 16; ++k) {
+      const f32x4 r0 = red[0][k][kq], r1 = red[1][k][kq];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a0[e] += r0[e];
+        a1[e] += r1[e];
+      }
+    }
     if (accumulate) {
-      f32x4 p0 = *reinterpret_cast<const f32x4*>(dW + i);
-      f32x4 p1 = *reinterpret_cast<const f32x4*>(dW + K + i);
+      const f32x4 p0 = *reinterpret_cast<const f32x4*>(dW + i);
+      const f32x4 p1 = *reinterpret_cast<const f32x4*>(dW + K + i);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         a0[e] += p0[e];
@@ -107,10 +124,18 @@ __global__ __launch_bounds__(256) void linear2_bwd_weight_kernel(const float* __
     *reinterpret_cast<f32x4*>(dW + i) = a0;
     *reinterpret_cast<f32x4*>(dW + K + i) = a1;
   }
-  if (blockIdx.x == 0 && threadIdx.x < 2) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dl[b * 2 + threadIdx.x];
-    dbias[threadIdx.x] = accumulate ? dbias[threadIdx.x] + s : s;
+  if (blockIdx.x == 0 && threadIdx.x < 64) {          // first wave: the two bias gradients (fixed shuffle tree)
+    float s0 = 0.f, s1 = 0.f;
+    for (int b = threadIdx.x; b < B; b += 64) {
+      s0 += dl[b * 2];
+      s1 += dl[b * 2 + 1];
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (threadIdx.x == 0) {
+      dbias[0] = accumulate ? dbias[0] + s0 : s0;
+      dbias[1] = accumulate ? dbias[1] + s1 : s1;
+    }
   }
 }
 
@@ -536,7 +561,7 @@ int da_linear2_bwd(const float* dlogits, const float* flat, const float* W, floa
     DA_CHECK_LAUNCH();
   }
   if (dW && dbias) {
-    hipLaunchKernelGGL(linear2_bwd_weight_kernel, dim3((K / 4 + 255) / 256), dim3(256), 0, stream, dlogits, flat, dW,
+    hipLaunchKernelGGL(linear2_bwd_weight_kernel, dim3((K / 4 + 15) / 16), dim3(256), 0, stream, dlogits, flat, dW,
                        dbias, B, K, accumulate);
     DA_CHECK_LAUNCH();
   }
