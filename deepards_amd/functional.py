@@ -76,11 +76,11 @@ _OVERLAP_STEM = os.environ.get('DA_WGRAD_OVERLAP', '1') != '0'
 _SIDE = {}
 
 
-def _side_stream():
-    dev = torch.cuda.current_device()
-    if dev not in _SIDE:
-        _SIDE[dev] = torch.cuda.Stream()
-    return _SIDE[dev]
+def _side_stream(which=0):
+    key = (torch.cuda.current_device(), which)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream()
+    return _SIDE[key]
 
 
 def _launch_wgrads(side=False):
@@ -232,6 +232,9 @@ class BasicBlockFunction(Function):
             y1, yd = H.conv_fwd_multi([(x, _pack(w1, False)[0], stride, 1), (x, _pack(wd, False)[0], stride, 0)])
         else:
             y1 = _conv_fwd(x, w1, stride, 1)
+        if pair:          # the downsample BatchNorm first: yd is still in L2 / MALL right after the shared launch
+            sd = _stats(yd, R, std)   # (forking it beside bn1 / conv2 on another stream was measured slower)
+            res = _bn_apply(yd, R, sd, std, gd, bd, False)
         s1 = _stats(y1, R, st1)
         h1 = _bn_apply(y1, R, s1, st1, g1, b1, True)
         y2 = _conv_fwd(h1, w2, 1, 1)
@@ -239,8 +242,8 @@ class BasicBlockFunction(Function):
         if wd is not None:
             if not pair:
                 yd = _conv_fwd(x, wd, stride, 0)
-            sd = _stats(yd, R, std)
-            res = _bn_apply(yd, R, sd, std, gd, bd, False)
+                sd = _stats(yd, R, std)
+                res = _bn_apply(yd, R, sd, std, gd, bd, False)
             md, idd = sd.mean, sd.invstd
         else:
             yd = md = idd = None
@@ -266,13 +269,14 @@ class BasicBlockFunction(Function):
         dout = dout.contiguous()
         # relu + residual add + bn2
         dy2, dg2, db2, g = _bn_bwd(dout, y2, R, m2, i2, g2, b2, 2, tg2, tb2, out=out, want_g=True)
+        if ctx.has_ds:    # the downsample BatchNorm's backward right away: g is still cache-resident
+            wd, gd, bd, yd, md, idd = s[15:]
+            dyd, dgd, dbd = _bn_bwd(g, yd, R, md, idd, gd, bd, 0, tgd, tbd, dx=g)
         dw2 = _wgrad(dy2, h1, 3, 1, 1, tw2)
         dh1 = _conv_dgrad(dy2, w2, 1, 1, h1.shape[1])
         dy1, dg1, db1 = _bn_bwd(dh1, y1, R, m1, i1, g1, b1, 1, tg1, tb1, dx=dh1)
         dw1 = _wgrad(dy1, x, 3, stride, 1, tw1)
         if ctx.has_ds:
-            wd, gd, bd, yd, md, idd = s[15:]
-            dyd, dgd, dbd = _bn_bwd(g, yd, R, md, idd, gd, bd, 0, tgd, tbd, dx=g)
             dwd = _wgrad(dyd, x, 1, stride, 0, twd)
             if stride == 2 and _PAIR_S2 and not _is_wino(w1, stride, 1):
                 dx = H.conv_dgrad_s2_pair(dy1, _pack(w1, False)[1], dyd, _pack(wd, False)[1], lin)
