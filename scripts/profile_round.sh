@@ -22,3 +22,10 @@ done
 cd $R
 python scripts/pmc_traffic.py $tag $out/prof_FETCH_SIZE $out/prof_WRITE_SIZE
 rm -rf $out/prof_stats $out/prof_FETCH_SIZE $out/prof_WRITE_SIZE
+# 4. matrix-pipe utilisation of the GEMM kernels (own PMC pass): SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs)
+#    against SQ_BUSY_CYCLES (summed over the 32 shader engines) -> gpurun_out/<tag>_pmc_mfma_busy.json
+cd /tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $out/prof_mfma -- python3 $R/bench.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-extra --no-roofline > $out/prof_mfma.log 2>&1 || { tail -5 $out/prof_mfma.log; exit 1; }
+cd $R
+python scripts/pmc_mfma_busy.py $out/prof_mfma > $out/${tag}_pmc_mfma_busy.json
+rm -rf $out/prof_mfma
