@@ -282,6 +282,32 @@ def test_fresh_inputs_vs_numpy_oracle(M):
                 assert e < 1e-4 * max(1.0, np.abs(rf).max()) or rel_l2(got, rf) < 5e-2, (n, e)
 
 
+@pytest.mark.parametrize('nb', [40, 8])
+def test_other_sub_batch_counts_vs_numpy_oracle(M, nb):
+    """n_sub_batches other than 20 (BASELINE config C5 runs nb40; BatchNorm windows of 40 rows go through the 16-channel
+    single-pass kernels or the two-stage path, the head is F*NB wide): logits and loss against the oracle."""
+    from deepards_amd.functional import bce_with_logits
+    from deepards_amd.train import HotPathTrainer
+    for backbone in ('resnet18', 'densenet18'):
+        bb = M.resnet18() if backbone == 'resnet18' else M.densenet18(drop_rate=0.0)
+        model = M.CNNLinearNetwork(bb, nb, 0)
+        p32 = seeded_params(backbone, 9, n_sub_batches=nb)
+        assert not model.load_state_dict({k: torch.from_numpy(v) for k, v in p32.items()}, strict=False).unexpected_keys
+        model = model.cuda().train()
+        x, t = seeded_batch(3, nb, 5, 'flow')
+        ref = np_ref.cnn_linear_forward_backward({k: v.astype(np.float64) for k, v in p32.items()}, x.astype(np.float64),
+                                                 t.astype(np.float64), backbone=backbone, n_sub_batches=nb, need_grads=False)
+        xt, tt = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+        out = model(xt, None)
+        loss = bce_with_logits(out, tt)
+        loss.backward()
+        err = np.abs(out.detach().cpu().numpy() - ref['logits']).max()
+        log(backbone, 'nb=%d: logits err %.3e loss %.7f vs %.7f' % (nb, err, float(loss), ref['loss']))
+        assert err < 1e-4 and abs(float(loss) - ref['loss']) < 1e-5
+        tr = HotPathTrainer(model, use_graph=True)
+        assert all(np.isfinite(float(tr.train_step(xt, tt))) for _ in range(3))
+
+
 def test_densenet_dropout_active_and_scaled(M):
     """drop_rate 0.2 is active in train mode (and the reference never leaves train mode): outputs
     differ run to run, and the test step still works under no_grad."""
