@@ -770,8 +770,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgradReduceTabl
   const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
   const int i = blockIdx.x * 256 + lane * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int sp = slot; sp < d.splits; sp += 4) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(d.slab + (size_t)sp * total + i);
+  int sp = slot;
+  for (; sp + 12 < d.splits; sp += 16) {             // four slabs in flight per lane (fixed order: deterministic)
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(d.slab + (size_t)sp * total + i);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(d.slab + (size_t)(sp + 4) * total + i);
+    const f32x4 v2 = *reinterpret_cast<const f32x4*>(d.slab + (size_t)(sp + 8) * total + i);
+    const f32x4 v3 = *reinterpret_cast<const f32x4*>(d.slab + (size_t)(sp + 12) * total + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+  }
+  for (; sp < d.splits; sp += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(d.slab + (size_t)sp * total + i);
 #pragma unroll
     for (int e = 0; e < 4; ++e) s[e] += v[e];
   }
