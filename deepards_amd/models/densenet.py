@@ -199,3 +199,26 @@ def densenet18(pretrained=False, progress=True, **kwargs):
     model = DenseNet(32, (2, 2, 2, 2), 64, **kwargs)
     model.network_name = 'densenet18'
     return model
+
+
+def _densenet(name, block_config, pretrained, **kwargs):
+    if pretrained:
+        raise NotImplementedError('no pretrained weights exist for the 1-D %s' % name)
+    model = DenseNet(32, block_config, 64, **kwargs)
+    model.network_name = name
+    return model
+
+
+def densenet121(pretrained=False, progress=True, **kwargs):
+    """reference models/densenet.py:234-242 (growth 32, blocks (6, 12, 24, 16))."""
+    return _densenet('densenet121', (6, 12, 24, 16), pretrained, **kwargs)
+
+
+def densenet169(pretrained=False, progress=True, **kwargs):
+    """reference models/densenet.py:256-264."""
+    return _densenet('densenet169', (6, 12, 32, 32), pretrained, **kwargs)
+
+
+def densenet201(pretrained=False, progress=True, **kwargs):
+    """reference models/densenet.py:267-275."""
+    return _densenet('densenet201', (6, 12, 48, 32), pretrained, **kwargs)

@@ -127,3 +127,10 @@ def resnet18(pretrained=False, **kwargs):
     model = ResNet(BasicBlock, [2, 2, 2, 2], **kwargs)
     model.network_name = 'resnet18'
     return model
+
+
+def resnet34(pretrained=False, **kwargs):
+    """reference models/resnet.py:178-187: BasicBlock [3, 4, 6, 3]."""
+    model = ResNet(BasicBlock, [3, 4, 6, 3], **kwargs)
+    model.network_name = 'resnet34'
+    return model

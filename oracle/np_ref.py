@@ -251,13 +251,19 @@ def _stem(t, x, conv, bn, pool_type='max'):
     return y3, (lambda d: b_conv(b_bn(b_relu(b_pool(d)))))
 
 
-def resnet18_features(t, x, prefix='breath_block.', first_pool_type='max'):
-    """ResNet.forward (resnet.py:141-163) with BasicBlock (resnet.py:24-40), layers [2,2,2,2]."""
+RESNET_LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3)}              # resnet.py:166-187
+DENSENET_BLOCKS = {'densenet18': (2, 2, 2, 2), 'densenet121': (6, 12, 24, 16),    # densenet.py:223-275 (growth 32)
+                   'densenet169': (6, 12, 32, 32), 'densenet201': (6, 12, 48, 32)}
+
+
+def resnet18_features(t, x, prefix='breath_block.', first_pool_type='max', layers=(2, 2, 2, 2)):
+    """ResNet.forward (resnet.py:141-163) with BasicBlock (resnet.py:24-40); layers [2,2,2,2] = resnet18,
+    [3,4,6,3] = resnet34."""
     h, b_stem = _stem(t, x, prefix + 'conv1.weight', prefix + 'bn1', first_pool_type)
     backs = [b_stem]
     inpl = 64
     for li, planes in enumerate([64, 128, 256, 512]):
-        for bi in range(2):
+        for bi in range(layers[li]):
             stride = 2 if (li > 0 and bi == 0) else 1
             bp = '%slayer%d.%d.' % (prefix, li + 1, bi)
             xin = h
@@ -293,7 +299,7 @@ def resnet18_features(t, x, prefix='breath_block.', first_pool_type='max'):
     return out, bwd
 
 
-def densenet18_features(t, x, prefix='breath_block.', drop_masks=None):
+def densenet18_features(t, x, prefix='breath_block.', drop_masks=None, block_config=(2, 2, 2, 2)):
     """DenseNet.forward (densenet.py:179-189): stem, 4 blocks x 2 _DenseLayer (densenet.py:18-41,
     pre-activation BN->ReLU->conv1x1->BN->ReLU->conv3 -> dropout -> cat), _Transition
     (densenet.py:68-79), norm5 -> relu -> AvgPool1d(7,1).  Dropout is OFF unless explicit
@@ -302,7 +308,7 @@ def densenet18_features(t, x, prefix='breath_block.', drop_masks=None):
     h, b_stem = _stem(t, x, fp + 'conv0.weight', fp + 'norm0', 'max')
     backs = [b_stem]
     for bi in range(1, 5):
-        for li in range(1, 3):
+        for li in range(1, block_config[bi - 1] + 1):
             lp = '%sdenseblock%d.denselayer%d.' % (fp, bi, li)
             xin = h
             o, b1 = _bn(t, xin, lp + 'norm1')
@@ -421,10 +427,10 @@ def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_ba
     b, nb, c, l = x.shape
     t = _Tape(params, nb)
     rows = x.reshape(b * nb, c, l)
-    if backbone == 'resnet18':
-        feat, fbwd = resnet18_features(t, rows, first_pool_type=first_pool_type)
-    elif backbone == 'densenet18':
-        feat, fbwd = densenet18_features(t, rows, drop_masks=drop_masks)
+    if backbone in RESNET_LAYERS:
+        feat, fbwd = resnet18_features(t, rows, first_pool_type=first_pool_type, layers=RESNET_LAYERS[backbone])
+    elif backbone in DENSENET_BLOCKS:
+        feat, fbwd = densenet18_features(t, rows, drop_masks=drop_masks, block_config=DENSENET_BLOCKS[backbone])
     else:
         raise ValueError(backbone)
     w, bias = params['linear_final.weight'], params['linear_final.bias']

@@ -24,7 +24,10 @@ def param_spec(backbone, n_sub_batches=20, in_ch=1, n_meta=0, head='linear', lst
         out.append((name + '.bias', (c,), 'bn_b'))
 
     p = 'breath_block.'
-    if backbone == 'resnet18':
+    layers = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3)}.get(backbone)
+    blocks = {'densenet18': (2, 2, 2, 2), 'densenet121': (6, 12, 24, 16), 'densenet169': (6, 12, 32, 32),
+              'densenet201': (6, 12, 48, 32)}.get(backbone)
+    if layers is not None:
         conv(p + 'conv1', 64, 1, 7)
         conv(p + 'conv1_alt', 64, 1, 3)      # dead unless double_conv_first (SURVEY finding 6)
         bn(p + 'bn1', 64)
@@ -32,7 +35,7 @@ def param_spec(backbone, n_sub_batches=20, in_ch=1, n_meta=0, head='linear', lst
         bn(p + 'bn2', 64)                    # dead
         inpl = 64
         for li, planes in enumerate([64, 128, 256, 512]):
-            for bi in range(2):
+            for bi in range(layers[li]):
                 bp = '%slayer%d.%d.' % (p, li + 1, bi)
                 stride = 2 if (li > 0 and bi == 0) else 1
                 conv(bp + 'conv1', planes, inpl, 3)
@@ -44,13 +47,13 @@ def param_spec(backbone, n_sub_batches=20, in_ch=1, n_meta=0, head='linear', lst
                     bn(bp + 'downsample.1', planes)
                 inpl = planes
         feat = 512
-    elif backbone == 'densenet18':
+    elif blocks is not None:
         fp = p + 'features.'
         conv(fp + 'conv0', 64, in_ch, 7)
         bn(fp + 'norm0', 64)
         nf = 64
         for bi in range(1, 5):
-            for li in range(1, 3):
+            for li in range(1, blocks[bi - 1] + 1):
                 lp = '%sdenseblock%d.denselayer%d.' % (fp, bi, li)
                 bn(lp + 'norm1', nf)
                 conv(lp + 'conv1', 128, nf, 1)

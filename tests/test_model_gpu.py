@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*net18_*.npz'))
               if not os.path.basename(p).startswith('head_'))
 HEAD_GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'head_*.npz')))
+BB_GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'bb_*.npz')))
 LOG = os.path.join(os.path.dirname(os.path.dirname(__file__)), 'gpurun_out', 'parity_model.log')
 
 
@@ -171,6 +172,43 @@ def test_sibling_heads_match_reference_golden(M, path):
         assert all(np.isfinite(l)) and abs(l[0] - float(g['loss64'])) < 1e-4
         lt, lg, pred = tr.test_step(x, t)
         assert pred.shape == tuple(g['logits64'].shape[:-1])
+
+
+@pytest.mark.parametrize('path', BB_GOLD, ids=[os.path.basename(p)[:-4] for p in BB_GOLD])
+def test_other_backbones_match_reference_golden(M, path):
+    """resnet34 and densenet121 (the other BasicBlock / growth-32 base networks of the reference) on the same kernels:
+    logits 1e-4, loss, gradients flip-tolerant (rel-l2 5e-2 or 1e-4 abs), a few trainer steps."""
+    from deepards_amd.functional import bce_with_logits
+    from deepards_amd.train import HotPathTrainer
+    g = _gold(path)
+    name = str(g['backbone'])
+    bb = M.base_networks[name]() if name.startswith('resnet') else M.base_networks[name](drop_rate=0.0)
+    assert bb.network_name == name
+    model = M.CNNLinearNetwork(bb, 20, 0)
+    sd = {k: torch.from_numpy(v) for k, v in seeded_params(name, int(g['seed'])).items()}
+    assert not model.load_state_dict(sd, strict=False).unexpected_keys
+    model = model.cuda().train()
+    x, t = torch.from_numpy(g['x']).cuda(), torch.from_numpy(g['target']).cuda()
+    out = model(x, None)
+    loss = bce_with_logits(out, t)
+    loss.backward()
+    err = np.abs(out.detach().cpu().numpy() - g['logits64']).max()
+    log(name, 'logits err %.3e loss %.7f vs %.7f' % (err, float(loss), float(g['loss64'])))
+    assert err < 1e-4 and abs(float(loss) - float(g['loss64'])) < 1e-5
+    bad = []
+    for n, p in model.named_parameters():
+        key = 'grad64/' + n
+        if key not in g:
+            assert p.grad is None, n
+            continue
+        d = digest(p.grad.cpu().numpy(), 24)
+        body = slice(None) if p.numel() <= 1024 else slice(0, -3)
+        abs_err = np.abs(d - g[key])[body].max()
+        if not (rel_l2(d[body], g[key][body]) <= 5e-2 or abs_err <= 1e-4 * max(1.0, np.abs(g[key][body]).max())):
+            bad.append((n, abs_err))
+    assert not bad, bad
+    tr = HotPathTrainer(model, use_graph=True)
+    assert all(np.isfinite(float(tr.train_step(x, t))) for _ in range(3))
 
 
 def test_window_independence_and_breath_block_call(M):

@@ -11,6 +11,7 @@ from oracle.weights import seeded_params, digest, DEAD_RESNET_PARAMS
 GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*net18_*.npz'))
               if not os.path.basename(p).startswith('head_'))
 HEAD_GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'head_*.npz')))
+BB_GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'bb_*.npz')))
 
 
 def _load(path):
@@ -66,6 +67,24 @@ def test_np_oracle_sibling_heads_match_reference(path):
         np.testing.assert_allclose(out['hx'], g['hx64'][0], rtol=0, atol=1e-12)
         np.testing.assert_allclose(out['cx'], g['cx64'][0], rtol=0, atol=1e-12)
         assert 'lstm.weight_hh_l0' in out['grads']
+
+
+@pytest.mark.parametrize('path', BB_GOLD, ids=[os.path.basename(p)[:-4] for p in BB_GOLD])
+def test_np_oracle_other_backbones_match_reference(path):
+    """resnet34 (models/resnet.py:178) and densenet121 (models/densenet.py:234) through the same oracle blocks vs the
+    reference classes (oracle/make_golden_backbones.py)."""
+    g = _load(path)
+    backbone = str(g['backbone'])
+    params = {k: v.astype(np.float64) for k, v in seeded_params(backbone, int(g['seed'])).items()}
+    out = np_ref.cnn_linear_forward_backward(params, g['x'].astype(np.float64), g['target'].astype(np.float64), backbone=backbone)
+    np.testing.assert_allclose(out['logits'], g['logits64'], rtol=0, atol=1e-10)
+    assert abs(out['loss'] - float(g['loss64'])) < 1e-12
+    checked = 0
+    for k in g:
+        if k.startswith('grad64/'):
+            np.testing.assert_allclose(digest(out['grads'][k[7:]], 24), g[k], rtol=1e-8, atol=1e-9, err_msg=k)
+            checked += 1
+    assert checked > 100
 
 
 def test_np_oracle_sgd_trajectory():
