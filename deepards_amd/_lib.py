@@ -50,6 +50,10 @@ class RepackDesc(ctypes.Structure):
 # name -> (restype, argtypes); must list exactly the symbols the header declares (tests check it)
 SIGNATURES = {
     'da_version': (_I, []),
+    'da_abi_sizes': (None, [ctypes.POINTER(_I)]),
+    'da_sizeof_wgrad_reduce_desc': (_I, []),
+    'da_sizeof_bn_running_desc': (_I, []),
+    'da_sizeof_bn_pgrad_desc': (_I, []),
     'da_hip_runtime_symbol': (_P, []),
     'da_conv_gemm': (_I, [_P, _P, _P] + [_I] * 12 + [_IP, _IP, _I, _P]),
     'da_conv_wgrad_workspace': (_Z, [_I] * 5),

@@ -612,6 +612,9 @@ typedef struct {
   int W, C;
 } da_bn_pgrad_desc;
 
+int da_sizeof_bn_running_desc(void) { return (int)sizeof(da_bn_running_desc); }
+int da_sizeof_bn_pgrad_desc(void) { return (int)sizeof(da_bn_pgrad_desc); }
+
 // chunk geometry shared by da_bn_stats_partial / da_bn_apply(part) / da_bn_bwd: P chunks of `chunk` positions
 void da_bn_chunks(int W, int Wn, int C, int* P, int* chunk) { bn_chunks(W, Wn, C, P, chunk); }
 

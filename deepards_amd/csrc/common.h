@@ -75,3 +75,8 @@ typedef struct {
   const float* w2;
   int tap_split;
 } da_conv_job;
+
+// sizeof helpers of descriptor structs that are private to one translation unit (da_abi_sizes, head_optim.hip)
+extern "C" int da_sizeof_wgrad_reduce_desc(void);
+extern "C" int da_sizeof_bn_running_desc(void);
+extern "C" int da_sizeof_bn_pgrad_desc(void);

@@ -1023,6 +1023,8 @@ typedef struct {
   int splits, ntaps, N, C;
 } da_wgrad_reduce_desc;
 
+int da_sizeof_wgrad_reduce_desc(void) { return (int)sizeof(da_wgrad_reduce_desc); }
+
 // dW (+)= sum of slabs for n convolutions (descs: HOST array), 32 per launch.
 int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumulate, hipStream_t stream) {
   DA_ENTER();

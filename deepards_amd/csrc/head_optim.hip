@@ -576,6 +576,8 @@ extern "C" {
 
 int da_version(void) { return 100; }
 
+
+
 // Address of the HIP runtime entry point this library is bound to: the Python loader compares it with
 // the runtime PyTorch uses, because two HIP runtimes in one process do not share streams or ordering.
 const void* da_hip_runtime_symbol(void) { return (const void*)&hipGetLastError; }
@@ -835,6 +837,18 @@ int da_dropout(const float* x, float* y, size_t n, const int64_t* seed, unsigned
   hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, stream, x, y, n, seed, salt, p);
   DA_CHECK_LAUNCH();
   return DA_OK;
+}
+
+// sizeof of the host-side descriptor structs as THIS library was compiled with them, in the order
+// {da_wgrad_job, da_conv_job, da_wgrad_reduce_desc, da_repack_desc, da_bn_running_desc, da_bn_pgrad_desc}:
+// tests compare them with the public header (compiled by gcc) and with the ctypes mirror.
+void da_abi_sizes(int* out) {
+  out[0] = (int)sizeof(da_wgrad_job);
+  out[1] = (int)sizeof(da_conv_job);
+  out[2] = da_sizeof_wgrad_reduce_desc();
+  out[3] = (int)sizeof(da_repack_desc);
+  out[4] = da_sizeof_bn_running_desc();
+  out[5] = da_sizeof_bn_pgrad_desc();
 }
 
 }  // extern "C"

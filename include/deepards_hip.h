@@ -28,6 +28,12 @@ extern "C" {
 typedef struct ihipStream_t* da_stream_t; /* == hipStream_t */
 
 int da_version(void);
+/* sizeof of {da_wgrad_job, da_conv_job, da_wgrad_reduce_desc, da_repack_desc, da_bn_running_desc, da_bn_pgrad_desc} as the
+   library was built (ABI drift check for bindings) */
+void da_abi_sizes(int* out);
+int da_sizeof_wgrad_reduce_desc(void);
+int da_sizeof_bn_running_desc(void);
+int da_sizeof_bn_pgrad_desc(void);
 /* address of hipGetLastError as bound by this library (loader sanity check: same HIP runtime as the host) */
 const void* da_hip_runtime_symbol(void);
 

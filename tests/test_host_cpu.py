@@ -26,6 +26,26 @@ def test_library_builds_loads_and_exports_header_symbols():
     assert lib.da_stem_wgrad_workspace(1280, 64) == 512 * 64 * 7 * 4
 
 
+def test_abi_structs_agree_between_header_library_and_binding(tmp_path):
+    """The descriptor structs exist three times: in the public header, in the library's sources and as ctypes mirrors.
+    sizeof of each must agree: header compiled by gcc, da_abi_sizes() of the built library, ctypes.sizeof."""
+    import ctypes
+    import subprocess
+    from deepards_amd import _lib
+    src = tmp_path / 'abi.c'
+    src.write_text('#include <stdio.h>\n#include "deepards_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", '
+                   'sizeof(da_wgrad_job), sizeof(da_conv_job), sizeof(da_wgrad_reduce_desc), sizeof(da_repack_desc), '
+                   'sizeof(da_bn_running_desc), sizeof(da_bn_pgrad_desc)); return 0; }\n')
+    exe = tmp_path / 'abi'
+    subprocess.check_call(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    header = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    out = (ctypes.c_int * 6)()
+    _lib.lib().da_abi_sizes(out)
+    binding = [ctypes.sizeof(c) for c in (_lib.WgradJob, _lib.ConvJob, _lib.WgradReduceDesc, _lib.RepackDesc,
+                                          _lib.BnRunningDesc, _lib.BnPgradDesc)]
+    assert header == list(out) == binding, (header, list(out), binding)
+
+
 def test_product_path_refuses_cpu_tensors():
     import deepards_amd.models as M
     from deepards_amd import hip_ops as H
