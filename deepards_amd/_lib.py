@@ -72,6 +72,9 @@ SIGNATURES = {
     'da_bn_fwd': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
     'da_bn_debug_two_stage': (_I, [_I]),
     'da_bn_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
+    'da_bn_mask_words': (_Z, [_I, _I, _I]),
+    'da_bn_fwd_mask': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P]),
+    'da_bn_bwd_mask': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'da_bn_bwd_add': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P]),
     'da_bn_param_grad_multi': (_I, [ctypes.POINTER(BnPgradDesc), _I, _I, _P]),
     'da_conv_wgrad_splits': (_I, [_I] * 5),

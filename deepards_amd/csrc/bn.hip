@@ -377,7 +377,8 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int relu, float eps,
                                                             float* __restrict__ mean_out,
-                                                            float* __restrict__ invstd_out) {
+                                                            float* __restrict__ invstd_out,
+                                                            unsigned long long* __restrict__ mask) {
   __shared__ float red[16 * CG];
   constexpr int NQ = 1 << QB, CGB = 4 * NQ;            // channel quads / channels per block (32 or 16)
   const int w = blockIdx.x, cg = blockIdx.y, P = blockDim.x >> QB;
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const float* __restr
   }
   const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
   const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c0);
+  unsigned long long bits = 0ull;
 #pragma unroll
   for (int k = 0; k < NPOS; ++k) {
     const int p = slot + k * P;
@@ -439,11 +441,17 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const float* __restr
       }
       if (relu) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        for (int e = 0; e < 4; ++e) {
+          bits |= (unsigned long long)(o[e] > 0.f) << (k * 4 + e);
+          o[e] = fmaxf(o[e], 0.f);
+        }
       }
       *reinterpret_cast<f32x4*>(ob + (uint32_t)(p * ldo + q * 4)) = o;
     }
   }
+  // ReLU decisions of this thread's 4 x NPOS elements: the backward kernel (same geometry, same thread -> element map)
+  // reads 8 bytes per thread instead of the whole output tensor
+  if (mask) mask[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x] = bits;
 }
 
 // same arithmetic as bn_bwd_reduce_kernel + bn_bwd_apply_kernel with the slab held in registers
@@ -457,7 +465,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int mask_mode,
                                                             float* __restrict__ ds1, float* __restrict__ ds2,
-                                                            const float* __restrict__ add, int ldadd) {
+                                                            const float* __restrict__ add, int ldadd,
+                                                            const unsigned long long* __restrict__ mask) {
   __shared__ float red[16 * 2 * CG];
   constexpr int NQ = 1 << QB, CGB = 4 * NQ;            // channel quads / channels per block (32 or 16)
   const int w = blockIdx.x, cg = blockIdx.y, P = blockDim.x >> QB;
@@ -487,12 +496,19 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restr
     }
   }
   f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const unsigned long long mbits =
+      mask ? mask[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x] : 0ull;
 #pragma unroll
   for (int k = 0; k < NPOS; ++k) {
     const int p = slot + k * P;
 #pragma unroll
     for (int e = 0; e < 4; ++e) xh[k][e] = (xh[k][e] - mu[e]) * is[e];
-    if (p < Wn) g[k] = bn_masked_g(g[k], xh[k], ga, be, mask_mode, ob, (uint32_t)(p * ldo + q * 4));
+    if (mask_mode == 3) {          // ReLU decisions recorded by the forward kernel (bn_fwd_fused_kernel, same geometry)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[k][e] = ((mbits >> (k * 4 + e)) & 1ull) ? g[k][e] : 0.f;
+    } else if (p < Wn) {
+      g[k] = bn_masked_g(g[k], xh[k], ga, be, mask_mode, ob, (uint32_t)(p * ldo + q * 4));
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       acc[0][e] += g[k][e];
@@ -711,9 +727,9 @@ int da_bn_apply(const float* x, int ldx, const float* res, int ldr, float* out, 
 // Statistics + normalisation in one call: mean/invstd [W][C] are OUTPUTS, out = act(bn(x) (+res)).
 // One single-pass kernel when a window slab fits a block's registers (Wn <= 1280), otherwise
 // da_bn_stats_partial + da_bn_apply.  scratch: da_bn_workspace() bytes.
-int da_bn_fwd(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
-              float* mean, float* invstd, const float* gamma, const float* beta, int relu, float eps, float* scratch,
-              hipStream_t stream) {
+static int bn_fwd_impl(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
+                       float* mean, float* invstd, const float* gamma, const float* beta, int relu, float eps,
+                       float* scratch, unsigned long long* mask, hipStream_t stream) {
   DA_ENTER();
   if (!x || !out || !mean || !invstd || !gamma || !beta || !scratch || C % CG || ldx % 4 || ldo % 4 ||
       (res && ldr % 4) || Wn < 1)
@@ -723,16 +739,23 @@ int da_bn_fwd(const float* x, int ldx, const float* res, int ldr, float* out, in
   if (int threads = bn_fused_geometry(W, Wn, C, &cgb)) {
     if (cgb == 32)
       hipLaunchKernelGGL((bn_fwd_fused_kernel<FUSED_NPOS, 3>), dim3(W, C / 32), dim3(threads), 0, stream, x, ldx, res,
-                         ldr, out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd);
+                         ldr, out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd, mask);
     else
       hipLaunchKernelGGL((bn_fwd_fused_kernel<FUSED_NPOS, 2>), dim3(W, C / 16), dim3(threads), 0, stream, x, ldx, res,
-                         ldr, out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd);
+                         ldr, out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd, mask);
     DA_CHECK_LAUNCH();
     return DA_OK;
   }
+  if (mask) return DA_EINVAL;                    // masks exist only for the single-pass geometry (da_bn_mask_words() > 0)
   int rc = da_bn_stats_partial(x, ldx, W, Wn, C, scratch, stream);
   if (rc) return rc;
   return da_bn_apply(x, ldx, res, ldr, out, ldo, W, Wn, C, mean, invstd, gamma, beta, relu, scratch, eps, stream);
+}
+
+int da_bn_fwd(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
+              float* mean, float* invstd, const float* gamma, const float* beta, int relu, float eps, float* scratch,
+              hipStream_t stream) {
+  return bn_fwd_impl(x, ldx, res, ldr, out, ldo, W, Wn, C, mean, invstd, gamma, beta, relu, eps, scratch, nullptr, stream);
 }
 
 // tests: 1 = always take the two-stage kernels (so both paths are checked against the oracle)
@@ -747,12 +770,14 @@ int da_bn_debug_two_stage(int on) {
 static int bn_bwd_impl(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
                        float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma,
-                       float* dbeta, int accumulate, const float* add, int ldadd, hipStream_t stream) {
+                       float* dbeta, int accumulate, const float* add, int ldadd, const unsigned long long* mask,
+                       hipStream_t stream) {
   DA_ENTER();
+  if (mask) mask_mode = 3;
   if (!dout || !x || !dx || !mean || !invstd || !gamma || !beta || !scratch || !ds) return DA_EINVAL;
   if (add && ldadd % 4) return DA_EINVAL;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return DA_EINVAL;
-  if (C % CG || ldd % 4 || ldx % 4 || lddx % 4 || (gout && ldg % 4) || mask_mode < 0 || mask_mode > 2)
+  if (C % CG || ldd % 4 || ldx % 4 || lddx % 4 || (gout && ldg % 4) || mask_mode < 0 || mask_mode > 3)
     return DA_EINVAL;
   if (mask_mode == 2 && (!out || ldo % 4)) return DA_EINVAL;
   if (W == 0) return DA_OK;
@@ -764,12 +789,13 @@ static int bn_bwd_impl(const float* dout, int ldd, const float* x, int ldx, cons
   if (int threads = bn_fused_geometry(W, Wn, C, &cgb)) {
     if (cgb == 32)
       hipLaunchKernelGGL((bn_bwd_fused_kernel<FUSED_NPOS, 3>), dim3(W, C / 32), dim3(threads), 0, stream, dout, ldd, x,
-                         ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2, add, ldadd);
+                         ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2, add, ldadd, mask);
     else
       hipLaunchKernelGGL((bn_bwd_fused_kernel<FUSED_NPOS, 2>), dim3(W, C / 16), dim3(threads), 0, stream, dout, ldd, x,
-                         ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2, add, ldadd);
+                         ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2, add, ldadd, mask);
     DA_CHECK_LAUNCH();
   } else {
+  if (mask) return DA_EINVAL;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(W, C / CG, P), dim3(256), 0, stream, dout, ldd, x, ldx, out, ldo, Wn, C,
                      chunk, mean, invstd, gamma, beta, mask_mode, scratch);
   DA_CHECK_LAUNCH();
@@ -791,7 +817,34 @@ int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* 
               const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma, float* dbeta, int accumulate,
               hipStream_t stream) {
   return bn_bwd_impl(dout, ldd, x, ldx, out, ldo, dx, lddx, gout, ldg, W, Wn, C, mean, invstd, gamma, beta, mask_mode,
-                     scratch, ds, dgamma, dbeta, accumulate, nullptr, 0, stream);
+                     scratch, ds, dgamma, dbeta, accumulate, nullptr, 0, nullptr, stream);
+}
+
+// 64-bit words a ReLU mask of da_bn_fwd_mask / da_bn_bwd_mask has for this shape (one per thread of the single-pass
+// kernel); 0: the shape takes the two-stage kernels, no mask form.
+size_t da_bn_mask_words(int W, int Wn, int C) {
+  int cgb = 0;
+  const int threads = bn_fused_geometry(W, Wn, C, &cgb);
+  return threads ? (size_t)W * (C / cgb) * threads : 0;
+}
+
+// da_bn_fwd (relu != 0) that also records the ReLU decisions, 1 bit per element (da_bn_mask_words() words).
+int da_bn_fwd_mask(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
+                   float* mean, float* invstd, const float* gamma, const float* beta, float eps, float* scratch,
+                   unsigned long long* mask, hipStream_t stream) {
+  if (!mask) return DA_EINVAL;
+  return bn_fwd_impl(x, ldx, res, ldr, out, ldo, W, Wn, C, mean, invstd, gamma, beta, 1, eps, scratch, mask, stream);
+}
+
+// da_bn_bwd of act = ReLU whose decisions come from the mask of da_bn_fwd_mask instead of the output tensor
+// (mask_mode 2 reads `out`, 18 MB per layer at B = 64, only for its sign).
+int da_bn_bwd_mask(const float* dout, int ldd, const float* x, int ldx, float* dx, int lddx, float* gout, int ldg, int W,
+                   int Wn, int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                   float* scratch, float* ds, float* dgamma, float* dbeta, int accumulate,
+                   const unsigned long long* mask, hipStream_t stream) {
+  if (!mask) return DA_EINVAL;
+  return bn_bwd_impl(dout, ldd, x, ldx, nullptr, 0, dx, lddx, gout, ldg, W, Wn, C, mean, invstd, gamma, beta, 3, scratch,
+                     ds, dgamma, dbeta, accumulate, nullptr, 0, mask, stream);
 }
 
 // da_bn_bwd with dx = (BatchNorm input gradient) + add[pos][0:C] (pitch ldadd): the pass-through gradient of a
@@ -802,7 +855,7 @@ int da_bn_bwd_add(const float* dout, int ldd, const float* x, int ldx, const flo
                   int accumulate, const float* add, int ldadd, hipStream_t stream) {
   if (!add) return DA_EINVAL;
   return bn_bwd_impl(dout, ldd, x, ldx, out, ldo, dx, lddx, gout, ldg, W, Wn, C, mean, invstd, gamma, beta, mask_mode,
-                     scratch, ds, dgamma, dbeta, accumulate, add, ldadd, stream);
+                     scratch, ds, dgamma, dbeta, accumulate, add, ldadd, nullptr, stream);
 }
 
 }  // extern "C"

@@ -105,6 +105,7 @@ def _launch_wgrads(side=False):
 
 
 _WINOGRAD = os.environ.get('DA_WINOGRAD', '1') != '0'
+_BN_MASK = os.environ.get('DA_BN_MASK', '1') != '0'       # block-output BatchNorm: ReLU decisions as a bit mask
 _PAIR_S2 = os.environ.get('DA_PAIR_S2', '1') != '0'      # stride-2 block heads: conv + downsample GEMMs share launches
 
 
@@ -144,17 +145,20 @@ def _tgt(*params):
 
 class _Stats(object):
     """Per-window statistics of one BatchNorm input (filled by the BatchNorm's consumer, _bn_apply)."""
-    __slots__ = ('mean', 'invstd')
+    __slots__ = ('mean', 'invstd', 'mask')
 
 
 def _stats(x, R, st):
     return _Stats()
 
 
-def _bn_apply(x, R, s, st, gamma, beta, relu, res=None):
-    """act(bn(x)(+res)): statistics and normalisation in one call; fills s.mean / s.invstd and books the running
-    update."""
-    out, s.mean, s.invstd = H.bn_fwd(x, R, gamma, beta, relu=relu, res=res, eps=st.eps)
+def _bn_apply(x, R, s, st, gamma, beta, relu, res=None, want_mask=False):
+    """act(bn(x)(+res)): statistics and normalisation in one call; fills s.mean / s.invstd (and s.mask: the ReLU
+    decisions as bits, for the backward) and books the running update."""
+    if want_mask:
+        out, s.mean, s.invstd, s.mask = H.bn_fwd(x, R, gamma, beta, relu=relu, res=res, eps=st.eps, want_mask=True)
+    else:
+        out, s.mean, s.invstd = H.bn_fwd(x, R, gamma, beta, relu=relu, res=res, eps=st.eps)
     _running(x, R, s, st)
     return out
 
@@ -199,14 +203,14 @@ class StemFunction(Function):
         return None, None if tw is not None else dw, dgamma, dbeta, None, None, None
 
 
-def _bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, tg, tb, out=None, dx=None, want_g=False, add=None):
+def _bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, tg, tb, out=None, dx=None, want_g=False, add=None, mask=None):
     """bn_bwd with optional direct gradient destinations; returns (dx, dgamma|None, dbeta|None[, g]).
     add = (tensor, channel offset): that slice is added to dx in the same pass (a concatenation's pass-through)."""
     direct = tg is not None and tb is not None
     defer = direct and _STEP['on']
     dx, dg, db, g, ds = H.bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, out=out, want_g=want_g, dx=dx,
                                  dgamma=tg if direct else None, dbeta=tb if direct else None, accumulate=direct,
-                                 defer_param_grads=defer, add=add)
+                                 defer_param_grads=defer, add=add, mask=mask)
     if defer:
         _STEP['pgrad'].append((ds, tg, tb))
     res = (dx, None if direct else dg, None if direct else db)
@@ -248,8 +252,9 @@ class BasicBlockFunction(Function):
         else:
             yd = md = idd = None
             res = x
-        out = _bn_apply(y2, R, s2, st2, g2, b2, True, res=res)
+        out = _bn_apply(y2, R, s2, st2, g2, b2, True, res=res, want_mask=_BN_MASK)
         m1, i1, m2, i2 = s1.mean, s1.invstd, s2.mean, s2.invstd
+        ctx.relu_mask = s2.mask if _BN_MASK else None       # 8 bytes per thread instead of re-reading `out` for its sign
         ctx.has_ds = wd is not None
         ctx.stride, ctx.R = stride, R
         ctx.gt = _tgt(w1, g1, b1, w2, g2, b2, wd, gd, bd)
@@ -268,7 +273,7 @@ class BasicBlockFunction(Function):
         lin = x.shape[1]
         dout = dout.contiguous()
         # relu + residual add + bn2
-        dy2, dg2, db2, g = _bn_bwd(dout, y2, R, m2, i2, g2, b2, 2, tg2, tb2, out=out, want_g=True)
+        dy2, dg2, db2, g = _bn_bwd(dout, y2, R, m2, i2, g2, b2, 2, tg2, tb2, out=out, want_g=True, mask=ctx.relu_mask)
         if ctx.has_ds:    # the downsample BatchNorm's backward right away: g is still cache-resident
             wd, gd, bd, yd, md, idd = s[15:]
             dyd, dgd, dbd = _bn_bwd(g, yd, R, md, idd, gd, bd, 0, tgd, tbd, dx=g)

@@ -387,9 +387,10 @@ def bn_apply(x, R, mean, invstd, gamma, beta, relu=True, res=None, out=None, par
     return out
 
 
-def bn_fwd(x, R, gamma, beta, relu=True, res=None, eps=1e-5, out=None):
+def bn_fwd(x, R, gamma, beta, relu=True, res=None, eps=1e-5, out=None, want_mask=False):
     """-> out, mean, invstd: per-window statistics and out = act(bn(x) (+res)) in one call (single pass over x when
-    a window slab fits a block's registers)."""
+    a window slab fits a block's registers).  want_mask (relu only): -> out, mean, invstd, mask with the ReLU decisions
+    as a bit mask for bn_bwd(mask=...) (None when the shape takes the two-stage kernels)."""
     _rlc(x, 'x')
     rows, l, c = x.shape
     if rows % R:
@@ -402,9 +403,18 @@ def bn_fwd(x, R, gamma, beta, relu=True, res=None, eps=1e-5, out=None):
     mean = torch.empty((w, c), device=x.device, dtype=torch.float32)
     invstd = torch.empty((w, c), device=x.device, dtype=torch.float32)
     scratch = _bn_ws(w, R * l, c, x.device)
-    _chk(_lib.lib().da_bn_fwd(_p(x), c, _p(res), c, _p(out), c, w, R * l, c, _p(mean), _p(invstd), _p(gamma), _p(beta),
-                              1 if relu else 0, eps, _p(scratch), _stream()), 'da_bn_fwd')
-    return out, mean, invstd
+    mask = None
+    if want_mask and relu:
+        words = _lib.lib().da_bn_mask_words(w, R * l, c)
+        if words:
+            mask = torch.empty((words,), device=x.device, dtype=torch.int64)
+    if mask is not None:
+        _chk(_lib.lib().da_bn_fwd_mask(_p(x), c, _p(res), c, _p(out), c, w, R * l, c, _p(mean), _p(invstd), _p(gamma),
+                                       _p(beta), eps, _p(scratch), _p(mask), _stream()), 'da_bn_fwd_mask')
+    else:
+        _chk(_lib.lib().da_bn_fwd(_p(x), c, _p(res), c, _p(out), c, w, R * l, c, _p(mean), _p(invstd), _p(gamma), _p(beta),
+                                  1 if relu else 0, eps, _p(scratch), _stream()), 'da_bn_fwd')
+    return (out, mean, invstd, mask) if want_mask else (out, mean, invstd)
 
 
 def bn_debug_two_stage(on):
@@ -412,7 +422,7 @@ def bn_debug_two_stage(on):
 
 
 def bn_bwd(dout, x, R, mean, invstd, gamma, beta, mask_mode, out=None, want_g=False, dx=None,
-           dgamma=None, dbeta=None, accumulate=False, defer_param_grads=False, add=None):
+           dgamma=None, dbeta=None, accumulate=False, defer_param_grads=False, add=None, mask=None):
     """-> dx, dgamma, dbeta, g, ds.  g = masked upstream gradient (only when want_g); ds (2,W,C) holds the
     per-window totals; with defer_param_grads dgamma/dbeta are not computed (fold ds with bn_param_grad_multi).
     add = (tensor (rows, L, Ca >= C), channel offset): dx += tensor[:, :, off:off+C] in the same pass."""
@@ -432,7 +442,14 @@ def bn_bwd(dout, x, R, mean, invstd, gamma, beta, mask_mode, out=None, want_g=Fa
             _p(invstd), _p(gamma), _p(beta), mask_mode, _p(scratch), _p(ds),
             None if defer_param_grads else _p(dgamma), None if defer_param_grads else _p(dbeta),
             1 if accumulate else 0)
-    if add is None:
+    if mask is not None:          # ReLU decisions from bn_fwd(want_mask=True) instead of reading `out`
+        if add is not None:
+            raise ValueError('bn_bwd: mask and add are exclusive')
+        _chk(_lib.lib().da_bn_bwd_mask(_p(dout), c, _p(x), c, _p(dx), c, _p(g), c, w, R * l, c, _p(mean), _p(invstd),
+                                       _p(gamma), _p(beta), _p(scratch), _p(ds),
+                                       None if defer_param_grads else _p(dgamma), None if defer_param_grads else _p(dbeta),
+                                       1 if accumulate else 0, _p(mask), _stream()), 'da_bn_bwd_mask')
+    elif add is None:
         _chk(_lib.lib().da_bn_bwd(*args, _stream()), 'da_bn_bwd')
     else:
         at, off = add

@@ -143,6 +143,17 @@ int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* 
               float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd,
               const float* gamma, const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma,
               float* dbeta, int accumulate, da_stream_t stream);
+/* ReLU decisions as a bit mask, 64 bits per thread of the single-pass kernels (da_bn_mask_words() words; 0 = this shape
+   takes the two-stage kernels, no mask form): da_bn_fwd_mask = da_bn_fwd(relu) + mask; da_bn_bwd_mask = da_bn_bwd of a
+   ReLU'd BatchNorm(+residual) that reads the mask instead of the output tensor (mask_mode 2 reads `out` only for its sign) */
+size_t da_bn_mask_words(int W, int Wn, int C);
+int da_bn_fwd_mask(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
+                   float* mean, float* invstd, const float* gamma, const float* beta, float eps, float* scratch,
+                   unsigned long long* mask, da_stream_t stream);
+int da_bn_bwd_mask(const float* dout, int ldd, const float* x, int ldx, float* dx, int lddx, float* gout, int ldg, int W,
+                   int Wn, int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                   float* scratch, float* ds, float* dgamma, float* dbeta, int accumulate,
+                   const unsigned long long* mask, da_stream_t stream);
 /* da_bn_bwd with dx = input gradient + add[pos][0:C] (pitch ldadd): a concatenation's pass-through gradient
    (densenet.py:41) joins in the same pass */
 int da_bn_bwd_add(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,

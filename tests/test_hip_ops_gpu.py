@@ -267,6 +267,13 @@ def _bn_fwd_bwd(H, C, L, R, W):
         slack_g = (np.abs(dout) * ~sure * xhat_abs).sum(axis=(0, 2))
         assert np.all(np.abs(dg.cpu().numpy() - dg_ref) <= 2e-5 * (1 + np.abs(dg_ref).max()) + slack_g), 'dgamma'
         assert np.all(np.abs(db.cpu().numpy() - db_ref) <= 2e-5 * (1 + np.abs(db_ref).max()) + slack), 'dbeta' 
+    # ReLU decisions as a bit mask (single-pass geometry only): same gradients as mask_mode 2 without reading `out`
+    o4, m4, i4, mk = H.bn_fwd(xt, R, gt, bt, relu=True, res=rlc(res), want_mask=True)
+    close(ncl(o4), out_ref, tol=5e-6, name='bn_fwd(want_mask) out')
+    if mk is not None:        # None: this shape / mode takes the two-stage kernels
+        a = H.bn_bwd(dt, xt, R, m4, i4, gt, bt, 2, out=o4, want_g=True, defer_param_grads=True)
+        b = H.bn_bwd(dt, xt, R, m4, i4, gt, bt, 2, want_g=True, defer_param_grads=True, mask=mk)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
     # pass-through gradient added in the same pass (a concatenation's backward, densenet.py:41)
     extra = rng.standard_normal((rows, C + 32, L))
     et = rlc(extra)
