@@ -96,6 +96,7 @@ SIGNATURES = {
     'da_linear2_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'da_clamp_sgd_nesterov': (_I, [_P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _P]),
     'da_clamp_adam': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _F, _F, _P]),
+    'da_clamp_adam_dev': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P, _F, _F, _P]),
     'da_gather_normalize': (_I, [_P, _P, ctypes.c_double, ctypes.c_double, _P, _I, _I, _P]),
     'da_window_median_fwd': (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     'da_window_median_bwd': (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),

@@ -173,6 +173,33 @@ __global__ __launch_bounds__(256) void clamp_adam_kernel(float* __restrict__ p, 
   }
 }
 
+// the same with the step count on the device (a captured graph replays it): *step_ptr is incremented by the first thread
+// of a preceding launch (counter_inc_kernel), every thread derives the bias corrections from it
+__global__ __launch_bounds__(256) void clamp_adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                             float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                             float lr, float b1, float b2, float eps,
+                                                             const long long* __restrict__ step_ptr, float clip,
+                                                             float gscale) {
+  const float t = (float)step_ptr[0];
+  const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+  const float step = lr / bc1;
+  const float rs = 1.0f / sqrtf(bc2);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) * rs + eps;
+    p[i] -= step * (mi / denom);
+  }
+}
+
+__global__ void counter_inc_kernel(long long* c) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) c[0] += 1;
+}
+
 // W[co][ci][k] (torch) -> Wf[k][co][ci] and Wd[k][ci][co]
 __global__ __launch_bounds__(256) void repack_conv_weight_kernel(const float* __restrict__ W, float* __restrict__ Wf,
                                                                  float* __restrict__ Wd, int Co, int Ci, int K) {
@@ -642,6 +669,21 @@ int da_clamp_adam(float* p, const float* g, float* m, float* v, size_t n, float 
   float bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(clamp_adam_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1,
                      beta2, eps, bc1, bc2, clip, gscale);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// da_clamp_adam with the step count in device memory (int64, starts at 0): incremented here, then used -- the whole
+// update is stream-ordered device work, so a captured graph can replay it (torch.optim.Adam, train_ards_detector.py:421).
+int da_clamp_adam_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                      long long* step, float clip, float gscale, hipStream_t stream) {
+  DA_ENTER();
+  if (!p || !g || !m || !v || !step) return DA_EINVAL;
+  hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(64), 0, stream, step);
+  DA_CHECK_LAUNCH();
+  if (n == 0) return DA_OK;
+  hipLaunchKernelGGL(clamp_adam_dev_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1,
+                     beta2, eps, step, clip, gscale);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

@@ -564,6 +564,14 @@ def clamp_adam_(p, g, m, v, lr, step, clip, beta1=0.9, beta2=0.999, eps=1e-8, gs
                                   clip if clip else 0.0, gscale, _stream()), 'da_clamp_adam')
 
 
+def clamp_adam_dev_(p, g, m, v, lr, step_dev, clip, beta1=0.9, beta2=0.999, eps=1e-8, gscale=1.0):
+    """clamp_adam_ with the step count in a device int64 tensor (incremented by the call): graph-capturable."""
+    if not (step_dev.is_cuda and step_dev.dtype == torch.int64 and step_dev.numel() == 1):
+        raise ValueError('step_dev must be a one-element int64 CUDA tensor')
+    _chk(_lib.lib().da_clamp_adam_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, _p(step_dev),
+                                      clip if clip else 0.0, gscale, _stream()), 'da_clamp_adam_dev')
+
+
 def concat2(a, b, drop=None):
     """cat([a, b], channels); drop = (seed, salt, p): dropout (the mask of dropout(b, ...)) on the b half on the way."""
     _rlc(a, 'a')

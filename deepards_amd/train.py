@@ -101,7 +101,7 @@ class HotPathTrainer(object):
         self.lr, self.wd, self.momentum = learning_rate, weight_decay, momentum
         self.clip = clip_val if clip_grad else 0.0
         self.world_size, self.rank, self.group = world_size, rank, process_group
-        self.use_graph = use_graph and optimizer == 'sgd'
+        self.use_graph = use_graph
         self.bucket = None
         self.state = {}
         self.steps = 0
@@ -135,8 +135,9 @@ class HotPathTrainer(object):
             if 'm' not in self.state:
                 self.state['m'] = torch.zeros_like(b.p)
                 self.state['v'] = torch.zeros_like(b.p)
-            H.clamp_adam_(b.p, b.g, self.state['m'], self.state['v'], self.lr, self.steps + 1, self.clip,
-                          gscale=gscale)
+                self.state['t'] = torch.zeros(1, dtype=torch.int64, device=b.p.device)   # step count on the device
+            H.clamp_adam_dev_(b.p, b.g, self.state['m'], self.state['v'], self.lr, self.state['t'], self.clip,
+                              gscale=gscale)
 
     def _first_step(self, inputs, target):
         """Eager step that discovers the live parameters (the reference's optimiser skips

@@ -193,6 +193,9 @@ int da_clamp_sgd_nesterov(float* p, const float* g, float* buf, size_t n, float 
                           float weight_decay, float clip, float gscale, int first, da_stream_t stream);
 int da_clamp_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                   float eps, int step, float clip, float gscale, da_stream_t stream);
+/* the same with the step count in device memory (int64, incremented by the call): graph-replayable */
+int da_clamp_adam_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                      long long* step, float clip, float gscale, da_stream_t stream);
 
 /* ---- device-resident window store: batch gather fused with the (x-mu)/std normalisation -------------------
  * ARDSRawDataset.__getitem__ dataset.py:1343-1404 (index map :1349-1350, normalisation :1364,1379 in float64)

@@ -256,7 +256,8 @@ def test_resnet_running_stats(M):
 @pytest.mark.parametrize('tag,opt,use_graph', [('resnet18_b2_randn', 'sgd', False), ('resnet18_b2_randn', 'sgd', True),
                                                ('densenet18_b2_randn', 'sgd', True), ('densenet18_b2_randn', 'adam', False),
                                                ('resnet18_b2_randn', 'adam', False), ('resnet18_b2_active', 'sgd', True),
-                                               ('densenet18_b2_active', 'sgd', True), ('resnet18_b2_active', 'adam', False)])
+                                               ('densenet18_b2_active', 'sgd', True), ('resnet18_b2_active', 'adam', False),
+                                               ('resnet18_b2_active', 'adam', True), ('densenet18_b2_randn', 'adam', True)])
 def test_trainer_trajectory_matches_reference(M, tag, opt, use_graph):
     """3 optimiser steps (clamp +-0.01, SGD-Nesterov wd 1e-4 / Adam): losses and parameters against the
     reference trajectory.  '*_active' goldens have no activation decision to flip -> strict bounds;
