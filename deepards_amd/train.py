@@ -281,6 +281,35 @@ def run_train_epoch(trainer, loader, batch_size=None):
     return losses
 
 
+def run_train_epoch_from_store(trainer, store, batch_size=16, shuffle=True, generator=None):
+    """One training epoch straight from a DeviceTileStore: the DataLoader / collate / cast / H2D of
+    train_ards_detector.py:139-152 is one gather+normalise kernel per batch, written IN PLACE into the buffers the
+    captured step reads once they exist (batches of the captured shape), so a steady-state step is: gather kernel,
+    graph replay.  Each rank takes its window shard of every batch.  Returns the device-resident per-batch losses."""
+    losses = []
+    for idx, _, _ in _epoch_indices(store, batch_size, shuffle, generator):
+        sl = shard_windows(len(idx), trainer.world_size, trainer.rank)
+        mine = idx[sl]
+        static = trainer.static_batch()
+        if static is not None and static[0].shape[0] == len(mine):
+            x, t = store.batch(mine, out=static)
+        else:
+            x, t = store.batch(mine)
+        losses.append(trainer.train_step(x, t).clone())
+    return losses
+
+
+def _epoch_indices(store, batch_size, shuffle, generator):
+    n = len(store)
+    order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
+    for s in range(0, n, batch_size):
+        idx = order[s:s + batch_size]
+        if batch_size != 1 and len(idx) % 2 == 1:          # clip_odd_batch_sizes (:146-147,482-494)
+            idx = idx[:-1]
+        if len(idx):
+            yield idx, None, None
+
+
 def run_test_epoch(trainer, store, patient_slot, batch_size=16):
     """BaseTraining.run_test_epoch (:424-465) + record_final_epoch_testing_results (:519-524) with the reductions on
     the device: no_grad forward in train mode, BCE loss, window argmax, per-patient vote table.  ``store`` is a

@@ -492,6 +492,31 @@ def test_in_place_batches_skip_the_input_copies(M):
         assert torch.equal(a, b), k
 
 
+def test_train_epoch_from_store(M):
+    """run_train_epoch_from_store == the same batches pushed through train_step by hand (in-place batch buffers after
+    the capture, odd last batch clipped like clip_odd_batch_sizes)."""
+    from deepards_amd.data import DeviceTileStore
+    from deepards_amd.train import HotPathTrainer, run_train_epoch_from_store
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'test_dataset_windows.npz'))
+    store = DeviceTileStore(z['x'], z['target'], float(z['mu']), float(z['std']))
+    ma, mb = build(M, 'resnet18', 2), build(M, 'resnet18', 2)
+    ta, tb = HotPathTrainer(ma, use_graph=True), HotPathTrainer(mb, use_graph=True)
+    la = []
+    for ep in range(2):
+        la += [float(l) for l in run_train_epoch_from_store(ta, store, batch_size=6, shuffle=False)]
+    lb = []
+    for ep in range(2):
+        for s0 in range(0, 20, 6):
+            idx = np.arange(s0, min(20, s0 + 6))
+            if len(idx) % 2:
+                idx = idx[:-1]
+            x, t = store.batch(idx)
+            lb.append(float(tb.train_step(x, t)))
+    assert la == lb and len(la) == 8
+    for (k, a), (_, b) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 def test_test_epoch_votes_on_device(M):
     """Window argmax + per-patient vote table (metrics.py:572-604) computed on the device vs numpy."""
     from deepards_amd.data import DeviceTileStore
