@@ -91,6 +91,8 @@ SIGNATURES = {
     'da_pool_bwd': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     'da_avgpool_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'da_avgpool_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    'da_avgpool_slide_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
+    'da_avgpool_slide_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     'da_linear2_fwd': (_I, [_P, _P, _P, _P, _I, _I, _P]),
     'da_bce_logits': (_I, [_P, _P, _I, _F, _P, _P, _P]),
     'da_linear2_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

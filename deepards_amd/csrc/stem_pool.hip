@@ -239,6 +239,55 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
   *reinterpret_cast<f32x4*>(dx + pi * lddx + q * 4) = g;
 }
 
+// AvgPool1d(k, stride=1) on a map longer than k, flattened the way `x.view(x.size(0), -1)` flattens (N, C, Lout):
+// feature index c * Lout + j (resnet.py:159-160 / densenet.py:183-184 on seq_len > 224, e.g. BASELINE config C5's 512).
+__global__ __launch_bounds__(256) void avgpool_slide_fwd_kernel(const float* __restrict__ x, int ldx,
+                                                                float* __restrict__ feat, int rows, int Lin, int Lout,
+                                                                int k, int C) {
+  const int nq = C >> 2;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)rows * Lout * nq;
+  if (idx >= total) return;
+  int q = (int)(idx % nq);
+  size_t po = idx / nq;
+  int j = (int)(po % Lout);
+  int row = (int)(po / Lout);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < k; ++t) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)row * Lin + j + t) * ldx + q * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += v[e];
+  }
+  const float inv = 1.0f / (float)k;
+  float* o = feat + (size_t)row * C * Lout + (size_t)(q * 4) * Lout + j;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[(size_t)e * Lout] = acc[e] * inv;
+}
+
+__global__ __launch_bounds__(256) void avgpool_slide_bwd_kernel(const float* __restrict__ dfeat, float* __restrict__ dx,
+                                                                int lddx, int rows, int Lin, int Lout, int k, int C) {
+  const int nq = C >> 2;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)rows * Lin * nq;
+  if (idx >= total) return;
+  int q = (int)(idx % nq);
+  size_t pi = idx / nq;
+  int l = (int)(pi % Lin);
+  int row = (int)(pi / Lin);
+  int j0 = l - k + 1 > 0 ? l - k + 1 : 0;
+  int j1 = l < Lout - 1 ? l : Lout - 1;
+  const float* d = dfeat + (size_t)row * C * Lout + (size_t)(q * 4) * Lout;
+  f32x4 g = {0.f, 0.f, 0.f, 0.f};
+  for (int j = j0; j <= j1; ++j) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] += d[(size_t)e * Lout + j];
+  }
+  const float inv = 1.0f / (float)k;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) g[e] *= inv;
+  *reinterpret_cast<f32x4*>(dx + pi * lddx + q * 4) = g;
+}
+
 static inline int grid1d(size_t total, int bs) { return (int)((total + bs - 1) / bs); }
 
 extern "C" {
@@ -317,6 +366,32 @@ int da_avgpool_fwd(const float* x, int ldx, float* out, int ldo, int rows, int L
   size_t total = (size_t)rows * Lout * (C / 4);
   hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, stream, x, ldx, out, ldo, rows, Lin,
                      Lout, k, C);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// AvgPool1d(k, stride 1) + view(rows, -1): feat is (rows, C * (Lin - k + 1)) with the channel index slowest.
+int da_avgpool_slide_fwd(const float* x, int ldx, float* feat, int rows, int Lin, int k, int C, hipStream_t stream) {
+  DA_ENTER();
+  if (!x || !feat || C % 4 || ldx % 4 || k < 1 || k > Lin) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  int Lout = Lin - k + 1;
+  size_t total = (size_t)rows * Lout * (C / 4);
+  hipLaunchKernelGGL(avgpool_slide_fwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, stream, x, ldx, feat, rows, Lin,
+                     Lout, k, C);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+int da_avgpool_slide_bwd(const float* dfeat, float* dx, int lddx, int rows, int Lin, int k, int C,
+                         hipStream_t stream) {
+  DA_ENTER();
+  if (!dfeat || !dx || C % 4 || lddx % 4 || k < 1 || k > Lin) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  int Lout = Lin - k + 1;
+  size_t total = (size_t)rows * Lin * (C / 4);
+  hipLaunchKernelGGL(avgpool_slide_bwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, stream, dfeat, dx, lddx, rows,
+                     Lin, Lout, k, C);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

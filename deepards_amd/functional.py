@@ -379,15 +379,20 @@ class NormReluFunction(Function):
 
 
 class GlobalAvgPoolFunction(Function):
-    """AvgPool1d(7, stride=1) on an L=7 map -> (rows, C)  (resnet.py:112,159-160; densenet.py:167,183-184)."""
+    """AvgPool1d(7, stride=1) + view(rows, -1): (rows, C) on an L=7 map, (rows, C*(L-6)) on longer ones
+    (resnet.py:112,159-160; densenet.py:167,183-184)."""
 
     @staticmethod
     def forward(ctx, x):
-        ctx.lin = x.shape[1]
+        ctx.lin, ctx.c = x.shape[1], x.shape[2]
+        if ctx.lin > 7:             # seq_len > 224: sliding window, flattened channel-major like view(N, -1)
+            return H.avgpool_slide_fwd(x, 7)
         return H.avgpool_fwd(x, x.shape[1]).view(x.shape[0], x.shape[2])
 
     @staticmethod
     def backward(ctx, dfeat):
+        if ctx.lin > 7:
+            return H.avgpool_slide_bwd(dfeat.contiguous(), ctx.lin, 7, ctx.c)
         d = dfeat.contiguous().view(dfeat.shape[0], 1, dfeat.shape[1])
         return H.avgpool_bwd(d, ctx.lin, ctx.lin)
 

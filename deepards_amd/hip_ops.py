@@ -513,6 +513,25 @@ def avgpool_bwd(dout, lin, k):
     return dx
 
 
+def avgpool_slide_fwd(x, k):
+    """AvgPool1d(k, stride=1) + ``view(rows, -1)``: (rows, L, C) -> (rows, C * (L - k + 1)), channel slowest."""
+    _rlc(x, 'x')
+    rows, lin, c = x.shape
+    feat = torch.empty((rows, c * (lin - k + 1)), device=x.device, dtype=torch.float32)
+    _chk(_lib.lib().da_avgpool_slide_fwd(_p(x), c, _p(feat), rows, lin, k, c, _stream()), 'da_avgpool_slide_fwd')
+    return feat
+
+
+def avgpool_slide_bwd(dfeat, lin, k, c):
+    _f32(dfeat, 'dfeat')
+    rows = dfeat.shape[0]
+    if dfeat.shape[1] != c * (lin - k + 1):
+        raise ValueError('dfeat must be (rows, C * (L - k + 1))')
+    dx = torch.empty((rows, lin, c), device=dfeat.device, dtype=torch.float32)
+    _chk(_lib.lib().da_avgpool_slide_bwd(_p(dfeat), _p(dx), c, rows, lin, k, c, _stream()), 'da_avgpool_slide_bwd')
+    return dx
+
+
 # ------------------------------------------------------------------------------------------------
 # head / loss
 # ------------------------------------------------------------------------------------------------

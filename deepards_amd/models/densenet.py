@@ -181,8 +181,8 @@ class DenseNet(nn.Module):
 
     def forward_windows(self, x, rows_per_window):
         h = self._features_rlc(x, rows_per_window)
-        if h.shape[1] != 7:
-            raise NotImplementedError('AvgPool1d(7, stride=1) is implemented for a final length of 7')
+        if h.shape[1] < 7:
+            raise ValueError('AvgPool1d(7, stride=1) needs a final length >= 7 (seq_len >= 224); got %d' % h.shape[1])
         return F_.GlobalAvgPoolFunction.apply(h)
 
     def forward(self, x):

@@ -113,9 +113,8 @@ class ResNet(nn.Module):
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
                 h = blk.forward_rlc(h, rows_per_window)
-        if h.shape[1] != 7:
-            raise NotImplementedError('AvgPool1d(7, stride=1) is implemented for a final length of 7 '
-                                      '(seq_len 224); got %d' % h.shape[1])
+        if h.shape[1] < 7:
+            raise ValueError('AvgPool1d(7, stride=1) needs a final length >= 7 (seq_len >= 224); got %d' % h.shape[1])
         return F_.GlobalAvgPoolFunction.apply(h)
 
     def forward(self, x):

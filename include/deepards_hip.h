@@ -175,6 +175,11 @@ int da_avgpool_fwd(const float* x, int ldx, float* out, int ldo, int rows, int L
                    da_stream_t stream);
 int da_avgpool_bwd(const float* dout, int ldd, float* dx, int lddx, int rows, int Lin, int k, int C,
                    da_stream_t stream);
+/* AvgPool1d(k, stride 1) on a map longer than k followed by x.view(x.size(0), -1) (resnet.py:159-160,
+ * densenet.py:183-184 when seq_len > 224): feat[row][c * Lout + j], Lout = Lin - k + 1. */
+int da_avgpool_slide_fwd(const float* x, int ldx, float* feat, int rows, int Lin, int k, int C, da_stream_t stream);
+int da_avgpool_slide_bwd(const float* dfeat, float* dx, int lddx, int rows, int Lin, int k, int C,
+                         da_stream_t stream);
 
 /* ---- head + loss ---------------------------------------------------------------------------
  * linear_final on view(-1) of the (NB,F) block: torch_cnn_linear_network.py:102,110-112 ;

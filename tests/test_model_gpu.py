@@ -347,6 +347,42 @@ def test_other_sub_batch_counts_vs_numpy_oracle(M, nb):
         assert all(np.isfinite(float(tr.train_step(xt, tt))) for _ in range(3))
 
 
+@pytest.mark.parametrize('backbone', ['resnet18', 'densenet18'])
+def test_long_sequences_breath_block_vs_numpy_oracle(M, backbone):
+    """BASELINE config C5's tile shape (nb 40, seq_len 512): ``breath_block((40, 1, 512))`` gives a 16-long final map,
+    AvgPool1d(7, 1) leaves 10 positions and ``view(N, -1)`` flattens channel-major (resnet.py:159-160,
+    densenet.py:183-184) -> (40, F * 10).  Features and every weight gradient against the oracle."""
+    nb, L = 40, 512
+    bb = M.resnet18() if backbone == 'resnet18' else M.densenet18(drop_rate=0.0)
+    model = M.CNNLinearNetwork(bb, nb, 0)
+    p32 = seeded_params(backbone, 4, n_sub_batches=nb)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in p32.items()}, strict=False)
+    model = model.cuda().train()
+    rng = np.random.RandomState(12)
+    x = rng.randn(nb, 1, L).astype(np.float32)
+    t = np_ref._Tape({k: v.astype(np.float64) for k, v in p32.items()}, nb)
+    fn = np_ref.resnet18_features if backbone == 'resnet18' else np_ref.densenet18_features
+    ref, bwd = fn(t, x.astype(np.float64))
+    F = bb.n_out_filters
+    assert ref.shape == (nb, F * 10)
+    w = rng.randn(*ref.shape) / np.sqrt(ref.size)
+    bwd(w)
+    feat = model.breath_block(torch.from_numpy(x).cuda())
+    assert tuple(feat.shape) == (nb, F * 10)
+    err = np.abs(feat.detach().cpu().numpy() - ref).max()
+    log(backbone, 'nb=40 L=512 features err %.3e' % err)
+    assert err < 1e-4
+    (feat * torch.from_numpy(w.astype(np.float32)).cuda()).sum().backward()
+    bad = []
+    for n, p in model.named_parameters():
+        if n in t.g and p.grad is not None:
+            got, rf = p.grad.cpu().numpy().astype(np.float64), t.g[n]
+            e = np.abs(got - rf).max()
+            if not (e < 1e-4 * max(1.0, np.abs(rf).max()) or rel_l2(got, rf) < 5e-2):
+                bad.append((n, e))
+    assert not bad, bad
+
+
 def test_densenet_dropout_active_and_scaled(M):
     """drop_rate 0.2 is active in train mode (and the reference never leaves train mode): outputs
     differ run to run, and the test step still works under no_grad."""
