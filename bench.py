@@ -62,7 +62,7 @@ class KernelTimer(object):
             return 2.0 * a[3] * a[4] * a[7] * a[10] * a[14]
         if name == 'da_conv_wgrad':      # dy,x,dw,ws,rows,Lm,Ldy,lddy,N,Lx,ldx,C,...,ntaps at index 15
             return 2.0 * a[4] * a[5] * a[8] * a[11] * a[15]
-        if name == 'da_conv3_winograd':  # x,u,y,rows,L,ldx,C,ldy,N,...: ALGORITHMIC flops = those of the direct 3-tap conv
+        if name in ('da_conv3_winograd', 'da_conv3_winograd4'):  # x,u,y,rows,L,ldx,C,ldy,N,...: ALGORITHMIC flops = those of the direct 3-tap conv
             return 2.0 * a[3] * a[4] * a[6] * a[8] * 3
         if name == 'da_conv_wgrad_multi':   # jobs (host array of da_wgrad_job), n
             return sum(2.0 * a[0][i].rows * a[0][i].Lm * a[0][i].N * a[0][i].C * a[0][i].ntaps for i in range(a[1]))
@@ -259,7 +259,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         # instrumented EAGER steps: HIP events around every C-ABI launch, on the launch stream
         kt = KernelTimer(lib, torch)
-        names = [n for n in _lib.SIGNATURES if n not in ('da_version', 'da_conv_wgrad_workspace', 'da_stem_wgrad_workspace', 'da_bn_workspace', 'da_debug_set', 'da_bn_chunks', 'da_conv_wgrad_splits', 'da_conv_wgrad_plan', 'da_bn_debug_two_stage', 'da_wino_debug_tail', 'da_wino_debug_pchunk', 'da_wino_weights',
+        names = [n for n in _lib.SIGNATURES if n not in ('da_version', 'da_conv_wgrad_workspace', 'da_stem_wgrad_workspace', 'da_bn_workspace', 'da_debug_set', 'da_bn_chunks', 'da_conv_wgrad_splits', 'da_conv_wgrad_plan', 'da_bn_debug_two_stage', 'da_wino_debug_tail', 'da_wino_debug_pchunk', 'da_wino_weights', 'da_wino4_weights',
                                                           'da_hip_runtime_symbol')]
         tr_e = HotPathTrainer(model, optimizer='sgd', use_graph=False)
         tr_e.bucket, tr_e.state = tr.bucket, tr.state

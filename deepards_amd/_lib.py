@@ -44,7 +44,8 @@ class ConvJob(ctypes.Structure):
 
 
 class RepackDesc(ctypes.Structure):
-    _fields_ = [('W', _P), ('Wf', _P), ('Wd', _P), ('Uf', _P), ('Ud', _P), ('Co', _I), ('Ci', _I), ('K', _I)]
+    _fields_ = [('W', _P), ('Wf', _P), ('Wd', _P), ('Uf', _P), ('Ud', _P), ('Co', _I), ('Ci', _I), ('K', _I),
+                ('points', _I)]
 
 
 # name -> (restype, argtypes); must list exactly the symbols the header declares (tests check it)
@@ -81,9 +82,11 @@ SIGNATURES = {
     'da_conv_wgrad_plan': (_I, [_I] * 6 + [ctypes.POINTER(_I)]),
     'da_conv_gemm_multi': (_I, [ctypes.POINTER(ConvJob), _I, _P]),
     'da_conv3_winograd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'da_conv3_winograd4': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'da_wino_debug_tail': (_I, [_I]),
     'da_wino_debug_pchunk': (_I, [_I]),
     'da_wino_weights': (_I, [_P, _P, _I, _I, _I, _P]),
+    'da_wino4_weights': (_I, [_P, _P, _I, _I, _I, _P]),
     'da_conv_wgrad_multi': (_I, [ctypes.POINTER(WgradJob), _I, _P]),
     'da_wgrad_reduce_multi': (_I, [ctypes.POINTER(WgradReduceDesc), _I, _I, _P]),
     'da_repack_multi': (_I, [ctypes.POINTER(RepackDesc), _I, _P]),

@@ -47,6 +47,18 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Winograd F(4,3) taps G g of one (output, input) channel pair, written at u[j * stride] (conv_wino.hip)
+__device__ __forceinline__ void wino4_taps(float g0, float g1, float g2, float* u, size_t stride) {
+  const float s = g0 + g2;
+  u[0] = g0 * 0.25f;
+  u[stride] = -(s + g1) * (1.0f / 6.0f);
+  u[2 * stride] = -(s - g1) * (1.0f / 6.0f);
+  const float t = fmaf(g0, 1.0f / 24.0f, g2 * (1.0f / 6.0f));
+  u[3 * stride] = fmaf(g1, 1.0f / 12.0f, t);
+  u[4 * stride] = fmaf(g1, -1.0f / 12.0f, t);
+  u[5 * stride] = g2;
+}
+
 // One weight-gradient GEMM of da_conv_wgrad_multi (include/deepards_hip.h); shared by conv_gemm.hip and conv_wino.hip.
 typedef struct {
   const float* dy;

@@ -241,7 +241,398 @@ __global__ __launch_bounds__(256) void conv3_wino_kernel(WinoArgs a, int nmini, 
   conv3_wino_body<false>(a, xcd_chunked(blockIdx.x - nmini_pad, full), 0, lds);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same convolution as Winograd F(4,3): four neighbouring outputs from six inputs d0..d5 = x[4i-1 .. 4i+4],
+//     D0 = 4 d0 - 5 d2 + d4                  U0 = g0 / 4
+//     D1 = (d4 - 4 d2) + (d3 - 4 d1)         U1 = -(g0 + g1 + g2) / 6
+//     D2 = (d4 - 4 d2) - (d3 - 4 d1)         U2 = -(g0 - g1 + g2) / 6
+//     D3 = (d4 - d2) + 2 (d3 - d1)           U3 = g0 / 24 + g1 / 12 + g2 / 6
+//     D4 = (d4 - d2) - 2 (d3 - d1)           U4 = g0 / 24 - g1 / 12 + g2 / 6
+//     D5 = 4 d1 - 5 d3 + d5                  U5 = g2
+//     y0 = m0 + m1 + m2 + m3 + m4            y1 = (m1 - m2) + 2 (m3 - m4)
+//     y2 = (m1 + m2) + 4 (m3 + m4)           y3 = (m1 - m2) + 8 (m3 - m4) + m5
+// 6 channel contractions per output QUAD instead of 12: half the direct convolution's MFMAs (3/4 of F(2,3)'s), fp32
+// error vs fp64 3e-6 of the output scale (F(2,3) 6e-7).  GEMM rows are output quads Q = row * QL + i, QL = ceil(L/4);
+// staging keeps the four position phases in four quad-indexed LDS panels, so d0 = Ph3[Q-1], d1..d4 = Ph0..Ph3[Q],
+// d5 = Ph0[Q+1] are unit-row-stride reads with the F(2,3) kernel's conflict-free lane geometry.
+// Block = 64 quads x 32 output channels, 4 waves of 16 quads: 12 accumulator tiles = 48 VGPRs; 64.8 KB of LDS.
+// ---------------------------------------------------------------------------------------------
+// B^T d as whole-vector fp32 arithmetic (the compiler pairs it into v_pk_fma_f32 / v_pk_add_f32 where it can)
+__device__ __forceinline__ void wino4_input_transform(const f32x4& d0, const f32x4& d1, const f32x4& d2,
+                                                      const f32x4& d3, const f32x4& d4, const f32x4& d5, f32x4* D) {
+  const f32x4 p = d4 - 4.f * d2, q = d3 - 4.f * d1;
+  const f32x4 r = d4 - d2, t = d3 - d1;
+  D[0] = 4.f * d0 + (d4 - 5.f * d2);
+  D[1] = p + q;
+  D[2] = p - q;
+  D[3] = r + 2.f * t;
+  D[4] = r - 2.f * t;
+  D[5] = 4.f * d1 + (d5 - 5.f * d3);
+}
+
+#define W4_LDS_FLOATS ((4 * 64 + 2) * WINO_PITCH + 6 * 32 * WINO_PITCH)
+
+template <bool MINI>
+__device__ __forceinline__ void conv3_wino4_body(const WinoArgs& a, const int tile, const int sub, float* lds) {
+  constexpr int PITCH = WINO_PITCH, QUADS = MINI ? 32 : 64;
+  float* Ph0 = lds;                              // [QUADS + 1][PITCH] positions 4i     of quads Q0 .. Q0+QUADS
+  float* Ph1 = Ph0 + (QUADS + 1) * PITCH;        // [QUADS][PITCH]     positions 4i + 1
+  float* Ph2 = Ph1 + QUADS * PITCH;              // [QUADS][PITCH]     positions 4i + 2
+  float* Ph3 = Ph2 + QUADS * PITCH;              // [QUADS + 1][PITCH] positions 4i + 3 of quads Q0-1 .. Q0+QUADS-1
+  float* Us = Ph3 + (QUADS + 1) * PITCH;         // [6][32][PITCH]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntn = a.N >> 5;
+  const int Q0 = (tile / ntn) * 64 + (MINI ? 32 * sub : 0), n_blk = (tile % ntn) * 32;
+  const int lr = tid >> 3, lq = tid & 7;
+  const int QL = a.PL;
+
+  constexpr int NA = MINI ? 5 : 9;
+  int aoff[NA];
+  bool aok[NA];
+#pragma unroll
+  for (int p = 0; p < NA; ++p) {
+    const bool extra = p == NA - 1;
+    const int phase = extra ? (((tid >> 3) & 1) ? 3 : 0) : (MINI ? p : (p >> 1));
+    const int e = extra ? (phase == 0 ? QUADS : -1) : (MINI ? lr : lr + 32 * (p & 1));
+    const int Q = Q0 + e;
+    bool ok = Q >= 0 && Q < a.MP && (!extra || tid < 16);
+    const uint32_t r = fdiv((uint32_t)(ok ? Q : 0), a.divPL);
+    const int i = (ok ? Q : 0) - (int)r * QL;
+    const int pos = 4 * i + phase;
+    ok = ok && pos < a.L;
+    aoff[p] = ((int)r * a.L + (ok ? pos : 0)) * a.ldx + lq * 4;
+    aok[p] = ok;
+  }
+  const float* ub = a.u + (size_t)(n_blk + lr) * a.C + lq * 4;
+  const size_t ustride = (size_t)a.N * a.C;
+
+  f32x4 ra[NA], rb[6];
+  auto gload_a = [&](int ks) {
+    const int c0 = ks << 5;
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (aok[p]) v = *reinterpret_cast<const f32x4*>(a.x + aoff[p] + c0);
+      ra[p] = v;
+    }
+  };
+  auto gload_b = [&](int ks) {
+    const int c0 = ks << 5;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) rb[j] = *reinterpret_cast<const f32x4*>(ub + j * ustride + c0);
+  };
+
+  const int prow = wino_row(lane & 15), g = lane >> 4;
+  const int wp = MINI ? (wave & 1) : wave, khalf = wave >> 1;
+  const int pr = wp * 16 + prow;                        // quad of this lane within the block
+  const int Q_lane = Q0 + pr;
+  const int Qc = Q_lane < a.MP ? Q_lane : 0;
+  const int i_lane = Qc - (int)fdiv((uint32_t)Qc, a.divPL) * QL;
+  const bool at_first = i_lane == 0, at_last = i_lane == QL - 1;
+
+  f32x4 acc[6][2];
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kc = a.C >> 5;
+  gload_a(0);
+  gload_b(0);
+  for (int ks = 0; ks < kc; ++ks) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NA - 1; ++p) {
+      const int phase = MINI ? p : (p >> 1);
+      const int e = MINI ? lr : lr + 32 * (p & 1);
+      float* panel = phase == 0 ? Ph0 : (phase == 1 ? Ph1 : (phase == 2 ? Ph2 : Ph3 + PITCH));
+      *reinterpret_cast<f32x4*>(&panel[e * PITCH + lq * 4]) = ra[p];
+    }
+    if (tid < 16) *reinterpret_cast<f32x4*>(&(((tid >> 3) & 1) ? Ph3 : Ph0 + QUADS * PITCH)[lq * 4]) = ra[NA - 1];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(&Us[(j * 32 + lr) * PITCH + lq * 4]) = rb[j];
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int col = (2 * g + half) * 4;
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < kc) {
+        if (half == 0) gload_b(ks + 1);
+        else gload_a(ks + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (MINI && half != khalf) continue;
+      f32x4 d0 = *reinterpret_cast<const f32x4*>(&Ph3[pr * PITCH + col]);
+      const f32x4 d1 = *reinterpret_cast<const f32x4*>(&Ph0[pr * PITCH + col]);
+      const f32x4 d2 = *reinterpret_cast<const f32x4*>(&Ph1[pr * PITCH + col]);
+      const f32x4 d3 = *reinterpret_cast<const f32x4*>(&Ph2[pr * PITCH + col]);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(&Ph3[(pr + 1) * PITCH + col]);
+      f32x4 d5 = *reinterpret_cast<const f32x4*>(&Ph0[(pr + 1) * PITCH + col]);
+      if (at_first) d0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (at_last) d5 = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 D[6];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = fmaf(-4.f, d2[e], d4[e]), q = fmaf(-4.f, d1[e], d3[e]);
+        const float r = d4[e] - d2[e], t = 2.f * (d3[e] - d1[e]);
+        D[0][e] = fmaf(4.f, d0[e], fmaf(-5.f, d2[e], d4[e]));
+        D[1][e] = p + q;
+        D[2][e] = p - q;
+        D[3][e] = r + t;
+        D[4][e] = r - t;
+        D[5][e] = fmaf(4.f, d1[e], fmaf(-5.f, d3[e], d5[e]));
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const f32x4 uf = *reinterpret_cast<const f32x4*>(&Us[(j * 32 + nt * 16 + prow) * PITCH + col]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(D[j][e], uf[e], acc[j][nt], 0, 0, 0);
+        }
+    }
+  }
+
+  if (MINI) {   // k half 1 hands its partial sums to k half 0
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(lds);          // [2 quad halves][12 tiles][64 lanes]
+    if (khalf == 1) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) red[((wp * 6 + j) * 2 + nt) * 64 + lane] = acc[j][nt];
+    }
+    __syncthreads();
+    if (khalf == 1) return;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 o = red[((wp * 6 + j) * 2 + nt) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][nt][e] += o[e];
+      }
+  }
+
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int Q = Q0 + wp * 16 + wino_row(g * 4 + r);
+    if (Q >= a.MP) continue;
+    const uint32_t rr = fdiv((uint32_t)Q, a.divPL);
+    const int i = Q - (int)rr * QL;
+    const int nvalid = a.L - 4 * i;                     // outputs of this quad inside the sequence (>= 1)
+    float* yp = a.y + ((size_t)rr * a.L + 4 * i) * a.ldy + n_blk + prow;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const float m0 = acc[0][nt][r], m1 = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r], m4 = acc[4][nt][r],
+                  m5 = acc[5][nt][r];
+      const float sa = m1 + m2, da = m1 - m2, sb = m3 + m4, db = m3 - m4;
+      float yv[4] = {m0 + sa + sb, fmaf(2.f, db, da), fmaf(4.f, sb, sa), fmaf(8.f, db, da) + m5};
+      float* q0 = yp + nt * 16;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (s < nvalid) {
+          float v = yv[s];
+          if (a.accumulate) v += q0[(size_t)s * a.ldy];
+          q0[(size_t)s * a.ldy] = v;
+        }
+      }
+    }
+  }
+}
+
+// K step of 16 channels: 36 KB of LDS instead of 65 (pitch 20 = 5 slots a row keeps odd / even tile rows on odd / even
+// slot residues like pitch 36; the lane groups of ds_read_b128 pair k groups (0,1) and (2,3), so k group g sits in slot
+// {0,2,1,3}[g]).
+#define W4K_PITCH 20
+#define W4K_LDS_FLOATS ((4 * 64 + 2) * W4K_PITCH + 6 * 32 * W4K_PITCH)
+
+template <bool MINI>
+__device__ __forceinline__ void conv3_wino4k_body(const WinoArgs& a, const int tile, const int sub, float* lds) {
+  constexpr int PITCH = W4K_PITCH, QUADS = MINI ? 32 : 64;
+  float* Ph0 = lds;
+  float* Ph1 = Ph0 + (QUADS + 1) * PITCH;
+  float* Ph2 = Ph1 + QUADS * PITCH;
+  float* Ph3 = Ph2 + QUADS * PITCH;              // row e + 1 = quad Q0 + e
+  float* Us = Ph3 + (QUADS + 1) * PITCH;         // [6][32][PITCH]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntn = a.N >> 5;
+  const int Q0 = (tile / ntn) * 64 + (MINI ? 32 * sub : 0), n_blk = (tile % ntn) * 32;
+  const int lr = tid >> 2, lq = tid & 3;
+  const int QL = a.PL;
+
+  constexpr int NP = MINI ? 2 : 4, NA = NP + 1;
+  int aoff[NA];
+  bool aok[NA];
+#pragma unroll
+  for (int p = 0; p < NA; ++p) {
+    const bool extra = p == NA - 1;
+    const int idx = p * 64 + lr;
+    const int phase = extra ? (((tid >> 2) & 1) ? 3 : 0) : idx / QUADS;
+    const int e = extra ? (phase == 0 ? QUADS : -1) : idx % QUADS;
+    const int Q = Q0 + e;
+    bool ok = Q >= 0 && Q < a.MP && (!extra || tid < 8);
+    const uint32_t r = fdiv((uint32_t)(ok ? Q : 0), a.divPL);
+    const int i = (ok ? Q : 0) - (int)r * QL;
+    const int pos = 4 * i + phase;
+    ok = ok && pos < a.L;
+    aoff[p] = ((int)r * a.L + (ok ? pos : 0)) * a.ldx + lq * 4;
+    aok[p] = ok;
+  }
+  // taps: 192 rows (point j, channel n) in 3 passes of 64
+  const float* ub[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const int idx = p * 64 + lr;
+    ub[p] = a.u + (size_t)(idx >> 5) * a.N * a.C + (size_t)(n_blk + (idx & 31)) * a.C + lq * 4;
+  }
+
+  f32x4 ra[NA], rb[3];
+  auto gload_a = [&](int ks) {
+    const int c0 = ks << 4;
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (aok[p]) v = *reinterpret_cast<const f32x4*>(a.x + aoff[p] + c0);
+      ra[p] = v;
+    }
+  };
+  auto gload_b = [&](int ks) {
+    const int c0 = ks << 4;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) rb[p] = *reinterpret_cast<const f32x4*>(ub[p] + c0);
+  };
+
+  const int prow = wino_row(lane & 15), g = lane >> 4;
+  const int col = (((g & 1) << 1) | (g >> 1)) * 4;       // slot {0,2,1,3}[g]
+  const int wp = MINI ? (wave & 1) : wave, khalf = wave >> 1;
+  const int pr = wp * 16 + prow;
+  const int Q_lane = Q0 + pr;
+  const int Qc = Q_lane < a.MP ? Q_lane : 0;
+  const int i_lane = Qc - (int)fdiv((uint32_t)Qc, a.divPL) * QL;
+  const bool at_first = i_lane == 0, at_last = i_lane == QL - 1;
+
+  f32x4 acc[6][2];
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kc = a.C >> 4;
+  gload_a(0);
+  gload_b(0);
+  for (int ks = 0; ks < kc; ++ks) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int idx = p * 64 + lr;
+      const int phase = idx / QUADS, e = idx % QUADS;
+      float* panel = phase == 0 ? Ph0 : (phase == 1 ? Ph1 : (phase == 2 ? Ph2 : Ph3 + PITCH));
+      *reinterpret_cast<f32x4*>(&panel[e * PITCH + lq * 4]) = ra[p];
+    }
+    if (tid < 8) *reinterpret_cast<f32x4*>(&(((tid >> 2) & 1) ? Ph3 : Ph0 + QUADS * PITCH)[lq * 4]) = ra[NA - 1];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<f32x4*>(&Us[(p * 64 + lr) * PITCH + lq * 4]) = rb[p];
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < kc) {
+      gload_b(ks + 1);
+      gload_a(ks + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (MINI && (ks & 1) != khalf) continue;
+    f32x4 d0 = *reinterpret_cast<const f32x4*>(&Ph3[pr * PITCH + col]);
+    const f32x4 d1 = *reinterpret_cast<const f32x4*>(&Ph0[pr * PITCH + col]);
+    const f32x4 d2 = *reinterpret_cast<const f32x4*>(&Ph1[pr * PITCH + col]);
+    const f32x4 d3 = *reinterpret_cast<const f32x4*>(&Ph2[pr * PITCH + col]);
+    const f32x4 d4 = *reinterpret_cast<const f32x4*>(&Ph3[(pr + 1) * PITCH + col]);
+    f32x4 d5 = *reinterpret_cast<const f32x4*>(&Ph0[(pr + 1) * PITCH + col]);
+    if (at_first) d0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (at_last) d5 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 D[6];
+    wino4_input_transform(d0, d1, d2, d3, d4, d5, D);
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 uf = *reinterpret_cast<const f32x4*>(&Us[(j * 32 + nt * 16 + prow) * PITCH + col]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(D[j][e], uf[e], acc[j][nt], 0, 0, 0);
+      }
+  }
+
+  if (MINI) {
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(lds);          // [2 quad halves][12 tiles][64 lanes] = 24.6 KB
+    if (khalf == 1) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) red[((wp * 6 + j) * 2 + nt) * 64 + lane] = acc[j][nt];
+    }
+    __syncthreads();
+    if (khalf == 1) return;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 o = red[((wp * 6 + j) * 2 + nt) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][nt][e] += o[e];
+      }
+  }
+
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int Q = Q0 + wp * 16 + wino_row(g * 4 + r);
+    if (Q >= a.MP) continue;
+    const uint32_t rr = fdiv((uint32_t)Q, a.divPL);
+    const int i = Q - (int)rr * QL;
+    const int nvalid = a.L - 4 * i;
+    float* yp = a.y + ((size_t)rr * a.L + 4 * i) * a.ldy + n_blk + prow;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const float m0 = acc[0][nt][r], m1 = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r], m4 = acc[4][nt][r],
+                  m5 = acc[5][nt][r];
+      const float sa = m1 + m2, da = m1 - m2, sb = m3 + m4, db = m3 - m4;
+      float yv[4] = {m0 + sa + sb, fmaf(2.f, db, da), fmaf(4.f, sb, sa), fmaf(8.f, db, da) + m5};
+      float* q0 = yp + nt * 16;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (s < nvalid) {
+          float v = yv[s];
+          if (a.accumulate) v += q0[(size_t)s * a.ldy];
+          q0[(size_t)s * a.ldy] = v;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 3) void conv3_wino4k_kernel(WinoArgs a, int nmini, int nmini_pad, int full) {
+  __shared__ float lds[W4K_LDS_FLOATS];
+  if ((int)blockIdx.x < nmini_pad) {
+    if ((int)blockIdx.x < nmini) conv3_wino4k_body<true>(a, full + ((int)blockIdx.x >> 1), blockIdx.x & 1, lds);
+    return;
+  }
+  conv3_wino4k_body<false>(a, xcd_chunked(blockIdx.x - nmini_pad, full), 0, lds);
+}
+
+__global__ __launch_bounds__(256) void conv3_wino4_kernel(WinoArgs a, int nmini, int nmini_pad, int full) {
+  __shared__ float lds[W4_LDS_FLOATS];
+  if ((int)blockIdx.x < nmini_pad) {
+    if ((int)blockIdx.x < nmini) conv3_wino4_body<true>(a, full + ((int)blockIdx.x >> 1), blockIdx.x & 1, lds);
+    return;
+  }
+  conv3_wino4_body<false>(a, xcd_chunked(blockIdx.x - nmini_pad, full), 0, lds);
+}
+
 static int g_wino_tail = 1;
+static int g_wino4_k16 = 1;
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient of the same convolution, Winograd form.  With dm = A dy = (dy0, dy0 + dy1, dy0 - dy1, -dy1) per
@@ -461,7 +852,60 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
   u[3 * total + idx] = g2;
 }
 
+// U[6][N][C] for F(4,3), same conventions.
+__global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int co,
+                                                           int ci, int transpose) {
+  const int N = transpose ? ci : co, C = transpose ? co : ci;
+  const size_t total = (size_t)N * C;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int n = (int)(idx / C), c = (int)(idx - (size_t)n * C);
+  const float* src = transpose ? w + ((size_t)c * ci + n) * 3 : w + ((size_t)n * ci + c) * 3;
+  const float g0 = transpose ? src[2] : src[0], g1 = src[1], g2 = transpose ? src[0] : src[2];
+  wino4_taps(g0, g1, g2, u + idx, total);
+}
+
 extern "C" {
+
+// F(4,3) variant of da_conv3_winograd; u = 6 * N * C floats from da_wino4_weights.
+int da_conv3_winograd4(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
+                       int accumulate, hipStream_t stream) {
+  DA_ENTER();
+  if (!x || !u || !y || rows < 0 || L < 1 || C % 32 || N % 32 || C < 32 || N < 32 || ldx % 4 || ldx < C || ldy < N)
+    return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  if ((uint64_t)rows * L * (uint64_t)(ldx > ldy ? ldx : ldy) >= 0x7fffffffull) return DA_EINVAL;
+  WinoArgs a;
+  a.x = x; a.u = u; a.y = y;
+  a.L = L; a.PL = (L + 3) / 4; a.MP = rows * a.PL;        // PL / MP count quads here
+  a.ldx = ldx; a.C = C; a.ldy = ldy; a.N = N; a.accumulate = accumulate;
+  a.divPL = make_fastdiv((uint32_t)a.PL);
+  if ((uint64_t)a.MP * (uint64_t)a.PL >= 0xffffffffull) return DA_EINVAL;
+  const int tiles = ((a.MP + 63) / 64) * (N / 32);
+  const int R = tiles % 256;
+  int nmini = 0, full = tiles;
+  if (g_wino_tail && tiles > 256 && R >= 1 && R <= 128) {
+    nmini = 2 * R;
+    full = tiles - R;
+  }
+  const int nmini_pad = (nmini + 7) / 8 * 8;
+  if (g_wino4_k16)
+    hipLaunchKernelGGL(conv3_wino4k_kernel, dim3(nmini_pad + full), dim3(256), 0, stream, a, nmini, nmini_pad, full);
+  else
+    hipLaunchKernelGGL(conv3_wino4_kernel, dim3(nmini_pad + full), dim3(256), 0, stream, a, nmini, nmini_pad, full);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+int da_wino4_weights(const float* w, float* u, int co, int ci, int transpose, hipStream_t stream) {
+  DA_ENTER();
+  if (!w || !u || co < 1 || ci < 1) return DA_EINVAL;
+  const size_t total = (size_t)co * ci;
+  hipLaunchKernelGGL(wino4_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, u, co, ci,
+                     transpose);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
 
 // y (+)= conv1d(x, k = 3, stride 1, pad 1) per row with the transformed taps u (da_wino_weights).
 // x: [rows][L][ldx] first C channels; y: [rows][L][ldy] first N channels.  replaces reference models/resnet.py:5-8
@@ -493,6 +937,10 @@ int da_conv3_winograd(const float* x, const float* u, float* y, int rows, int L,
 
 // tuning / tests: 0 = no half tiles for the last round; pchunk > 0: pairs per weight-gradient split
 int da_wino_debug_tail(int on) {
+  if (on & ~1) {                 // 2 / 3: F(4,3) K step 32 / 16
+    g_wino4_k16 = on & 1;
+    return DA_OK;
+  }
   g_wino_tail = on;
   return DA_OK;
 }

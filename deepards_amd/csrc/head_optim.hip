@@ -214,14 +214,28 @@ __global__ __launch_bounds__(256) void repack_conv_weight_kernel(const float* __
   }
 }
 
+// Winograd taps of one (n, c) pair at u[j * tot]: F(2,3) (4 points, the arithmetic of wino_weight_kernel) or
+// F(4,3) (6 points, wino4_taps)
+__device__ __forceinline__ void emit_wino_taps(float* u, size_t tot, float g0, float g1, float g2, int points) {
+  if (points == 6) {
+    wino4_taps(g0, g1, g2, u, tot);
+    return;
+  }
+  u[0] = g0;
+  u[tot] = (g0 + g1 + g2) * 0.5f;
+  u[2 * tot] = (g0 - g1 + g2) * 0.5f;
+  u[3 * tot] = g2;
+}
+
 // the same repack for up to 32 weights in one launch (blockIdx.y = which weight)
 struct RepackDesc {
   const float* W;
   float* Wf;
   float* Wd;
-  float* Uf;   // K == 3 only: Winograd F(2,3) taps [4][Co][Ci] (forward) ...
-  float* Ud;   // ... and [4][Ci][Co] (data gradient), same arithmetic as wino_weight_kernel (conv_wino.hip)
+  float* Uf;   // K == 3 only: Winograd taps [points][Co][Ci] (forward) ...
+  float* Ud;   // ... and [points][Ci][Co] (data gradient), same arithmetic as the weight kernels of conv_wino.hip
   int Co, Ci, K;
+  int points;  // 6: F(4,3) taps, otherwise F(2,3) (4)
 };
 struct RepackTable {
   RepackDesc d[32];
@@ -240,18 +254,10 @@ __global__ __launch_bounds__(256) void repack_multi_kernel(RepackTable t) {
       const float w0 = v, w1 = d.W[i + 1], w2 = d.W[i + 2];
       const size_t tot = (size_t)d.Co * d.Ci;
       if (d.Uf) {
-        const size_t o = (size_t)co * d.Ci + ci;
-        d.Uf[o] = w0;
-        d.Uf[tot + o] = (w0 + w1 + w2) * 0.5f;
-        d.Uf[2 * tot + o] = (w0 - w1 + w2) * 0.5f;
-        d.Uf[3 * tot + o] = w2;
+        emit_wino_taps(d.Uf + (size_t)co * d.Ci + ci, tot, w0, w1, w2, d.points);
       }
       if (d.Ud) {                              // taps reversed: g_t = w[..][2 - t]
-        const size_t o = (size_t)ci * d.Co + co;
-        d.Ud[o] = w2;
-        d.Ud[tot + o] = (w2 + w1 + w0) * 0.5f;
-        d.Ud[2 * tot + o] = (w2 - w1 + w0) * 0.5f;
-        d.Ud[3 * tot + o] = w0;
+        emit_wino_taps(d.Ud + (size_t)ci * d.Co + co, tot, w2, w1, w0, d.points);
       }
     }
   }
@@ -285,11 +291,7 @@ __global__ __launch_bounds__(256) void repack_tiled_kernel(RepackTable t) {
       if (d.Wf)
         for (int k = 0; k < K; ++k) d.Wf[(size_t)k * tot + o] = w[k];
       if (d.Uf) {
-        const float w0 = w[0], w1 = w[1], w2 = w[2];
-        d.Uf[o] = w0;
-        d.Uf[tot + o] = (w0 + w1 + w2) * 0.5f;
-        d.Uf[2 * tot + o] = (w0 - w1 + w2) * 0.5f;
-        d.Uf[3 * tot + o] = w2;
+        emit_wino_taps(d.Uf + o, tot, w[0], w[1], w[2], d.points);
       }
     }
     // data-gradient packs: ci = a, co = b (co contiguous)
@@ -299,11 +301,7 @@ __global__ __launch_bounds__(256) void repack_tiled_kernel(RepackTable t) {
       if (d.Wd)
         for (int k = 0; k < K; ++k) d.Wd[(size_t)k * tot + o] = w[k];
       if (d.Ud) {                                               // taps reversed: g_t = w[..][2 - t]
-        const float w0 = w[0], w1 = w[1], w2 = w[2];
-        d.Ud[o] = w2;
-        d.Ud[tot + o] = (w2 + w1 + w0) * 0.5f;
-        d.Ud[2 * tot + o] = (w2 - w1 + w0) * 0.5f;
-        d.Ud[3 * tot + o] = w0;
+        emit_wino_taps(d.Ud + o, tot, w[2], w[1], w[0], d.points);
       }
     }
   }
@@ -796,6 +794,7 @@ typedef struct {
   float* Uf;
   float* Ud;
   int Co, Ci, K;
+  int points;
 } da_repack_desc;
 
 // repack n conv weights (descs: HOST array) with one launch per 32.
@@ -808,7 +807,7 @@ int da_repack_multi(const da_repack_desc* descs, int n, hipStream_t stream) {
     for (int i = 0; i < m; ++i) {
       const da_repack_desc& s = descs[base + i];
       if (!s.W || (!s.Wf && !s.Wd && !s.Uf && !s.Ud) || ((s.Uf || s.Ud) && s.K != 3)) return DA_EINVAL;
-      t.d[i] = {s.W, s.Wf, s.Wd, s.Uf, s.Ud, s.Co, s.Ci, s.K};
+      t.d[i] = {s.W, s.Wf, s.Wd, s.Uf, s.Ud, s.Co, s.Ci, s.K, s.points};
     }
     bool tiled = true;
     int maxtiles = 0;

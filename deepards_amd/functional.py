@@ -109,9 +109,16 @@ _BN_MASK = os.environ.get('DA_BN_MASK', '1') != '0'       # block-output BatchNo
 _PAIR_S2 = os.environ.get('DA_PAIR_S2', '1') != '0'      # stride-2 block heads: conv + downsample GEMMs share launches
 
 
+_WINO4_MIN_C = int(os.environ.get('DA_WINO4_MINC', '512'))   # channels from which F(4,3) beats F(2,3) (scripts/bench_wino.py)
+
+
 def _is_wino(w, stride, pad):
-    """k3 s1 p1 convs run as Winograd F(2,3) (2/3 of the direct conv's MFMAs, fp32 throughout)."""
-    return _WINOGRAD and w.shape[2] == 3 and stride == 1 and pad == 1 and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0
+    """k3 s1 p1 convs run as Winograd (fp32 throughout): 0 = direct, 4 = F(2,3) (2/3 of the direct conv's MFMAs),
+    6 = F(4,3) (1/2 of them; pays once both channel counts reach _WINO4_MIN_C)."""
+    if not (_WINOGRAD and w.shape[2] == 3 and stride == 1 and pad == 1 and w.shape[0] % 32 == 0
+            and w.shape[1] % 32 == 0):
+        return 0
+    return 6 if min(w.shape[0], w.shape[1]) >= _WINO4_MIN_C else 4
 
 
 def _pack(w, wino):

@@ -87,23 +87,25 @@ def conv_fwd(x, wf, stride, pad, out=None):
     return out
 
 
-def wino_weights(w, transpose=False):
-    """Winograd F(2,3) taps of a (Co, Ci, 3) conv weight: (4, Co, Ci) for the forward, (4, Ci, Co) (transpose) for the
-    data gradient."""
+def wino_weights(w, transpose=False, points=4):
+    """Winograd taps of a (Co, Ci, 3) conv weight: (points, Co, Ci) for the forward, (points, Ci, Co) (transpose) for
+    the data gradient; points = 4: F(2,3), 6: F(4,3)."""
     co, ci, k = w.shape
-    if k != 3 or not w.is_contiguous():
-        raise ValueError('wino_weights: (Co, Ci, 3) contiguous weight expected')
-    u = torch.empty((4, ci, co) if transpose else (4, co, ci), device=w.device, dtype=torch.float32)
-    _chk(_lib.lib().da_wino_weights(_p(w), _p(u), co, ci, 1 if transpose else 0, _stream()), 'da_wino_weights')
+    if k != 3 or not w.is_contiguous() or points not in (4, 6):
+        raise ValueError('wino_weights: (Co, Ci, 3) contiguous weight expected, points 4 or 6')
+    u = torch.empty((points, ci, co) if transpose else (points, co, ci), device=w.device, dtype=torch.float32)
+    fn = _lib.lib().da_wino_weights if points == 4 else _lib.lib().da_wino4_weights
+    _chk(fn(_p(w), _p(u), co, ci, 1 if transpose else 0, _stream()), 'da_wino_weights')
     return u
 
 
 def conv3_winograd(x, u, out=None, accumulate=False):
-    """k3 s1 p1 conv of x (rows, L, C) with taps u (4, N, C) from wino_weights -> (rows, L, N)."""
+    """k3 s1 p1 conv of x (rows, L, C) with taps u from wino_weights -> (rows, L, N): (4, N, C) taps run
+    F(2,3), (6, N, C) taps F(4,3)."""
     _rlc(x, 'x')
     rows, l, c = x.shape
     four, n, c2 = u.shape
-    if four != 4 or c2 != c or c % 32 or n % 32:
+    if four not in (4, 6) or c2 != c or c % 32 or n % 32:
         raise ValueError('conv3_winograd: unsupported shape x%s u%s' % (tuple(x.shape), tuple(u.shape)))
     if out is None:
         if accumulate:
@@ -111,8 +113,8 @@ def conv3_winograd(x, u, out=None, accumulate=False):
         out = torch.empty((rows, l, n), device=x.device, dtype=torch.float32)
     elif tuple(out.shape) != (rows, l, n):
         raise ValueError('conv3_winograd: bad out shape')
-    _chk(_lib.lib().da_conv3_winograd(_p(x), _p(u), _p(out), rows, l, c, c, n, n, 1 if accumulate else 0, _stream()),
-         'da_conv3_winograd')
+    fn = _lib.lib().da_conv3_winograd if four == 4 else _lib.lib().da_conv3_winograd4
+    _chk(fn(_p(x), _p(u), _p(out), rows, l, c, c, n, n, 1 if accumulate else 0, _stream()), 'da_conv3_winograd')
     return out
 
 
@@ -276,21 +278,23 @@ def wgrad_reduce_multi(items, accumulate=True):
 
 
 def repack_multi(weights, winograd=None):
-    """[(Co,Ci,K) weights] -> [(wf, wd, uf, ud)] with one launch per 32 weights.  winograd[i] (K == 3): emit the
-    Winograd taps uf (4,Co,Ci) / ud (4,Ci,Co) INSTEAD of the direct packs wf / wd (None in the tuple)."""
+    """[(Co,Ci,K) weights] -> [(wf, wd, uf, ud)] with one launch per 32 weights.  winograd[i] (K == 3; True / 4:
+    F(2,3), 6: F(4,3)): emit the Winograd taps uf (points,Co,Ci) / ud (points,Ci,Co) INSTEAD of the direct packs
+    wf / wd (None in the tuple)."""
     outs = []
     arr = (_lib.RepackDesc * len(weights))()
     for n, (d, w) in enumerate(zip(arr, weights)):
         _f32(w, 'w')
         co, ci, k = w.shape
         wino = bool(winograd[n]) if winograd is not None else False
+        pts = 6 if wino and winograd[n] == 6 else 4
         if wino and k != 3:
             raise ValueError('winograd taps need a 3-tap weight')
         mk = lambda *shape: torch.empty(shape, device=w.device, dtype=torch.float32)
         wf, wd = (None, None) if wino else (mk(k, co, ci), mk(k, ci, co))
-        uf, ud = (mk(4, co, ci), mk(4, ci, co)) if wino else (None, None)
+        uf, ud = (mk(pts, co, ci), mk(pts, ci, co)) if wino else (None, None)
         d.W, d.Wf, d.Wd, d.Uf, d.Ud = w.data_ptr(), _p(wf), _p(wd), _p(uf), _p(ud)
-        d.Co, d.Ci, d.K = co, ci, k
+        d.Co, d.Ci, d.K, d.points = co, ci, k, pts
         outs.append((wf, wd, uf, ud))
     if weights:
         _chk(_lib.lib().da_repack_multi(arr, len(weights), _stream()), 'da_repack_multi')

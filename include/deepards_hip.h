@@ -73,11 +73,16 @@ int da_conv_gemm_multi(const da_conv_job* jobs, int n, da_stream_t stream);
    replaces nn.Conv1d(k=3, s=1, p=1) forward / input-grad, reference models/resnet.py:5-8,27-38, models/densenet.py:25-32 */
 int da_conv3_winograd(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
                       int accumulate, da_stream_t stream);
-/* tuning / tests: 0 = the partly filled last round of tiles is NOT cut into split-K half tiles */
+/* tuning / tests: 0 = the partly filled last round of tiles is NOT cut into split-K half tiles (1 = default);
+   2 / 3 = da_conv3_winograd4 with a K step of 32 / 16 (default) channels */
 int da_wino_debug_tail(int on);
 int da_wino_debug_pchunk(int pchunk);
 /* u[4][co][ci] (transpose = 0, forward) or u[4][ci][co] (transpose = 1, data gradient) from w[co][ci][3] */
 int da_wino_weights(const float* w, float* u, int co, int ci, int transpose, da_stream_t stream);
+/* Winograd F(4,3) variants (half the direct conv's MFMAs): u = 6 * N * C floats. */
+int da_conv3_winograd4(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
+                       int accumulate, da_stream_t stream);
+int da_wino4_weights(const float* w, float* u, int co, int ci, int transpose, da_stream_t stream);
 /* all weight-gradient GEMMs of a step in one launch per tile shape (jobs: HOST array); slabs only, reduce afterwards */
 typedef struct {
   const float* dy; const float* x; float* workspace;
@@ -95,8 +100,9 @@ int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumula
 
 /* torch [Co][Ci][K] -> Wf [K][Co][Ci] (forward) and Wd [K][Ci][Co] (data gradient). */
 int da_repack_conv_weight(const float* W, float* Wf, float* Wd, int Co, int Ci, int K, da_stream_t stream);
-/* Uf / Ud (K == 3 only, may be NULL): the Winograd taps of da_wino_weights for the forward / data gradient */
-typedef struct { const float* W; float* Wf; float* Wd; float* Uf; float* Ud; int Co, Ci, K; } da_repack_desc;
+/* Uf / Ud (K == 3 only, may be NULL): the Winograd taps of da_wino_weights (points != 6) or da_wino4_weights
+   (points == 6) for the forward / data gradient */
+typedef struct { const float* W; float* Wf; float* Wd; float* Uf; float* Ud; int Co, Ci, K; int points; } da_repack_desc;
 int da_repack_multi(const da_repack_desc* descs, int n, da_stream_t stream);
 
 /* ---- stem: Conv1d(1, C0, k7, s2, p3)  resnet.py:86-87,142 ; densenet.py:118-119 ----------- */

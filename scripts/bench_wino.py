@@ -25,5 +25,11 @@ for ci, co, L in ((64, 64, 56), (128, 128, 28), (256, 256, 14), (512, 512, 7), (
     err = (y - y2).abs().max().item() / y.abs().max().item()
     td = graph_time(lambda: H.conv_fwd(x, wf, 1, 1, out=y))
     tw = graph_time(lambda: H.conv3_winograd(x, u, out=y2))
+    u6 = H.wino_weights(w, points=6)
+    y3 = torch.empty_like(y)
+    H.conv3_winograd(x, u6, out=y3)
+    err4 = (y - y3).abs().max().item() / y.abs().max().item()
+    t4 = graph_time(lambda: H.conv3_winograd(x, u6, out=y3))
     fl = 2.0 * ROWS * L * ci * co * 3
+    print('   F(4,3) %7.1f us %6.1f TF(alg)  x%.2f vs F(2,3)  maxdiff %.1e' % (t4, fl / t4 / 1e6, tw / t4, err4))
     print('%4d->%4d L %2d  direct %7.1f us %6.1f TF | winograd %7.1f us %6.1f TF(alg)  x%.2f  maxdiff %.1e' % (ci, co, L, td, fl / td / 1e6, tw, fl / tw / 1e6, td / tw, err))

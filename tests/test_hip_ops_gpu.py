@@ -164,6 +164,42 @@ def test_conv3_winograd(H, ci, co, L, rows):
     close(ncl(bt), base + dx_ref, tol=4e-6, name='winograd dgrad+acc')
 
 
+@pytest.mark.parametrize('ksteps', [16, 32])
+@pytest.mark.parametrize('ci,co,L,rows', [(512, 512, 7, 40), (256, 256, 14, 40), (64, 64, 56, 20), (128, 32, 9, 5),
+                                          (32, 32, 1, 7), (32, 64, 2, 33), (32, 32, 3, 4), (64, 32, 5, 9),
+                                          (512, 512, 7, 300), (64, 64, 57, 300), (96, 64, 6, 1040)])
+def test_conv3_winograd_f43(H, ci, co, L, rows, ksteps):
+    """Winograd F(4,3) (six contractions per output quad): taps (stand-alone kernel and batched repack), forward, data
+    gradient and accumulate form vs the oracle, lengths that leave 1, 2 or 3 outputs in the last quad, launches whose
+    last round runs as half tiles; both K-step variants of the kernel."""
+    from deepards_amd import _lib
+    _lib.lib().da_wino_debug_tail(3 if ksteps == 16 else 2)
+    try:
+        rng = np.random.default_rng(ci + co + L + rows)
+        x = rng.standard_normal((rows, ci, L))
+        w = rng.standard_normal((co, ci, 3)) * np.sqrt(2.0 / (3 * co))
+        y_ref = np_ref.conv1d_fwd(x, w, 1, 1)
+        dy = rng.standard_normal(y_ref.shape)
+        dx_ref, _ = np_ref.conv1d_bwd(x, w, dy, 1, 1)
+        xt, wt, dyt = rlc(x), cu(w), rlc(dy)
+        uf, ud = H.wino_weights(wt, points=6), H.wino_weights(wt, transpose=True, points=6)
+        g0, g1, g2 = (w.astype(np.float32).astype(np.float64)[:, :, t] for t in range(3))
+        taps = lambda a, b, c: np.stack([a / 4, -(a + b + c) / 6, -(a - b + c) / 6, a / 24 + b / 12 + c / 6,
+                                         a / 24 - b / 12 + c / 6, c])
+        close(uf.cpu().numpy(), taps(g0, g1, g2), tol=1e-6, name='F(4,3) taps fwd')
+        close(ud.cpu().numpy(), taps(g2.T, g1.T, g0.T), tol=1e-6, name='F(4,3) taps dgrad')
+        (wf2, wd2, uf2, ud2), = H.repack_multi([wt], [6])
+        assert wf2 is None and wd2 is None and torch.equal(uf2, uf) and torch.equal(ud2, ud)
+        close(ncl(H.conv3_winograd(xt, uf)), y_ref, tol=2e-5, name='F(4,3) fwd')
+        close(ncl(H.conv3_winograd(dyt, ud)), dx_ref, tol=2e-5, name='F(4,3) dgrad')
+        base = rng.standard_normal(dx_ref.shape)
+        bt = rlc(base)
+        H.conv3_winograd(dyt, ud, out=bt, accumulate=True)
+        close(ncl(bt), base + dx_ref, tol=2e-5, name='F(4,3) dgrad+acc')
+    finally:
+        _lib.lib().da_wino_debug_tail(3)
+
+
 @pytest.mark.parametrize('ci,co,L,rows', [(64, 128, 56, 40), (128, 256, 28, 23), (256, 512, 14, 300), (64, 128, 56, 300)])
 def test_stride2_block_head_shared_launches(H, ci, co, L, rows):
     """The k3 s2 p1 conv and the k1 s2 downsample of a block: forward pair in one launch (da_conv_gemm_multi), the
