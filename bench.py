@@ -178,11 +178,20 @@ def main():
         raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the product path')
+    # DA_BENCH_REHEARSE=gloo: rehearsal of the N > 1 launch on a box with fewer GPUs than ranks (ranks share the
+    # cards, gradients travel through gloo's host staging).  Exercises rendezvous, sharding, the barrier-bracketed
+    # timing and the max over ranks; its throughput means nothing and the JSON line says so.
+    rehearse = os.environ.get('DA_BENCH_REHEARSE', '') == 'gloo'
+    if rehearse:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from deepards_amd import _lib
     lib = _lib.lib()                                     # fail loudly if the HIP library is missing
@@ -247,6 +256,8 @@ def main():
                    'hipgraph': not args.no_graph},
         'final_loss': round(loss, 6),
     }
+    if rehearse:
+        out['rehearsal'] = 'gloo: %d ranks sharing %d GPU(s); throughput is NOT a measurement' % (world, torch.cuda.device_count())
     step_flops = w['flops'] * B * 20
     step_bytes = (w['act_bytes'] * B * 20) + 8 * 4 * w['params']
     per_gpu_dt = dt / args.steps

@@ -461,7 +461,10 @@ __device__ __forceinline__ void conv3_wino4k_body(const WinoArgs& a, const int t
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntn = a.N >> 5;
   const int Q0 = (tile / ntn) * 64 + (MINI ? 32 * sub : 0), n_blk = (tile % ntn) * 32;
-  const int lr = tid >> 2, lq = tid & 3;
+  // loader rows: ds_write_b128 is served 8 lanes at a time on 32 banks, and with 5 slots a row two NEIGHBOURING rows
+  // overlap in one bank group; rows 4 apart do not, so lanes 4..7 of every 8 take the row 4 below lanes 0..3
+  const int lm = tid >> 3;
+  const int lr = (lm >> 2) * 8 + (lm & 3) + 4 * ((tid >> 2) & 1), lq = tid & 3;
   const int QL = a.PL;
 
   constexpr int NP = MINI ? 2 : 4, NA = NP + 1;
