@@ -1,6 +1,6 @@
 """Debug: per-block gradient comparison HIP vs torch CPU fp64 (resnet18, golden b2 input)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import torch.nn.functional as F
 from oracle.weights import seeded_params, seeded_batch

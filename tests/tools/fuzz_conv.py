@@ -1,7 +1,7 @@
 """Randomised shape fuzz of the conv kernels (not part of the test suite): Winograd forward / data gradient / weight
 gradient and the shared-launch forms against the direct kernels and, on small cases, the numpy oracle."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from deepards_amd import hip_ops as H
 from oracle import np_ref
@@ -20,6 +20,13 @@ for case in range(n_cases):
     dx_d = H.conv_dgrad(dy, wd, 1, 1, L); dx_w = H.conv3_winograd(dy, ud)
     sc = lambda a: float(a.abs().max()) + 1e-12
     e1 = float((y_d - y_w).abs().max()) / sc(y_d); e2 = float((dx_d - dx_w).abs().max()) / sc(dx_d)
+    (_, _, uf6, ud6), = H.repack_multi([w], [6])                     # F(4,3): both K-step variants of the kernel
+    from deepards_amd import _lib
+    _lib.lib().da_wino_debug_tail(2 + case % 2)
+    e1 = max(e1, float((y_d - H.conv3_winograd(x, uf6)).abs().max()) / sc(y_d))
+    base = torch.randn_like(dx_d); acc = base.clone(); H.conv3_winograd(dy, ud6, out=acc, accumulate=True)
+    e2 = max(e2, float((dx_d + base - acc).abs().max()) / sc(dx_d))
+    _lib.lib().da_wino_debug_tail(3)
     try:          # the direct weight-gradient kernels exist for the tile pairs the networks need, not for every (co, ci)
         dw_d = H.conv_wgrad(dy, x, 3, 1, 1)
         slabs = H.conv_wgrad_multi([(dy, x, 3, 1, 1)])

@@ -1,7 +1,7 @@
 """Ad-hoc robustness sweep: whole-model forward/backward at many batch sizes, fast paths (Winograd, tail tiles, paired
 launches, fused BN) vs the plain direct kernels (subprocess with the switches off): logits and gradients must agree."""
 import os, sys, subprocess, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 if len(sys.argv) > 1 and sys.argv[1] == 'child':
     import numpy as np, torch
     import deepards_amd.models as M
