@@ -26,6 +26,16 @@ class DeviceTileStore(object):
         self.mu, self.std = float(mu), float(std)
         self.kfold_indexes = None                     # absolute indices of the current fold (dataset.py:765-772)
 
+    @classmethod
+    def with_derived_scaling(cls, windows, targets, indices=None, device='cuda'):
+        """Store whose (mu, std) are derived from the windows `indices` (the train fold; None: all) the way
+        ``derive_scaling_factors`` / ``_get_scaling_factors_for_indices`` do (dataset.py:627-673)."""
+        from .tiles import scaling_factors_for_indices
+        mu, std = scaling_factors_for_indices(windows, indices)
+        if mu.shape != (1,):
+            raise ValueError('the tile store holds one-channel flow windows')
+        return cls(windows, targets, float(mu[0]), float(std[0]), device=device)
+
     def __len__(self):
         return self.tiles.shape[0] if self.kfold_indexes is None else len(self.kfold_indexes)
 

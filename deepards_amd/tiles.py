@@ -1,0 +1,122 @@
+"""Host-side tile forming and scaling factors -- ingest-time numpy, no GPU work.
+
+What a "(sub_batch, 1, seq_len) waveform tile" is in the ``unpadded_centered_sequences`` dataset
+(reference deepards/dataset.py:1021-1081 ``get_unpadded_sequences_dataset`` with the processing function
+``_unpadded_centered_processing`` :1279-1288 and the frame filter ``_should_we_drop_frame`` :1308-1321):
+
+* whole breaths (50 Hz flow samples) are concatenated into a row until the row holds ``seq_len`` samples; the breath
+  that crosses the boundary is truncated, THE REST OF IT IS DISCARDED, and the next row starts with the next breath;
+* breaths shorter than 21 samples are skipped (:1044-1045);
+* ``n_sub_batches`` consecutive rows make one window ``(NB, 1, seq_len)``; the window is dropped when the ventilator
+  breath numbers of the breaths that went into it have more than ``int(NB * 0.5)`` gaps in total (unless the gap is
+  the 16-bit counter wrapping), and the collection restarts empty either way;
+* a new patient restarts the row and the window.
+
+``scaling_factors_for_indices`` restates ``_get_scaling_factors_for_indices`` (:627-649): per-channel mean and
+POPULATION standard deviation over the chosen windows, float64, two passes (the second pass centres on the first's
+mean).  The reference broadcasts both to (NB, C, seq_len) arrays; ``DeviceTileStore`` keeps the per-channel scalars
+and folds ``(x - mu) / std`` into the batch gather.
+
+Neither function is pinned by a reference fixture: ``dataset.py`` does not import here (ventmap, imblearn, ...), and
+``tests/test_dataset.pkl`` holds finished windows and the TRAIN fold's factors, not the raw breaths -- parity unpinned;
+the tests pin the rules above on hand-built breaths.
+"""
+import numpy as np
+
+MIN_BREATH_SAMPLES = 21          # dataset.py:1044
+VENT_BN_FRAC_MISSING = 0.5       # dataset.py:393
+
+
+def scaling_factors_for_indices(windows, indices=None):
+    """windows: (N, NB, C, L) array-like (or a list of (NB, C, L) arrays); indices: the windows of the fold (None: all).
+    Returns (mu, std) as float64 arrays of shape (C,) -- dataset.py:627-649."""
+    idx = list(range(len(windows)) if indices is None else indices)
+    if not idx:
+        raise ValueError('no windows to derive scaling factors from')
+    chans = np.asarray(windows[idx[0]]).shape[1]
+    mean_sum = np.zeros(chans, dtype=np.float64)
+    std_sum = np.zeros(chans, dtype=np.float64)
+    obs_count = 0
+    for i in idx:
+        obs = np.asarray(windows[i], dtype=np.float64)
+        obs_count += obs.shape[0] * obs.shape[-1]
+        mean_sum += obs.sum(axis=-1).sum(axis=0)
+    mu = mean_sum / obs_count
+    for i in idx:
+        obs = np.asarray(windows[i], dtype=np.float64)
+        std_sum += ((obs - mu.reshape(1, chans, 1)) ** 2).sum(axis=-1).sum(axis=0)
+    return mu, np.sqrt(std_sum / obs_count)
+
+
+def should_drop_frame(seq_vent_bns, n_sub_batches, frac_missing=VENT_BN_FRAC_MISSING):
+    """The vent-BN continuity rule of ``_should_we_drop_frame`` (:1308-1321; the optional autocorrelation filter
+    ``drop_if_under_r2`` is off by default and not restated)."""
+    bns = np.asarray(seq_vent_bns)
+    if bns.size < 2:
+        return False
+    missing = int(np.abs(bns[:-1] + 1 - bns[1:]).sum())
+    thresh = int(n_sub_batches * frac_missing)
+    if missing > thresh and not abs(missing - 2 ** 16) <= thresh:
+        return True
+    return False
+
+
+class UnpaddedCenteredTiler(object):
+    """Streams breaths of ONE patient at a time into ``(NB, 1, seq_len)`` float64 windows.
+
+    ``add_breath(flow, vent_bn, seq_hour)`` returns a finished window ``(window, hours)`` or None; ``new_patient()``
+    forgets the partial row / window (dataset.py:1028-1035).  ``frames_dropped`` counts the windows the vent-BN rule
+    rejected."""
+
+    def __init__(self, n_sub_batches=20, seq_len=224):
+        self.n_sub_batches, self.seq_len = int(n_sub_batches), int(seq_len)
+        self.frames_dropped = 0
+        self.new_patient()
+
+    def new_patient(self):
+        self.batch_arr, self.breath_arr, self.seq_vent_bns, self.batch_seq_hours = [], [], [], []
+
+    def _process(self, flow, seq_hour):
+        # _unpadded_centered_processing, dataset.py:1279-1288
+        if len(flow) + len(self.breath_arr) < self.seq_len:
+            self.breath_arr.extend(flow)
+        else:
+            remaining = self.seq_len - len(self.breath_arr)
+            self.breath_arr.extend(flow[:remaining])
+            self.batch_arr.append(np.array(self.breath_arr, dtype=np.float64))
+            self.batch_seq_hours.append(seq_hour)
+            self.breath_arr = []
+
+    def add_breath(self, flow, vent_bn, seq_hour=0.0):
+        flow = list(flow)
+        if len(flow) < MIN_BREATH_SAMPLES:
+            return None
+        self.seq_vent_bns.append(vent_bn)
+        self._process(flow, seq_hour)
+        out = None
+        if len(self.batch_arr) == self.n_sub_batches:
+            raw = np.array(self.batch_arr)
+            drop = should_drop_frame(self.seq_vent_bns, self.n_sub_batches)
+            hours = self.batch_seq_hours
+            self.batch_arr, self.seq_vent_bns, self.batch_seq_hours = [], [], []
+            if drop:
+                self.frames_dropped += 1
+                self.breath_arr = []
+                return None
+            out = (raw.reshape(self.n_sub_batches, 1, self.seq_len), hours)
+        if len(self.batch_arr) > 0 and self.breath_arr == []:      # dataset.py:1080-1081
+            self.batch_seq_hours.append(seq_hour)
+        return out
+
+
+def tile_patient(breaths, n_sub_batches=20, seq_len=224):
+    """breaths: iterable of (flow, vent_bn) or (flow, vent_bn, seq_hour) of one patient, in time order.
+    Returns (windows (W, NB, 1, seq_len) float64, frames_dropped)."""
+    t = UnpaddedCenteredTiler(n_sub_batches, seq_len)
+    wins = []
+    for b in breaths:
+        r = t.add_breath(*b)
+        if r is not None:
+            wins.append(r[0])
+    w = np.stack(wins) if wins else np.zeros((0, n_sub_batches, 1, seq_len))
+    return w, t.frames_dropped

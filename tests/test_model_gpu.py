@@ -443,6 +443,25 @@ def test_device_tile_store_matches_reference_getitem():
     assert sizes == [2, 2] and len(store) == 5          # the odd last batch of 1 is clipped away
 
 
+def test_device_tile_store_from_tiled_breaths_with_derived_scaling():
+    """Ingest path end to end: breaths -> (20, 1, 224) windows (deepards_amd.tiles, dataset.py:1021-1081) -> store whose
+    factors come from the train fold (dataset.py:627-649) -> batches == float64 (x - mu) / std cast to float32."""
+    from deepards_amd.data import DeviceTileStore
+    from deepards_amd.tiles import tile_patient, scaling_factors_for_indices
+    rng = np.random.default_rng(3)
+    wins = np.concatenate([tile_patient([(rng.standard_normal(int(rng.integers(60, 220))) * 25 + 2, i)
+                                         for i in range(150)])[0] for _ in range(3)])
+    tg = np.eye(2, dtype=np.float32)[rng.integers(0, 2, len(wins))]
+    train = list(range(0, len(wins), 2))
+    store = DeviceTileStore.with_derived_scaling(wins, tg, train)
+    mu, std = scaling_factors_for_indices(wins, train)
+    assert store.mu == mu[0] and store.std == std[0]
+    x, t = store.batch([1, 0, len(wins) - 1])
+    ref = ((wins - mu[0]) / std[0]).astype(np.float32)
+    assert np.array_equal(x.cpu().numpy(), ref[[1, 0, len(wins) - 1]])
+    assert np.array_equal(t.cpu().numpy(), tg[[1, 0, len(wins) - 1]])
+
+
 def test_test_step_graph_replay_matches_eager(M):
     """test_step captured per batch shape (packs once per step, batched small kernels) == the eager form, bit for
     bit, including the BatchNorm running statistics a train-mode forward moves (run_test_epoch never calls eval())."""
