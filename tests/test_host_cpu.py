@@ -165,3 +165,27 @@ def test_data_parallel_gloo_world2_matches_full_batch():
     full = np_ref.cnn_linear_forward_backward(params64, x.astype(np.float64), t.astype(np.float64), backbone='densenet18')
     ref = np.concatenate([full['grads'][n].ravel() for n in names])
     assert np.abs(g0 - ref).max() < 1e-6 * (1 + np.abs(ref).max())
+
+
+def test_driver_mirror_names_and_no_cpu_path():
+    """deepards_amd.train_ards_detector keeps the reference driver's names (train_ards_detector.py:45-69, 73-512,
+    925-939, 1410-1436) and refuses to run without a GPU."""
+    from deepards_amd import train_ards_detector as T
+    assert set(T.network_map) <= {'cnn_lstm', 'cnn_linear', 'cnn_double_linear', 'cnn_single_breath_linear',
+                                  'cnn_linear_compr_to_rf', 'cnn_linear_to_mean'}
+    assert T.network_map['cnn_linear'] is T.CNNLinearModel and 'resnet18' in T.base_networks
+    for name in ('run_train_epoch', 'handle_train_optimization', 'get_splits', 'train_and_test', 'get_base_network',
+                 'get_optimizer', 'run_test_epoch', 'get_model', 'clip_odd_batch_sizes', 'set_loss_criterion',
+                 'calc_loss', 'get_network', '_process_test_batch_results'):
+        assert callable(getattr(T.CNNLinearModel, name)), name
+    args = T.make_args()
+    assert (args.network, args.base_network, args.batch_size, args.optimizer, args.learning_rate, args.n_sub_batches,
+            args.weight_decay, args.clip_val, args.epochs) == ('cnn_linear', 'densenet18', 16, 'sgd', 0.001, 20, 0.0001,
+                                                               0.01, 10)                      # defaults.yml
+    with pytest.raises(TypeError):
+        T.make_args(not_an_argument=1)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        T.CNNLinearModel(T.make_args(cuda=False))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            T.CNNLinearModel(T.make_args())

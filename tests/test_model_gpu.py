@@ -617,3 +617,41 @@ def test_data_parallel_step_structure_on_one_gpu(M):
         FlatBucket.allreduce = orig
     for (n, p), (_, q) in zip(ref_model.named_parameters(), dp_model.named_parameters()):
         assert torch.equal(p, q), n
+
+
+def test_driver_mirror_train_and_test_on_the_fixture():
+    """``network_map[args.network](args).train_and_test()`` (train_ards_detector.py:1589-1590) on the reference
+    fixture's windows == the same epochs driven by hand through HotPathTrainer, loss for loss, and a test epoch whose
+    patient votes add up."""
+    from deepards_amd import train_ards_detector as T
+    from deepards_amd.data import DeviceTileStore
+    from deepards_amd.train import HotPathTrainer, run_train_epoch_from_store
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'test_dataset_windows.npz'))
+    mk = lambda: DeviceTileStore(z['x'], z['target'], float(z['mu']), float(z['std']))
+    slot = torch.from_numpy(z['patient_slot'].astype(np.int64)) if 'patient_slot' in z.files else \
+        torch.arange(20, dtype=torch.int64) % 6
+    args = T.make_args(base_network='resnet18', epochs=2, batch_size=4, clip_grad=True, seed=5, train_store=mk(),
+                       test_store=mk(), test_patient_slot=slot)
+    cls = T.network_map[args.network](args)
+    res = cls.train_and_test()
+    got = res.get_meter('loss', 0)
+    assert len(got) == 10 and all(np.isfinite(got))                 # 2 epochs x 5 batches of 4 windows
+    # by hand: same seed -> same init, same shuffles
+    torch.manual_seed(5)
+    import deepards_amd.models as M
+    model = M.CNNLinearNetwork(M.resnet18(initial_planes=64, first_pool_type='max', double_conv_first=False), 20, 0).cuda()
+    tr = HotPathTrainer(model, optimizer='sgd', learning_rate=0.001, weight_decay=0.0001, clip_grad=True, clip_val=0.01)
+    store, want = mk(), []
+    for epoch in (1, 2):
+        g = torch.Generator().manual_seed(5 + epoch)
+        want += [float(l) for l in run_train_epoch_from_store(tr, store, batch_size=4, shuffle=True, generator=g)]
+    assert got == want
+    for (_, p), (_, q) in zip(cls.model.named_parameters(), model.named_parameters()):
+        assert torch.equal(p, q)
+    r = res.patient_results[(0, 2)]
+    assert r['votes'].sum() == 20 and r['votes'].shape == (int(slot.max()) + 1, 2) and np.isfinite(r['mean_loss'])
+    assert len(cls.preds) == 20 and sorted(cls.pred_idx) == list(range(20))
+    # eager-style entry point of the batch loop
+    x, t = store.batch([0, 1])
+    l = cls.handle_train_optimization(cls.optimizer, None, t, x, 0, 1, 0, 3, cls.model)
+    assert np.isfinite(float(l)) and len(res.get_meter('loss_epoch_3', 0)) == 1
