@@ -326,7 +326,13 @@ def run_test_epoch(trainer, store, patient_slot, batch_size=16):
         gidx = idx.to(dev)
         if store.kfold_indexes is not None:
             gidx = store.kfold_indexes[gidx]
-        preds.append(H.vote_counts(logits, slot[gidx], votes))
+        grp = slot[gidx]
+        if logits.dim() == 3:                       # per-breath heads: every breath votes for its window's patient
+            nb = logits.shape[1]                    # (PerBreathClassifierMixin, train_ards_detector.py:548-555)
+            grp = grp.repeat_interleave(nb)
+            idx = idx.repeat_interleave(nb)
+            logits = logits.reshape(-1, 2)
+        preds.append(H.vote_counts(logits.contiguous(), grp, votes))
         losses.append(loss.reshape(1).clone())      # static graph output: copy before the next replay
         order.append(idx)
     v = votes.cpu().numpy()

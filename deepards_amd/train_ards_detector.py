@@ -252,8 +252,33 @@ class CNNLinearComprToRFModel(CNNLinearModel):
         return M.CNNLinearComprToRF(base_network)
 
 
+class PerBreathClassifierMixin(object):
+    """:539-555: the window target repeated over the breaths for the loss (the trainer's step does that for (B, NB, 2)
+    outputs), one prediction and one patient vote per breath."""
+
+    def calc_loss(self, outputs, target, inputs):
+        if self.args.batch_size > 1:
+            target = target.unsqueeze(1)
+        return self.criterion(outputs, target.repeat((1, outputs.shape[1], 1)))
+
+    def _process_test_batch_results(self, outputs, target, inputs, fold_num):
+        return outputs.argmax(dim=-1).cpu().view(-1).tolist()
+
+    def transform_obs_idx(self, obs_idx, outputs):
+        return obs_idx.reshape((outputs.shape[0], 1)).repeat((1, outputs.shape[1])).view(-1)
+
+
+class CNNSingleBreathLinearModel(PerBreathClassifierMixin, BaseTraining, PatientClassifierMixin):
+    def __init__(self, args):
+        super(CNNSingleBreathLinearModel, self).__init__(args)
+
+    def get_network(self, base_network):
+        return M.CNNSingleBreathLinearNetwork(base_network)
+
+
 network_map = {
     'cnn_linear': CNNLinearModel,
+    'cnn_single_breath_linear': CNNSingleBreathLinearModel,
     'cnn_double_linear': CNNDoubleLinearModel,
     'cnn_linear_to_mean': CNNLinearToMeanModel,
     'cnn_linear_compr_to_rf': CNNLinearComprToRFModel,
