@@ -1,0 +1,200 @@
+// k3 stride-1 pad-1 Conv1d forward / data gradient with bf16 matrix arithmetic (BASELINE config C3: "resnet18-1D ...
+// bf16"): replaces the same nn.Conv1d calls as conv_wino.hip (reference models/resnet.py:5-8,27-38) when the host
+// selects dtype bf16.  Activations stay fp32 in HBM; they are rounded to bf16 (round-to-nearest-even,
+// v_cvt_pk_bf16_f32) while being staged into LDS, the weights come pre-packed in bf16 (da_pack_conv3_bf16), products
+// run on v_mfma_f32_32x32x16_bf16 and accumulate in fp32; the output is fp32.  Direct 3-tap form (no Winograd: at the
+// bf16 matrix rate the kernel is bound by the LDS / load path, not by multiplies).
+//
+// GEMM rows are flat positions P = row * L + l, so a tile's input panel is the contiguous range P0-1 .. P0+TM of
+// positions; a tap that would cross a sequence edge (l = 0 with tap 0, l = L-1 with tap 2) is zeroed on the A
+// fragment.  Block = 128 positions x 64 output channels, 4 waves of 64 x 32 (two 32x32 accumulators); K step = 32
+// channels: X panel [130][32] and W panel [3][64][32] in bf16 with an 80-byte row pitch (5 16-byte slots: 16 rows of
+// one k group, in the lane groups ds_read_b128 is served in, fall on 16 different slots mod 16).
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+struct ConvBf16Args {
+  const float* x;       // [M][ldx] fp32, first C channels
+  const __bf16* w;      // [3][N][C] bf16 taps
+  float* y;             // [M][ldy] fp32, first N channels
+  int M, L, ldx, C, ldy, N, accumulate;
+  FastDiv divL;
+};
+
+#define CB_TM 128
+#define CB_TN 64
+#define CB_PITCH 80                                   // bytes per LDS row (64 data + 16 pad)
+#define CB_XROWS (CB_TM + 2)
+#define CB_LDS_BYTES ((CB_XROWS + 3 * CB_TN) * CB_PITCH)
+
+__device__ __forceinline__ f32x2v cvt4_bf16(const f32x4& v) {       // 4 bf16 (nearest-even) as the bits of 2 floats
+  const f32x2v lo = {v[0], v[1]}, hi = {v[2], v[3]};
+  const bf16x2 a = __builtin_convertvector(lo, bf16x2), b = __builtin_convertvector(hi, bf16x2);
+  return f32x2v{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)};
+}
+
+__global__ __launch_bounds__(256) void conv3_bf16_kernel(ConvBf16Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[CB_LDS_BYTES];
+  unsigned char* Xs = lds;                            // [130][80 B]: positions P0-1 .. P0+128
+  unsigned char* Ws = lds + CB_XROWS * CB_PITCH;      // [3][64][80 B]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntn = a.N / CB_TN;
+  const int tile = blockIdx.x;
+  const int P0 = (tile / ntn) * CB_TM, n_blk = (tile % ntn) * CB_TN;
+
+  // X loader: 32 rows x 8 channel quads per pass; lanes 8..15 of every 16 take the row 4 below lanes 0..7 so that a
+  // ds_write_b64 group (16 lanes on 32 banks) covers 16 different 8-byte slots
+  const int xm = tid >> 4, xq = tid & 7;
+  const int xrow = (xm >> 2) * 8 + (xm & 3) + 4 * ((tid >> 3) & 1);
+  constexpr int NXP = (CB_XROWS + 31) / 32;           // 5 passes, the last one 2 rows
+  long xoff[NXP];
+  bool xok[NXP];
+#pragma unroll
+  for (int p = 0; p < NXP; ++p) {
+    const int r = p * 32 + xrow;
+    const long P = (long)P0 - 1 + r;
+    xok[p] = r < CB_XROWS && P >= 0 && P < a.M;
+    xoff[p] = (xok[p] ? P : 0) * a.ldx + xq * 4;
+  }
+  // W loader: 64 rows x 4 slots of 8 channels per pass (rows 4 apart per 8 lanes: ds_write_b128), 3 passes = 3 taps
+  const int wm_ = tid >> 3, ws = tid & 3;
+  const int wrow = (wm_ >> 2) * 8 + (wm_ & 3) + 4 * ((tid >> 2) & 1);
+  const __bf16* wsrc = a.w + (size_t)(n_blk + wrow) * a.C + ws * 8;
+  const size_t wtap = (size_t)a.N * a.C;
+
+  f32x4 rx[NXP];
+  f32x4 rw[3];                                        // 8 bf16 each, as bits
+  auto gload = [&](int ks) {
+    const int c0 = ks << 5;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) rw[t] = *reinterpret_cast<const f32x4*>(wsrc + t * wtap + c0);
+#pragma unroll
+    for (int p = 0; p < NXP; ++p) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (xok[p]) v = *reinterpret_cast<const f32x4*>(a.x + xoff[p] + c0);
+      rx[p] = v;
+    }
+  };
+
+  // fragment geometry (32x32x16: lane = (row l%32, k group l/32 of 8 channels))
+  const int frow = lane & 31, kg = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  bool at_first[2], at_last[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const long P = (long)P0 + wm * 64 + mt * 32 + frow;
+    const uint32_t Pc = (uint32_t)(P < a.M ? P : 0);
+    const int l = (int)(Pc - fdiv(Pc, a.divL) * (uint32_t)a.L);
+    at_first[mt] = l == 0;
+    at_last[mt] = l == a.L - 1;
+  }
+  const unsigned char* xfrag = Xs + (wm * 64 + frow) * CB_PITCH + kg * 16;
+  const unsigned char* wfrag = Ws + (wn * 32 + frow) * CB_PITCH + kg * 16;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  const int kc = a.C >> 5;
+  gload(0);
+  for (int ks = 0; ks < kc; ++ks) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NXP; ++p) {
+      const int r = p * 32 + xrow;
+      if (r < CB_XROWS) *reinterpret_cast<f32x2v*>(Xs + r * CB_PITCH + xq * 8) = cvt4_bf16(rx[p]);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) *reinterpret_cast<f32x4*>(Ws + (t * CB_TN + wrow) * CB_PITCH + ws * 16) = rw[t];
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < kc) gload(ks + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(wfrag + t * CB_TN * CB_PITCH + kk * 32);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          f32x4 av = *reinterpret_cast<const f32x4*>(xfrag + (mt * 32 + t) * CB_PITCH + kk * 32);   // 8 bf16 as bits
+          if ((t == 0 && at_first[mt]) || (t == 2 && at_last[mt])) av = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b, acc[mt], 0, 0, 0);
+        }
+      }
+  }
+
+  // lane holds output channel n_blk + wn*32 + l%32 of the positions (r & 3) + 8 (r >> 2) + 4 (l / 32) of each 32-row tile
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long P = (long)P0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      if (P < a.M) {
+        float* o = a.y + P * a.ldy + n_blk + wn * 32 + frow;
+        float v = acc[mt][r];
+        if (a.accumulate) v += *o;
+        *o = v;
+      }
+    }
+}
+
+// wf[t][co][ci] = bf16(w[co][ci][t]) (forward taps), wd[t][ci][co] = bf16(w[co][ci][2 - t]) (data-gradient taps)
+__global__ __launch_bounds__(256) void pack_conv3_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wf,
+                                                              __bf16* __restrict__ wd, int co, int ci) {
+  const size_t total = (size_t)co * ci;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int o = (int)(idx / ci), i = (int)(idx - (size_t)o * ci);
+  const float* src = w + idx * 3;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const __bf16 v = (__bf16)src[t];
+    if (wf) wf[(size_t)t * total + idx] = v;
+    if (wd) wd[(size_t)(2 - t) * total + (size_t)i * co + o] = v;
+  }
+}
+
+extern "C" {
+
+// y (+)= conv1d(x, k = 3, stride 1, pad 1) per row of L positions, bf16 products / fp32 sums.  x: [rows][L][ldx] fp32
+// (first C channels), wpk: [3][N][C] bf16 from da_pack_conv3_bf16, y: [rows][L][ldy] fp32 (first N channels).
+// C % 32 == 0, N % 64 == 0.  replaces reference models/resnet.py:5-8 (conv2x2) under dtype bf16
+int da_conv3_bf16(const float* x, const void* wpk, float* y, int rows, int L, int ldx, int C, int ldy, int N,
+                  int accumulate, hipStream_t stream) {
+  DA_ENTER();
+  if (!x || !wpk || !y || rows < 0 || L < 1 || C % 32 || N % CB_TN || C < 32 || N < CB_TN || ldx % 4 || ldx < C || ldy < N)
+    return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  const long M = (long)rows * L;
+  if (M >= 0x7fffffffl) return DA_EINVAL;
+  ConvBf16Args a;
+  a.x = x; a.w = reinterpret_cast<const __bf16*>(wpk); a.y = y;
+  a.M = (int)M; a.L = L; a.ldx = ldx; a.C = C; a.ldy = ldy; a.N = N; a.accumulate = accumulate;
+  a.divL = make_fastdiv((uint32_t)L);
+  const long tiles = ((M + CB_TM - 1) / CB_TM) * (N / CB_TN);
+  if (tiles > 0x7fffffffl) return DA_EINVAL;
+  hipLaunchKernelGGL(conv3_bf16_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, a);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// bf16 tap packs of one (Co, Ci, 3) fp32 conv weight: wf [3][Co][Ci] (forward), wd [3][Ci][Co] (data gradient; taps
+// reversed); either may be NULL.  Round-to-nearest-even.
+int da_pack_conv3_bf16(const float* w, void* wf, void* wd, int co, int ci, hipStream_t stream) {
+  DA_ENTER();
+  if (!w || (!wf && !wd) || co < 1 || ci < 1) return DA_EINVAL;
+  const size_t total = (size_t)co * ci;
+  hipLaunchKernelGGL(pack_conv3_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w,
+                     reinterpret_cast<__bf16*>(wf), reinterpret_cast<__bf16*>(wd), co, ci);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+}  // extern "C"

@@ -118,6 +118,36 @@ def conv3_winograd(x, u, out=None, accumulate=False):
     return out
 
 
+def pack_conv3_bf16(w):
+    """(Co, Ci, 3) fp32 conv weight -> (wf (3, Co, Ci), wd (3, Ci, Co)) bf16 tap packs for conv3_bf16."""
+    _f32(w, 'w')
+    co, ci, k = w.shape
+    if k != 3:
+        raise ValueError('pack_conv3_bf16: (Co, Ci, 3) weight expected')
+    wf = torch.empty((3, co, ci), device=w.device, dtype=torch.bfloat16)
+    wd = torch.empty((3, ci, co), device=w.device, dtype=torch.bfloat16)
+    _chk(_lib.lib().da_pack_conv3_bf16(_p(w), _p(wf), _p(wd), co, ci, _stream()), 'da_pack_conv3_bf16')
+    return wf, wd
+
+
+def conv3_bf16(x, wpk, out=None, accumulate=False):
+    """k3 s1 p1 conv of x (rows, L, C) fp32 with bf16 taps wpk (3, N, C): bf16 products, fp32 sums -> (rows, L, N)."""
+    _rlc(x, 'x')
+    rows, l, c = x.shape
+    three, n, c2 = wpk.shape
+    if three != 3 or c2 != c or c % 32 or n % 64 or wpk.dtype != torch.bfloat16 or not wpk.is_contiguous():
+        raise ValueError('conv3_bf16: unsupported shape x%s w%s' % (tuple(x.shape), tuple(wpk.shape)))
+    if out is None:
+        if accumulate:
+            raise ValueError('accumulate needs out')
+        out = torch.empty((rows, l, n), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (rows, l, n):
+        raise ValueError('conv3_bf16: bad out shape')
+    _chk(_lib.lib().da_conv3_bf16(_p(x), _p(wpk), _p(out), rows, l, c, c, n, n, 1 if accumulate else 0, _stream()),
+         'da_conv3_bf16')
+    return out
+
+
 def conv_dgrad(dy, wd, stride, pad, l_in, out=None, accumulate=False):
     """dy (rows,Lo,Co), wd packed (K,Ci,Co) -> dx (rows,l_in,Ci).  With accumulate the result is
     added into `out`; positions no tap reaches are left untouched (accumulate) or zeroed."""

@@ -83,6 +83,15 @@ int da_wino_weights(const float* w, float* u, int co, int ci, int transpose, da_
 int da_conv3_winograd4(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
                        int accumulate, da_stream_t stream);
 int da_wino4_weights(const float* w, float* u, int co, int ci, int transpose, da_stream_t stream);
+
+/* ---- bf16 matrix arithmetic for the k3 s1 p1 convs (BASELINE config C3) ----------------------
+ * same nn.Conv1d calls as da_conv3_winograd (resnet.py:5-8,27-38): fp32 activations in and out, rounded to bf16
+ * (nearest-even) on the way into LDS, bf16 taps wpk [3][N][C] from da_pack_conv3_bf16, v_mfma_f32_32x32x16_bf16 with
+ * fp32 accumulation.  C % 32 == 0, N % 64 == 0.  wf [3][Co][Ci] forward taps, wd [3][Ci][Co] data-gradient taps
+ * (reversed); either may be NULL. */
+int da_conv3_bf16(const float* x, const void* wpk, float* y, int rows, int L, int ldx, int C, int ldy, int N,
+                  int accumulate, da_stream_t stream);
+int da_pack_conv3_bf16(const float* w, void* wf, void* wd, int co, int ci, da_stream_t stream);
 /* all weight-gradient GEMMs of a step in one launch per tile shape (jobs: HOST array); slabs only, reduce afterwards */
 typedef struct {
   const float* dy; const float* x; float* workspace;
