@@ -31,6 +31,7 @@ WORK = {
     'densenet18': dict(flops=33.404e6, act_bytes=1052.8e3, params=214850),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), headline sparsity figure NOT used
 PEAK_HBM_GBS = 8000.0
 
 
@@ -46,6 +47,9 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary densenet18 measurement')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help="arithmetic of the k3 s1 convs' forward / data gradient: f32 (the headline, BASELINE configs[1]) or "
+                         "bf16 operands with fp32 sums (BASELINE configs[2])")
     return ap.parse_args()
 
 
@@ -53,7 +57,7 @@ class KernelTimer(object):
     """Wraps C-ABI entry points with HIP events recorded on the launch stream (eager mode only)."""
 
     REPEAT = 8                              # launches per bracket in the repeated measurement
-    REPEATED = ('da_conv3_winograd', 'da_conv3_winograd4')     # x,u,y,rows,L,ldx,C,ldy,N,accumulate,stream
+    REPEATED = ('da_conv3_winograd', 'da_conv3_winograd4', 'da_conv3_bf16')     # x,u,y,rows,L,ldx,C,ldy,N,accumulate,stream
 
     def __init__(self, lib, torch):
         self.lib, self.torch = lib, torch
@@ -86,7 +90,7 @@ class KernelTimer(object):
             return 2.0 * a[3] * a[4] * a[7] * a[10] * a[14]
         if name == 'da_conv_wgrad':      # dy,x,dw,ws,rows,Lm,Ldy,lddy,N,Lx,ldx,C,...,ntaps at index 15
             return 2.0 * a[4] * a[5] * a[8] * a[11] * a[15]
-        if name in ('da_conv3_winograd', 'da_conv3_winograd4'):  # x,u,y,rows,L,ldx,C,ldy,N,...: ALGORITHMIC flops = those of the direct 3-tap conv
+        if name in ('da_conv3_winograd', 'da_conv3_winograd4', 'da_conv3_bf16'):  # x,u,y,rows,L,ldx,C,ldy,N,...: ALGORITHMIC flops = those of the direct 3-tap conv
             return 2.0 * a[3] * a[4] * a[6] * a[8] * 3
         if name == 'da_conv_wgrad_multi':   # jobs (host array of da_wgrad_job), n
             return sum(2.0 * a[0][i].rows * a[0][i].Lm * a[0][i].N * a[0][i].C * a[0][i].ntaps for i in range(a[1]))
@@ -227,6 +231,8 @@ def main():
     import deepards_amd.models as M
     from deepards_amd.train import HotPathTrainer
 
+    from deepards_amd import functional as F_
+    F_.set_conv_dtype(args.dtype)
     torch.manual_seed(0)                                 # same init on every rank (replicas start identical)
     bb = M.resnet18() if args.backbone == 'resnet18' else M.densenet18()
     model = M.CNNLinearNetwork(bb, 20, 0).to(dev)
@@ -277,9 +283,11 @@ def main():
         'metric': 'breath-sequences/sec (train step) cnn_linear nb20 seq224',
         'value': round(value, 1), 'unit': 'breath-sequences/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) fp32 train step '
-                               '(BASELINE configs[1])' % (args.backbone, B),
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': ('cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) fp32 train step (BASELINE configs[1])'
+                                if args.dtype == 'f32' else
+                                'cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) train step, bf16 operands / fp32 sums in the '
+                                'k3 s1 conv forward + data gradient, everything else fp32 (BASELINE configs[2])') % (args.backbone, B),
                    'backbone': args.backbone, 'batch_per_gpu': B, 'global_batch': B * world, 'n_sub_batches': 20,
                    'seq_len': 224, 'optimizer': 'sgd-nesterov+clamp', 'parallelism': 'dp%d' % world,
                    'hipgraph': not args.no_graph},
@@ -315,15 +323,23 @@ def main():
                                         'F(2,3) on v_mfma_f32_16x16x4_f32; algorithmic = direct-conv FLOPs, 2/3 of them executed)',
                    'da_conv_gemm': 'conv_gemm_tailed_kernel<*> / conv_gemm_kernel<*> (da_conv_gemm: conv fwd + dgrad implicit '
                                    'GEMM, v_mfma_f32_32x32x2_f32)'}
+        PEAK = {}
+        if args.dtype == 'bf16':                       # configs[2]: the fp32 weight-gradient batch dominates, then the bf16 convs
+            KERNELS = {'da_conv_wgrad_multi': 'wino_wgrad_multi_kernel + conv_wgrad_multi_kernel<*> (da_conv_wgrad_multi: all '
+                                              'weight gradients of the step, fp32 MFMA)',
+                       'da_conv3_bf16': 'conv3_bf16_kernel (da_conv3_bf16: k3 s1 conv forward + data gradient, '
+                                        'v_mfma_f32_32x32x16_bf16; LDS / load-path bound, priced against the dense bf16 peak)'}
+            PEAK = {'da_conv3_bf16': PEAK_BF16_MFMA_TFLOPS}
         dname = max(KERNELS, key=lambda k: summ[k]['total_ms'] if k in summ else -1.0)      # the dominant kernel family
         dom = summ[dname]
         single_us = dom['avg_us']
         if 'rep_total_ms' in dom:                 # per-launch time from the 8-launch brackets (see KernelTimer._repeat)
             dom = dict(dom, total_ms=dom['rep_total_ms'], avg_us=dom['rep_avg_us'])
         ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
+        peak = PEAK.get(dname, PEAK_FP32_MFMA_TFLOPS)
         out['roofline'] = {'bound': 'mfma', 'kernel': KERNELS[dname],
-                           'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(dname),
+                           'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                           'frac': round(ach / peak, 4), 'traffic': pmc_traffic(dname),
                            'launches_per_step': dom['calls'] // nprof, 'avg_launch_us': round(dom['avg_us'], 2),
                            'avg_launch_us_single_bracket': round(single_us, 2),
                            'alg_flops_per_launch': round(dom['flops'] / dom['calls'], 1)}
@@ -369,6 +385,30 @@ def main():
             'alg_gbs': round((w2['act_bytes'] * B * 20 + 32 * w2['params']) / d2 / 1e9, 1),
             'note': 'cnn_linear+densenet18 (reference default backbone), drop_rate 0.2 active'}
         say('densenet18 extra done')
+
+    if world == 1 and not args.no_extra and args.backbone == 'resnet18' and args.dtype == 'f32':
+        # BASELINE configs[2] ("resnet18-1D ... bf16"): same step with bf16 operands in the k3 s1 conv forward / data gradient
+        F_.set_conv_dtype('bf16')
+        try:
+            torch.manual_seed(0)
+            m3 = M.CNNLinearNetwork(M.resnet18(), 20, 0).to(dev)
+            tr3 = HotPathTrainer(m3, optimizer='sgd', use_graph=not args.no_graph)
+            for _ in range(3):
+                tr3.train_step(x, t)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                l3 = tr3.train_step(x, t)
+            torch.cuda.synchronize()
+            d3 = (time.perf_counter() - t1) / args.steps
+            out.setdefault('extra', {})['resnet18_bf16_convs'] = {
+                'value': round(B * 20 / d3, 1), 'ms_per_step': round(1e3 * d3, 4), 'dtype': 'bf16',
+                'final_loss': round(float(l3), 6),
+                'note': 'cnn_linear+resnet18, k3 s1 conv forward + data gradient on v_mfma_f32_32x32x16_bf16 (operands '
+                        'rounded to bf16, fp32 sums); storage, statistics, weight gradients and optimizer fp32'}
+        finally:
+            F_.set_conv_dtype('f32')
+        say('bf16 extra done')
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         say('cpu baseline ...')

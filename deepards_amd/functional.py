@@ -112,35 +112,64 @@ _PAIR_S2 = os.environ.get('DA_PAIR_S2', '1') != '0'      # stride-2 block heads:
 _WINO4_MIN_C = int(os.environ.get('DA_WINO4_MINC', '512'))   # channels from which F(4,3) beats F(2,3) (scripts/bench_wino.py)
 
 
+# Arithmetic of the k3 s1 p1 convs' forward / data gradient: 'f32' (default: Winograd on the fp32 matrix cores, the
+# path every 1e-4 parity claim is about) or 'bf16' (BASELINE config C3: operands rounded to bf16, fp32 sums, conv_bf16.hip).
+_CONV_DTYPE = os.environ.get('DA_CONV_DTYPE', 'f32')
+
+
+def set_conv_dtype(name):
+    """'f32' or 'bf16' (see _CONV_DTYPE); captured steps keep the arithmetic they were captured with."""
+    global _CONV_DTYPE
+    if name not in ('f32', 'bf16'):
+        raise ValueError("conv dtype must be 'f32' or 'bf16'")
+    _CONV_DTYPE = name
+
+
+def conv_dtype():
+    return _CONV_DTYPE
+
+
 def _is_wino(w, stride, pad):
-    """k3 s1 p1 convs run as Winograd (fp32 throughout): 0 = direct, 4 = F(2,3) (2/3 of the direct conv's MFMAs),
-    6 = F(4,3) (1/2 of them; pays once both channel counts reach _WINO4_MIN_C)."""
-    if not (_WINOGRAD and w.shape[2] == 3 and stride == 1 and pad == 1 and w.shape[0] % 32 == 0
-            and w.shape[1] % 32 == 0):
+    """How a conv's forward / data gradient runs: 0 = direct fp32 kernel; k3 s1 p1 convs: 4 = Winograd F(2,3) (2/3 of
+    the direct conv's MFMAs, fp32 throughout), 6 = F(4,3) (1/2 of them; pays once both channel counts reach
+    _WINO4_MIN_C), 16 = bf16 products with fp32 sums (conv dtype 'bf16', channel counts multiples of 64)."""
+    if not (w.shape[2] == 3 and stride == 1 and pad == 1 and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0):
+        return 0
+    if _CONV_DTYPE == 'bf16' and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
+        return 16
+    if not _WINOGRAD:
         return 0
     return 6 if min(w.shape[0], w.shape[1]) >= _WINO4_MIN_C else 4
 
 
-def _pack(w, wino):
-    """(wf, wd, uf, ud) of a conv weight: direct packs or Winograd taps, repacked once per step."""
+def _pack(w, code):
+    """(wf, wd, uf, ud) of a conv weight: direct packs (code 0), Winograd taps or bf16 tap packs (in the uf / ud
+    places), repacked once per step."""
     e = _STEP['pack'].get(w.data_ptr()) if _STEP['on'] else None
-    if e is None or (e[2] is None if wino else e[0] is None):
-        e = H.repack_multi([w], [wino])[0]
+    want = 3 if code == 16 else (code if code else 0)
+    if e is None or (e[2] is None if code else e[0] is None) or (code and e[2].shape[0] != want):
+        e = H.repack_multi([w], [code])[0]
         if _STEP['on']:
             _STEP['pack'][w.data_ptr()] = e
     return e
 
 
 def _conv_fwd(x, w, stride, pad):
-    if _is_wino(w, stride, pad):
-        return H.conv3_winograd(x, _pack(w, True)[2])
-    return H.conv_fwd(x, _pack(w, False)[0], stride, pad)
+    code = _is_wino(w, stride, pad)
+    if code == 16:
+        return H.conv3_bf16(x, _pack(w, code)[2])
+    if code:
+        return H.conv3_winograd(x, _pack(w, code)[2])
+    return H.conv_fwd(x, _pack(w, 0)[0], stride, pad)
 
 
 def _conv_dgrad(dy, w, stride, pad, l_in, out=None, accumulate=False):
-    if _is_wino(w, stride, pad):
-        return H.conv3_winograd(dy, _pack(w, True)[3], out=out, accumulate=accumulate)
-    return H.conv_dgrad(dy, _pack(w, False)[1], stride, pad, l_in, out=out, accumulate=accumulate)
+    code = _is_wino(w, stride, pad)
+    if code == 16:
+        return H.conv3_bf16(dy, _pack(w, code)[3], out=out, accumulate=accumulate)
+    if code:
+        return H.conv3_winograd(dy, _pack(w, code)[3], out=out, accumulate=accumulate)
+    return H.conv_dgrad(dy, _pack(w, 0)[1], stride, pad, l_in, out=out, accumulate=accumulate)
 
 
 def _tgt(*params):

@@ -310,24 +310,29 @@ def wgrad_reduce_multi(items, accumulate=True):
 def repack_multi(weights, winograd=None):
     """[(Co,Ci,K) weights] -> [(wf, wd, uf, ud)] with one launch per 32 weights.  winograd[i] (K == 3; True / 4:
     F(2,3), 6: F(4,3)): emit the Winograd taps uf (points,Co,Ci) / ud (points,Ci,Co) INSTEAD of the direct packs
-    wf / wd (None in the tuple)."""
-    outs = []
-    arr = (_lib.RepackDesc * len(weights))()
-    for n, (d, w) in enumerate(zip(arr, weights)):
+    wf / wd (None in the tuple); 16: bf16 tap packs of conv3_bf16 in the uf / ud places (a launch of their own)."""
+    outs, descs = [], []
+    for n, w in enumerate(weights):
         _f32(w, 'w')
         co, ci, k = w.shape
-        wino = bool(winograd[n]) if winograd is not None else False
-        pts = 6 if wino and winograd[n] == 6 else 4
+        code = winograd[n] if winograd is not None else 0
+        wino = bool(code)
         if wino and k != 3:
             raise ValueError('winograd taps need a 3-tap weight')
+        if wino and code == 16:
+            outs.append((None, None) + pack_conv3_bf16(w))
+            continue
+        pts = 6 if wino and code == 6 else 4
         mk = lambda *shape: torch.empty(shape, device=w.device, dtype=torch.float32)
         wf, wd = (None, None) if wino else (mk(k, co, ci), mk(k, ci, co))
         uf, ud = (mk(pts, co, ci), mk(pts, ci, co)) if wino else (None, None)
-        d.W, d.Wf, d.Wd, d.Uf, d.Ud = w.data_ptr(), _p(wf), _p(wd), _p(uf), _p(ud)
-        d.Co, d.Ci, d.K, d.points = co, ci, k, pts
+        descs.append((w.data_ptr(), _p(wf), _p(wd), _p(uf), _p(ud), co, ci, k, pts))
         outs.append((wf, wd, uf, ud))
-    if weights:
-        _chk(_lib.lib().da_repack_multi(arr, len(weights), _stream()), 'da_repack_multi')
+    if descs:
+        arr = (_lib.RepackDesc * len(descs))()
+        for d, v in zip(arr, descs):
+            d.W, d.Wf, d.Wd, d.Uf, d.Ud, d.Co, d.Ci, d.K, d.points = v
+        _chk(_lib.lib().da_repack_multi(arr, len(descs), _stream()), 'da_repack_multi')
     return outs
 
 

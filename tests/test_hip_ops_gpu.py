@@ -200,6 +200,43 @@ def test_conv3_winograd_f43(H, ci, co, L, rows, ksteps):
         _lib.lib().da_wino_debug_tail(3)
 
 
+@pytest.mark.parametrize('ci,co,L,rows', [(64, 64, 56, 40), (128, 128, 28, 23), (512, 512, 7, 40), (32, 64, 1, 7),
+                                          (96, 128, 2, 33), (64, 192, 3, 5), (64, 64, 57, 9), (256, 64, 14, 1),
+                                          (64, 64, 56, 1280)])
+def test_conv3_bf16(H, ci, co, L, rows):
+    """bf16-MFMA k3 s1 p1 conv (BASELINE config C3 arithmetic): tap packs == torch's round-to-nearest-even bfloat16;
+    forward, data gradient and accumulate form == the fp64 convolution of the bf16-ROUNDED operands to fp32 rounding
+    (the kernel's only approximation is the operand rounding), and within bf16's 2^-8 of the unrounded one."""
+    rng = np.random.default_rng(ci + co + L + rows)
+    x = rng.standard_normal((rows, ci, L))
+    w = rng.standard_normal((co, ci, 3)) * np.sqrt(2.0 / (3 * co))
+    dy = rng.standard_normal((rows, co, L))
+    xt, wt, dyt = rlc(x), cu(w), rlc(dy)
+    wf, wd = H.pack_conv3_bf16(wt)
+    assert torch.equal(wf, wt.permute(2, 0, 1).contiguous().bfloat16())
+    assert torch.equal(wd, wt.flip(2).permute(2, 1, 0).contiguous().bfloat16())
+    rb = np_ref.round_bf16
+    assert np.array_equal(rb(w), torch.from_numpy(w.astype(np.float32)).bfloat16().double().numpy())
+    y_b = np_ref.conv1d_fwd(rb(x), rb(w), 1, 1)
+    dx_b, _ = np_ref.conv1d_bwd(rb(x), rb(w), rb(dy), 1, 1)
+    close(ncl(H.conv3_bf16(xt, wf)), y_b, tol=3e-6, name='bf16 fwd vs rounded operands')
+    if ci % 64 == 0:                                 # the data gradient's output channels are the conv's inputs
+        close(ncl(H.conv3_bf16(dyt, wd)), dx_b, tol=3e-6, name='bf16 dgrad vs rounded operands')
+        base = rng.standard_normal(dx_b.shape)
+        bt = rlc(base)
+        H.conv3_bf16(dyt, wd, out=bt, accumulate=True)
+        close(ncl(bt), base.astype(np.float32).astype(np.float64) + dx_b, tol=3e-6, name='bf16 dgrad+acc')
+    else:
+        with pytest.raises(ValueError):
+            H.conv3_bf16(dyt, wd)
+    y_ref = np_ref.conv1d_fwd(x, w, 1, 1)
+    close(ncl(H.conv3_bf16(xt, wf)), y_ref, tol=8e-3, name='bf16 fwd vs exact')
+    (a, b, uf, ud), = H.repack_multi([wt], [16])
+    assert a is None and b is None and torch.equal(uf, wf) and torch.equal(ud, wd)
+    with pytest.raises(ValueError):
+        H.conv3_bf16(xt, wf[:, :32])                                # N must be a multiple of 64, taps contiguous
+
+
 @pytest.mark.parametrize('ci,co,L,rows', [(64, 128, 56, 40), (128, 256, 28, 23), (256, 512, 14, 300), (64, 128, 56, 300)])
 def test_stride2_block_head_shared_launches(H, ci, co, L, rows):
     """The k3 s2 p1 conv and the k1 s2 downsample of a block: forward pair in one launch (da_conv_gemm_multi), the
