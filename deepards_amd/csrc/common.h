@@ -66,13 +66,18 @@ typedef struct {
   float* workspace;      // splits * ntaps*N*C floats: receives the split-K slabs
   int rows, Lm, Ldy, lddy, N, Lx, ldx, C, dy_stride, dy_off, src_stride, ntaps;
   int src_off[3];
-  int winograd;          // != 0 (k3 s1 p1, N and C multiples of 64): Winograd F(2,3) form, da_conv_wgrad_plan(winograd = 1)
+  int winograd;          // k3 s1 p1, N and C multiples of 64 -- 1: Winograd F(2,3) form (fp32), 16: bf16 operands /
+                         // fp32 sums (conv_bf16.hip); the matching da_conv_wgrad_plan(winograd = 1 / 16) sizes the workspace
 } da_wgrad_job;
 
 // conv_wino.hip
 bool wino_wgrad_eligible(const da_wgrad_job& j);
 void wino_wgrad_plan(int rows, int L, int* splits, int* pchunk);
 int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream);
+
+// conv_bf16.hip: jobs with winograd == 16 (the same eligibility; bf16 operands, padded-position K)
+void bf16_wgrad_plan(int rows, int L, int* splits, int* pchunk);
+int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream);
 
 // One problem of da_conv_gemm_multi: the arguments of da_conv_gemm (include/deepards_hip.h).
 typedef struct {

@@ -161,6 +161,194 @@ __global__ __launch_bounds__(256) void pack_conv3_bf16_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of the same convolution with bf16 operands:  dW[t][n][c] = sum_P dy[P][n] * x[P + t - 1][c]  (fp32
+// sums).  Both operands are contracted over POSITIONS but sit position-major in HBM, so the LDS images keep that layout
+// ([position][channel] bf16, filled with plain 8-byte stores) and the fragments come out of ds_read_b64_tr_b16, the
+// transposing read: per 16 lanes it takes a block of 4 positions x 16 channels and hands lane i channel i's 4 positions.
+// Sequence edges need no masks: K runs over PADDED positions P' = row * (L + 1) + l whose l = L slot is a zero row in
+// both images, so x[P' - 1] of a first and x[P' + 1] of a last position are zeros (1 / (L + 1) more K steps).
+// Block = 64 n x 64 c, 4 waves of 32 x 32 with one accumulator per tap; K step = 64 padded positions; split over
+// chunks of padded positions into slabs [split][3][N][C] = the direct kernel's layout, shared reduction.
+// Image rows are 192 bytes (128 data + 64 pad): the 4 rows of a transposed read fall on disjoint bank ranges.
+// ---------------------------------------------------------------------------------------------
+struct WgradBf16Args {
+  const float* dy;
+  const float* x;
+  float* slab;
+  int rows, L, Kpad, lddy, N, ldx, C, pchunk;
+  FastDiv divL1;        // by L + 1
+};
+
+#define WB_KP 64
+#define WB_PITCH 192
+#define WB_LDS_BYTES ((WB_KP + WB_KP + 2) * WB_PITCH)
+
+__device__ __forceinline__ f32x2v ds_read_tr16(const unsigned char* p) {
+  f32x2v v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
+  return v;
+}
+
+__device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const int block_id, unsigned char* lds) {
+  unsigned char* Ys = lds;                              // [64][192 B]  dY at padded positions k0 .. k0+63
+  unsigned char* Xs = lds + WB_KP * WB_PITCH;           // [66][192 B]  X at padded positions k0-1 .. k0+64
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntc = a.C >> 6, tiles = (a.N >> 6) * ntc;
+  const int bx = block_id % tiles, split = block_id / tiles;
+  const int n_blk = (bx / ntc) * 64, c_blk = (bx % ntc) * 64;
+  const int k_beg = split * a.pchunk, k_end = min(a.Kpad, k_beg + a.pchunk);
+  const int L1 = a.L + 1;
+
+  const int lq = tid & 15, lr = tid >> 4;               // loader: 16 rows x 16 channel quads per pass
+  f32x4 ry[4], rx[5];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int Pp = k0 + lr + 16 * p;                  // padded position of dY row
+      bool ok = Pp < k_end;
+      const uint32_t sq = fdiv((uint32_t)(ok ? Pp : 0), a.divL1);
+      const int l = (ok ? Pp : 0) - (int)sq * L1;
+      ok = ok && l < a.L;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)sq * a.L + l) * a.lddy + n_blk + lq * 4);
+      ry[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      const int r = p < 4 ? lr + 16 * p : 64 + lr;      // image row; rows 64, 65 by the first 32 threads
+      const int Pp = k0 - 1 + r;
+      bool ok = Pp >= 0 && Pp < a.Kpad && (p < 4 || tid < 32);
+      const uint32_t sq = fdiv((uint32_t)(ok ? Pp : 0), a.divL1);
+      const int l = (ok ? Pp : 0) - (int)sq * L1;
+      ok = ok && l < a.L;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)sq * a.L + l) * a.ldx + c_blk + lq * 4);
+      rx[p] = v;
+    }
+  };
+
+  // transposed-read geometry: group g = lane / 16 serves channels 16 (g & 1) .. + 15 at positions + 8 (g >> 1);
+  // lane 4q + p of the group supplies the address of position row q, channels 4p .. 4p + 3
+  const int wn = wave >> 1, wc = wave & 1;
+  const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const unsigned char* yfrag = Ys + (8 * (g >> 1) + tq) * WB_PITCH + (wn * 32 + 16 * (g & 1) + 4 * tp) * 2;
+  const unsigned char* xfrag = Xs + (8 * (g >> 1) + tq) * WB_PITCH + (wc * 32 + 16 * (g & 1) + 4 * tp) * 2;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  if (k_beg < k_end) gload(k_beg);
+  for (int k0 = k_beg; k0 < k_end; k0 += WB_KP) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<f32x2v*>(Ys + (lr + 16 * p) * WB_PITCH + lq * 8) = cvt4_bf16(ry[p]);
+      *reinterpret_cast<f32x2v*>(Xs + (lr + 16 * p) * WB_PITCH + lq * 8) = cvt4_bf16(rx[p]);
+    }
+    if (tid < 32) *reinterpret_cast<f32x2v*>(Xs + (64 + lr) * WB_PITCH + lq * 8) = cvt4_bf16(rx[4]);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (k0 + WB_KP < k_end) gload(k0 + WB_KP);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < WB_KP / 16; ++kk) {
+      const unsigned char* yp = yfrag + kk * 16 * WB_PITCH;
+      const unsigned char* xp = xfrag + kk * 16 * WB_PITCH;
+      f32x2v y0 = ds_read_tr16(yp), y1 = ds_read_tr16(yp + 4 * WB_PITCH);
+      f32x2v b0[3], b1[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {                     // X image row j + t holds the position dY row j meets at tap t
+        b0[t] = ds_read_tr16(xp + t * WB_PITCH);
+        b1[t] = ds_read_tr16(xp + (t + 4) * WB_PITCH);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(y0), "+v"(y1), "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]), "+v"(b1[2]));
+      const f32x4 av = {y0[0], y0[1], y1[0], y1[1]};
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const f32x4 bv = {b0[t][0], b0[t][1], b1[t][0], b1[t][1]};
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                         acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  float* out = a.slab + (size_t)split * 3 * a.N * a.C;
+  const size_t plane = (size_t)a.N * a.C;
+  const int frow = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n_blk + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      out[t * plane + (size_t)n * a.C + c_blk + wc * 32 + frow] = acc[t][r];
+    }
+}
+
+struct WgradBf16Table {
+  WgradBf16Args d[24];
+  int first_block[25];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void wgrad_bf16_multi_kernel(WgradBf16Table t) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[WB_LDS_BYTES];
+  int i = 0;
+  while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
+  wgrad_bf16_body(t.d[i], blockIdx.x - t.first_block[i], lds);
+}
+
+static int g_wb_pchunk = 1024;
+
+// padded positions per split (a multiple of the K step) and the number of slabs
+void bf16_wgrad_plan(int rows, int L, int* splits, int* pchunk) {
+  const long K = (long)rows * (L + 1);
+  long sp = (K + g_wb_pchunk - 1) / g_wb_pchunk;
+  if (sp < 1) sp = 1;
+  long pc = ((K + sp - 1) / sp + WB_KP - 1) / WB_KP * WB_KP;
+  if (pc < WB_KP) pc = WB_KP;
+  *splits = (int)((K + pc - 1) / pc > 0 ? (K + pc - 1) / pc : 1);
+  *pchunk = (int)pc;
+}
+
+int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s) {
+  WgradBf16Table t;
+  int cnt = 0, blocks = 0;
+  auto flush = [&]() -> int {
+    if (!cnt) return DA_OK;
+    t.n = cnt;
+    t.first_block[cnt] = blocks;
+    hipLaunchKernelGGL(wgrad_bf16_multi_kernel, dim3(blocks), dim3(256), 0, s, t);
+    DA_CHECK_LAUNCH();
+    cnt = 0;
+    blocks = 0;
+    return DA_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    const da_wgrad_job& j = jobs[i];
+    if (j.winograd != 16) continue;
+    int splits, pchunk;
+    bf16_wgrad_plan(j.rows, j.Lm, &splits, &pchunk);
+    WgradBf16Args& a = t.d[cnt];
+    a.dy = j.dy; a.x = j.x; a.slab = j.workspace;
+    a.rows = j.rows; a.L = j.Lm; a.Kpad = j.rows * (j.Lm + 1);
+    a.lddy = j.lddy; a.N = j.N; a.ldx = j.ldx; a.C = j.C; a.pchunk = pchunk;
+    a.divL1 = make_fastdiv((uint32_t)(j.Lm + 1));
+    t.first_block[cnt] = blocks;
+    blocks += (j.N / 64) * (j.C / 64) * splits;
+    if (++cnt == 24) {
+      int rc = flush();
+      if (rc) return rc;
+    }
+  }
+  return flush();
+}
+
 extern "C" {
 
 // y (+)= conv1d(x, k = 3, stride 1, pad 1) per row of L positions, bf16 products / fp32 sums.  x: [rows][L][ldx] fp32

@@ -987,6 +987,7 @@ int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
   }
   int rc;
   if ((rc = wino_wgrad_launch(jobs, n, stream))) return rc;   // the heaviest blocks first
+  if ((rc = bf16_wgrad_launch(jobs, n, stream))) return rc;
   if ((rc = launch_wgrad_group<2, 2, 2, 2>(jobs, n, 128, 128, stream))) return rc;
   if ((rc = launch_wgrad_group<2, 1, 2, 2>(jobs, n, 128, 64, stream))) return rc;
   if ((rc = launch_wgrad_group<1, 2, 2, 2>(jobs, n, 64, 128, stream))) return rc;
@@ -1009,7 +1010,8 @@ int da_conv_wgrad_plan(int rows, int Lm, int N, int C, int ntaps, int winograd, 
   if (winograd) {
     if (ntaps != 3 || N % 64 || C % 64) return DA_EINVAL;
     out[0] = 64; out[1] = 64;
-    wino_wgrad_plan(rows, Lm, &out[2], &out[3]);
+    if (winograd == 16) bf16_wgrad_plan(rows, Lm, &out[2], &out[3]);     // kchunk counts padded positions
+    else wino_wgrad_plan(rows, Lm, &out[2], &out[3]);
     return DA_OK;
   }
   WgradPlan p = wgrad_plan(rows * Lm, N, C, ntaps);

@@ -819,7 +819,7 @@ int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s) {
   };
   for (int i = 0; i < n; ++i) {
     const da_wgrad_job& j = jobs[i];
-    if (!j.winograd) continue;
+    if (j.winograd != 1) continue;
     int splits, pchunk;
     wino_wgrad_plan(j.rows, j.Lm, &splits, &pchunk);
     WinoWgradArgs& a = t.d[cnt];

@@ -113,7 +113,8 @@ _WINO4_MIN_C = int(os.environ.get('DA_WINO4_MINC', '512'))   # channels from whi
 
 
 # Arithmetic of the k3 s1 p1 convs' forward / data gradient: 'f32' (default: Winograd on the fp32 matrix cores, the
-# path every 1e-4 parity claim is about) or 'bf16' (BASELINE config C3: operands rounded to bf16, fp32 sums, conv_bf16.hip).
+# path every 1e-4 parity claim is about) or 'bf16' (BASELINE config C3: operands rounded to bf16, fp32 sums, conv_bf16.hip;
+# also the k3 s1 weight gradients unless DA_WGRAD_BF16=0).
 _CONV_DTYPE = os.environ.get('DA_CONV_DTYPE', 'f32')
 
 
@@ -123,10 +124,14 @@ def set_conv_dtype(name):
     if name not in ('f32', 'bf16'):
         raise ValueError("conv dtype must be 'f32' or 'bf16'")
     _CONV_DTYPE = name
+    H.WGRAD_BF16 = name == 'bf16' and os.environ.get('DA_WGRAD_BF16', '1') != '0'
 
 
 def conv_dtype():
     return _CONV_DTYPE
+
+
+set_conv_dtype(_CONV_DTYPE)
 
 
 def _is_wino(w, stride, pad):

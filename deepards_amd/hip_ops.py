@@ -262,12 +262,13 @@ def conv_wgrad(dy, x, k, stride, pad, out=None, accumulate=False, defer=False):
 
 
 WINOGRAD_WGRAD = os.environ.get('DA_WINOGRAD_WGRAD', '1') != '0'
+WGRAD_BF16 = False        # set by functional.set_conv_dtype('bf16'): k3 s1 weight gradients on the bf16 matrix cores
 
 
 def conv_wgrad_multi(jobs):
     """jobs: [(dy, x, k, stride, pad)] -> [(slab, splits, k, co, ci)]: every weight-gradient GEMM of the list in
     one launch per tile shape (slabs only; reduce with wgrad_reduce_multi).  k3 s1 p1 jobs with 64-multiple
-    channel counts take the Winograd F(2,3) form."""
+    channel counts take the Winograd F(2,3) form, or the bf16-operand kernel while WGRAD_BF16 is set."""
     if not jobs:
         return []
     L = _lib.lib()
@@ -282,6 +283,8 @@ def conv_wgrad_multi(jobs):
         if rows != rows2 or lo != conv_out_len(l, k, stride, pad) or k > 3 or ci % 32 or co % 32:
             raise ValueError('conv_wgrad_multi: unsupported shape')
         wino = 1 if (WINOGRAD_WGRAD and k == 3 and stride == 1 and pad == 1 and co % 64 == 0 and ci % 64 == 0) else 0
+        if WGRAD_BF16 and k == 3 and stride == 1 and pad == 1 and co % 64 == 0 and ci % 64 == 0:
+            wino = 16                                # bf16 operands / fp32 sums (conv dtype bf16)
         _chk(L.da_conv_wgrad_plan(rows, lo, co, ci, k, wino, plan), 'da_conv_wgrad_plan')
         ws = torch.empty((plan[2] * k * co * ci,), device=x.device, dtype=torch.float32)
         d.dy, d.x, d.workspace = dy.data_ptr(), x.data_ptr(), ws.data_ptr()
@@ -310,7 +313,7 @@ def wgrad_reduce_multi(items, accumulate=True):
 def repack_multi(weights, winograd=None):
     """[(Co,Ci,K) weights] -> [(wf, wd, uf, ud)] with one launch per 32 weights.  winograd[i] (K == 3; True / 4:
     F(2,3), 6: F(4,3)): emit the Winograd taps uf (points,Co,Ci) / ud (points,Ci,Co) INSTEAD of the direct packs
-    wf / wd (None in the tuple); 16: bf16 tap packs of conv3_bf16 in the uf / ud places (a launch of their own)."""
+    wf / wd (None in the tuple); 16: bf16 tap packs of conv3_bf16 in the uf / ud places."""
     outs, descs = [], []
     for n, w in enumerate(weights):
         _f32(w, 'w')
@@ -319,13 +322,16 @@ def repack_multi(weights, winograd=None):
         wino = bool(code)
         if wino and k != 3:
             raise ValueError('winograd taps need a 3-tap weight')
-        if wino and code == 16:
-            outs.append((None, None) + pack_conv3_bf16(w))
-            continue
-        pts = 6 if wino and code == 6 else 4
+        pts = code if wino and code in (6, 16) else 4
         mk = lambda *shape: torch.empty(shape, device=w.device, dtype=torch.float32)
         wf, wd = (None, None) if wino else (mk(k, co, ci), mk(k, ci, co))
-        uf, ud = (mk(pts, co, ci), mk(pts, ci, co)) if wino else (None, None)
+        if pts == 16:                                # bf16 tap packs (3, Co, Ci) / (3, Ci, Co)
+            if co % 32 or ci % 32:
+                raise ValueError('bf16 tap packs need channel counts that are multiples of 32')
+            uf = torch.empty((3, co, ci), device=w.device, dtype=torch.bfloat16)
+            ud = torch.empty((3, ci, co), device=w.device, dtype=torch.bfloat16)
+        else:
+            uf, ud = (mk(pts, co, ci), mk(pts, ci, co)) if wino else (None, None)
         descs.append((w.data_ptr(), _p(wf), _p(wd), _p(uf), _p(ud), co, ci, k, pts))
         outs.append((wf, wd, uf, ud))
     if descs:

@@ -109,8 +109,9 @@ int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumula
 
 /* torch [Co][Ci][K] -> Wf [K][Co][Ci] (forward) and Wd [K][Ci][Co] (data gradient). */
 int da_repack_conv_weight(const float* W, float* Wf, float* Wd, int Co, int Ci, int K, da_stream_t stream);
-/* Uf / Ud (K == 3 only, may be NULL): the Winograd taps of da_wino_weights (points != 6) or da_wino4_weights
-   (points == 6) for the forward / data gradient */
+/* Uf / Ud (K == 3 only, may be NULL): the Winograd taps of da_wino_weights (points 0 / 4) or da_wino4_weights
+   (points == 6) for the forward / data gradient; points == 16: Uf / Ud point at bf16 buffers and receive the tap packs
+   of da_pack_conv3_bf16 (Co and Ci multiples of 32) */
 typedef struct { const float* W; float* Wf; float* Wd; float* Uf; float* Ud; int Co, Ci, K; int points; } da_repack_desc;
 int da_repack_multi(const da_repack_desc* descs, int n, da_stream_t stream);
 

@@ -219,7 +219,7 @@ def round_bf16(a):
 def _conv(t, x, name, stride, pad, need_dx=True):
     w = t.p[name]
     # BASELINE config C3 arithmetic (build-side, not in the reference): the forward and the data gradient of the k3 s1 p1
-    # convs with channel counts that are multiples of 64 see bf16-rounded operands; sums, the weight gradient and
+    # convs with channel counts that are multiples of 64, and their weight gradient, see bf16-rounded operands; sums and
     # everything else stay exact here (fp32 on the device)
     bf16 = getattr(t, 'bf16_convs', False) and w.shape[2] == 3 and stride == 1 and pad == 1 and \
         w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
@@ -227,8 +227,9 @@ def _conv(t, x, name, stride, pad, need_dx=True):
 
     def bwd(dy):
         dx, dw = conv1d_bwd(x, w, dy, stride, pad, need_dx)
-        if bf16 and need_dx:
-            dx, _ = conv1d_bwd(x, round_bf16(w), round_bf16(dy), stride, pad, True)
+        if bf16:                                      # dx from rounded (dy, w), dw from rounded (dy, x)
+            dx, _ = conv1d_bwd(x, round_bf16(w), round_bf16(dy), stride, pad, need_dx)
+            _, dw = conv1d_bwd(round_bf16(x), w, round_bf16(dy), stride, pad, False)
         t.acc(name, dw)
         return dx
     return y, bwd

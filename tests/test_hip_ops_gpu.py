@@ -237,6 +237,47 @@ def test_conv3_bf16(H, ci, co, L, rows):
         H.conv3_bf16(xt, wf[:, :32])                                # N must be a multiple of 64, taps contiguous
 
 
+@pytest.mark.parametrize('ci,co,L,rows', [(64, 64, 56, 40), (128, 128, 28, 23), (512, 512, 7, 40), (64, 128, 1, 7),
+                                          (128, 64, 2, 33), (64, 192, 3, 5), (64, 64, 57, 9), (256, 64, 14, 1),
+                                          (64, 64, 56, 300), (192, 128, 9, 130)])
+def test_conv3_wgrad_bf16(H, ci, co, L, rows):
+    """bf16-operand weight gradient of the k3 s1 p1 conv (ds_read_b64_tr_b16 fragments, K over padded positions):
+    slabs + shared reduction == the fp64 weight gradient of the bf16-ROUNDED (dy, x) to fp32 rounding, within bf16's
+    2^-8 of the exact one; batched with a Winograd-form and a direct job in one call; accumulate form."""
+    rng = np.random.default_rng(ci + co + L + rows)
+    x = rng.standard_normal((rows, ci, L))
+    dy = rng.standard_normal((rows, co, L))
+    rb = np_ref.round_bf16
+    w0 = np.zeros((co, ci, 3))
+    _, dw_b = np_ref.conv1d_bwd(rb(x), w0, rb(dy), 1, 1, need_dx=False)
+    _, dw_ref = np_ref.conv1d_bwd(x, w0, dy, 1, 1, need_dx=False)
+    xt, dyt = rlc(x), rlc(dy)
+    H.WGRAD_BF16 = True
+    try:
+        (slab,) = H.conv_wgrad_multi([(dyt, xt, 3, 1, 1)])
+        dw = torch.zeros(co, ci, 3, device='cuda')
+        H.wgrad_reduce_multi([(slab, dw)], accumulate=False)
+        close(dw.cpu().numpy(), dw_b, tol=3e-6, name='bf16 wgrad vs rounded operands')
+        close(dw.cpu().numpy(), dw_ref, tol=1.5e-2, name='bf16 wgrad vs exact')
+        H.wgrad_reduce_multi([(slab, dw)], accumulate=True)
+        close(dw.cpu().numpy(), 2 * dw_b, tol=3e-6, name='bf16 wgrad accumulate')
+        # mixed batch: a stride-2 job (direct fp32 kernel) rides along
+        if L % 2 == 0 and L >= 2:
+            dy2 = rng.standard_normal((rows, co, L // 2))
+            _, dw2_ref = np_ref.conv1d_bwd(x, w0, dy2, 2, 1, need_dx=False)
+            s1, s2 = H.conv_wgrad_multi([(dyt, xt, 3, 1, 1), (rlc(dy2), xt, 3, 2, 1)])
+            d1, d2 = torch.zeros(co, ci, 3, device='cuda'), torch.zeros(co, ci, 3, device='cuda')
+            H.wgrad_reduce_multi([(s1, d1), (s2, d2)], accumulate=False)
+            close(d1.cpu().numpy(), dw_b, tol=3e-6, name='bf16 wgrad in a mixed batch')
+            close(d2.cpu().numpy(), dw2_ref, tol=3e-6, name='direct wgrad in a mixed batch')
+    finally:
+        H.WGRAD_BF16 = False
+    (slab32,) = H.conv_wgrad_multi([(dyt, xt, 3, 1, 1)])             # the flag is off again: fp32 Winograd form
+    dw32 = torch.zeros(co, ci, 3, device='cuda')
+    H.wgrad_reduce_multi([(slab32, dw32)], accumulate=False)
+    close(dw32.cpu().numpy(), dw_ref, tol=4e-6, name='fp32 wgrad after the flag')
+
+
 @pytest.mark.parametrize('ci,co,L,rows', [(64, 128, 56, 40), (128, 256, 28, 23), (256, 512, 14, 300), (64, 128, 56, 300)])
 def test_stride2_block_head_shared_launches(H, ci, co, L, rows):
     """The k3 s2 p1 conv and the k1 s2 downsample of a block: forward pair in one launch (da_conv_gemm_multi), the
