@@ -287,7 +287,7 @@ def main():
         'config': {'workload': ('cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) fp32 train step (BASELINE configs[1])'
                                 if args.dtype == 'f32' else
                                 'cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) train step, bf16 operands / fp32 sums in the '
-                                'k3 s1 convs (forward, data and weight gradient), everything else fp32 (BASELINE configs[2])') % (args.backbone, B),
+                                'residual-block convs (forward, data and weight gradient), everything else fp32 (BASELINE configs[2])') % (args.backbone, B),
                    'backbone': args.backbone, 'batch_per_gpu': B, 'global_batch': B * world, 'n_sub_batches': 20,
                    'seq_len': 224, 'optimizer': 'sgd-nesterov+clamp', 'parallelism': 'dp%d' % world,
                    'hipgraph': not args.no_graph},
@@ -405,8 +405,8 @@ def main():
                 'value': round(B * 20 / d3, 1), 'ms_per_step': round(1e3 * d3, 4), 'dtype': 'bf16',
                 'final_loss': round(float(l3), 6),
                 'note': 'cnn_linear+resnet18, k3 s1 conv forward, data gradient and weight gradient on '
-                        'v_mfma_f32_32x32x16_bf16 (operands rounded to bf16, fp32 sums); storage, statistics, the stride-2 / '
-                        '1x1 convs and the optimizer fp32'}
+                        'v_mfma_f32_32x32x16_bf16 (operands rounded to bf16, fp32 sums), the stride-2 / 1x1 convs too; storage, '
+                        'statistics, stem and optimizer fp32'}
         finally:
             F_.set_conv_dtype('f32')
         say('bf16 extra done')

@@ -76,6 +76,7 @@ void wino_wgrad_plan(int rows, int L, int* splits, int* pchunk);
 int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream);
 
 // conv_bf16.hip: jobs with winograd == 16 (the same eligibility; bf16 operands, padded-position K)
+bool bf16_wgrad_eligible(const da_wgrad_job& j);
 void bf16_wgrad_plan(int rows, int L, int* splits, int* pchunk);
 int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream);
 

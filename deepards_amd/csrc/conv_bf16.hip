@@ -145,6 +145,155 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(ConvBf16Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// General form for the stride-2 block heads and 1x1 downsamples (forward and data gradient), the contract of
+// da_conv_gemm with bf16 operands:
+//     Y[row][j * dst_stride + dst_off][n] (+)= sum_t sum_c X[row][j * SS + src_off[t]][c] * Wp[wtap[t]][n][c],  j in [0, Lm)
+// with Lsrc == SS * Lm, so that the source of flat output m = row * Lm + j is the flat position SS * m + src_off[t] and a
+// tile's panel is one contiguous range of positions.  SS = 2 keeps even and odd panel rows in two halves: the rows a
+// tap needs are then unit-stride in m (conflict-free ds_read_b128), whatever the tap's parity.
+// ---------------------------------------------------------------------------------------------
+struct ConvBf16GenArgs {
+  const float* x;
+  const __bf16* w;      // [taps][N][C]
+  float* y;
+  int M, Lm, Lsrc, ldx, C, Ldst, ldy, N, dst_stride, dst_off, ntaps, accumulate;
+  int src_off[3], wtap[3];
+  long Msrc;            // rows * Lsrc
+  FastDiv divLm;
+};
+
+template <int SS>
+__global__ __launch_bounds__(256) void conv_bf16_gen_kernel(ConvBf16GenArgs a) {
+  constexpr int HROWS = CB_TM + 1;                               // rows per parity half (SS = 2)
+  constexpr int NR = SS * (CB_TM - 1) + 3;                       // panel rows at most (span of the taps <= 2)
+  constexpr int XBYTES = (SS == 2 ? 2 * HROWS : NR) * CB_PITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[XBYTES + 3 * CB_TN * CB_PITCH];
+  unsigned char* Xs = lds;
+  unsigned char* Ws = lds + XBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntn = a.N / CB_TN;
+  const int tile = blockIdx.x;
+  const int M0 = (tile / ntn) * CB_TM, n_blk = (tile % ntn) * CB_TN;
+  int smin = a.src_off[0];
+#pragma unroll
+  for (int t = 1; t < 3; ++t)
+    if (t < a.ntaps && a.src_off[t] < smin) smin = a.src_off[t];
+  const long p0 = (long)SS * M0 + smin;                          // flat source position of panel row 0
+
+  // X loader: 32 rows x 8 channel quads per pass; the two 8-lane halves of a ds_write_b64 group take rows 4 SS apart
+  const int xm = tid >> 4, xq = tid & 7, xsub = (tid >> 3) & 1;
+  const int xrow = SS == 1 ? (xm >> 2) * 8 + (xm & 3) + 4 * xsub : (xm >> 3) * 16 + (xm & 7) + 8 * xsub;
+  constexpr int NXP = (NR + 31) / 32;
+  long xoff[NXP];
+  bool xok[NXP];
+#pragma unroll
+  for (int p = 0; p < NXP; ++p) {
+    const int r = p * 32 + xrow;
+    const long P = p0 + r;
+    xok[p] = r < NR && P >= 0 && P < a.Msrc;
+    xoff[p] = (xok[p] ? P : 0) * a.ldx + xq * 4;
+  }
+  const int wm_ = tid >> 3, ws = tid & 3;
+  const int wrow = (wm_ >> 2) * 8 + (wm_ & 3) + 4 * ((tid >> 2) & 1);
+  const size_t wtapsz = (size_t)a.N * a.C;
+  const __bf16* wsrc = a.w + (size_t)(n_blk + wrow) * a.C + ws * 8;
+
+  f32x4 rx[NXP], rw[3];
+  auto gload = [&](int ks) {
+    const int c0 = ks << 5;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      if (t < a.ntaps) rw[t] = *reinterpret_cast<const f32x4*>(wsrc + a.wtap[t] * wtapsz + c0);
+#pragma unroll
+    for (int p = 0; p < NXP; ++p) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (xok[p]) v = *reinterpret_cast<const f32x4*>(a.x + xoff[p] + c0);
+      rx[p] = v;
+    }
+  };
+
+  const int frow = lane & 31, kg = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  bool ok[2][3];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const long m = (long)M0 + wm * 64 + mt * 32 + frow;
+    const uint32_t mc = (uint32_t)(m < a.M ? m : 0);
+    const int j = (int)(mc - fdiv(mc, a.divLm) * (uint32_t)a.Lm);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int src = j * SS + a.src_off[t < a.ntaps ? t : 0];
+      ok[mt][t] = m < a.M && src >= 0 && src < a.Lsrc;
+    }
+  }
+  int tapoff[3];                                                 // LDS byte offset of tap t's row for output row 0
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int d = a.src_off[t < a.ntaps ? t : 0] - smin;
+    tapoff[t] = SS == 1 ? d * CB_PITCH : (d & 1) * HROWS * CB_PITCH + (d >> 1) * CB_PITCH;
+  }
+  const unsigned char* xfrag = Xs + (wm * 64 + frow) * CB_PITCH + kg * 16;
+  const unsigned char* wfrag = Ws + (wn * 32 + frow) * CB_PITCH + kg * 16;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  const int kc = a.C >> 5;
+  gload(0);
+  for (int ks = 0; ks < kc; ++ks) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NXP; ++p) {
+      const int r = p * 32 + xrow;
+      if (r < NR) {
+        const int off = SS == 1 ? r * CB_PITCH : (r & 1) * HROWS * CB_PITCH + (r >> 1) * CB_PITCH;
+        *reinterpret_cast<f32x2v*>(Xs + off + xq * 8) = cvt4_bf16(rx[p]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      if (t < a.ntaps) *reinterpret_cast<f32x4*>(Ws + (t * CB_TN + wrow) * CB_PITCH + ws * 16) = rw[t];
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < kc) gload(ks + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if (t >= a.ntaps) break;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(wfrag + t * CB_TN * CB_PITCH + kk * 32);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          f32x4 av = *reinterpret_cast<const f32x4*>(xfrag + tapoff[t] + mt * 32 * CB_PITCH + kk * 32);
+          if (!ok[mt][t]) av = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), b, acc[mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long m = (long)M0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      if (m < a.M) {
+        const uint32_t rq = fdiv((uint32_t)m, a.divLm);
+        const int j = (int)((uint32_t)m - rq * (uint32_t)a.Lm);
+        float* o = a.y + ((size_t)rq * a.Ldst + (size_t)j * a.dst_stride + a.dst_off) * a.ldy + n_blk + wn * 32 + frow;
+        float v = acc[mt][r];
+        if (a.accumulate) v += *o;
+        *o = v;
+      }
+    }
+}
+
 // wf[t][co][ci] = bf16(w[co][ci][t]) (forward taps), wd[t][ci][co] = bf16(w[co][ci][2 - t]) (data-gradient taps)
 __global__ __launch_bounds__(256) void pack_conv3_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wf,
                                                               __bf16* __restrict__ wd, int co, int ci) {
@@ -178,11 +327,15 @@ struct WgradBf16Args {
   float* slab;
   int rows, L, Kpad, lddy, N, ldx, C, pchunk;
   FastDiv divL1;        // by L + 1
+  int mode;             // 0: k3 s1 p1;  1: k3 s2 p1;  2: k1 s2 p0  (L = OUTPUT length; the input is 2 L long for 1 / 2)
+  FastDiv divLx2;       // modes 1 / 2: by 2 L + 2
 };
 
 #define WB_KP 64
 #define WB_PITCH 192
-#define WB_LDS_BYTES ((WB_KP + WB_KP + 2) * WB_PITCH)
+#define WB_XPITCH2 160                                 // stride-2 X image: rows 2 apart per transposed read
+#define WB_X2ROWS (2 * WB_KP + 3)
+#define WB_LDS_BYTES (WB_KP * WB_PITCH + WB_X2ROWS * WB_XPITCH2)      // >= the stride-1 images
 
 __device__ __forceinline__ f32x2v ds_read_tr16(const unsigned char* p) {
   f32x2v v;
@@ -290,6 +443,118 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const in
     }
 }
 
+// Stride-2 convs (k3 s2 p1 block heads, NTAPS = 3; k1 s2 downsamples, NTAPS = 1):
+//     dW[t][n][c] = sum_j dy[j][n] * x[2 j + t - 1][c]        (k1: the t = 1 term alone)
+// K runs over padded OUTPUT positions P' = row (Lo + 1) + j; with the input padded to Lx + 2 = 2 (Lo + 1) slots a row
+// (slot 0 and slot Lx + 1 zero) the input slot of (P', t) is Q' = 2 P' + t -- linear, so the X image of a K step is the
+// contiguous range Q' = 2 k0 .. 2 k0 + 130 and a transposed read takes rows 2 apart (160-byte rows keep its 4 rows on
+// disjoint banks).
+template <int NTAPS>
+__device__ __forceinline__ void wgrad_bf16_s2_body(const WgradBf16Args& a, const int block_id, unsigned char* lds) {
+  unsigned char* Ys = lds;                              // [64][192 B]
+  unsigned char* Xs = lds + WB_KP * WB_PITCH;           // [131][160 B]: input slots 2 k0 .. 2 k0 + 130
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntc = a.C >> 6, tiles = (a.N >> 6) * ntc;
+  const int bx = block_id % tiles, split = block_id / tiles;
+  const int n_blk = (bx / ntc) * 64, c_blk = (bx % ntc) * 64;
+  const int k_beg = split * a.pchunk, k_end = min(a.Kpad, k_beg + a.pchunk);
+  const int L1 = a.L + 1, Lx = 2 * a.L, Lx2 = Lx + 2;
+
+  const int lq = tid & 15, lr = tid >> 4;
+  constexpr int NXP = (WB_X2ROWS + 15) / 16;            // 9 passes of 16 rows, the last one 3 rows
+  f32x4 ry[4], rx[NXP];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int Pp = k0 + lr + 16 * p;
+      bool ok = Pp < k_end;
+      const uint32_t sq = fdiv((uint32_t)(ok ? Pp : 0), a.divL1);
+      const int j = (ok ? Pp : 0) - (int)sq * L1;
+      ok = ok && j < a.L;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)sq * a.L + j) * a.lddy + n_blk + lq * 4);
+      ry[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < NXP; ++p) {
+      const int r = lr + 16 * p;
+      const long Qp = 2l * k0 + r;                      // padded input slot
+      bool ok = r < WB_X2ROWS && Qp < 2l * a.Kpad;
+      const uint32_t sq = fdiv((uint32_t)(ok ? Qp : 0), a.divLx2);
+      const int sl = (int)((ok ? Qp : 0) - (long)sq * Lx2);
+      ok = ok && sl >= 1 && sl <= Lx;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)sq * Lx + (sl - 1)) * a.ldx + c_blk + lq * 4);
+      rx[p] = v;
+    }
+  };
+
+  const int wn = wave >> 1, wc = wave & 1;
+  const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const unsigned char* yfrag = Ys + (8 * (g >> 1) + tq) * WB_PITCH + (wn * 32 + 16 * (g & 1) + 4 * tp) * 2;
+  const unsigned char* xfrag = Xs + 2 * (8 * (g >> 1) + tq) * WB_XPITCH2 + (wc * 32 + 16 * (g & 1) + 4 * tp) * 2;
+
+  f32x16 acc[NTAPS];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  if (k_beg < k_end) gload(k_beg);
+  for (int k0 = k_beg; k0 < k_end; k0 += WB_KP) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x2v*>(Ys + (lr + 16 * p) * WB_PITCH + lq * 8) = cvt4_bf16(ry[p]);
+#pragma unroll
+    for (int p = 0; p < NXP; ++p) {
+      const int r = lr + 16 * p;
+      if (r < WB_X2ROWS) *reinterpret_cast<f32x2v*>(Xs + r * WB_XPITCH2 + lq * 8) = cvt4_bf16(rx[p]);
+    }
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (k0 + WB_KP < k_end) gload(k0 + WB_KP);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < WB_KP / 16; ++kk) {
+      const unsigned char* yp = yfrag + kk * 16 * WB_PITCH;
+      const unsigned char* xp = xfrag + kk * 32 * WB_XPITCH2;
+      f32x2v y0 = ds_read_tr16(yp), y1 = ds_read_tr16(yp + 4 * WB_PITCH);
+      f32x2v b0[NTAPS], b1[NTAPS];
+#pragma unroll
+      for (int t = 0; t < NTAPS; ++t) {                 // input slot of (output row j, tap t) = 2 j + t (k1: t = 1)
+        const int tt = NTAPS == 1 ? 1 : t;
+        b0[t] = ds_read_tr16(xp + tt * WB_XPITCH2);
+        b1[t] = ds_read_tr16(xp + (tt + 8) * WB_XPITCH2);
+      }
+      if (NTAPS == 3)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(y0), "+v"(y1), "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[NTAPS - 1]), "+v"(b1[NTAPS - 1]),
+                       "+v"(b0[NTAPS / 2]), "+v"(b1[NTAPS / 2]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y0), "+v"(y1), "+v"(b0[0]), "+v"(b1[0]));
+      const f32x4 av = {y0[0], y0[1], y1[0], y1[1]};
+#pragma unroll
+      for (int t = 0; t < NTAPS; ++t) {
+        const f32x4 bv = {b0[t][0], b0[t][1], b1[t][0], b1[t][1]};
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                         acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  float* out = a.slab + (size_t)split * NTAPS * a.N * a.C;
+  const size_t plane = (size_t)a.N * a.C;
+  const int frow = lane & 31, fh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n_blk + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      out[t * plane + (size_t)n * a.C + c_blk + wc * 32 + frow] = acc[t][r];
+    }
+}
+
 struct WgradBf16Table {
   WgradBf16Args d[24];
   int first_block[25];
@@ -300,7 +565,19 @@ __global__ __launch_bounds__(256) void wgrad_bf16_multi_kernel(WgradBf16Table t)
   __shared__ __attribute__((aligned(16))) unsigned char lds[WB_LDS_BYTES];
   int i = 0;
   while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
-  wgrad_bf16_body(t.d[i], blockIdx.x - t.first_block[i], lds);
+  const int b = blockIdx.x - t.first_block[i];
+  if (t.d[i].mode == 0) wgrad_bf16_body(t.d[i], b, lds);
+  else if (t.d[i].mode == 1) wgrad_bf16_s2_body<3>(t.d[i], b, lds);
+  else wgrad_bf16_s2_body<1>(t.d[i], b, lds);
+}
+
+// jobs the bf16 kernels take: channel counts multiples of 64 and  k3 s1 p1 | k3 s2 p1 | k1 s2 p0 (even input length)
+bool bf16_wgrad_eligible(const da_wgrad_job& j) {
+  if (j.N % 64 || j.C % 64 || j.N < 64 || j.C < 64 || j.dy_stride != 1 || j.dy_off != 0 || j.Lm != j.Ldy) return false;
+  if (j.src_stride == 1) return j.ntaps == 3 && j.src_off[0] == -1 && j.src_off[1] == 0 && j.src_off[2] == 1 && j.Lx == j.Lm;
+  if (j.src_stride != 2 || j.Lx != 2 * j.Lm) return false;
+  if (j.ntaps == 3) return j.src_off[0] == -1 && j.src_off[1] == 0 && j.src_off[2] == 1;
+  return j.ntaps == 1 && j.src_off[0] == 0;
 }
 
 static int g_wb_pchunk = 1024;
@@ -339,6 +616,8 @@ int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s) {
     a.rows = j.rows; a.L = j.Lm; a.Kpad = j.rows * (j.Lm + 1);
     a.lddy = j.lddy; a.N = j.N; a.ldx = j.ldx; a.C = j.C; a.pchunk = pchunk;
     a.divL1 = make_fastdiv((uint32_t)(j.Lm + 1));
+    a.mode = j.src_stride == 1 ? 0 : (j.ntaps == 3 ? 1 : 2);
+    a.divLx2 = make_fastdiv((uint32_t)(2 * j.Lm + 2));
     t.first_block[cnt] = blocks;
     blocks += (j.N / 64) * (j.C / 64) * splits;
     if (++cnt == 24) {
@@ -369,6 +648,45 @@ int da_conv3_bf16(const float* x, const void* wpk, float* y, int rows, int L, in
   const long tiles = ((M + CB_TM - 1) / CB_TM) * (N / CB_TN);
   if (tiles > 0x7fffffffl) return DA_EINVAL;
   hipLaunchKernelGGL(conv3_bf16_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, a);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// da_conv_gemm's contract with bf16 operands (fp32 in / out / sums), for the cases whose sources are linear in the
+// flat output index: Lsrc == src_stride * Lm, src_stride 1 or 2, source offsets within a span of 2.
+// Y[row][j*dst_stride+dst_off][n] (+)= sum_t sum_c X[row][j*src_stride+src_off[t]][c] * Wp[wtap[t]][n][c]; Wp bf16
+// [taps][N][C].  replaces reference models/resnet.py:5-8,126-128 (stride-2 conv, 1x1 downsample) under dtype bf16
+int da_conv_bf16(const float* x, const void* wpk, float* y, int rows, int Lm, int Lsrc, int ldx, int C, int Ldst,
+                 int ldy, int N, int dst_stride, int dst_off, int src_stride, int ntaps, const int* src_off,
+                 const int* wtap, int accumulate, hipStream_t stream) {
+  DA_ENTER();
+  if (!x || !wpk || !y || !src_off || !wtap || rows < 0 || Lm < 1 || C % 32 || N % CB_TN || C < 32 || N < CB_TN ||
+      ldx % 4 || ldx < C || ldy < N || ntaps < 1 || ntaps > 3 || (src_stride != 1 && src_stride != 2) ||
+      Lsrc != src_stride * Lm || dst_stride < 1 || dst_off < 0 || (Lm - 1) * dst_stride + dst_off >= Ldst)
+    return DA_EINVAL;
+  int lo = src_off[0], hi = src_off[0];
+  for (int t = 0; t < ntaps; ++t) {
+    if (wtap[t] < 0 || wtap[t] > 2) return DA_EINVAL;
+    lo = src_off[t] < lo ? src_off[t] : lo;
+    hi = src_off[t] > hi ? src_off[t] : hi;
+  }
+  if (hi - lo > 2) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  const long M = (long)rows * Lm;
+  if (M >= 0x7fffffffl || (long)rows * Lsrc >= 0x7fffffffl || (long)rows * Ldst >= 0x7fffffffl) return DA_EINVAL;
+  ConvBf16GenArgs a;
+  a.x = x; a.w = reinterpret_cast<const __bf16*>(wpk); a.y = y;
+  a.M = (int)M; a.Lm = Lm; a.Lsrc = Lsrc; a.ldx = ldx; a.C = C; a.Ldst = Ldst; a.ldy = ldy; a.N = N;
+  a.dst_stride = dst_stride; a.dst_off = dst_off; a.ntaps = ntaps; a.accumulate = accumulate;
+  for (int t = 0; t < 3; ++t) {
+    a.src_off[t] = t < ntaps ? src_off[t] : src_off[0];
+    a.wtap[t] = t < ntaps ? wtap[t] : wtap[0];
+  }
+  a.Msrc = (long)rows * Lsrc;
+  a.divLm = make_fastdiv((uint32_t)Lm);
+  const long tiles = ((M + CB_TM - 1) / CB_TM) * (N / CB_TN);
+  if (src_stride == 1) hipLaunchKernelGGL(conv_bf16_gen_kernel<1>, dim3((unsigned)tiles), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(conv_bf16_gen_kernel<2>, dim3((unsigned)tiles), dim3(256), 0, stream, a);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

@@ -983,7 +983,9 @@ int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
     if (!j.dy || !j.x || !j.workspace || j.ntaps < 1 || j.ntaps > 3 || j.C % 32 || j.N % 32 || j.lddy % 4 || j.ldx % 4)
       return DA_EINVAL;
     if ((uint64_t)j.rows * j.Lm * (uint64_t)j.Lm >= 0xffffffffull) return DA_EINVAL;
-    if (j.winograd ? !wino_wgrad_eligible(j) : !wgrad_plan(j.rows * j.Lm, j.N, j.C, j.ntaps).tn) return DA_EINVAL;
+    if (j.winograd == 16 ? !bf16_wgrad_eligible(j)
+                         : (j.winograd ? !wino_wgrad_eligible(j) : !wgrad_plan(j.rows * j.Lm, j.N, j.C, j.ntaps).tn))
+      return DA_EINVAL;
   }
   int rc;
   if ((rc = wino_wgrad_launch(jobs, n, stream))) return rc;   // the heaviest blocks first
@@ -1008,7 +1010,7 @@ int da_conv_wgrad_splits(int rows, int Lm, int N, int C, int ntaps) {
 int da_conv_wgrad_plan(int rows, int Lm, int N, int C, int ntaps, int winograd, int* out) {
   if (!out || ntaps < 1 || ntaps > 3 || N % 32 || C % 32) return DA_EINVAL;
   if (winograd) {
-    if (ntaps != 3 || N % 64 || C % 64) return DA_EINVAL;
+    if ((ntaps != 3 && winograd != 16) || N % 64 || C % 64) return DA_EINVAL;
     out[0] = 64; out[1] = 64;
     if (winograd == 16) bf16_wgrad_plan(rows, Lm, &out[2], &out[3]);     // kchunk counts padded positions
     else wino_wgrad_plan(rows, Lm, &out[2], &out[3]);

@@ -291,9 +291,9 @@ __global__ __launch_bounds__(256) void repack_tiled_kernel(RepackTable t) {
       if (d.Wf)
         for (int k = 0; k < K; ++k) d.Wf[(size_t)k * tot + o] = w[k];
       if (d.Uf) {
-        if (d.points == 16) {                                     // bf16 tap packs of conv_bf16.hip: [3][Co][Ci]
+        if (d.points == 16) {                                     // bf16 tap packs of conv_bf16.hip: [K][Co][Ci]
           __bf16* u = reinterpret_cast<__bf16*>(d.Uf);
-          for (int k = 0; k < 3; ++k) u[(size_t)k * tot + o] = (__bf16)w[k];
+          for (int k = 0; k < K; ++k) u[(size_t)k * tot + o] = (__bf16)w[k];
         } else {
           emit_wino_taps(d.Uf + o, tot, w[0], w[1], w[2], d.points);
         }
@@ -306,9 +306,9 @@ __global__ __launch_bounds__(256) void repack_tiled_kernel(RepackTable t) {
       if (d.Wd)
         for (int k = 0; k < K; ++k) d.Wd[(size_t)k * tot + o] = w[k];
       if (d.Ud) {                                               // taps reversed: g_t = w[..][2 - t]
-        if (d.points == 16) {                                     // [3][Ci][Co] bf16
+        if (d.points == 16) {                                     // [K][Ci][Co] bf16, taps reversed
           __bf16* u = reinterpret_cast<__bf16*>(d.Ud);
-          for (int k = 0; k < 3; ++k) u[(size_t)k * tot + o] = (__bf16)w[2 - k];
+          for (int k = 0; k < K; ++k) u[(size_t)k * tot + o] = (__bf16)w[K - 1 - k];
         } else {
           emit_wino_taps(d.Ud + o, tot, w[2], w[1], w[0], d.points);
         }
@@ -816,7 +816,7 @@ int da_repack_multi(const da_repack_desc* descs, int n, hipStream_t stream) {
     int m = n - base < 32 ? n - base : 32;
     for (int i = 0; i < m; ++i) {
       const da_repack_desc& s = descs[base + i];
-      if (!s.W || (!s.Wf && !s.Wd && !s.Uf && !s.Ud) || ((s.Uf || s.Ud) && s.K != 3)) return DA_EINVAL;
+      if (!s.W || (!s.Wf && !s.Wd && !s.Uf && !s.Ud) || ((s.Uf || s.Ud) && s.K != 3 && s.points != 16)) return DA_EINVAL;
       if (s.points == 16 && (s.Co % 32 || s.Ci % 32)) return DA_EINVAL;        // bf16 packs: tiled kernel only
       t.d[i] = {s.W, s.Wf, s.Wd, s.Uf, s.Ud, s.Co, s.Ci, s.K, s.points};
     }

@@ -137,11 +137,13 @@ set_conv_dtype(_CONV_DTYPE)
 def _is_wino(w, stride, pad):
     """How a conv's forward / data gradient runs: 0 = direct fp32 kernel; k3 s1 p1 convs: 4 = Winograd F(2,3) (2/3 of
     the direct conv's MFMAs, fp32 throughout), 6 = F(4,3) (1/2 of them; pays once both channel counts reach
-    _WINO4_MIN_C), 16 = bf16 products with fp32 sums (conv dtype 'bf16', channel counts multiples of 64)."""
+    _WINO4_MIN_C), 16 = bf16 products with fp32 sums (conv dtype 'bf16', channel counts multiples of 64; also the
+    k3 s2 p1 and k1 s2 p0 convs)."""
+    if _CONV_DTYPE == 'bf16' and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0 and (
+            (w.shape[2] == 3 and pad == 1 and stride in (1, 2)) or (w.shape[2] == 1 and pad == 0 and stride == 2)):
+        return 16                                   # also the stride-2 block heads and 1x1 downsamples (even lengths)
     if not (w.shape[2] == 3 and stride == 1 and pad == 1 and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0):
         return 0
-    if _CONV_DTYPE == 'bf16' and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
-        return 16
     if not _WINOGRAD:
         return 0
     return 6 if min(w.shape[0], w.shape[1]) >= _WINO4_MIN_C else 4
@@ -151,8 +153,9 @@ def _pack(w, code):
     """(wf, wd, uf, ud) of a conv weight: direct packs (code 0), Winograd taps or bf16 tap packs (in the uf / ud
     places), repacked once per step."""
     e = _STEP['pack'].get(w.data_ptr()) if _STEP['on'] else None
-    want = 3 if code == 16 else (code if code else 0)
-    if e is None or (e[2] is None if code else e[0] is None) or (code and e[2].shape[0] != want):
+    want = w.shape[2] if code == 16 else (code if code else 0)
+    if e is None or (e[2] is None if code else e[0] is None) or \
+            (code and (e[2].shape[0] != want or (e[2].dtype == torch.bfloat16) != (code == 16))):
         e = H.repack_multi([w], [code])[0]
         if _STEP['on']:
             _STEP['pack'][w.data_ptr()] = e
@@ -161,8 +164,10 @@ def _pack(w, code):
 
 def _conv_fwd(x, w, stride, pad):
     code = _is_wino(w, stride, pad)
+    if code == 16 and stride == 2 and x.shape[1] % 2:
+        code = 0                                    # odd length: the fp32 kernel
     if code == 16:
-        return H.conv3_bf16(x, _pack(w, code)[2])
+        return H.conv3_bf16(x, _pack(w, code)[2]) if stride == 1 else H.conv_fwd_bf16_s2(x, _pack(w, code)[2])
     if code:
         return H.conv3_winograd(x, _pack(w, code)[2])
     return H.conv_fwd(x, _pack(w, 0)[0], stride, pad)
@@ -170,7 +175,11 @@ def _conv_fwd(x, w, stride, pad):
 
 def _conv_dgrad(dy, w, stride, pad, l_in, out=None, accumulate=False):
     code = _is_wino(w, stride, pad)
+    if code == 16 and stride == 2 and l_in % 2:
+        code = 0
     if code == 16:
+        if stride == 2:
+            return H.conv_dgrad_bf16_s2(dy, _pack(w, code)[3], l_in, out=out, accumulate=accumulate)
         return H.conv3_bf16(dy, _pack(w, code)[3], out=out, accumulate=accumulate)
     if code:
         return H.conv3_winograd(dy, _pack(w, code)[3], out=out, accumulate=accumulate)

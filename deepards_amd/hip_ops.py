@@ -148,6 +148,56 @@ def conv3_bf16(x, wpk, out=None, accumulate=False):
     return out
 
 
+def _conv_bf16(x, wpk, out, lm, lsrc, ldst, dst_stride, dst_off, src_stride, src_off, wtap, accumulate):
+    rows, _, c = x.shape
+    n = wpk.shape[1]
+    so, wt = (ctypes.c_int * 3)(*(list(src_off) + [0] * (3 - len(src_off)))), \
+        (ctypes.c_int * 3)(*(list(wtap) + [0] * (3 - len(wtap))))
+    _chk(_lib.lib().da_conv_bf16(_p(x), _p(wpk), _p(out), rows, lm, lsrc, c, c, ldst, n, n, dst_stride, dst_off,
+                                 src_stride, len(src_off), so, wt, 1 if accumulate else 0, _stream()), 'da_conv_bf16')
+
+
+def conv_fwd_bf16_s2(x, wf16):
+    """Stride-2 forward with bf16 operands: wf16 (3, N, C) = k3 s2 p1 block head, (1, N, C) = k1 s2 p0 downsample;
+    x (rows, L, C) fp32 with L even -> (rows, L / 2, N) fp32."""
+    _rlc(x, 'x')
+    rows, l, c = x.shape
+    k, n, c2 = wf16.shape
+    if k not in (1, 3) or c2 != c or c % 32 or n % 64 or l % 2 or wf16.dtype != torch.bfloat16 or not wf16.is_contiguous():
+        raise ValueError('conv_fwd_bf16_s2: unsupported shape x%s w%s' % (tuple(x.shape), tuple(wf16.shape)))
+    out = torch.empty((rows, l // 2, n), device=x.device, dtype=torch.float32)
+    if k == 3:
+        _conv_bf16(x, wf16, out, l // 2, l, l // 2, 1, 0, 2, [-1, 0, 1], [0, 1, 2], False)
+    else:
+        _conv_bf16(x, wf16, out, l // 2, l, l // 2, 1, 0, 2, [0], [0], False)
+    return out
+
+
+def conv_dgrad_bf16_s2(dy, wd16, l_in, out=None, accumulate=False):
+    """Data gradient of the stride-2 convs with bf16 operands: wd16 (3, Ci, Co) (taps reversed, as the packs come) or
+    (1, Ci, Co); dy (rows, l_in / 2, Co) -> dx (rows, l_in, Ci).  k3: even positions take tap 1, odd ones taps 0 / 2
+    of the neighbouring outputs (two launches); k1: even positions only (odd ones zero unless accumulating)."""
+    _rlc(dy, 'dy')
+    rows, lo, co = dy.shape
+    k, ci, co2 = wd16.shape
+    if k not in (1, 3) or co2 != co or co % 32 or ci % 64 or l_in != 2 * lo or wd16.dtype != torch.bfloat16:
+        raise ValueError('conv_dgrad_bf16_s2: unsupported shape')
+    if out is None:
+        if accumulate:
+            raise ValueError('accumulate needs out')
+        out = (torch.zeros if k == 1 else torch.empty)((rows, l_in, ci), device=dy.device, dtype=torch.float32)
+    elif tuple(out.shape) != (rows, l_in, ci):
+        raise ValueError('conv_dgrad_bf16_s2: bad out shape')
+    elif k == 1 and not accumulate:
+        out.zero_()
+    if k == 3:       # wd16[t'] = w[..][2 - t']: dx[2j] = dy[j] w1;  dx[2j+1] = dy[j] w2 + dy[j+1] w0
+        _conv_bf16(dy, wd16, out, lo, lo, l_in, 2, 0, 1, [0], [1], accumulate)
+        _conv_bf16(dy, wd16, out, lo, lo, l_in, 2, 1, 1, [0, 1], [0, 2], accumulate)
+    else:
+        _conv_bf16(dy, wd16, out, lo, lo, l_in, 2, 0, 1, [0], [0], accumulate)
+    return out
+
+
 def conv_dgrad(dy, wd, stride, pad, l_in, out=None, accumulate=False):
     """dy (rows,Lo,Co), wd packed (K,Ci,Co) -> dx (rows,l_in,Ci).  With accumulate the result is
     added into `out`; positions no tap reaches are left untouched (accumulate) or zeroed."""
@@ -283,7 +333,9 @@ def conv_wgrad_multi(jobs):
         if rows != rows2 or lo != conv_out_len(l, k, stride, pad) or k > 3 or ci % 32 or co % 32:
             raise ValueError('conv_wgrad_multi: unsupported shape')
         wino = 1 if (WINOGRAD_WGRAD and k == 3 and stride == 1 and pad == 1 and co % 64 == 0 and ci % 64 == 0) else 0
-        if WGRAD_BF16 and k == 3 and stride == 1 and pad == 1 and co % 64 == 0 and ci % 64 == 0:
+        if WGRAD_BF16 and co % 64 == 0 and ci % 64 == 0 and (
+                (k == 3 and stride == 1 and pad == 1) or
+                (stride == 2 and l % 2 == 0 and ((k == 3 and pad == 1) or (k == 1 and pad == 0)))):
             wino = 16                                # bf16 operands / fp32 sums (conv dtype bf16)
         _chk(L.da_conv_wgrad_plan(rows, lo, co, ci, k, wino, plan), 'da_conv_wgrad_plan')
         ws = torch.empty((plan[2] * k * co * ci,), device=x.device, dtype=torch.float32)
@@ -320,7 +372,7 @@ def repack_multi(weights, winograd=None):
         co, ci, k = w.shape
         code = winograd[n] if winograd is not None else 0
         wino = bool(code)
-        if wino and k != 3:
+        if wino and k != 3 and not (code == 16 and k == 1):
             raise ValueError('winograd taps need a 3-tap weight')
         pts = code if wino and code in (6, 16) else 4
         mk = lambda *shape: torch.empty(shape, device=w.device, dtype=torch.float32)
@@ -328,8 +380,8 @@ def repack_multi(weights, winograd=None):
         if pts == 16:                                # bf16 tap packs (3, Co, Ci) / (3, Ci, Co)
             if co % 32 or ci % 32:
                 raise ValueError('bf16 tap packs need channel counts that are multiples of 32')
-            uf = torch.empty((3, co, ci), device=w.device, dtype=torch.bfloat16)
-            ud = torch.empty((3, ci, co), device=w.device, dtype=torch.bfloat16)
+            uf = torch.empty((k, co, ci), device=w.device, dtype=torch.bfloat16)
+            ud = torch.empty((k, ci, co), device=w.device, dtype=torch.bfloat16)
         else:
             uf, ud = (mk(pts, co, ci), mk(pts, ci, co)) if wino else (None, None)
         descs.append((w.data_ptr(), _p(wf), _p(wd), _p(uf), _p(ud), co, ci, k, pts))

@@ -18,10 +18,29 @@ MI355X-first differences (results identical, see tests):
     the optimizer kernel.  BatchNorm never crosses windows, so no SyncBN is needed (finding 3).
   * no per-step device->host sync: losses stay on the device until asked for.
 """
+import contextlib
+import gc
+
 import torch
 
 from . import functional as F_
 from . import hip_ops as H
+
+
+@contextlib.contextmanager
+def _capture_graph(graph):
+    """torch.cuda.graph(graph) with the Python garbage collector held off: a collection that runs in the middle of a
+    stream capture can finalise CUDA objects of earlier, unrelated work (graphs, events, cached blocks in reference
+    cycles), and freeing those while the stream is capturing aborts the process."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def clip_odd_batch_sizes(obs_idx, seq, metadata, target):
@@ -177,11 +196,11 @@ class HotPathTrainer(object):
                 b.copy_(c)
         torch.cuda.current_stream().wait_stream(s)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with _capture_graph(self._graph):
             self._static_out = self._eager_single_gpu_parts(*self._static)
         if self.world_size > 1:
             self._graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_opt):
+            with _capture_graph(self._graph_opt):
                 self._optimizer_step()
 
     def _eager_single_gpu_parts(self, inputs, target):
@@ -254,7 +273,7 @@ class HotPathTrainer(object):
                     b.copy_(c)
             torch.cuda.current_stream().wait_stream(s)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _capture_graph(g):
                 out = self._test_forward(*static)
             ent = self._test_graphs[key] = (g, static, out)
         g, static, out = ent

@@ -92,6 +92,12 @@ int da_wino4_weights(const float* w, float* u, int co, int ci, int transpose, da
 int da_conv3_bf16(const float* x, const void* wpk, float* y, int rows, int L, int ldx, int C, int ldy, int N,
                   int accumulate, da_stream_t stream);
 int da_pack_conv3_bf16(const float* w, void* wf, void* wd, int co, int ci, da_stream_t stream);
+/* da_conv_gemm's contract with bf16 operands for the stride-2 block heads and 1x1 downsamples (resnet.py:5-8,126-128),
+ * forward and data gradient: Lsrc == src_stride * Lm, src_stride 1 or 2, source offsets within a span of 2, wpk bf16
+ * [taps][N][C] (da_repack_desc.points = 16 emits them for K = 1 and K = 3). */
+int da_conv_bf16(const float* x, const void* wpk, float* y, int rows, int Lm, int Lsrc, int ldx, int C, int Ldst,
+                 int ldy, int N, int dst_stride, int dst_off, int src_stride, int ntaps, const int* src_off,
+                 const int* wtap, int accumulate, da_stream_t stream);
 /* all weight-gradient GEMMs of a step in one launch per tile shape (jobs: HOST array); slabs only, reduce afterwards */
 typedef struct {
   const float* dy; const float* x; float* workspace;
@@ -111,7 +117,7 @@ int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumula
 int da_repack_conv_weight(const float* W, float* Wf, float* Wd, int Co, int Ci, int K, da_stream_t stream);
 /* Uf / Ud (K == 3 only, may be NULL): the Winograd taps of da_wino_weights (points 0 / 4) or da_wino4_weights
    (points == 6) for the forward / data gradient; points == 16: Uf / Ud point at bf16 buffers and receive the tap packs
-   of da_pack_conv3_bf16 (Co and Ci multiples of 32) */
+   of da_pack_conv3_bf16 (K = 3) or [1][Co][Ci] / [1][Ci][Co] (K = 1); Co and Ci multiples of 32 */
 typedef struct { const float* W; float* Wf; float* Wd; float* Uf; float* Ud; int Co, Ci, K; int points; } da_repack_desc;
 int da_repack_multi(const da_repack_desc* descs, int n, da_stream_t stream);
 

@@ -218,17 +218,21 @@ def round_bf16(a):
 
 def _conv(t, x, name, stride, pad, need_dx=True):
     w = t.p[name]
-    # BASELINE config C3 arithmetic (build-side, not in the reference): the forward and the data gradient of the k3 s1 p1
-    # convs with channel counts that are multiples of 64, and their weight gradient, see bf16-rounded operands; sums and
-    # everything else stay exact here (fp32 on the device)
-    bf16 = getattr(t, 'bf16_convs', False) and w.shape[2] == 3 and stride == 1 and pad == 1 and \
-        w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
-    y = conv1d_fwd(round_bf16(x), round_bf16(w), stride, pad) if bf16 else conv1d_fwd(x, w, stride, pad)
+    # BASELINE config C3 arithmetic (build-side, not in the reference): the k3 s1 p1 / k3 s2 p1 / k1 s2 p0 convs with
+    # channel counts that are multiples of 64 (stride 2: even lengths) see bf16-rounded operands in the forward, the
+    # data gradient and the weight gradient; sums and everything else stay exact here (fp32 on the device)
+    on = getattr(t, 'bf16_convs', False) and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
+    k = w.shape[2]
+    bf_w = on and ((k == 3 and pad == 1 and stride in (1, 2)) or (k == 1 and pad == 0 and stride == 2)) and \
+        (stride == 1 or x.shape[2] % 2 == 0)
+    bf_fd = bf_w
+    y = conv1d_fwd(round_bf16(x), round_bf16(w), stride, pad) if bf_fd else conv1d_fwd(x, w, stride, pad)
 
     def bwd(dy):
         dx, dw = conv1d_bwd(x, w, dy, stride, pad, need_dx)
-        if bf16:                                      # dx from rounded (dy, w), dw from rounded (dy, x)
+        if bf_fd:                                     # dx from rounded (dy, w)
             dx, _ = conv1d_bwd(x, round_bf16(w), round_bf16(dy), stride, pad, need_dx)
+        if bf_w:                                      # dw from rounded (dy, x)
             _, dw = conv1d_bwd(round_bf16(x), w, round_bf16(dy), stride, pad, False)
         t.acc(name, dw)
         return dx

@@ -261,21 +261,66 @@ def test_conv3_wgrad_bf16(H, ci, co, L, rows):
         close(dw.cpu().numpy(), dw_ref, tol=1.5e-2, name='bf16 wgrad vs exact')
         H.wgrad_reduce_multi([(slab, dw)], accumulate=True)
         close(dw.cpu().numpy(), 2 * dw_b, tol=3e-6, name='bf16 wgrad accumulate')
-        # mixed batch: a stride-2 job (direct fp32 kernel) rides along
+        # mixed batch: the stride-2 forms (k3 s2 p1 block head, k1 s2 downsample) ride along, bf16 too
         if L % 2 == 0 and L >= 2:
             dy2 = rng.standard_normal((rows, co, L // 2))
-            _, dw2_ref = np_ref.conv1d_bwd(x, w0, dy2, 2, 1, need_dx=False)
-            s1, s2 = H.conv_wgrad_multi([(dyt, xt, 3, 1, 1), (rlc(dy2), xt, 3, 2, 1)])
+            _, dw2_b = np_ref.conv1d_bwd(rb(x), w0, rb(dy2), 2, 1, need_dx=False)
+            _, dw1_b = np_ref.conv1d_bwd(rb(x), np.zeros((co, ci, 1)), rb(dy2), 2, 0, need_dx=False)
+            s1, s2, s3 = H.conv_wgrad_multi([(dyt, xt, 3, 1, 1), (rlc(dy2), xt, 3, 2, 1), (rlc(dy2), xt, 1, 2, 0)])
             d1, d2 = torch.zeros(co, ci, 3, device='cuda'), torch.zeros(co, ci, 3, device='cuda')
-            H.wgrad_reduce_multi([(s1, d1), (s2, d2)], accumulate=False)
+            d3 = torch.zeros(co, ci, 1, device='cuda')
+            H.wgrad_reduce_multi([(s1, d1), (s2, d2), (s3, d3)], accumulate=False)
             close(d1.cpu().numpy(), dw_b, tol=3e-6, name='bf16 wgrad in a mixed batch')
-            close(d2.cpu().numpy(), dw2_ref, tol=3e-6, name='direct wgrad in a mixed batch')
+            close(d2.cpu().numpy(), dw2_b, tol=3e-6, name='bf16 k3 s2 wgrad')
+            close(d3.cpu().numpy(), dw1_b, tol=3e-6, name='bf16 k1 s2 wgrad')
+        elif L >= 3:                                  # odd input length: the stride-2 job stays on the fp32 kernel
+            lo = (L - 1) // 2 + 1
+            dy2 = rng.standard_normal((rows, co, lo))
+            _, dw2_ref = np_ref.conv1d_bwd(x, w0, dy2, 2, 1, need_dx=False)
+            (s2,) = H.conv_wgrad_multi([(rlc(dy2), xt, 3, 2, 1)])
+            d2 = torch.zeros(co, ci, 3, device='cuda')
+            H.wgrad_reduce_multi([(s2, d2)], accumulate=False)
+            close(d2.cpu().numpy(), dw2_ref, tol=3e-6, name='direct wgrad for an odd length')
     finally:
         H.WGRAD_BF16 = False
     (slab32,) = H.conv_wgrad_multi([(dyt, xt, 3, 1, 1)])             # the flag is off again: fp32 Winograd form
     dw32 = torch.zeros(co, ci, 3, device='cuda')
     H.wgrad_reduce_multi([(slab32, dw32)], accumulate=False)
     close(dw32.cpu().numpy(), dw_ref, tol=4e-6, name='fp32 wgrad after the flag')
+
+
+@pytest.mark.parametrize('ci,co,L,rows', [(64, 128, 56, 40), (128, 256, 28, 23), (256, 512, 14, 40), (64, 64, 2, 7),
+                                          (128, 64, 6, 33), (64, 128, 56, 300), (192, 128, 10, 130)])
+def test_stride2_convs_bf16(H, ci, co, L, rows):
+    """Stride-2 block head (k3 s2 p1) and 1x1 downsample (k1 s2 p0) with bf16 operands: forward and data gradient
+    (even positions: one tap; odd positions: two taps of neighbouring outputs; accumulate form) == the fp64 results
+    on the bf16-rounded operands to fp32 rounding; bf16 packs for K = 1 and K = 3 from the batched repack."""
+    rng = np.random.default_rng(ci + co + L + rows)
+    rb = np_ref.round_bf16
+    x = rng.standard_normal((rows, ci, L))
+    xt = rlc(x)
+    for k, pad in ((3, 1), (1, 0)):
+        w = rng.standard_normal((co, ci, k)) * np.sqrt(2.0 / (k * co))
+        wt = cu(w)
+        (a, b, wf16, wd16), = H.repack_multi([wt], [16])
+        assert a is None and b is None and tuple(wf16.shape) == (k, co, ci) and tuple(wd16.shape) == (k, ci, co)
+        assert torch.equal(wf16, wt.permute(2, 0, 1).contiguous().bfloat16())
+        assert torch.equal(wd16, wt.flip(2).permute(2, 1, 0).contiguous().bfloat16())
+        y_b = np_ref.conv1d_fwd(rb(x), rb(w), 2, pad)
+        close(ncl(H.conv_fwd_bf16_s2(xt, wf16)), y_b, tol=3e-6, name='bf16 s2 fwd k%d' % k)
+        dy = rng.standard_normal(y_b.shape)
+        dx_b, _ = np_ref.conv1d_bwd(rb(x), rb(w), rb(dy), 2, pad)
+        dyt = rlc(dy)
+        close(ncl(H.conv_dgrad_bf16_s2(dyt, wd16, L)), dx_b, tol=3e-6, name='bf16 s2 dgrad k%d' % k)
+        base = rng.standard_normal(dx_b.shape)
+        bt = rlc(base)
+        H.conv_dgrad_bf16_s2(dyt, wd16, L, out=bt, accumulate=True)
+        close(ncl(bt), base.astype(np.float32).astype(np.float64) + dx_b, tol=3e-6, name='bf16 s2 dgrad+acc k%d' % k)
+        junk = torch.full_like(bt, 7.0)                            # non-accumulating form overwrites every position
+        H.conv_dgrad_bf16_s2(dyt, wd16, L, out=junk, accumulate=False)
+        close(ncl(junk), dx_b, tol=3e-6, name='bf16 s2 dgrad overwrite k%d' % k)
+    with pytest.raises(ValueError):
+        H.conv_fwd_bf16_s2(rlc(rng.standard_normal((2, ci, 7))), wf16)          # odd length
 
 
 @pytest.mark.parametrize('ci,co,L,rows', [(64, 128, 56, 40), (128, 256, 28, 23), (256, 512, 14, 300), (64, 128, 56, 300)])
