@@ -85,7 +85,7 @@ SIGNATURES = {
     'da_conv3_winograd4': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'da_conv3_bf16': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'da_pack_conv3_bf16': (_I, [_P, _P, _P, _I, _I, _P]),
-    'da_conv_bf16': (_I, [_P, _P, _P] + [_I] * 12 + [_IP, _IP, _I, _P]),
+    'da_conv_bf16_multi': (_I, [ctypes.POINTER(ConvJob), _I, _P]),
     'da_wino_debug_tail': (_I, [_I]),
     'da_wino_debug_pchunk': (_I, [_I]),
     'da_wino_weights': (_I, [_P, _P, _I, _I, _I, _P]),

@@ -164,17 +164,15 @@ struct ConvBf16GenArgs {
 };
 
 template <int SS>
-__global__ __launch_bounds__(256) void conv_bf16_gen_kernel(ConvBf16GenArgs a) {
+__device__ __forceinline__ void conv_bf16_gen_body(const ConvBf16GenArgs& a, const int tile, unsigned char* lds) {
   constexpr int HROWS = CB_TM + 1;                               // rows per parity half (SS = 2)
   constexpr int NR = SS * (CB_TM - 1) + 3;                       // panel rows at most (span of the taps <= 2)
   constexpr int XBYTES = (SS == 2 ? 2 * HROWS : NR) * CB_PITCH;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[XBYTES + 3 * CB_TN * CB_PITCH];
   unsigned char* Xs = lds;
   unsigned char* Ws = lds + XBYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntn = a.N / CB_TN;
-  const int tile = blockIdx.x;
   const int M0 = (tile / ntn) * CB_TM, n_blk = (tile % ntn) * CB_TN;
   int smin = a.src_off[0];
 #pragma unroll
@@ -292,6 +290,24 @@ __global__ __launch_bounds__(256) void conv_bf16_gen_kernel(ConvBf16GenArgs a) {
         *o = v;
       }
     }
+}
+
+// up to 4 independent problems of one source stride in a launch (a block head's conv and its downsample read the same
+// input; the even and the odd positions of a stride-2 data gradient are disjoint outputs): these launches are
+// latency-bound, so sharing one costs the longest of them, not the sum
+struct ConvBf16GenTable {
+  ConvBf16GenArgs d[4];
+  int first_block[5];
+  int n;
+};
+
+template <int SS>
+__global__ __launch_bounds__(256) void conv_bf16_gen_kernel(ConvBf16GenTable t) {
+  constexpr int XBYTES = (SS == 2 ? 2 * (CB_TM + 1) : SS * (CB_TM - 1) + 3) * CB_PITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[XBYTES + 3 * CB_TN * CB_PITCH];
+  int i = 0;
+  while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
+  conv_bf16_gen_body<SS>(t.d[i], blockIdx.x - t.first_block[i], lds);
 }
 
 // wf[t][co][ci] = bf16(w[co][ci][t]) (forward taps), wd[t][ci][co] = bf16(w[co][ci][2 - t]) (data-gradient taps)
@@ -652,42 +668,57 @@ int da_conv3_bf16(const float* x, const void* wpk, float* y, int rows, int L, in
   return DA_OK;
 }
 
-// da_conv_gemm's contract with bf16 operands (fp32 in / out / sums), for the cases whose sources are linear in the
-// flat output index: Lsrc == src_stride * Lm, src_stride 1 or 2, source offsets within a span of 2.
-// Y[row][j*dst_stride+dst_off][n] (+)= sum_t sum_c X[row][j*src_stride+src_off[t]][c] * Wp[wtap[t]][n][c]; Wp bf16
-// [taps][N][C].  replaces reference models/resnet.py:5-8,126-128 (stride-2 conv, 1x1 downsample) under dtype bf16
-int da_conv_bf16(const float* x, const void* wpk, float* y, int rows, int Lm, int Lsrc, int ldx, int C, int Ldst,
-                 int ldy, int N, int dst_stride, int dst_off, int src_stride, int ntaps, const int* src_off,
-                 const int* wtap, int accumulate, hipStream_t stream) {
+// da_conv_gemm_multi's contract with bf16 operands (fp32 in / out / sums) for the cases whose sources are linear in the
+// flat output index: per job Lsrc == src_stride * Lm, source offsets within a span of 2, one source (x2 == NULL); all
+// jobs of a call share src_stride (1 or 2); w: bf16 [taps][N][C].  Up to 4 jobs per launch.
+// Y[row][j*dst_stride+dst_off][n] (+)= sum_t sum_c X[row][j*src_stride+src_off[t]][c] * Wp[wtap[t]][n][c]
+// replaces reference models/resnet.py:5-8,126-128 (stride-2 conv, 1x1 downsample) under dtype bf16
+int da_conv_bf16_multi(const da_conv_job* jobs, int n, hipStream_t stream) {
   DA_ENTER();
-  if (!x || !wpk || !y || !src_off || !wtap || rows < 0 || Lm < 1 || C % 32 || N % CB_TN || C < 32 || N < CB_TN ||
-      ldx % 4 || ldx < C || ldy < N || ntaps < 1 || ntaps > 3 || (src_stride != 1 && src_stride != 2) ||
-      Lsrc != src_stride * Lm || dst_stride < 1 || dst_off < 0 || (Lm - 1) * dst_stride + dst_off >= Ldst)
-    return DA_EINVAL;
-  int lo = src_off[0], hi = src_off[0];
-  for (int t = 0; t < ntaps; ++t) {
-    if (wtap[t] < 0 || wtap[t] > 2) return DA_EINVAL;
-    lo = src_off[t] < lo ? src_off[t] : lo;
-    hi = src_off[t] > hi ? src_off[t] : hi;
+  if (n < 0 || (n && !jobs)) return DA_EINVAL;
+  for (int base = 0; base < n; base += 4) {
+    ConvBf16GenTable t;
+    const int m = n - base < 4 ? n - base : 4;
+    int blocks = 0, cnt = 0;
+    const int ss = jobs[base].src_stride;
+    for (int i = 0; i < m; ++i) {
+      const da_conv_job& j = jobs[base + i];
+      if (!j.x || !j.w || !j.y || j.x2 || j.rows < 0 || j.Lm < 1 || j.C % 32 || j.N % CB_TN || j.C < 32 || j.N < CB_TN ||
+          j.ldx % 4 || j.ldx < j.C || j.ldy < j.N || j.ntaps < 1 || j.ntaps > 3 || (ss != 1 && ss != 2) ||
+          j.src_stride != ss || j.Lsrc != ss * j.Lm || j.dst_stride < 1 || j.dst_off < 0 ||
+          (j.Lm - 1) * j.dst_stride + j.dst_off >= j.Ldst)
+        return DA_EINVAL;
+      int lo = j.src_off[0], hi = j.src_off[0];
+      for (int k = 0; k < j.ntaps; ++k) {
+        if (j.wtap[k] < 0 || j.wtap[k] > 2) return DA_EINVAL;
+        lo = j.src_off[k] < lo ? j.src_off[k] : lo;
+        hi = j.src_off[k] > hi ? j.src_off[k] : hi;
+      }
+      if (hi - lo > 2) return DA_EINVAL;
+      const long M = (long)j.rows * j.Lm;
+      if (M >= 0x7fffffffl || (long)j.rows * j.Lsrc >= 0x7fffffffl || (long)j.rows * j.Ldst >= 0x7fffffffl) return DA_EINVAL;
+      if (M == 0) continue;
+      ConvBf16GenArgs& a = t.d[cnt];
+      a.x = j.x; a.w = reinterpret_cast<const __bf16*>(j.w); a.y = j.y;
+      a.M = (int)M; a.Lm = j.Lm; a.Lsrc = j.Lsrc; a.ldx = j.ldx; a.C = j.C; a.Ldst = j.Ldst; a.ldy = j.ldy; a.N = j.N;
+      a.dst_stride = j.dst_stride; a.dst_off = j.dst_off; a.ntaps = j.ntaps; a.accumulate = j.accumulate;
+      for (int k = 0; k < 3; ++k) {
+        a.src_off[k] = k < j.ntaps ? j.src_off[k] : j.src_off[0];
+        a.wtap[k] = k < j.ntaps ? j.wtap[k] : j.wtap[0];
+      }
+      a.Msrc = (long)j.rows * j.Lsrc;
+      a.divLm = make_fastdiv((uint32_t)j.Lm);
+      t.first_block[cnt] = blocks;
+      blocks += (int)(((M + CB_TM - 1) / CB_TM) * (j.N / CB_TN));
+      ++cnt;
+    }
+    if (!cnt) continue;
+    t.n = cnt;
+    t.first_block[cnt] = blocks;
+    if (ss == 1) hipLaunchKernelGGL(conv_bf16_gen_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, t);
+    else hipLaunchKernelGGL(conv_bf16_gen_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, t);
+    DA_CHECK_LAUNCH();
   }
-  if (hi - lo > 2) return DA_EINVAL;
-  if (rows == 0) return DA_OK;
-  const long M = (long)rows * Lm;
-  if (M >= 0x7fffffffl || (long)rows * Lsrc >= 0x7fffffffl || (long)rows * Ldst >= 0x7fffffffl) return DA_EINVAL;
-  ConvBf16GenArgs a;
-  a.x = x; a.w = reinterpret_cast<const __bf16*>(wpk); a.y = y;
-  a.M = (int)M; a.Lm = Lm; a.Lsrc = Lsrc; a.ldx = ldx; a.C = C; a.Ldst = Ldst; a.ldy = ldy; a.N = N;
-  a.dst_stride = dst_stride; a.dst_off = dst_off; a.ntaps = ntaps; a.accumulate = accumulate;
-  for (int t = 0; t < 3; ++t) {
-    a.src_off[t] = t < ntaps ? src_off[t] : src_off[0];
-    a.wtap[t] = t < ntaps ? wtap[t] : wtap[0];
-  }
-  a.Msrc = (long)rows * Lsrc;
-  a.divLm = make_fastdiv((uint32_t)Lm);
-  const long tiles = ((M + CB_TM - 1) / CB_TM) * (N / CB_TN);
-  if (src_stride == 1) hipLaunchKernelGGL(conv_bf16_gen_kernel<1>, dim3((unsigned)tiles), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(conv_bf16_gen_kernel<2>, dim3((unsigned)tiles), dim3(256), 0, stream, a);
-  DA_CHECK_LAUNCH();
   return DA_OK;
 }
 

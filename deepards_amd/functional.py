@@ -281,8 +281,12 @@ class BasicBlockFunction(Function):
 
     @staticmethod
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, R, st1, st2, std):
-        pair = wd is not None and stride == 2 and _PAIR_S2 and not _is_wino(w1, stride, 1)
-        if pair:      # the stride-2 conv and the 1x1 downsample read the same input: one launch
+        bf16_pair = wd is not None and stride == 2 and _PAIR_S2 and x.shape[1] % 2 == 0 and \
+            _is_wino(w1, stride, 1) == 16 and _is_wino(wd, stride, 0) == 16
+        pair = bf16_pair or (wd is not None and stride == 2 and _PAIR_S2 and not _is_wino(w1, stride, 1))
+        if bf16_pair:     # conv dtype bf16: the same shared launch on the bf16 kernel
+            y1, yd = H.conv_fwd_bf16_s2(x, _pack(w1, 16)[2], _pack(wd, 16)[2])
+        elif pair:    # the stride-2 conv and the 1x1 downsample read the same input: one launch
             y1, yd = H.conv_fwd_multi([(x, _pack(w1, False)[0], stride, 1), (x, _pack(wd, False)[0], stride, 0)])
         else:
             y1 = _conv_fwd(x, w1, stride, 1)

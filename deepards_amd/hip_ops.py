@@ -148,40 +148,50 @@ def conv3_bf16(x, wpk, out=None, accumulate=False):
     return out
 
 
-def _conv_bf16(x, wpk, out, lm, lsrc, ldst, dst_stride, dst_off, src_stride, src_off, wtap, accumulate):
-    rows, _, c = x.shape
-    n = wpk.shape[1]
-    so, wt = (ctypes.c_int * 3)(*(list(src_off) + [0] * (3 - len(src_off)))), \
-        (ctypes.c_int * 3)(*(list(wtap) + [0] * (3 - len(wtap))))
-    _chk(_lib.lib().da_conv_bf16(_p(x), _p(wpk), _p(out), rows, lm, lsrc, c, c, ldst, n, n, dst_stride, dst_off,
-                                 src_stride, len(src_off), so, wt, 1 if accumulate else 0, _stream()), 'da_conv_bf16')
+def _conv_bf16_multi(jobs):
+    """jobs: [(x, wpk, out, lm, lsrc, ldst, dst_stride, dst_off, src_stride, src_off, wtap, accumulate)] in one call."""
+    arr = (_lib.ConvJob * len(jobs))()
+    for d, (x, wpk, out, lm, lsrc, ldst, dst_stride, dst_off, src_stride, so, wt, acc) in zip(arr, jobs):
+        rows, _, c = x.shape
+        n = wpk.shape[1]
+        _conv_job(d, x, wpk, out, rows, lm, lsrc, c, c, ldst, n, n, dst_stride, dst_off, src_stride, so, wt, acc)
+    _chk(_lib.lib().da_conv_bf16_multi(arr, len(jobs), _stream()), 'da_conv_bf16_multi')
 
 
-def conv_fwd_bf16_s2(x, wf16):
-    """Stride-2 forward with bf16 operands: wf16 (3, N, C) = k3 s2 p1 block head, (1, N, C) = k1 s2 p0 downsample;
-    x (rows, L, C) fp32 with L even -> (rows, L / 2, N) fp32."""
+def _check_bf16_pack(x, w16, name):
+    k, n, c2 = w16.shape
+    if k not in (1, 3) or c2 != x.shape[2] or c2 % 32 or n % 64 or w16.dtype != torch.bfloat16 or not w16.is_contiguous():
+        raise ValueError('%s: unsupported shape x%s w%s' % (name, tuple(x.shape), tuple(w16.shape)))
+    return k, n
+
+
+def conv_fwd_bf16_s2(x, *packs):
+    """Stride-2 forward with bf16 operands, one launch for all packs: wf16 (3, N, C) = k3 s2 p1 block head, (1, N, C) = k1
+    s2 p0 downsample; x (rows, L, C) fp32 with L even -> (rows, L / 2, N) fp32 per pack (a single tensor for one pack)."""
     _rlc(x, 'x')
     rows, l, c = x.shape
-    k, n, c2 = wf16.shape
-    if k not in (1, 3) or c2 != c or c % 32 or n % 64 or l % 2 or wf16.dtype != torch.bfloat16 or not wf16.is_contiguous():
-        raise ValueError('conv_fwd_bf16_s2: unsupported shape x%s w%s' % (tuple(x.shape), tuple(wf16.shape)))
-    out = torch.empty((rows, l // 2, n), device=x.device, dtype=torch.float32)
-    if k == 3:
-        _conv_bf16(x, wf16, out, l // 2, l, l // 2, 1, 0, 2, [-1, 0, 1], [0, 1, 2], False)
-    else:
-        _conv_bf16(x, wf16, out, l // 2, l, l // 2, 1, 0, 2, [0], [0], False)
-    return out
+    if l % 2 or not packs:
+        raise ValueError('conv_fwd_bf16_s2: even length and at least one pack expected')
+    jobs, outs = [], []
+    for wf16 in packs:
+        k, n = _check_bf16_pack(x, wf16, 'conv_fwd_bf16_s2')
+        out = torch.empty((rows, l // 2, n), device=x.device, dtype=torch.float32)
+        so, wt = ([-1, 0, 1], [0, 1, 2]) if k == 3 else ([0], [0])
+        jobs.append((x, wf16, out, l // 2, l, l // 2, 1, 0, 2, so, wt, False))
+        outs.append(out)
+    _conv_bf16_multi(jobs)
+    return outs[0] if len(outs) == 1 else outs
 
 
 def conv_dgrad_bf16_s2(dy, wd16, l_in, out=None, accumulate=False):
     """Data gradient of the stride-2 convs with bf16 operands: wd16 (3, Ci, Co) (taps reversed, as the packs come) or
     (1, Ci, Co); dy (rows, l_in / 2, Co) -> dx (rows, l_in, Ci).  k3: even positions take tap 1, odd ones taps 0 / 2
-    of the neighbouring outputs (two launches); k1: even positions only (odd ones zero unless accumulating)."""
+    of the neighbouring outputs (two problems, one launch); k1: even positions only (odd ones zero unless accumulating)."""
     _rlc(dy, 'dy')
     rows, lo, co = dy.shape
-    k, ci, co2 = wd16.shape
-    if k not in (1, 3) or co2 != co or co % 32 or ci % 64 or l_in != 2 * lo or wd16.dtype != torch.bfloat16:
-        raise ValueError('conv_dgrad_bf16_s2: unsupported shape')
+    k, ci = _check_bf16_pack(dy, wd16, 'conv_dgrad_bf16_s2')
+    if l_in != 2 * lo:
+        raise ValueError('conv_dgrad_bf16_s2: l_in must be twice the output length')
     if out is None:
         if accumulate:
             raise ValueError('accumulate needs out')
@@ -191,10 +201,10 @@ def conv_dgrad_bf16_s2(dy, wd16, l_in, out=None, accumulate=False):
     elif k == 1 and not accumulate:
         out.zero_()
     if k == 3:       # wd16[t'] = w[..][2 - t']: dx[2j] = dy[j] w1;  dx[2j+1] = dy[j] w2 + dy[j+1] w0
-        _conv_bf16(dy, wd16, out, lo, lo, l_in, 2, 0, 1, [0], [1], accumulate)
-        _conv_bf16(dy, wd16, out, lo, lo, l_in, 2, 1, 1, [0, 1], [0, 2], accumulate)
+        _conv_bf16_multi([(dy, wd16, out, lo, lo, l_in, 2, 0, 1, [0], [1], accumulate),
+                          (dy, wd16, out, lo, lo, l_in, 2, 1, 1, [0, 1], [0, 2], accumulate)])
     else:
-        _conv_bf16(dy, wd16, out, lo, lo, l_in, 2, 0, 1, [0], [0], accumulate)
+        _conv_bf16_multi([(dy, wd16, out, lo, lo, l_in, 2, 0, 1, [0], [0], accumulate)])
     return out
 
 

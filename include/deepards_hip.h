@@ -92,12 +92,11 @@ int da_wino4_weights(const float* w, float* u, int co, int ci, int transpose, da
 int da_conv3_bf16(const float* x, const void* wpk, float* y, int rows, int L, int ldx, int C, int ldy, int N,
                   int accumulate, da_stream_t stream);
 int da_pack_conv3_bf16(const float* w, void* wf, void* wd, int co, int ci, da_stream_t stream);
-/* da_conv_gemm's contract with bf16 operands for the stride-2 block heads and 1x1 downsamples (resnet.py:5-8,126-128),
- * forward and data gradient: Lsrc == src_stride * Lm, src_stride 1 or 2, source offsets within a span of 2, wpk bf16
- * [taps][N][C] (da_repack_desc.points = 16 emits them for K = 1 and K = 3). */
-int da_conv_bf16(const float* x, const void* wpk, float* y, int rows, int Lm, int Lsrc, int ldx, int C, int Ldst,
-                 int ldy, int N, int dst_stride, int dst_off, int src_stride, int ntaps, const int* src_off,
-                 const int* wtap, int accumulate, da_stream_t stream);
+/* da_conv_gemm_multi's contract with bf16 operands for the stride-2 block heads and 1x1 downsamples
+ * (resnet.py:5-8,126-128), forward and data gradient: per job Lsrc == src_stride * Lm, source offsets within a span of
+ * 2, x2 == NULL, w = bf16 [taps][N][C] (da_repack_desc.points = 16 emits them for K = 1 and K = 3); the jobs of a call
+ * share src_stride (1 or 2); up to 4 per launch. */
+int da_conv_bf16_multi(const da_conv_job* jobs, int n, da_stream_t stream);
 /* all weight-gradient GEMMs of a step in one launch per tile shape (jobs: HOST array); slabs only, reduce afterwards */
 typedef struct {
   const float* dy; const float* x; float* workspace;

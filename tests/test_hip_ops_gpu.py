@@ -321,6 +321,11 @@ def test_stride2_convs_bf16(H, ci, co, L, rows):
         close(ncl(junk), dx_b, tol=3e-6, name='bf16 s2 dgrad overwrite k%d' % k)
     with pytest.raises(ValueError):
         H.conv_fwd_bf16_s2(rlc(rng.standard_normal((2, ci, 7))), wf16)          # odd length
+    # the block head and its downsample in one launch == the two single launches, bit for bit
+    w3, w1 = cu(rng.standard_normal((co, ci, 3)) * 0.05), cu(rng.standard_normal((co, ci, 1)) * 0.1)
+    (_, _, f3, _), (_, _, f1, _) = H.repack_multi([w3, w1], [16, 16])
+    y3, y1 = H.conv_fwd_bf16_s2(xt, f3, f1)
+    assert torch.equal(y3, H.conv_fwd_bf16_s2(xt, f3)) and torch.equal(y1, H.conv_fwd_bf16_s2(xt, f1))
 
 
 @pytest.mark.parametrize('ci,co,L,rows', [(64, 128, 56, 40), (128, 256, 28, 23), (256, 512, 14, 300), (64, 128, 56, 300)])
