@@ -25,6 +25,49 @@ class DeviceTileStore(object):
             raise ValueError('targets must be (N, 2) one-hot')
         self.mu, self.std = float(mu), float(std)
         self.kfold_indexes = None                     # absolute indices of the current fold (dataset.py:765-772)
+        self.patients = self.total_kfolds = self.kfold_patient_splits = self.scaling_factors = None
+        self.train = True
+
+    # ---- k-fold plumbing of ARDSRawDataset (dataset.py:651-670, 672-700, 765-830) --------------------------------
+    def enable_kfolds(self, patients, total_kfolds, train=True, random_kfold=False):
+        """Patient-wise stratified folds over this store's windows; per-fold scaling factors from each fold's TRAIN
+        windows (``derive_scaling_factors``).  ``set_kfold_indexes_for_fold(k)`` then selects fold k's train (or, with
+        train=False, test) windows and that fold's factors."""
+        from .tiles import kfold_patient_splits, patient_map_to_loc, scaling_factors_for_indices
+        import numpy as np
+        self.patients = np.asarray(patients)
+        if self.patients.shape != (self.tiles.shape[0],):
+            raise ValueError('one patient id per window expected')
+        labels = self.targets.argmax(dim=1).cpu().numpy()
+        self.total_kfolds, self.train = int(total_kfolds), bool(train)
+        self.kfold_patient_splits = kfold_patient_splits(self.patients, labels, self.total_kfolds, random_kfold)
+        host = self.tiles.cpu().numpy()
+        self.scaling_factors = {}
+        for k, sp in self.kfold_patient_splits.items():
+            mu, std = scaling_factors_for_indices(host, patient_map_to_loc(self.patients, sp['train']))
+            self.scaling_factors[k] = (float(mu[0]), float(std[0]))
+        return self
+
+    def make_test_store_if_kfold(self):
+        """``ARDSRawDataset.make_test_dataset_if_kfold`` (dataset.py:672-700): the same windows, splits and TRAIN-fold
+        scaling factors, serving the test patients of each fold (no copy of the device tiles)."""
+        if self.total_kfolds is None:
+            raise ValueError('enable_kfolds first')
+        other = object.__new__(DeviceTileStore)
+        other.__dict__.update(self.__dict__)
+        other.train, other.kfold_indexes = False, None
+        return other
+
+    def get_kfold_indexes_for_fold(self, kfold_num):
+        from .tiles import patient_map_to_loc
+        sp = self.kfold_patient_splits[kfold_num]
+        return patient_map_to_loc(self.patients, sp['train'] if self.train else sp['test'])
+
+    def set_kfold_indexes_for_fold(self, kfold_num):
+        if self.total_kfolds is None:
+            raise ValueError('enable_kfolds first')
+        self.set_kfold_indexes(self.get_kfold_indexes_for_fold(kfold_num))
+        self.mu, self.std = self.scaling_factors[kfold_num]
 
     @classmethod
     def with_derived_scaling(cls, windows, targets, indices=None, device='cuda'):

@@ -120,3 +120,39 @@ def tile_patient(breaths, n_sub_batches=20, seq_len=224):
             wins.append(r[0])
     w = np.stack(wins) if wins else np.zeros((0, n_sub_batches, 1, seq_len))
     return w, t.frames_dropped
+
+
+def kfold_patient_splits(patients, labels, total_kfolds, random_kfold=False):
+    """Patient-wise stratified folds, ``set_kfold_patient_splits`` (dataset.py:774-791): the patients in order of first
+    appearance, non-ARDS (label 0) first and ARDS (1) after them, ``StratifiedKFold(n_splits, shuffle=random_kfold)``
+    over (patient, pathology).  patients: (N,) ids per window; labels: (N,) window labels (argmax of the one-hot target).
+    Returns {fold: {'train': patient ids, 'test': patient ids}}."""
+    from sklearn.model_selection import StratifiedKFold          # the reference's own splitter (dataset.py:787)
+    patients, labels = np.asarray(patients), np.asarray(labels)
+    if patients.shape != labels.shape or patients.ndim != 1:
+        raise ValueError('patients and labels must be (N,) arrays')
+
+    def uniq(mask):                                               # pandas .unique(): order of first appearance
+        seen, out = set(), []
+        for p in patients[mask].tolist():
+            if p not in seen:
+                seen.add(p)
+                out.append(p)
+        return out
+    other, ards = uniq(labels == 0), uniq(labels == 1)
+    all_patients = np.array(other + ards)
+    patho = [0] * len(other) + [1] * len(ards)
+    splits = {}
+    kf = StratifiedKFold(n_splits=total_kfolds, shuffle=random_kfold)
+    for k, (tr, te) in enumerate(kf.split(all_patients, patho)):
+        splits[k] = {'train': all_patients[tr], 'test': all_patients[te]}
+    return splits
+
+
+def patient_map_to_loc(patients, selected):
+    """Window indices of the selected patients, patient by patient (``_patient_map_to_loc``, dataset.py:811-820)."""
+    patients = np.asarray(patients)
+    locs = []
+    for pt in selected:
+        locs.extend(np.nonzero(patients == pt)[0].tolist())
+    return locs

@@ -193,7 +193,7 @@ class BaseTraining(object):
             if self.args.only_fold and fold_num != self.args.only_fold:
                 continue
             model = self.get_model()
-            optimizer = self.get_optimizer(model)
+            optimizer = self.get_optimizer(model, *self._data_parallel())
             for epoch_num in range(1, self.args.epochs + 1):
                 if not self.args.no_train:
                     self.run_train_epoch(model, train_loader, optimizer, epoch_num, fold_num)
@@ -204,6 +204,15 @@ class BaseTraining(object):
                            '%s-fold%d.pth' % (self.args.save_model.rsplit('.pth', 1)[0], fold_num))
             self.model, self.optimizer = model, optimizer
         return self.results
+
+    @staticmethod
+    def _data_parallel():
+        """(world_size, rank, group): one process per GPU under torch.distributed (RCCL) instead of nn.DataParallel (:96);
+        every rank takes its window shard of each batch, gradients meet in one all-reduce (deepards_amd.train)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(), dist.get_rank(), None
+        return 1, 0, None
 
     def clip_odd_batch_sizes(self, obs_idx, seq, metadata, target):
         from .train import clip_odd_batch_sizes

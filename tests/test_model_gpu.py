@@ -722,3 +722,40 @@ def test_bf16_conv_arithmetic_resnet18(M):
         F_.set_conv_dtype('f32')
     with torch.no_grad():
         assert np.abs(build(M, 'resnet18', 6)(xt, None).cpu().numpy() - exact['logits']).max() < 1e-4
+
+
+def test_driver_mirror_kfolds_on_device_store():
+    """BASELINE config C4's fold loop (train_ards_detector.py:317-338, dataset.py:765-830): patient-wise stratified folds
+    on the device tile store, each fold with the scaling factors of ITS train windows, a fresh model per fold, the test
+    epoch over the fold's test patients only."""
+    from deepards_amd import train_ards_detector as T
+    from deepards_amd.data import DeviceTileStore
+    from deepards_amd.tiles import scaling_factors_for_indices
+    rng = np.random.default_rng(8)
+    n_pat, per = 8, 3
+    pts = np.repeat(np.arange(n_pat), per)
+    label_of = np.arange(n_pat) % 2
+    wins = rng.standard_normal((n_pat * per, 20, 1, 224)) * (20 + 2 * pts)[:, None, None, None] + pts[:, None, None, None]
+    tg = np.eye(2, dtype=np.float32)[label_of[pts]]
+    train = DeviceTileStore(wins, tg, 0.0, 1.0).enable_kfolds(pts, 2)
+    test = train.make_test_store_if_kfold()
+    assert test.tiles.data_ptr() == train.tiles.data_ptr()
+    args = T.make_args(base_network='densenet18', epochs=1, batch_size=4, kfolds=2, seed=2, train_store=train,
+                       test_store=test, test_patient_slot=torch.from_numpy(pts))
+    cls = T.network_map[args.network](args)
+    res = cls.train_and_test()
+    for k in (0, 1):
+        tr_idx = train.get_kfold_indexes_for_fold(k)
+        te_idx = test.get_kfold_indexes_for_fold(k)
+        assert not set(pts[tr_idx]) & set(pts[te_idx]) and len(tr_idx) + len(te_idx) == n_pat * per
+        mu, std = scaling_factors_for_indices(wins, tr_idx)
+        assert train.scaling_factors[k] == (float(mu[0]), float(std[0])) == test.scaling_factors[k]
+        assert len(res.get_meter('loss', k)) == len(tr_idx) // 4
+        r = res.patient_results[(k, 1)]
+        assert r['votes'].sum() == len(te_idx)
+        assert set(np.nonzero(r['votes'].sum(axis=1))[0].tolist()) == set(pts[te_idx].tolist())
+    assert train.scaling_factors[0] != train.scaling_factors[1]
+    x, _ = test.batch([0])                                  # fold 1 is the current one: its factors normalise
+    mu, std = train.scaling_factors[1]
+    ref = ((wins[test.get_kfold_indexes_for_fold(1)[0]] - mu) / std).astype(np.float32)
+    assert np.array_equal(x.cpu().numpy()[0], ref)

@@ -10,8 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from deepards_amd.tiles import (UnpaddedCenteredTiler, scaling_factors_for_indices, should_drop_frame,   # noqa: E402
-                                tile_patient)
+from deepards_amd.tiles import (UnpaddedCenteredTiler, kfold_patient_splits, patient_map_to_loc,   # noqa: E402
+                                scaling_factors_for_indices, should_drop_frame, tile_patient)
 
 
 def breath(n, start):
@@ -101,3 +101,26 @@ def test_fixture_windows_normalise_with_their_fold_factors():
     mu, std = scaling_factors_for_indices(z['x'])
     n = (z['x'] - mu[0]) / std[0]
     assert abs(n.mean()) < 1e-12 and abs(n.std() - 1.0) < 1e-12
+
+
+def test_kfold_patient_splits_are_patientwise_and_stratified():
+    """set_kfold_patient_splits (dataset.py:774-791): folds split PATIENTS (never windows of one patient), stratified by
+    pathology, non-ARDS patients listed first; deterministic without random_kfold."""
+    rng = np.random.default_rng(5)
+    pts = np.repeat(np.arange(20), rng.integers(3, 9, 20))            # 20 patients, 3..8 windows each
+    rng.shuffle(pts)
+    label_of = (np.arange(20) % 2 == 0).astype(int)                   # 10 ARDS, 10 other
+    labels = label_of[pts]
+    sp = kfold_patient_splits(pts, labels, 5)
+    assert sorted(sp) == [0, 1, 2, 3, 4]
+    seen_test = []
+    for k in range(5):
+        tr, te = set(sp[k]['train'].tolist()), set(sp[k]['test'].tolist())
+        assert not (tr & te) and len(tr | te) == 20 and len(te) == 4
+        assert sum(label_of[p] for p in te) == 2                      # 2 ARDS + 2 other in every test fold
+        seen_test += sorted(te)
+        loc = patient_map_to_loc(pts, sp[k]['test'])
+        assert set(pts[loc].tolist()) == te and len(loc) == int(np.isin(pts, list(te)).sum())
+    assert sorted(seen_test) == list(range(20))                       # every patient tested exactly once
+    sp2 = kfold_patient_splits(pts, labels, 5)
+    assert all(np.array_equal(sp[k]['test'], sp2[k]['test']) for k in range(5))
