@@ -383,6 +383,39 @@ def test_long_sequences_breath_block_vs_numpy_oracle(M, backbone):
     assert not bad, bad
 
 
+def test_long_sequences_bf16_convs(M):
+    """BASELINE config C5's tile shape AND arithmetic (resnet18, nb 40, seq_len 512, bf16 operands): features against the
+    oracle with the same operand rounding (5e-3, see test_bf16_conv_arithmetic_resnet18) and finite gradients."""
+    from deepards_amd import functional as F_
+    nb, L = 40, 512
+    p32 = seeded_params('resnet18', 4, n_sub_batches=nb)
+    rng = np.random.RandomState(13)
+    x = rng.randn(nb, 1, L).astype(np.float32)
+    t = np_ref._Tape({k: v.astype(np.float64) for k, v in p32.items()}, nb)
+    t.bf16_convs = True
+    ref, _ = np_ref.resnet18_features(t, x.astype(np.float64))
+    exact, _ = np_ref.resnet18_features(np_ref._Tape({k: v.astype(np.float64) for k, v in p32.items()}, nb),
+                                        x.astype(np.float64))
+    try:
+        F_.set_conv_dtype('bf16')
+        model = M.CNNLinearNetwork(M.resnet18(), nb, 0)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in p32.items()}, strict=False)
+        model = model.cuda().train()
+        feat = model.breath_block(torch.from_numpy(x).cuda())
+        got = feat.detach().cpu().numpy()
+        err, drift = np.abs(got - ref).max(), np.abs(got - exact).max()
+        r2, d2 = rel_l2(got, ref), rel_l2(got, exact)
+        log('resnet18 bf16 nb=40 L=512 features: max err %.3e / rel L2 %.3e vs same-rounding oracle, %.3e / %.3e vs '
+            'exact (scale %.2f)' % (err, r2, drift, d2, np.abs(ref).max()))
+        # 204 800 feature values behind 17 rounding layers: the rounding-flip noise is bounded in rel L2 (measured 6e-3
+        # against the same-rounding oracle, 1.4e-2 against the exact one) and 2 % of the scale at the worst element
+        assert tuple(feat.shape) == (nb, 5120) and r2 < 1.5e-2 and r2 < 0.8 * d2 and err < 2e-2 * max(1.0, np.abs(ref).max())
+        feat.square().mean().backward()
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    finally:
+        F_.set_conv_dtype('f32')
+
+
 def test_densenet_dropout_active_and_scaled(M):
     """drop_rate 0.2 is active in train mode (and the reference never leaves train mode): outputs
     differ run to run, and the test step still works under no_grad."""
