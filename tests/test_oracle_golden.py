@@ -201,3 +201,17 @@ def test_reference_fixture_windows_through_both_oracles():
         pt = {k: torch.from_numpy(v) for k, v in seeded_params(backbone, 3).items()}
         lt = torch_ref.cnn_linear(pt, torch.from_numpy(xb).float(), backbone).detach().numpy()
         assert np.abs(lt - out['logits']).max() < 1e-5
+
+
+def test_round_bf16_is_round_to_nearest_even():
+    """np_ref.round_bf16 (the operand rounding of the bf16 conv arithmetic) == torch's float32 -> bfloat16 conversion,
+    bit for bit, including ties, negative values and values that round up into the next exponent."""
+    import torch
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(20000) * 10.0 ** rng.integers(-6, 6, 20000),
+                        np.array([0.0, -0.0, 1.0, 1.00390625, 1.0078125, 1.01171875, -1.00390625, 255.5, 3.3895e38,
+                                  1e-30, 65280.0, 65408.0])]).astype(np.float32)
+    got = np_ref.round_bf16(x)
+    want = torch.from_numpy(x).bfloat16().double().numpy()
+    assert np.array_equal(got, want)
+    assert np_ref.round_bf16(np.float32(1.00390625)) == 1.0 and np_ref.round_bf16(np.float32(1.01171875)) == 1.015625   # ties to even
