@@ -30,6 +30,8 @@ class CNNLinearNetwork(nn.Module):
         # input should be in shape: (batches, breaths in seq, chans, 224)
         if x.shape[-1] != 224:
             raise Exception('input breaths must have sequence length of 224')
+        if x.shape[0] == 0:           # the reference indexes x[0] first (torch_cnn_linear_network.py:110)
+            raise IndexError('index 0 is out of bounds for dimension 0 with size 0')
         if self.metadata_features:
             # the reference builds the head wider but never concatenates metadata -> shape error there too
             raise NotImplementedError('metadata_features > 0 is not runnable in the reference either '
@@ -44,6 +46,8 @@ def _windows(model, x):
     # input should be in shape: (batches, breaths in seq, chans, 224)
     if x.shape[-1] != 224:
         raise Exception('input breaths must have sequence length of 224')
+    if x.shape[0] == 0:           # the reference indexes x[0] first (torch_cnn_linear_network.py:110)
+        raise IndexError('index 0 is out of bounds for dimension 0 with size 0')
     b, nb, c, l = x.shape
     return b, nb, model.breath_block.forward_windows(x.reshape(b * nb, c, l), nb)    # (B*NB, F)
 

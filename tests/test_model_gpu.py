@@ -234,6 +234,13 @@ def test_sequence_length_check(M):
     model = build(M, 'densenet18', 0)
     with pytest.raises(Exception, match='sequence length of 224'):
         model(torch.zeros(2, 20, 1, 200, device='cuda'), None)
+    with pytest.raises(IndexError, match='index 0 is out of bounds'):       # the reference's x[0] on an empty batch
+        model(torch.zeros(0, 20, 1, 224, device='cuda'), None)
+    for nb in (1, 3):                                                       # degenerate sub-batch counts still run
+        m = M.CNNLinearNetwork(M.resnet18(), nb, 0).cuda().train()
+        out = m(torch.randn(1, nb, 1, 224, device='cuda'), None)
+        out.sum().backward()
+        assert tuple(out.shape) == (1, 2) and all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
     cpu_model = M.CNNLinearNetwork(M.resnet18(), 20, 0)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         cpu_model(torch.zeros(2, 20, 1, 224), None)
