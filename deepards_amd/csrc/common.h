@@ -79,6 +79,7 @@ int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream);
 bool bf16_wgrad_eligible(const da_wgrad_job& j);
 void bf16_wgrad_plan(int rows, int L, int* splits, int* pchunk);
 int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream);
+void bf16_wgrad_set_pchunk(int pchunk);
 
 // One problem of da_conv_gemm_multi: the arguments of da_conv_gemm (include/deepards_hip.h).
 typedef struct {

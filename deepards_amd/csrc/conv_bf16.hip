@@ -596,7 +596,8 @@ bool bf16_wgrad_eligible(const da_wgrad_job& j) {
   return j.ntaps == 1 && j.src_off[0] == 0;
 }
 
-static int g_wb_pchunk = 1024;
+static int g_wb_pchunk = 2048;
+void bf16_wgrad_set_pchunk(int pchunk) { g_wb_pchunk = pchunk; }
 
 // padded positions per split (a multiple of the K step) and the number of slabs
 void bf16_wgrad_plan(int rows, int L, int* splits, int* pchunk) {

@@ -949,6 +949,7 @@ int da_wino_debug_tail(int on) {
 }
 int da_wino_debug_pchunk(int pchunk) {
   if (pchunk > 0) g_ww_pchunk = pchunk;
+  if (pchunk < 0) bf16_wgrad_set_pchunk(-pchunk);          // negative: padded positions per split of the bf16 kernels
   return DA_OK;
 }
 
