@@ -76,6 +76,8 @@ int da_conv3_winograd(const float* x, const float* u, float* y, int rows, int L,
 /* tuning / tests: 0 = the partly filled last round of tiles is NOT cut into split-K half tiles (1 = default);
    2 / 3 = da_conv3_winograd4 with a K step of 32 / 16 (default) channels */
 int da_wino_debug_tail(int on);
+/* tuning: pchunk > 0 = output pairs per split of the Winograd weight gradient (default 512); pchunk < 0 = -pchunk padded
+   positions per split of the bf16 weight gradient (default 2048) */
 int da_wino_debug_pchunk(int pchunk);
 /* u[4][co][ci] (transpose = 0, forward) or u[4][ci][co] (transpose = 1, data gradient) from w[co][ci][3] */
 int da_wino_weights(const float* w, float* u, int co, int ci, int transpose, da_stream_t stream);
