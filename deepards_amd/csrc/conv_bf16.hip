@@ -16,6 +16,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
+// block id -> work item so that CONSECUTIVE work items share an XCD (blocks are dealt to the 8 XCDs round-robin): the
+// channel tiles of one position tile, which read the same activation panel, then hit the same L2 (conv_gemm.hip)
+__device__ __forceinline__ int xcd_chunked_bf(int id, int total) {
+  const int q = total >> 3, r = total & 7;
+  const int xcd = id & 7, s = id >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + s;
+}
+
 struct ConvBf16Args {
   const float* x;       // [M][ldx] fp32, first C channels
   const __bf16* w;      // [3][N][C] bf16 taps
@@ -43,7 +51,7 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(ConvBf16Args a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntn = a.N / CB_TN;
-  const int tile = blockIdx.x;
+  const int tile = xcd_chunked_bf(blockIdx.x, gridDim.x);
   const int P0 = (tile / ntn) * CB_TM, n_blk = (tile % ntn) * CB_TN;
 
   // X loader: 32 rows x 8 channel quads per pass; lanes 8..15 of every 16 take the row 4 below lanes 0..7 so that a
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(256) void conv_bf16_gen_kernel(ConvBf16GenTable t) 
   __shared__ __attribute__((aligned(16))) unsigned char lds[XBYTES + 3 * CB_TN * CB_PITCH];
   int i = 0;
   while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
-  conv_bf16_gen_body<SS>(t.d[i], blockIdx.x - t.first_block[i], lds);
+  conv_bf16_gen_body<SS>(t.d[i], xcd_chunked_bf(blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i]), lds);
 }
 
 // wf[t][co][ci] = bf16(w[co][ci][t]) (forward taps), wd[t][ci][co] = bf16(w[co][ci][2 - t]) (data-gradient taps)
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_multi_kernel(WgradBf16Table t)
   __shared__ __attribute__((aligned(16))) unsigned char lds[WB_LDS_BYTES];
   int i = 0;
   while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
-  const int b = blockIdx.x - t.first_block[i];
+  const int b = xcd_chunked_bf(blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i]);   // a split's tiles share an XCD
   if (t.d[i].mode == 0) wgrad_bf16_body(t.d[i], b, lds);
   else if (t.d[i].mode == 1) wgrad_bf16_s2_body<3>(t.d[i], b, lds);
   else wgrad_bf16_s2_body<1>(t.d[i], b, lds);
