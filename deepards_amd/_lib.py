@@ -168,6 +168,8 @@ def lib():
             l.da_wino_debug_tail(int(os.environ['DA_WINO_TAIL']))
         if os.environ.get('DA_WINO_PCHUNK'):
             l.da_wino_debug_pchunk(int(os.environ['DA_WINO_PCHUNK']))
+        if os.environ.get('DA_BN_BLOCKS'):           # >= 2: blocks per launch the single-pass BatchNorm geometry aims for
+            l.da_bn_debug_two_stage(int(os.environ['DA_BN_BLOCKS']))
         _lib = l
     return _lib
 

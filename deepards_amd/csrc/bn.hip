@@ -542,12 +542,13 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restr
 
 // geometry of the single-pass kernels for W windows of Wn positions: channels per block (32, or 16 when 32 would
 // leave CUs without a block or the window too long for one block) and block size; 0: use the two-stage path
+static int g_bn_target_blocks = 256;   // blocks a launch should have before the channel group per block stops shrinking
 static int bn_fused_geometry(int W, int Wn, int C, int* cgb) {
   if (Wn < 1 || g_bn_two_stage) return 0;
-  const int max32 = FUSED_NPOS * 128, max16 = FUSED_NPOS * 256;
-  int nq = 8;
-  if (Wn > max32 || (long)W * (C / 32) < 256) nq = 4;
-  if (Wn > (nq == 8 ? max32 : max16)) return 0;
+  int nq = 8;                                                  // channel quads per block: 32, 16 or 8 channels
+  while (nq > 2 && (Wn > FUSED_NPOS * (1024 / nq) || (long)W * (C / (4 * nq)) < g_bn_target_blocks)) nq >>= 1;
+  if (nq == 2 && g_bn_target_blocks <= 256) nq = 4;           // 8-channel blocks only on request (32-byte row segments)
+  if (Wn > FUSED_NPOS * (1024 / nq) || C % (4 * nq)) return 0;
   const int mult = 64 / nq;                                  // whole waves
   int P = (Wn + FUSED_NPOS - 1) / FUSED_NPOS;
   P = (P + mult - 1) / mult * mult;
@@ -740,8 +741,11 @@ static int bn_fwd_impl(const float* x, int ldx, const float* res, int ldr, float
     if (cgb == 32)
       hipLaunchKernelGGL((bn_fwd_fused_kernel<FUSED_NPOS, 3>), dim3(W, C / 32), dim3(threads), 0, stream, x, ldx, res,
                          ldr, out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd, mask);
-    else
+    else if (cgb == 16)
       hipLaunchKernelGGL((bn_fwd_fused_kernel<FUSED_NPOS, 2>), dim3(W, C / 16), dim3(threads), 0, stream, x, ldx, res,
+                         ldr, out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd, mask);
+    else
+      hipLaunchKernelGGL((bn_fwd_fused_kernel<FUSED_NPOS, 1>), dim3(W, C / 8), dim3(threads), 0, stream, x, ldx, res,
                          ldr, out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd, mask);
     DA_CHECK_LAUNCH();
     return DA_OK;
@@ -760,6 +764,10 @@ int da_bn_fwd(const float* x, int ldx, const float* res, int ldr, float* out, in
 
 // tests: 1 = always take the two-stage kernels (so both paths are checked against the oracle)
 int da_bn_debug_two_stage(int on) {
+  if (on >= 2) {                 // tuning: blocks per launch the single-pass geometry aims for (default 256)
+    g_bn_target_blocks = on;
+    return DA_OK;
+  }
   g_bn_two_stage = on;
   return DA_OK;
 }
@@ -790,8 +798,11 @@ static int bn_bwd_impl(const float* dout, int ldd, const float* x, int ldx, cons
     if (cgb == 32)
       hipLaunchKernelGGL((bn_bwd_fused_kernel<FUSED_NPOS, 3>), dim3(W, C / 32), dim3(threads), 0, stream, dout, ldd, x,
                          ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2, add, ldadd, mask);
-    else
+    else if (cgb == 16)
       hipLaunchKernelGGL((bn_bwd_fused_kernel<FUSED_NPOS, 2>), dim3(W, C / 16), dim3(threads), 0, stream, dout, ldd, x,
+                         ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2, add, ldadd, mask);
+    else
+      hipLaunchKernelGGL((bn_bwd_fused_kernel<FUSED_NPOS, 1>), dim3(W, C / 8), dim3(threads), 0, stream, dout, ldd, x,
                          ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2, add, ldadd, mask);
     DA_CHECK_LAUNCH();
   } else {
