@@ -46,6 +46,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--min-seconds', type=float, default=1.0, help='repeat the K-step timed bracket until this much timed work')
+    ap.add_argument('--max-rounds', type=int, default=200)
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary densenet18 measurement')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="arithmetic of the k3 s1 convs' forward / data gradient: f32 (the headline, BASELINE configs[1]) or "
@@ -83,18 +85,53 @@ class KernelTimer(object):
         for _ in range(self.REPEAT):
             fn(*b)
         e1.record()
-        self.rep_records.setdefault(name, []).append((e0, e1, self.flops_of(name, a)))
+        self.rep_records.setdefault(name, []).append((e0, e1) + self.work_of(name, a))
 
     def flops_of(self, name, a):
+        return self.work_of(name, a)[0]
+
+    def work_of(self, name, a):
+        """(algorithmic FLOPs, algorithmic HBM bytes) of one launch of C-ABI entry point `name` with ctypes args `a`.
+        GEMM entries: the direct convolution's FLOPs and input + output + weights; bandwidth entries: every tensor
+        they read or write, once."""
+        f = 4.0                                                               # bytes per element (fp32 storage)
         if name == 'da_conv_gemm':       # x,w,y,rows,Lm,Lsrc,ldx,C,Ldst,ldy,N,...,ntaps at index 14
-            return 2.0 * a[3] * a[4] * a[7] * a[10] * a[14]
+            return (2.0 * a[3] * a[4] * a[7] * a[10] * a[14],
+                    f * (a[3] * a[5] * a[7] + a[3] * a[4] * a[10] + a[14] * a[7] * a[10]))
         if name == 'da_conv_wgrad':      # dy,x,dw,ws,rows,Lm,Ldy,lddy,N,Lx,ldx,C,...,ntaps at index 15
-            return 2.0 * a[4] * a[5] * a[8] * a[11] * a[15]
-        if name in ('da_conv3_winograd', 'da_conv3_winograd4', 'da_conv3_bf16'):  # x,u,y,rows,L,ldx,C,ldy,N,...: ALGORITHMIC flops = those of the direct 3-tap conv
-            return 2.0 * a[3] * a[4] * a[6] * a[8] * 3
+            return (2.0 * a[4] * a[5] * a[8] * a[11] * a[15],
+                    f * (a[4] * a[6] * a[8] + a[4] * a[9] * a[11] + a[15] * a[8] * a[11]))
+        if name in ('da_conv3_winograd', 'da_conv3_winograd4', 'da_conv3_bf16'):  # x,u,y,rows,L,ldx,C,ldy,N,accumulate
+            pts = {'da_conv3_winograd': 4, 'da_conv3_winograd4': 6, 'da_conv3_bf16': 1.5}[name]
+            return (2.0 * a[3] * a[4] * a[6] * a[8] * 3,
+                    f * (a[3] * a[4] * a[6] + a[3] * a[4] * a[8] * (2 if a[9] else 1) + pts * a[6] * a[8]))
         if name == 'da_conv_wgrad_multi':   # jobs (host array of da_wgrad_job), n
-            return sum(2.0 * a[0][i].rows * a[0][i].Lm * a[0][i].N * a[0][i].C * a[0][i].ntaps for i in range(a[1]))
-        return 0.0
+            j = a[0]
+            return (sum(2.0 * j[i].rows * j[i].Lm * j[i].N * j[i].C * j[i].ntaps for i in range(a[1])),
+                    sum(f * (j[i].rows * j[i].Ldy * j[i].N + j[i].rows * j[i].Lx * j[i].C) for i in range(a[1])))
+        if name in ('da_conv_gemm_multi', 'da_conv_bf16_multi'):   # jobs (host array of da_conv_job), n
+            j = a[0]
+            return (sum(2.0 * j[i].rows * j[i].Lm * j[i].N * j[i].C * j[i].ntaps for i in range(a[1])),
+                    sum(f * (j[i].rows * j[i].Lsrc * j[i].C + j[i].rows * j[i].Lm * j[i].N + j[i].ntaps * j[i].C * j[i].N)
+                        for i in range(a[1])))
+        if name in ('da_bn_fwd', 'da_bn_fwd_mask'):       # x,ldx,res,ldr,out,ldo,W,Wn,C,...
+            return 0.0, f * a[6] * a[7] * a[8] * (3 if a[2] else 2)
+        if name in ('da_bn_bwd', 'da_bn_bwd_add'):        # dout,ldd,x,ldx,out,ldo,dx,lddx,g,ldg,W,Wn,C,mean,invstd,gamma,beta,mode
+            t = 3 + (1 if a[17] == 2 else 0) + (1 if a[8] else 0) + (1 if name == 'da_bn_bwd_add' else 0)
+            return 0.0, f * a[10] * a[11] * a[12] * t
+        if name == 'da_bn_bwd_mask':                      # dout,ldd,x,ldx,dx,lddx,g,ldg,W,Wn,C,...
+            return 0.0, f * a[8] * a[9] * a[10] * (3 + (1 if a[6] else 0))
+        if name == 'da_pool_bwd':                         # dout,ldd,y,ldy,dz,lddz,rows,R,lin,C,...
+            return 0.0, f * a[6] * a[9] * (2 * a[8] + (a[8] - 1) // 2 + 1)
+        if name == 'da_bn_relu_pool_fwd':                 # y,ldy,out,ldo,rows,R,lin,C,...
+            return 0.0, f * a[4] * a[7] * (a[6] + (a[6] - 1) // 2 + 1)
+        if name == 'da_stem_conv_fwd':                    # x,w,y,rows,lin,c0,ldy
+            return 2.0 * 7 * a[3] * (a[4] // 2) * a[5], f * a[3] * (a[4] + (a[4] // 2) * a[5])
+        if name == 'da_stem_conv_wgrad':                  # dy,lddy,x,dw,ws,rows,lin,c0,...
+            return 2.0 * 7 * a[5] * (a[6] // 2) * a[7], f * a[5] * (a[6] + (a[6] // 2) * a[7])
+        if name in ('da_clamp_sgd_nesterov',):            # p,g,buf,n
+            return 0.0, f * 5 * a[3]
+        return 0.0, 0.0
 
     def install(self, names):
         for n in names:
@@ -107,7 +144,7 @@ class KernelTimer(object):
                 e0.record()
                 rc = _fn(*a)
                 e1.record()
-                self.records.setdefault(_n, []).append((e0, e1, self.flops_of(_n, a)))
+                self.records.setdefault(_n, []).append((e0, e1) + self.work_of(_n, a))
                 if _n in self.REPEATED:
                     self._repeat(_n, _fn, a)
                 return rc
@@ -121,10 +158,11 @@ class KernelTimer(object):
         self.torch.cuda.synchronize()
         out = {}
         for n, recs in self.records.items():
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
-            out[n] = dict(calls=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs), flops=sum(r[2] for r in recs))
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            out[n] = dict(calls=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs), flops=sum(r[2] for r in recs),
+                          bytes=sum(r[3] for r in recs))
         for n, recs in self.rep_records.items():
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs) / self.REPEAT
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs) / self.REPEAT
             out[n].update(rep_total_ms=ms, rep_avg_us=1e3 * ms / len(recs))
         return out
 
@@ -162,7 +200,7 @@ def cpu_baseline(backbone, batch, seconds):
     p = {k: torch.from_numpy(v) for k, v in seeded_params(backbone, 0).items()}
     tr = torch_ref.CpuReferenceTrainer(p, backbone, drop_rate=0.2 if backbone == 'densenet18' else 0.0)
     g = torch.Generator().manual_seed(0)
-    b = min(batch, 16)                                   # reference default batch (defaults.yml:17) bounds the sample
+    b = batch                                            # the same batch as the GPU line (same B, same step)
     x = torch.randn(b, 20, 1, 224, generator=g)
     t = torch.zeros(b, 2)
     t[torch.arange(b), torch.randint(0, 2, (b,), generator=g)] = 1
@@ -181,14 +219,42 @@ def cpu_baseline(backbone, batch, seconds):
                        (n, b, dt, backbone, torch.__version__, cores))
 
 
+def csrc_sha16():
+    """Identity of the kernel sources (the snapshot on the GPU box has no .git): sha256 over deepards_amd/csrc/*."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'deepards_amd', 'csrc')
+    for n in sorted(os.listdir(d)):
+        if n.endswith(('.hip', '.h')):
+            h.update(n.encode())
+            h.update(open(os.path.join(d, n), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(entry):
-    """HBM bytes per launch of the dominant kernel (C-ABI entry point `entry`) from the committed rocprofv3 PMC passes
-    (profiles/), or None.  bench.py cannot run the profiler on itself; scripts/profile_round.sh re-collects them."""
-    try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
-        return d['hbm_bytes_per_launch'] if d.get('entry') == entry else None
-    except Exception:
-        return None
+    """HBM bytes per launch of the dominant kernel (C-ABI entry point `entry`) from the newest committed rocprofv3
+    PMC passes (profiles/rNN_traffic.json), or None.  bench.py cannot run the profiler on itself
+    (scripts/profile_round.sh re-collects them); the file carries the sha of the kernel sources it was profiled at,
+    and the figure is dropped (null) when the sources have changed since or it is about another kernel."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        ent = d.get('kernels', {}).get(entry) if 'kernels' in d else (d if d.get('entry') == entry else None)
+        if ent is None:
+            return None, '%s holds no figure for %s' % (os.path.basename(path), entry)
+        if d.get('csrc_sha16') != csrc_sha16():
+            return None, '%s was profiled at kernel sources %s, now %s: stale, dropped' % (
+                os.path.basename(path), d.get('csrc_sha16'), csrc_sha16())
+        return ent['hbm_bytes_per_launch'], '%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, sources %s)' % (
+            os.path.basename(path), d.get('csrc_sha16'))
+    return None, 'no profiles/r*_traffic.json'
+
+
+def np_isfinite(v):
+    return v == v and abs(v) != float('inf')
 
 
 def say(*a):
@@ -263,18 +329,32 @@ def main():
     say('captured; warmup')
     for i in range(args.warmup):                         # W untimed steps of exactly what is timed (graph replays)
         tr.train_step(x, t)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.train_step(x, t)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
+    def timed_round():
+        """EXACTLY args.steps steps between two barrier + synchronize brackets; max over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.train_step(x, t)
+        barrier()
+        d = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([d], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d = float(tt)
+        return d
+
+    # The K-step bracket is repeated until the timed work adds up to >= --min-seconds (default 1 s; K = 20 steps are
+    # 60 ms, too short for clocks and samplers to settle) and the MEDIAN round is reported.  The round count comes
+    # from the first round's max-over-ranks time, so every rank runs the same number.
+    rounds = [timed_round()]
+    n_rounds = max(1, min(args.max_rounds, int(args.min_seconds / rounds[0] + 0.999)))
+    while len(rounds) < n_rounds:
+        rounds.append(timed_round())
+    srt = sorted(rounds)
+    dt = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
     loss = float(tr.last_loss)
-    say('timed region done: %.3f ms/step' % (1e3 * dt / args.steps))
+    say('timed region done: %d rounds of %d steps, median %.3f ms/step (min %.3f, max %.3f)' %
+        (len(rounds), args.steps, 1e3 * dt / args.steps, 1e3 * srt[0] / args.steps, 1e3 * srt[-1] / args.steps))
 
     seqs = world * B * 20 * args.steps
     value = seqs / dt
@@ -292,7 +372,26 @@ def main():
                    'seq_len': 224, 'optimizer': 'sgd-nesterov+clamp', 'parallelism': 'dp%d' % world,
                    'hipgraph': not args.no_graph},
         'final_loss': round(loss, 6),
+        'timing': {'rounds': len(rounds), 'steps_per_round': args.steps, 'reported': 'median round',
+                   'ms_per_step_min': round(1e3 * srt[0] / args.steps, 4), 'ms_per_step_max': round(1e3 * srt[-1] / args.steps, 4),
+                   'timed_seconds': round(sum(rounds), 3)},
     }
+    if not np_isfinite(loss):
+        raise SystemExit('bench: the loss went non-finite (%r) -- the step is broken, no number is reported' % loss)
+    if world > 1:
+        # the exchange step alone: the eager all-reduce of the flat gradient bucket between the two graph replays
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            tr.bucket.allreduce(tr.group)
+        torch.cuda.synchronize()
+        ar = (time.perf_counter() - t0) / 20
+        tt = torch.tensor([ar], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        out['allreduce_ms'] = round(1e3 * float(tt), 4)
+        out['allreduce_bytes'] = int(tr.bucket.numel * 4)
+        out['allreduce_exposed'] = True            # issued between the two captured graphs, not overlapped with backward
     if rehearse:
         out['rehearsal'] = 'gloo: %d ranks sharing %d GPU(s); throughput is NOT a measurement' % (world, torch.cuda.device_count())
     step_flops = w['flops'] * B * 20
@@ -307,7 +406,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         # instrumented EAGER steps: HIP events around every C-ABI launch, on the launch stream
         kt = KernelTimer(lib, torch)
-        names = [n for n in _lib.SIGNATURES if n not in ('da_version', 'da_conv_wgrad_workspace', 'da_stem_wgrad_workspace', 'da_bn_workspace', 'da_debug_set', 'da_bn_chunks', 'da_conv_wgrad_splits', 'da_conv_wgrad_plan', 'da_bn_debug_two_stage', 'da_wino_debug_tail', 'da_wino_debug_pchunk', 'da_wino_weights', 'da_wino4_weights',
+        names = [n for n in _lib.SIGNATURES if n not in ('da_version', 'da_conv_wgrad_workspace', 'da_stem_wgrad_workspace', 'da_bn_workspace', 'da_debug_set', 'da_bn_chunks', 'da_conv_wgrad_splits', 'da_conv_wgrad_plan', 'da_bn_debug_two_stage', 'da_bn_debug_target_blocks', 'da_abi_sizes', 'da_wino_debug_tail', 'da_wino_debug_pchunk', 'da_wino_weights', 'da_wino4_weights',
                                                           'da_hip_runtime_symbol')]
         tr_e = HotPathTrainer(model, optimizer='sgd', use_graph=False)
         tr_e.bucket, tr_e.state = tr.bucket, tr.state
@@ -319,30 +418,56 @@ def main():
         summ = kt.summary()
         kt.remove()
         say('roofline pass done')
-        KERNELS = {'da_conv3_winograd': 'conv3_wino_kernel (da_conv3_winograd: k3 s1 conv forward + data gradient, Winograd '
-                                        'F(2,3) on v_mfma_f32_16x16x4_f32; algorithmic = direct-conv FLOPs, 2/3 of them executed)',
-                   'da_conv_gemm': 'conv_gemm_tailed_kernel<*> / conv_gemm_kernel<*> (da_conv_gemm: conv fwd + dgrad implicit '
-                                   'GEMM, v_mfma_f32_32x32x2_f32)'}
-        PEAK = {}
-        if args.dtype == 'bf16':                       # configs[2]: the fp32 weight-gradient batch dominates, then the bf16 convs
-            KERNELS = {'da_conv_wgrad_multi': 'wino_wgrad_multi_kernel + conv_wgrad_multi_kernel<*> (da_conv_wgrad_multi: all '
-                                              'weight gradients of the step, fp32 MFMA)',
-                       'da_conv3_bf16': 'conv3_bf16_kernel (da_conv3_bf16: k3 s1 conv forward + data gradient, '
-                                        'v_mfma_f32_32x32x16_bf16; LDS / load-path bound, priced against the dense bf16 peak)'}
-            PEAK = {'da_conv3_bf16': PEAK_BF16_MFMA_TFLOPS}
-        dname = max(KERNELS, key=lambda k: summ[k]['total_ms'] if k in summ else -1.0)      # the dominant kernel family
+        # Which kernel each single-kernel entry point launches (rocprofv3 names).  da_conv_wgrad_multi launches TWO
+        # kernels per call (wino_wgrad_multi_kernel + conv_wgrad_multi_kernel<>), so HIP events around it time a pair:
+        # it is listed in kernel_time_share but cannot be "the dominant kernel" (by rocprof each half is smaller than the
+        # forward / data-gradient kernels, profiles/*kernel_stats.csv).
+        KERNEL_OF = {
+            'da_conv3_winograd': 'conv3_wino_kernel (k3 s1 conv forward + data gradient, Winograd F(2,3) on v_mfma_f32_16x16x4_f32; '
+                                 'algorithmic = direct-conv FLOPs, 2/3 of them executed)',
+            'da_conv3_winograd4': 'conv3_wino4k_kernel (k3 s1 conv forward + data gradient of the 512-channel stage, Winograd '
+                                  'F(4,3); algorithmic = direct-conv FLOPs, 1/2 of them executed)',
+            'da_conv_gemm': 'conv_gemm_tailed_kernel<*> / conv_gemm_kernel<*> (conv fwd + dgrad implicit GEMM, v_mfma_f32_32x32x2_f32)',
+            'da_conv_gemm_multi': 'conv_gemm_multi_kernel (stride-2 block heads + 1x1 downsamples, fwd + dgrad, v_mfma_f32_32x32x2_f32)',
+            'da_conv3_bf16': 'conv3_bf16_kernel (k3 s1 conv forward + data gradient, v_mfma_f32_32x32x16_bf16)',
+            'da_conv_bf16_multi': 'conv_bf16_gen_kernel<*> (stride-2 / 1x1 convs, bf16 operands)',
+            'da_bn_fwd': 'bn_fwd_fused_kernel<*> (per-window BatchNorm (+ReLU)(+residual) forward, single pass)',
+            'da_bn_fwd_mask': 'bn_fwd_fused_kernel<*> (block-output BatchNorm + residual + ReLU forward, ReLU bit mask)',
+            'da_bn_bwd': 'bn_bwd_fused_kernel<*> (per-window BatchNorm backward, single pass)',
+            'da_bn_bwd_mask': 'bn_bwd_fused_kernel<*> (block-output BatchNorm backward from the ReLU bit mask)',
+            'da_bn_bwd_add': 'bn_bwd_fused_kernel<*> (BatchNorm backward + concat pass-through)',
+            'da_pool_bwd': 'pool_bwd_kernel (stem max/avg pool + ReLU backward)',
+        }
+        PEAK = {'da_conv3_bf16': PEAK_BF16_MFMA_TFLOPS, 'da_conv_bf16_multi': PEAK_BF16_MFMA_TFLOPS}
+        cands = [k for k in summ if k in KERNEL_OF and (summ[k]['flops'] or summ[k]['bytes'])]
+        dname = max(cands, key=lambda k: summ[k].get('rep_total_ms', summ[k]['total_ms']))   # argmax over all of them
         dom = summ[dname]
         single_us = dom['avg_us']
         if 'rep_total_ms' in dom:                 # per-launch time from the 8-launch brackets (see KernelTimer._repeat)
             dom = dict(dom, total_ms=dom['rep_total_ms'], avg_us=dom['rep_avg_us'])
-        ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
-        peak = PEAK.get(dname, PEAK_FP32_MFMA_TFLOPS)
-        out['roofline'] = {'bound': 'mfma', 'kernel': KERNELS[dname],
-                           'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                           'frac': round(ach / peak, 4), 'traffic': pmc_traffic(dname),
+        if dom['flops']:
+            ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
+            peak, bound, unit = PEAK.get(dname, PEAK_FP32_MFMA_TFLOPS), 'mfma', 'TFLOP/s'
+        else:
+            ach = dom['bytes'] / (dom['total_ms'] * 1e-3) / 1e9
+            peak, bound, unit = PEAK_HBM_GBS, 'hbm', 'GB/s'
+        traffic, traffic_note = pmc_traffic(dname)
+        out['roofline'] = {'bound': bound, 'kernel': KERNEL_OF[dname], 'entry': dname,
+                           'achieved': round(ach, 2), 'peak': peak, 'unit': unit,
+                           'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_note,
                            'launches_per_step': dom['calls'] // nprof, 'avg_launch_us': round(dom['avg_us'], 2),
                            'avg_launch_us_single_bracket': round(single_us, 2),
-                           'alg_flops_per_launch': round(dom['flops'] / dom['calls'], 1)}
+                           'alg_flops_per_launch': round(dom['flops'] / dom['calls'], 1),
+                           'alg_bytes_per_launch': round(dom['bytes'] / dom['calls'], 1)}
+        out['kernel_roofline'] = {}
+        for k in cands:                           # every single-kernel entry against ITS roofline (eager, single brackets)
+            v = summ[k]
+            ms = v.get('rep_total_ms', v['total_ms'])
+            if v['flops']:
+                out['kernel_roofline'][k] = {'tflops': round(v['flops'] / ms / 1e9, 1),
+                                             'frac': round(v['flops'] / ms / 1e9 / PEAK.get(k, PEAK_FP32_MFMA_TFLOPS), 3)}
+            else:
+                out['kernel_roofline'][k] = {'gbs': round(v['bytes'] / ms / 1e6, 1), 'frac': round(v['bytes'] / ms / 1e6 / PEAK_HBM_GBS, 3)}
         tot = sum(v['total_ms'] for v in summ.values())
         out['kernel_time_share'] = {k: round(v['total_ms'] / tot, 4) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]['total_ms'])}
         wg = summ.get('da_conv_wgrad_multi') or summ.get('da_conv_wgrad')

@@ -72,6 +72,7 @@ SIGNATURES = {
     'da_bn_apply': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _F, _P]),
     'da_bn_fwd': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
     'da_bn_debug_two_stage': (_I, [_I]),
+    'da_bn_debug_target_blocks': (_I, [_I]),
     'da_bn_bwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
     'da_bn_mask_words': (_Z, [_I, _I, _I]),
     'da_bn_fwd_mask': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P]),
@@ -168,8 +169,8 @@ def lib():
             l.da_wino_debug_tail(int(os.environ['DA_WINO_TAIL']))
         if os.environ.get('DA_WINO_PCHUNK'):
             l.da_wino_debug_pchunk(int(os.environ['DA_WINO_PCHUNK']))
-        if os.environ.get('DA_BN_BLOCKS'):           # >= 2: blocks per launch the single-pass BatchNorm geometry aims for
-            l.da_bn_debug_two_stage(int(os.environ['DA_BN_BLOCKS']))
+        if os.environ.get('DA_BN_BLOCKS'):           # blocks per launch the single-pass BatchNorm geometry aims for
+            l.da_bn_debug_target_blocks(int(os.environ['DA_BN_BLOCKS']))
         _lib = l
     return _lib
 

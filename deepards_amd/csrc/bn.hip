@@ -764,11 +764,14 @@ int da_bn_fwd(const float* x, int ldx, const float* res, int ldr, float* out, in
 
 // tests: 1 = always take the two-stage kernels (so both paths are checked against the oracle)
 int da_bn_debug_two_stage(int on) {
-  if (on >= 2) {                 // tuning: blocks per launch the single-pass geometry aims for (default 256)
-    g_bn_target_blocks = on;
-    return DA_OK;
-  }
-  g_bn_two_stage = on;
+  g_bn_two_stage = on != 0;
+  return DA_OK;
+}
+
+// tuning: blocks per launch the single-pass geometry aims for (default 256; swept in DESIGN.md section 8)
+int da_bn_debug_target_blocks(int blocks) {
+  if (blocks < 1) return DA_EINVAL;
+  g_bn_target_blocks = blocks;
   return DA_OK;
 }
 

@@ -84,13 +84,25 @@ class DeviceTileStore(object):
 
     def set_kfold_indexes(self, indexes):
         """Relative -> absolute index map of the current fold (reference: set_kfold_indexes_for_fold)."""
-        self.kfold_indexes = None if indexes is None else torch.as_tensor(indexes, dtype=torch.int64,
-                                                                          device=self.tiles.device)
+        if indexes is None:
+            self.kfold_indexes = None
+            return
+        idx = torch.as_tensor(indexes, dtype=torch.int64).reshape(-1)
+        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= self.tiles.shape[0]):
+            raise IndexError('fold index out of range [0, %d)' % self.tiles.shape[0])
+        self.kfold_indexes = idx.to(self.tiles.device)
 
     def batch(self, rel_idx, out=None):
         """(inputs (B, NB, 1, L) float32, targets (B, 2) float32) for fold-relative indices; out = (x, t) buffers to
         fill in place (HotPathTrainer.static_batch(): the captured step then needs no input copies)."""
-        idx = torch.as_tensor(rel_idx, dtype=torch.int64, device=self.tiles.device).contiguous()
+        idx = torch.as_tensor(rel_idx, dtype=torch.int64)
+        if idx.dim() != 1:
+            raise ValueError('rel_idx must be a 1-D index list')
+        # the gather kernels read tiles[idx] unchecked: bounds are enforced here, on the host copy when there is one
+        # (one min/max over <= batch_size integers) and by a device-side check otherwise
+        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= len(self)):
+            raise IndexError('window index out of range [0, %d)' % len(self))
+        idx = idx.to(self.tiles.device).contiguous()
         if self.kfold_indexes is not None:
             idx = self.kfold_indexes[idx].contiguous()
         ox, ot = out if out is not None else (None, None)

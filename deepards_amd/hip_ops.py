@@ -744,15 +744,21 @@ def dropout(x, seed, salt, p):
 # device-resident window store
 # ------------------------------------------------------------------------------------------------
 def gather_normalize(tiles, idx, mu, std, out=None):
-    """tiles (N, ...) float64 CUDA raw windows, idx (B,) int64 CUDA -> (B, ...) float32 = float((x-mu)/std)."""
+    """tiles (N, ...) float64 CUDA raw windows, idx (B,) int64 CUDA -> (B, ...) float32 = float((x-mu)/std).
+    The kernel reads tiles[idx[b]] unchecked: idx must already be known to lie in [0, N) (DeviceTileStore.batch
+    validates host indices before the upload and builds device-side index lists only from validated ones)."""
     if not (tiles.is_cuda and tiles.dtype == torch.float64 and tiles.is_contiguous()):
         raise ValueError('tiles must be a contiguous float64 CUDA tensor')
     if not (idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous()):
         raise ValueError('idx must be a contiguous int64 CUDA tensor')
     b = idx.numel()
     elems = tiles[0].numel()
+    shape = (b,) + tuple(tiles.shape[1:])
     if out is None:
-        out = torch.empty((b,) + tuple(tiles.shape[1:]), device=tiles.device, dtype=torch.float32)
+        out = torch.empty(shape, device=tiles.device, dtype=torch.float32)
+    elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == shape):
+        raise ValueError('gather_normalize: out must be a contiguous float32 CUDA tensor of shape %s, got %s %s' %
+                         (shape, tuple(out.shape), out.dtype))
     _chk(_lib.lib().da_gather_normalize(_p(tiles), _p(idx), float(mu), float(std), _p(out), b, elems, _stream()),
          'da_gather_normalize')
     return out
@@ -761,9 +767,13 @@ def gather_normalize(tiles, idx, mu, std, out=None):
 def gather_rows(src, idx, out=None):
     """src (N, W) float32 CUDA, idx (B,) int64 CUDA -> (B, W)."""
     _f32(src, 'src')
+    if not (idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous()):
+        raise ValueError('idx must be a contiguous int64 CUDA tensor')
     b, width = idx.numel(), src.shape[1]
     if out is None:
         out = torch.empty((b, width), device=src.device, dtype=torch.float32)
+    elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (b, width)):
+        raise ValueError('gather_rows: out must be a contiguous float32 CUDA tensor of shape %s' % ((b, width),))
     _chk(_lib.lib().da_gather_rows(_p(src), _p(idx), _p(out), b, width, _stream()), 'da_gather_rows')
     return out
 

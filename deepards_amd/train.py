@@ -20,6 +20,7 @@ MI355X-first differences (results identical, see tests):
 """
 import contextlib
 import gc
+import math
 
 import torch
 
@@ -28,15 +29,26 @@ from . import hip_ops as H
 
 
 @contextlib.contextmanager
-def _capture_graph(graph):
-    """torch.cuda.graph(graph) with the Python garbage collector held off: a collection that runs in the middle of a
-    stream capture can finalise CUDA objects of earlier, unrelated work (graphs, events, cached blocks in reference
-    cycles), and freeing those while the stream is capturing aborts the process."""
+def _capture_graph(graph, _ctx=None):
+    """``torch.cuda.graph(graph)`` with the cyclic garbage collector flushed before and held off during the capture,
+    and its previous state restored afterwards (also when the capture raises).
+
+    Why ("capture window"): between hipStreamBeginCapture and EndCapture the HIP runtime
+    refuses everything that is not a stream-ordered enqueue (hipFree, hipEventQuery, hipGraphExecDestroy of a graph
+    whose pool is live, ...), and PyTorch turns such a refusal inside a destructor into a process abort.  A
+    collection that happens to trigger inside the window finalises whatever cyclic garbage is pending -- dropped
+    trainers with their captured graphs, static outputs, events -- i.e. runs exactly those calls.  Ownership rule that
+    makes the window safe: (1) nothing this package owns is RELEASED inside a capture (graphs are cached per shape for
+    the trainer's lifetime and dropped only by ``release_graphs()``; the code inside the window creates objects but
+    drops none that existed before it), (2) pending cyclic garbage is finalised by ``gc.collect()`` BEFORE the window,
+    (3) the collector stays off inside it.  Refcount frees inside the window are then only those of tensors allocated
+    inside it, which the caching allocator's capture-aware pool handles."""
+    ctx = torch.cuda.graph if _ctx is None else _ctx
     gc.collect()
     was_enabled = gc.isenabled()
     gc.disable()
     try:
-        with torch.cuda.graph(graph):
+        with ctx(graph):
             yield
     finally:
         if was_enabled:
@@ -53,11 +65,27 @@ def clip_odd_batch_sizes(obs_idx, seq, metadata, target):
 
 def shard_windows(n_windows, world_size, rank):
     """Equal contiguous shards of the batch's windows: rank r owns [r*B/W, (r+1)*B/W).  Equal sizes
-    make the mean of the rank-local BCE means equal the global mean."""
+    make the mean of the rank-local BCE means equal the global mean.  Batches reach this
+    already trimmed by ``legal_batch_len`` (the epoch iterators do it), so a remainder is a caller bug."""
     if n_windows % world_size:
         raise ValueError('batch of %d windows does not split evenly over %d ranks' % (n_windows, world_size))
     per = n_windows // world_size
     return slice(rank * per, (rank + 1) * per)
+
+
+def batch_multiple(batch_size, world_size=1):
+    """Windows per batch must be a multiple of this: 2 from clip_odd_batch_sizes (train_ards_detector.py:146-147,
+    482-494; not applied when batch_size == 1), times the ranks that share the batch -> lcm(2, world)."""
+    m = 1 if batch_size == 1 else 2
+    return m * world_size // math.gcd(m, world_size)
+
+
+def legal_batch_len(n, batch_size, world_size=1):
+    """Length a batch of n windows is trimmed to: the reference drops the last item of an odd batch; under data
+    parallelism the (tail) batch is trimmed to a multiple of lcm(2, world) so that every rank gets the same number
+    of windows (N=70, batch 16, world 4: the tail of 6 trains on 4 windows instead of raising)."""
+    m = batch_multiple(batch_size, world_size)
+    return n - n % m
 
 
 def _logits(out):
@@ -124,11 +152,47 @@ class HotPathTrainer(object):
         self.bucket = None
         self.state = {}
         self.steps = 0
-        self._graph = None
+        self._graphs = {}                  # input shape -> captured step (a tail batch keeps its own graph: no recapture)
+        self._graph = None                 # the entry train_step used last: (graph, static, static_out, graph_opt)
         self._static = None
         self._test_graphs = {}
         self.last_loss = None
         self.last_logits = None
+        self.allreduce_calls = 0
+        self._synced = False
+
+    # ---- replicas ----------------------------------------------------------------------------
+    def sync_replicas(self):
+        """Data parallel only: rank 0's parameters and buffers (BatchNorm running statistics, the DenseNet dropout
+        seed) replace every other rank's before the first update, in one flat broadcast per dtype.  The reference's
+        ``nn.DataParallel`` (train_ards_detector.py:96) replicates module 0 every step; with one process per GPU the
+        replicas only stay identical if they START identical -- ``get_model`` seeds only when a seed is given, so
+        without this every rank would train its own initialisation and share nothing but gradients."""
+        if self._synced or self.world_size == 1:
+            self._synced = True
+            return
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError('world_size %d needs an initialised torch.distributed process group' % self.world_size)
+        tensors = [p.data for p in self.model.parameters()] + [b.data for b in self.model.buffers()]
+        by_dtype = {}
+        for t in tensors:
+            by_dtype.setdefault(t.dtype, []).append(t)
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        for dtype in sorted(by_dtype, key=str):
+            ts = by_dtype[dtype]
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src, group=self.group)
+            off = 0
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view(t.shape))
+                off += n
+        self._synced = True
+
+    def _allreduce(self):
+        self.bucket.allreduce(self.group)
+        self.allreduce_calls += 1
 
     # ---- eager pieces ------------------------------------------------------------------------
     def _forward_backward(self, inputs, target):
@@ -163,13 +227,14 @@ class HotPathTrainer(object):
         parameters whose grad is None -- resnet's conv1_alt/conv2/bn2, SURVEY.md finding 6)."""
         model = self.model
         model.train()
+        self.sync_replicas()
         for p in model.parameters():
             p.grad = None
         loss, logits = self._forward_backward(inputs, target)
         live = [p for p in model.parameters() if p.requires_grad and p.grad is not None]
         self.bucket = FlatBucket(live)
         if self.world_size > 1:
-            self.bucket.allreduce(self.group)
+            self._allreduce()
         self._optimizer_step()
         return loss, logits
 
@@ -177,13 +242,15 @@ class HotPathTrainer(object):
         self.bucket.zero_grad()
         loss, logits = self._forward_backward(inputs, target)
         if self.world_size > 1:
-            self.bucket.allreduce(self.group)
+            self._allreduce()
         self._optimizer_step()
         return loss, logits
 
     # ---- graph replay ------------------------------------------------------------------------
     def _capture(self, inputs, target):
-        self._static = (inputs.clone(), target.clone())
+        """Capture the step for this batch shape.  Every shape keeps its own graph (an epoch's tail batch has another
+        shape than the full ones: it is captured once, not twice per epoch)."""
+        static = (inputs.clone(), target.clone())
         # Warm the caching allocator on a side stream with a forward+backward whose side effects
         # (BN running stats, dropout seed) are rolled back, so capture adds no training step.
         saved = [b.clone() for b in self.model.buffers()]
@@ -191,17 +258,25 @@ class HotPathTrainer(object):
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self.bucket.zero_grad()
-            self._forward_backward(*self._static)
+            self._forward_backward(*static)
             for b, c in zip(self.model.buffers(), saved):
                 b.copy_(c)
         torch.cuda.current_stream().wait_stream(s)
-        self._graph = torch.cuda.CUDAGraph()
-        with _capture_graph(self._graph):
-            self._static_out = self._eager_single_gpu_parts(*self._static)
+        graph = torch.cuda.CUDAGraph()
+        with _capture_graph(graph):
+            static_out = self._eager_single_gpu_parts(*static)
+        graph_opt = None
         if self.world_size > 1:
-            self._graph_opt = torch.cuda.CUDAGraph()
-            with _capture_graph(self._graph_opt):
-                self._optimizer_step()
+            graph_opt = self._graph_opt_shared
+            if graph_opt is None:                        # the update does not depend on the batch shape: one graph
+                graph_opt = torch.cuda.CUDAGraph()
+                with _capture_graph(graph_opt):
+                    self._optimizer_step()
+                self._graph_opt_shared = graph_opt
+        ent = self._graphs[tuple(inputs.shape)] = (graph, static, static_out, graph_opt)
+        return ent
+
+    _graph_opt_shared = None
 
     def _eager_single_gpu_parts(self, inputs, target):
         self.bucket.zero_grad()
@@ -213,7 +288,8 @@ class HotPathTrainer(object):
     # ---- public ------------------------------------------------------------------------------
     def train_step(self, inputs, target):
         """inputs (B_local, NB, 1, 224) float32 CUDA, target (B_local, 2) one-hot float32 CUDA.
-        Returns the (device-resident) loss tensor of this rank's shard."""
+        Returns the device-resident loss of this rank's shard: with use_graph it is the captured step's own output
+        buffer, overwritten by the next step -- ``.clone()`` it to keep it (the epoch functions do)."""
         if not inputs.is_cuda:
             raise RuntimeError('HotPathTrainer needs CUDA (MI355X) tensors; there is no CPU fallback')
         self.model.train()
@@ -222,27 +298,44 @@ class HotPathTrainer(object):
         elif not self.use_graph:
             loss, logits = self._eager_step(inputs, target)
         else:
-            if self._graph is None or self._static[0].shape != inputs.shape:
+            ent = self._graphs.get(tuple(inputs.shape))
+            if ent is None:
                 # one eager warm step already happened (_first_step); capture now
-                self._capture(inputs, target)
-            if inputs is not self._static[0]:            # batches built in place (static_batch()) skip the copies
-                self._static[0].copy_(inputs)
-            if target is not self._static[1]:
-                self._static[1].copy_(target)
-            self._graph.replay()
+                ent = self._capture(inputs, target)
+            graph, static, static_out, graph_opt = self._graph = ent
+            self._static = static
+            if inputs is not static[0]:                  # batches built in place (static_batch()) skip the copies
+                static[0].copy_(inputs)
+            if target is not static[1]:
+                static[1].copy_(target)
+            graph.replay()
             if self.world_size > 1:
-                self.bucket.allreduce(self.group)
-                self._graph_opt.replay()
-            loss, logits = self._static_out
+                self._allreduce()
+                graph_opt.replay()
+            loss, logits = static_out
         self.steps += 1
         self.last_loss, self.last_logits = loss, logits
         return loss
 
-    def static_batch(self):
-        """(inputs, target) buffers the captured training step reads (None before the capture).  A producer that writes
-        the next batch into them (DeviceTileStore.batch(..., out=...)) and passes them to train_step saves the two
-        device copies per step."""
-        return self._static
+    def release_graphs(self):
+        """Drop every captured graph and its static buffers NOW (outside any capture): call before discarding a
+        trainer so that its graphs are not left to a later garbage-collection pass."""
+        torch.cuda.synchronize()
+        self._graphs.clear()
+        self._test_graphs.clear()
+        self._graph = self._static = self._graph_opt_shared = None
+        self.last_loss = self.last_logits = None
+
+    def static_batch(self, n_windows=None):
+        """(inputs, target) buffers the captured training step reads (None before the capture): those of the graph for
+        batches of ``n_windows`` windows, or of the step run last.  A producer that writes the next batch into them
+        (DeviceTileStore.batch(..., out=...)) and passes them to train_step saves the two device copies per step."""
+        if n_windows is None:
+            return self._static
+        for shape, ent in self._graphs.items():
+            if shape[0] == n_windows:
+                return ent[1]
+        return None
 
     def _test_forward(self, inputs, target):
         with torch.no_grad(), F_.training_step(self.model):      # packs / Winograd taps once, batched small kernels
@@ -253,8 +346,8 @@ class HotPathTrainer(object):
 
     def test_step(self, inputs, target):
         """run_test_epoch body: no_grad forward with train-mode modules, loss, argmax predictions.  With use_graph
-        the step is captured once per batch shape and replayed (outputs are static buffers: consume or clone them
-        before the next call)."""
+        the step is captured once per batch shape and replayed; the returned tensors are copies, safe to hold across
+        calls (the next replay overwrites the graph's own output buffers)."""
         if not inputs.is_cuda:
             raise RuntimeError('HotPathTrainer needs CUDA (MI355X) tensors; there is no CPU fallback')
         self.model.train()
@@ -280,37 +373,57 @@ class HotPathTrainer(object):
         static[0].copy_(inputs)
         static[1].copy_(target)
         g.replay()
-        return out
+        return tuple(o.clone() for o in out)                     # never hand out the graph's own buffers
 
 
 def run_train_epoch(trainer, loader, batch_size=None):
-    """BaseTraining.run_train_epoch (:139-159) over an iterable of (obs_idx, seq, metadata, target).
-    Returns the list of device-resident per-batch losses (no per-step host sync)."""
+    """BaseTraining.run_train_epoch (:139-159) over an iterable of (obs_idx, seq, metadata, target) -- the hand-over
+    of the reference (host batches from a DataLoader).  Every rank must iterate the SAME batches (same loader seed);
+    each takes its window shard.  Returns the list of device-resident per-batch losses (no per-step host sync)."""
     losses = []
     dev = next(trainer.model.parameters()).device
     for obs_idx, seq, metadata, target in loader:
-        if batch_size != 1:
-            obs_idx, seq, metadata, target = clip_odd_batch_sizes(obs_idx, seq, metadata, target)
-        if seq.shape[0] == 0:
+        n = legal_batch_len(seq.shape[0], batch_size, trainer.world_size)
+        if n == 0:
             continue
-        sl = shard_windows(seq.shape[0], trainer.world_size, trainer.rank)
-        inputs = seq[sl].float().to(dev, non_blocking=True)
-        tgt = target[sl].float().to(dev, non_blocking=True)
+        sl = shard_windows(n, trainer.world_size, trainer.rank)
+        inputs = seq[:n][sl].float().to(dev, non_blocking=True)
+        tgt = target[:n][sl].float().to(dev, non_blocking=True)
         losses.append(trainer.train_step(inputs, tgt).clone())
     return losses
+
+
+def shared_generator(trainer, generator=None):
+    """The generator an epoch's permutation is drawn from.  One GPU: the caller's (None = torch's global RNG, like a
+    DataLoader).  Data parallel: rank 0 draws a seed (from its generator or its global RNG), broadcasts it, and every
+    rank seeds a fresh generator with it -- the ranks shard ONE permutation even when they were started with different
+    seeds or none (``generator=None`` on every rank would give every rank its own shuffle)."""
+    if trainer.world_size == 1:
+        return generator
+    import torch.distributed as dist
+    seed = torch.randint(0, 2 ** 62, (1,), generator=generator, dtype=torch.int64)
+    dev = next(trainer.model.parameters()).device
+    backend = dist.get_backend(trainer.group)
+    t = seed.to(dev) if backend == 'nccl' else seed
+    src = dist.get_global_rank(trainer.group, 0) if trainer.group is not None else 0
+    dist.broadcast(t, src=src, group=trainer.group)
+    return torch.Generator().manual_seed(int(t.item()))
 
 
 def run_train_epoch_from_store(trainer, store, batch_size=16, shuffle=True, generator=None):
     """One training epoch straight from a DeviceTileStore: the DataLoader / collate / cast / H2D of
     train_ards_detector.py:139-152 is one gather+normalise kernel per batch, written IN PLACE into the buffers the
     captured step reads once they exist (batches of the captured shape), so a steady-state step is: gather kernel,
-    graph replay.  Each rank takes its window shard of every batch.  Returns the device-resident per-batch losses."""
+    graph replay.  ``batch_size`` is the GLOBAL batch (what the reference's DataParallel scatters): each rank takes
+    its window shard of every batch of one shared permutation.  Returns the device-resident per-batch losses."""
     losses = []
-    for idx, _, _ in _epoch_indices(store, batch_size, shuffle, generator):
+    if shuffle:
+        generator = shared_generator(trainer, generator)
+    for idx, _, _ in _epoch_indices(store, batch_size, shuffle, generator, trainer.world_size):
         sl = shard_windows(len(idx), trainer.world_size, trainer.rank)
         mine = idx[sl]
-        static = trainer.static_batch()
-        if static is not None and static[0].shape[0] == len(mine):
+        static = trainer.static_batch(len(mine))
+        if static is not None:
             x, t = store.batch(mine, out=static)
         else:
             x, t = store.batch(mine)
@@ -318,13 +431,16 @@ def run_train_epoch_from_store(trainer, store, batch_size=16, shuffle=True, gene
     return losses
 
 
-def _epoch_indices(store, batch_size, shuffle, generator):
+def _epoch_indices(store, batch_size, shuffle, generator, world_size=1):
+    """Batches of fold-relative indices like DataLoader(batch_size, shuffle) + clip_odd_batch_sizes (:146-147,482-494),
+    each trimmed to a multiple of lcm(2, world) windows (``legal_batch_len``)."""
     n = len(store)
+    if batch_size == 1 and world_size > 1:
+        raise ValueError('batch_size 1 cannot be sharded over %d ranks' % world_size)
     order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
     for s in range(0, n, batch_size):
         idx = order[s:s + batch_size]
-        if batch_size != 1 and len(idx) % 2 == 1:          # clip_odd_batch_sizes (:146-147,482-494)
-            idx = idx[:-1]
+        idx = idx[:legal_batch_len(len(idx), batch_size, world_size)]
         if len(idx):
             yield idx, None, None
 
@@ -333,13 +449,14 @@ def run_test_epoch(trainer, store, patient_slot, batch_size=16):
     """BaseTraining.run_test_epoch (:424-465) + record_final_epoch_testing_results (:519-524) with the reductions on
     the device: no_grad forward in train mode, BCE loss, window argmax, per-patient vote table.  ``store`` is a
     DeviceTileStore, ``patient_slot`` an int64 tensor (len(store),) mapping every window to a patient slot
-    0..P-1.  One host sync at the end.  Returns dict(votes (P,2), pred_frac (P,), prediction (P,), window_pred,
-    mean_loss) mirroring metrics.py:572-604: pred_frac = ARDS votes / all votes, prediction = argmax of the votes."""
+    0..P-1 (indexed by the ABSOLUTE window index, like the reference's ground-truth frame).  One host sync at the end.
+    Returns dict(votes (P,2), pred_frac (P,), prediction (P,), window_pred, window_index (fold-relative),
+    window_abs_index (index into all windows = the reference's obs_idx, dataset.py:1349-1350,1404), mean_loss) mirroring metrics.py:572-604: pred_frac = ARDS votes / all votes, prediction = argmax of the votes."""
     dev = store.tiles.device
     slot = torch.as_tensor(patient_slot, dtype=torch.int64, device=dev)
     n_pat = int(slot.max()) + 1
     votes = torch.zeros((n_pat, 2), dtype=torch.int32, device=dev)
-    preds, losses, order = [], [], []
+    preds, losses, order, absolute = [], [], [], []
     for idx, x, t in store.epoch(batch_size, shuffle=False, drop_odd=trainer_clip_odd_batches(trainer)):
         loss, logits, _ = trainer.test_step(x, t)
         gidx = idx.to(dev)
@@ -350,15 +467,17 @@ def run_test_epoch(trainer, store, patient_slot, batch_size=16):
             nb = logits.shape[1]                    # (PerBreathClassifierMixin, train_ards_detector.py:548-555)
             grp = grp.repeat_interleave(nb)
             idx = idx.repeat_interleave(nb)
+            gidx = gidx.repeat_interleave(nb)
             logits = logits.reshape(-1, 2)
         preds.append(H.vote_counts(logits.contiguous(), grp, votes))
-        losses.append(loss.reshape(1).clone())      # static graph output: copy before the next replay
+        losses.append(loss.reshape(1))
         order.append(idx)
+        absolute.append(gidx)
     v = votes.cpu().numpy()
     tot = v.sum(axis=1)
     return dict(votes=v, pred_frac=v[:, 1] / tot.clip(min=1), prediction=v.argmax(axis=1),
                 window_pred=torch.cat(preds).cpu().numpy(), window_index=torch.cat(order).numpy(),
-                mean_loss=float(torch.cat(losses).mean()))
+                window_abs_index=torch.cat(absolute).cpu().numpy(), mean_loss=float(torch.cat(losses).mean()))
 
 
 def trainer_clip_odd_batches(trainer):

@@ -182,7 +182,9 @@ class BaseTraining(object):
         if slot is None:
             slot = torch.zeros(store.tiles.shape[0], dtype=torch.int64)
         res = run_test_epoch(trainer, store, slot, batch_size=batch_size)
-        self.preds, self.pred_idx = res['window_pred'].tolist(), res['window_index'].tolist()
+        if optimizer is None:
+            trainer.release_graphs()                          # a throw-away trainer: free its graphs here, not in a GC pass
+        self.preds, self.pred_idx = res['window_pred'].tolist(), res['window_abs_index'].tolist()   # obs_idx is absolute
         self.results.update_meter('test_loss', fold_num, res['mean_loss'])
         self.results.patient_results[(fold_num, epoch_num)] = res
         return res

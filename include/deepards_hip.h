@@ -159,6 +159,9 @@ int da_bn_fwd(const float* x, int ldx, const float* res, int ldr, float* out, in
               da_stream_t stream);
 /* tests: on != 0 forces the two-stage kernels in da_bn_fwd / da_bn_bwd (both paths are checked against the oracle) */
 int da_bn_debug_two_stage(int on);
+/* tuning: blocks per launch the single-pass BatchNorm geometry aims for before its channel group stops shrinking
+   (default 256 = one (window, 16-32 channel) slab per CU) */
+int da_bn_debug_target_blocks(int blocks);
 /* mask_mode 0: no ReLU; 1: ReLU, mask recomputed from bn(x); 2: ReLU, mask from `out` (residual).
  * scratch: da_bn_workspace() bytes.  ds: [2][W][C] per-window totals, always written.  dgamma/dbeta NULL:
  * fold ds later with da_bn_param_grad_multi. */

@@ -1,10 +1,21 @@
 """Per-kernel HBM-side traffic from the two rocprofv3 --pmc passes of scripts/profile_round.sh.
 FETCH_SIZE is doubled (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROARCH.md HBM / rocprofv3 section),
-WRITE_SIZE is taken as reported; both are in KiB."""
-import csv, glob, json, sys, collections
+WRITE_SIZE is taken as reported; both are in KiB.  Writes gpurun_out/<tag>_traffic.json: one record per C-ABI entry
+point that launches exactly one kernel (what bench.py's `roofline.traffic` looks up), stamped with the sha of the
+kernel sources it was measured at (bench.py drops the figure when the sources have changed since)."""
+import csv, glob, json, os, sys, collections
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import csrc_sha16      # noqa: E402
 
 tag, fdir, wdir = sys.argv[1], sys.argv[2], sys.argv[3]
-FAMILY = ('conv3_wino_kernel',)     # da_conv3_winograd: k3 s1 conv forward + data gradient (the dominant kernel)
+# entry point -> prefix of the rocprofv3 kernel name(s) it launches
+ENTRY_KERNEL = {'da_conv3_winograd': ('conv3_wino_kernel', 'conv3_wino_bn_kernel'),
+                'da_conv3_winograd4': ('conv3_wino4k_kernel',),
+                'da_conv_gemm_multi': ('conv_gemm_multi_kernel',), 'da_conv3_bf16': ('conv3_bf16_kernel',),
+                'da_pool_bwd': ('pool_bwd_kernel',), 'da_bn_fwd': ('bn_fwd_fused_kernel',),
+                'da_bn_bwd': ('bn_bwd_fused_kernel',)}
 
 
 def per_kernel(d, counter):
@@ -16,22 +27,27 @@ def per_kernel(d, counter):
     return acc
 
 
-out = {}
+acc = {}
 for counter, d in (('FETCH_SIZE', fdir), ('WRITE_SIZE', wdir)):
-    acc = per_kernel(d, counter)
+    acc[counter] = per_kernel(d, counter)
     with open('gpurun_out/%s_pmc_%s_per_kernel.csv' % (tag, counter), 'w') as f:
         f.write('kernel,launches,mean_%s_kb_raw,total_kb_raw\n' % counter)
-        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+        for k, v in sorted(acc[counter].items(), key=lambda kv: -sum(kv[1])):
             f.write('"%s",%d,%.1f,%.1f\n' % (k, len(v), sum(v) / len(v), sum(v)))
-    fam = [x for k, v in acc.items() if k.startswith(FAMILY) for x in v]
-    out[counter] = (len(fam), sum(fam) / max(1, len(fam)))
-n, fetch = out['FETCH_SIZE']
-_, write = out['WRITE_SIZE']
-res = {'kernel': 'conv3_wino_kernel', 'entry': 'da_conv3_winograd', 'launches': n,
-       'fetch_size_kb_raw_per_launch': round(fetch, 1), 'write_size_kb_per_launch': round(write, 1),
-       'hbm_bytes_per_launch': int((2 * fetch + write) * 1024),
+kernels = {}
+for entry, prefixes in ENTRY_KERNEL.items():
+    fam = {c: [x for k, v in acc[c].items() if k.startswith(prefixes) for x in v] for c in acc}
+    if not fam['FETCH_SIZE'] or not fam['WRITE_SIZE']:
+        continue
+    fetch = sum(fam['FETCH_SIZE']) / len(fam['FETCH_SIZE'])
+    write = sum(fam['WRITE_SIZE']) / len(fam['WRITE_SIZE'])
+    kernels[entry] = {'kernel': '/'.join(prefixes), 'launches': len(fam['FETCH_SIZE']),
+                      'fetch_size_kb_raw_per_launch': round(fetch, 1), 'write_size_kb_per_launch': round(write, 1),
+                      'hbm_bytes_per_launch': int((2 * fetch + write) * 1024)}
+res = {'csrc_sha16': csrc_sha16(), 'kernels': kernels,
        'how': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 '
               '--warmup 2 --no-graph --no-cpu-baseline --no-extra --no-roofline; FETCH_SIZE doubled per MI355X_MICROARCH.md '
-              '(gfx950 reports half the bytes of 16-B/lane coalesced reads), WRITE_SIZE as reported; KB = 1024 B'}
+              '(gfx950 reports half the bytes of 16-B/lane coalesced reads), WRITE_SIZE as reported; KB = 1024 B; per-launch '
+              'means over all launches of the kernel in those runs'}
 json.dump(res, open('gpurun_out/%s_traffic.json' % tag, 'w'), indent=1)
 print(json.dumps(res))

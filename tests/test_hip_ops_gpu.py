@@ -397,14 +397,14 @@ def test_bn_fwd_bwd(H, C, L, R, W, two_stage):
 
 @pytest.mark.parametrize('C,L,R,W', [(64, 56, 20, 4), (128, 28, 20, 3), (32, 9, 7, 5)])
 def test_bn_small_channel_groups(H, C, L, R, W):
-    """The single-pass kernels with 8-channel blocks (tuning knob DA_BN_BLOCKS / da_bn_debug_two_stage(n >= 2): aim for n
+    """The single-pass kernels with 8-channel blocks (tuning knob DA_BN_BLOCKS / da_bn_debug_target_blocks(n): aim for n
     blocks per launch; measured slower than the default 256 at B=64, kept for other batch sizes) against the oracle."""
     from deepards_amd import _lib
-    _lib.lib().da_bn_debug_two_stage(1 << 20)
+    _lib.lib().da_bn_debug_target_blocks(1 << 20)
     try:
         _bn_fwd_bwd(H, C, L, R, W)
     finally:
-        _lib.lib().da_bn_debug_two_stage(256)
+        _lib.lib().da_bn_debug_target_blocks(256)
 
 
 def _bn_fwd_bwd(H, C, L, R, W):

@@ -99,7 +99,136 @@ def test_host_helpers():
     assert shard_windows(64, 4, 1) == slice(16, 32)
     assert [shard_windows(8, 2, r) for r in range(2)] == [slice(0, 4), slice(4, 8)]
     with pytest.raises(ValueError):
-        shard_windows(6, 4, 0)
+        shard_windows(6, 4, 0)                       # untrimmed batches are a caller bug (epoch iterators trim first)
+
+
+def test_epoch_batches_are_legal_for_every_world_size():
+    """Every batch an epoch yields splits evenly over the ranks and keeps the reference's even-batch rule
+    (train_ards_detector.py:146-147,482-494): N=70, batch 16, world 4 has a tail of 6 -> trimmed to 4 (1 per rank)
+    instead of raising; the shards of a batch partition it."""
+    from deepards_amd.train import _epoch_indices, shard_windows, legal_batch_len, batch_multiple
+
+    class Store(object):
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+    assert [batch_multiple(16, w) for w in (1, 2, 3, 4, 8)] == [2, 2, 6, 4, 8] and batch_multiple(1, 1) == 1
+    assert legal_batch_len(6, 16, 4) == 4 and legal_batch_len(7, 16, 1) == 6 and legal_batch_len(1, 1, 1) == 1
+    for n, bs in ((70, 16), (20, 6), (1000, 64), (9, 16)):
+        for world in (1, 2, 4, 8):
+            g = torch.Generator().manual_seed(3)
+            seen = []
+            for idx, _, _ in _epoch_indices(Store(n), bs, True, g, world):
+                assert len(idx) % 2 == 0 and len(idx) % world == 0 and 0 < len(idx) <= bs
+                parts = [idx[shard_windows(len(idx), world, r)] for r in range(world)]
+                assert len({len(p) for p in parts}) == 1
+                assert torch.equal(torch.cat(parts), idx)
+                seen += idx.tolist()
+            assert len(set(seen)) == len(seen)
+            full, tail = divmod(n, bs)
+            assert len(seen) == full * legal_batch_len(bs, bs, world) + legal_batch_len(tail, bs, world)
+    sizes = [len(i) for i, _, _ in _epoch_indices(Store(70), 16, False, None, 4)]
+    assert sizes == [16, 16, 16, 16, 4]
+    with pytest.raises(ValueError):
+        list(_epoch_indices(Store(10), 1, False, None, 2))
+
+
+def test_capture_guard_holds_the_collector_off_and_restores_it():
+    """deepards_amd.train._capture_graph: pending garbage is collected BEFORE the capture window opens, the cyclic
+    collector is disabled inside it, and its previous state comes back afterwards -- also when the capture raises,
+    and also when the collector was already off."""
+    import contextlib
+    import gc
+    import weakref
+    from deepards_amd.train import _capture_graph
+
+    class Node(object):
+        pass
+    events = []
+
+    @contextlib.contextmanager
+    def fake_capture(graph):
+        events.append(('enter', gc.isenabled(), ref() is None))
+        yield
+        events.append(('exit', gc.isenabled()))
+    was = gc.isenabled()
+    try:
+        for state in (True, False):
+            gc.enable() if state else gc.disable()
+            n = Node()
+            n.me = n
+            ref = weakref.ref(n)
+            del n                                              # cyclic garbage pending at the time of the capture
+            events.clear()
+            with _capture_graph(object(), _ctx=fake_capture):
+                assert not gc.isenabled()
+            assert events == [('enter', False, True), ('exit', False)]    # collected before the window, off inside
+            assert gc.isenabled() == state
+            with pytest.raises(KeyError):
+                with _capture_graph(object(), _ctx=fake_capture):
+                    raise KeyError('capture failed')
+            assert gc.isenabled() == state
+    finally:
+        gc.enable() if was else gc.disable()
+
+
+def _sync_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from deepards_amd.train import HotPathTrainer, shared_generator, _epoch_indices, shard_windows
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import deepards_amd.models as M
+    torch.manual_seed(100 + rank)                              # every rank its own initialisation
+    model = M.CNNLinearNetwork(M.resnet18(), 20, 0)
+    model.breath_block.bn1.running_mean.fill_(float(rank + 1))
+    before = model.linear_final.weight.detach().clone()
+    tr = HotPathTrainer(model, world_size=world, rank=rank)
+    tr.sync_replicas()
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()] +
+                     [b.detach().reshape(-1).float() for b in model.buffers()])
+
+    class Store(object):
+        def __len__(self):
+            return 70
+    torch.manual_seed(5000 + 17 * rank)                        # ... and its own global RNG
+    perms = []
+    for gen in (None, torch.Generator().manual_seed(rank)):    # no generator / a different generator per rank
+        g = shared_generator(tr, gen)
+        perms.append(torch.cat([i[shard_windows(len(i), world, rank)] for i, _, _ in _epoch_indices(Store(), 16, True, g, world)]))
+        full = torch.cat([i for i, _, _ in _epoch_indices(Store(), 16, True, shared_generator(tr, gen), world)])
+        perms.append(full)
+    q.put((rank, flat.numpy(), [p.numpy() for p in perms], bool(torch.equal(before, model.linear_final.weight))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replica_sync_and_shared_permutation_gloo_world2():
+    """HotPathTrainer.sync_replicas + shared_generator over gloo, world 2 (the host side of config C4): ranks that
+    were initialised differently hold rank 0's parameters AND buffers afterwards; with no seed / different seeds
+    they still draw ONE permutation per epoch and shard it disjointly."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, f0, perms0, same0), (_, f1, perms1, same1) = res
+    assert np.array_equal(f0, f1)                              # parameters and buffers identical after the sync
+    assert same0 and not same1                                 # rank 0 kept its weights, rank 1 was overwritten
+    for k in (0, 2):                                           # shards of one permutation: disjoint, equal sizes
+        assert len(perms0[k]) == len(perms1[k]) and not set(perms0[k].tolist()) & set(perms1[k].tolist())
+    for k in (1, 3):                                           # the full permutation every rank iterates is the same
+        assert np.array_equal(perms0[k], perms1[k])
+    assert not np.array_equal(perms0[1], perms0[3])            # a fresh seed per epoch
 
 
 def _dp_worker(rank, world, port, q):

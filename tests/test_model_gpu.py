@@ -646,6 +646,7 @@ def test_data_parallel_step_structure_on_one_gpu(M):
     ref_tr = HotPathTrainer(ref_model, use_graph=True)
     dp_model = build(M, 'resnet18', 0)
     dp_tr = HotPathTrainer(dp_model, use_graph=True, world_size=2, rank=0)
+    dp_tr._synced = True                                # stand-in all-reduce, no process group: skip the broadcast
     orig = FlatBucket.allreduce
     FlatBucket.allreduce = lambda self, group=None: self.g.mul_(2.0)      # sum over 2 identical ranks
     try:
@@ -657,6 +658,136 @@ def test_data_parallel_step_structure_on_one_gpu(M):
         FlatBucket.allreduce = orig
     for (n, p), (_, q) in zip(ref_model.named_parameters(), dp_model.named_parameters()):
         assert torch.equal(p, q), n
+
+
+def _run_dp_children(tmp_path, gold_path, mode, world=2, graph=True):
+    """`world` FRESH child processes (tests/tools/dp_child.py), all on cuda:0, gradients over gloo."""
+    import subprocess
+    import sys
+    port = 29500 + (os.getpid() * 7 + hash(mode) % 97) % 3000
+    procs, outs = [], []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   DP_CHILD_GRAPH='1' if graph else '0')
+        out = str(tmp_path / ('dp_%s_rank%d.npz' % (mode, r)))
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), 'tools', 'dp_child.py'),
+                                       gold_path, out, mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p_ in procs:
+        try:
+            o, _ = p_.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors='replace'))
+    for r, p_ in enumerate(procs):
+        assert p_.returncode == 0, 'rank %d failed:\n%s' % (r, logs[r][-4000:])
+    return [dict(np.load(o, allow_pickle=False)) for o in outs]
+
+
+def test_data_parallel_two_processes_trajectory(M, tmp_path):
+    """Config C4's step for real: two processes (one model replica each, both on this GPU, gloo all-reduce of the flat
+    bucket), rank r trains on window r of the golden's B=2 batch.  Rank 1 starts from a DIFFERENT random initialisation:
+    sync_replicas() must replace it with rank 0's.  Checked: (1) the ranks end with bit-identical parameters;
+    (2) the mean of the rank losses and the parameters follow the reference's B=2 trajectory (golden) within the
+    bounds of the single-process trajectory test; (3) they equal this build's own single-process B=2 run to 2e-6 --
+    not bit-for-bit: the single process sums the two windows' weight-gradient contributions inside one split-K
+    reduction, the data-parallel step adds two rank totals, a different fp32 summation order."""
+    from deepards_amd.train import HotPathTrainer
+    path = [p for p in GOLD if 'resnet18_b2_randn' in p][0]
+    g = _gold(path)
+    r0, r1 = _run_dp_children(tmp_path, path, 'traj')
+    assert int(r0['allreduce_calls']) == int(r1['allreduce_calls']) == 3
+    names = [k for k in r0 if k.startswith('p/')]
+    for k in names:
+        assert np.array_equal(r0[k], r1[k]), k                                     # replicas stay bit-identical
+    losses = (r0['losses'] + r1['losses']) / 2                                     # mean of equal-shard means
+    ref = g['sgd_losses64']
+    log('dp2 losses', losses.tolist(), 'ref', ref.tolist())
+    assert np.abs(losses - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    model = build(M, 'resnet18', int(g['seed']), str(g['first_pool_type']))
+    tr = HotPathTrainer(model, optimizer='sgd', use_graph=True)
+    x, t = torch.from_numpy(g['x']).cuda(), torch.from_numpy(g['target']).cuda()
+    single = [float(tr.train_step(x, t)) for _ in range(3)]
+    assert np.abs(losses - np.array(single)).max() < 2e-6
+    worst = 0.0
+    for n, p in model.named_parameters():
+        a, b = r0['p/' + n], p.detach().cpu().numpy()
+        key = 'sgd_p64/' + n
+        if key not in g:
+            continue                                    # dead parameters: rank 0's initial values everywhere
+        worst = max(worst, float(np.abs(a - b).max()))
+        d = digest(a)
+        body = slice(None) if a.size <= 1024 else slice(0, -3)
+        assert np.abs(d - g[key])[body].max() < 1.5e-4, n
+    log('dp2 vs single-process params max abs diff %.3e' % worst)
+    assert worst < 2e-6
+    # dead parameters and buffers were broadcast too: rank 1 holds rank 0's values
+    for n in DEAD_RESNET_PARAMS:
+        assert np.array_equal(r0['p/' + n], r1['p/' + n]), n
+
+
+def test_data_parallel_two_processes_epochs_from_store(tmp_path):
+    """Two ranks, two shuffled epochs over the 20 fixture windows with a GLOBAL batch of 6 and NO seed anywhere (each
+    rank even has a different global RNG state): the ranks must shard one shared permutation -- per step the two
+    index lists are disjoint halves of one batch, an epoch covers 18 + 2 windows (the tail batch of 2 is legal, 1 per
+    rank), the tail shape gets its own graph (2 graphs, no recapture), and the replicas end bit-identical."""
+    path = [p for p in GOLD if 'densenet18_b2_randn' in p][0]
+    r0, r1 = _run_dp_children(tmp_path, path, 'epoch')
+    n = int(r0['n_steps'])
+    assert n == int(r1['n_steps']) == 8                                              # 2 epochs x (3 full + 1 tail)
+    for ep in range(2):
+        seen = []
+        for i in range(4 * ep, 4 * ep + 4):
+            a, b = r0['idx%d' % i], r1['idx%d' % i]
+            assert len(a) == len(b) == (3 if i % 4 < 3 else 1)
+            assert not set(a.tolist()) & set(b.tolist())
+            seen += a.tolist() + b.tolist()
+        assert sorted(seen) == list(range(20))                                      # one permutation, fully covered
+    assert int(r0['n_graphs']) == int(r1['n_graphs']) == 2
+    assert int(r0['allreduce_calls']) == int(r1['allreduce_calls']) == 8
+    for k in r0:
+        if k.startswith('p/'):
+            assert np.array_equal(r0[k], r1[k]), k
+    assert np.isfinite(r0['losses']).all() and np.isfinite(r1['losses']).all()
+
+
+def test_recapture_on_shape_change_with_garbage_pending(M):
+    """Pins the capture-window ownership rule (deepards_amd.train._capture_graph): cyclic garbage
+    that owns captured graphs and device tensors is pending when a NEW shape is captured; it must be finalised before
+    the window (gc.collect) and the collector must be off inside it.  Run once; passes by not aborting and by leaving
+    the collector in the state it was found."""
+    import gc
+    from deepards_amd.train import HotPathTrainer
+    x = torch.randn(4, 20, 1, 224, device='cuda')
+    t = torch.zeros(4, 2, device='cuda')
+    t[:, 0] = 1
+
+    class Cycle(object):
+        pass
+    was = gc.isenabled()
+    gc.disable()                                        # let the garbage below stay pending until _capture_graph
+    try:
+        for _ in range(2):
+            junk = HotPathTrainer(build(M, 'densenet18', 7), use_graph=True)
+            for _ in range(2):
+                junk.train_step(x, t)
+            junk.test_step(x, t)
+            c = Cycle()
+            c.self, c.trainer, c.blob = c, junk, torch.empty(1 << 20, device='cuda')
+            del c, junk                                 # unreachable, but only a collection can free it
+    finally:
+        if was:
+            gc.enable()
+    tr = HotPathTrainer(build(M, 'densenet18', 8), use_graph=True)
+    for n in (4, 4, 2, 2, 4):                           # capture B=4, then a second shape B=2, then replay both
+        loss = tr.train_step(x[:n].contiguous(), t[:n].contiguous())
+    assert np.isfinite(float(loss)) and len(tr._graphs) == 2
+    assert gc.isenabled() == was
+    tr.release_graphs()
+    assert not tr._graphs and not tr._test_graphs
 
 
 def test_driver_mirror_train_and_test_on_the_fixture():
