@@ -26,13 +26,24 @@ class DeviceTileStore(object):
         self.mu, self.std = float(mu), float(std)
         self.kfold_indexes = None                     # absolute indices of the current fold (dataset.py:765-772)
         self.patients = self.total_kfolds = self.kfold_patient_splits = self.scaling_factors = None
+        self.kfold_num = None
         self.train = True
+        # sampling knobs of ARDSRawDataset (dataset.py:360-372); only the oversampling ones are on the hot path
+        self.oversample_minority = False
+        self.oversample_all_factor = 1.0
+        self.undersample_factor = -1
+        self.train_patient_fraction = 1.0
+        self.sampling_rng = None                      # np.random.RandomState for the oversampler; None: numpy's global RNG
+        self.hours = None                             # (N, NB) seq_hours of the windows when ingested from a pickle
+        self.patient_slot = None                      # (N,) patient slot per window when ingested from a pickle
 
     # ---- k-fold plumbing of ARDSRawDataset (dataset.py:651-670, 672-700, 765-830) --------------------------------
-    def enable_kfolds(self, patients, total_kfolds, train=True, random_kfold=False):
+    def enable_kfolds(self, patients, total_kfolds, train=True, random_kfold=False, splits=None, scaling_factors=None):
         """Patient-wise stratified folds over this store's windows; per-fold scaling factors from each fold's TRAIN
         windows (``derive_scaling_factors``).  ``set_kfold_indexes_for_fold(k)`` then selects fold k's train (or, with
-        train=False, test) windows and that fold's factors."""
+        train=False, test) windows and that fold's factors.  ``splits`` / ``scaling_factors``: the ones a dataset
+        pickle already carries are kept instead of derived, as ``from_pickle`` does (``set_kfold_patient_splits`` only
+        fills an empty dict, dataset.py:774-781; factors are re-derived only for new FFT channels, :757-762)."""
         from .tiles import kfold_patient_splits, patient_map_to_loc, scaling_factors_for_indices
         import numpy as np
         self.patients = np.asarray(patients)
@@ -40,12 +51,21 @@ class DeviceTileStore(object):
             raise ValueError('one patient id per window expected')
         labels = self.targets.argmax(dim=1).cpu().numpy()
         self.total_kfolds, self.train = int(total_kfolds), bool(train)
-        self.kfold_patient_splits = kfold_patient_splits(self.patients, labels, self.total_kfolds, random_kfold)
-        host = self.tiles.cpu().numpy()
-        self.scaling_factors = {}
-        for k, sp in self.kfold_patient_splits.items():
-            mu, std = scaling_factors_for_indices(host, patient_map_to_loc(self.patients, sp['train']))
-            self.scaling_factors[k] = (float(mu[0]), float(std[0]))
+        if splits:
+            self.kfold_patient_splits = {int(k): {'train': np.asarray(v['train']), 'test': np.asarray(v['test'])}
+                                         for k, v in splits.items()}
+            if sorted(self.kfold_patient_splits) != list(range(self.total_kfolds)):
+                raise ValueError('the given patient splits do not cover folds 0..%d' % (self.total_kfolds - 1))
+        else:
+            self.kfold_patient_splits = kfold_patient_splits(self.patients, labels, self.total_kfolds, random_kfold)
+        if scaling_factors:
+            self.scaling_factors = {int(k): (float(m), float(s_)) for k, (m, s_) in scaling_factors.items()}
+        else:
+            host = self.tiles.cpu().numpy()
+            self.scaling_factors = {}
+            for k, sp in self.kfold_patient_splits.items():
+                mu, std = scaling_factors_for_indices(host, patient_map_to_loc(self.patients, sp['train']))
+                self.scaling_factors[k] = (float(mu[0]), float(std[0]))
         return self
 
     def make_test_store_if_kfold(self):
@@ -56,6 +76,7 @@ class DeviceTileStore(object):
         other = object.__new__(DeviceTileStore)
         other.__dict__.update(self.__dict__)
         other.train, other.kfold_indexes = False, None
+        other.oversample_minority, other.oversample_all_factor = False, 1.0      # dataset.py:689-690
         return other
 
     def get_kfold_indexes_for_fold(self, kfold_num):
@@ -66,8 +87,40 @@ class DeviceTileStore(object):
     def set_kfold_indexes_for_fold(self, kfold_num):
         if self.total_kfolds is None:
             raise ValueError('enable_kfolds first')
+        self.kfold_num = kfold_num
         self.set_kfold_indexes(self.get_kfold_indexes_for_fold(kfold_num))
         self.mu, self.std = self.scaling_factors[kfold_num]
+        # dataset.py:768-772: fractional patients, undersampling, then oversampling
+        if self.train_patient_fraction != 1.0:
+            raise NotImplementedError('train_pt_frac != 1.0 is outside the accelerated hot path')
+        if self.undersample_factor != -1:
+            raise NotImplementedError('patient-level undersampling is outside the accelerated hot path')
+        self.set_oversampling_indices()
+
+    def set_oversampling_indices(self):
+        """``ARDSRawDataset.set_oversampling_indices`` (dataset.py:561-582) on the current fold's index list: with
+        ``oversample_minority`` the minority class's windows are re-drawn with replacement until the classes are even;
+        with ``oversample_all_factor`` > 1 both classes grow to ``int(n_class * factor)``.  The reference delegates to
+        ``imblearn.over_sampling.RandomOverSampler`` (imbalanced-learn, pinned 0.4.3 in environment-py2.yml, absent
+        here); ``tiles.random_over_sample`` restates its published algorithm -- parity unpinned."""
+        from .tiles import random_over_sample
+        if not self.train:
+            return                                               # "Cannot oversample with testing set"
+        if self.oversample_minority and not self.total_kfolds:
+            raise NotImplementedError('We havent implemented oversampling for holdout sets yet')
+        if not self.oversample_minority and not self.oversample_all_factor > 1.0:
+            return
+        if self.kfold_indexes is None:
+            raise ValueError('set_kfold_indexes_for_fold first')
+        labels = self.targets.argmax(dim=1).cpu().numpy()
+        x = self.kfold_indexes.cpu().numpy()
+        if self.oversample_minority:
+            x = random_over_sample(x, labels[x], None, self.sampling_rng)
+        if self.oversample_all_factor > 1.0:
+            y = labels[x]
+            want = {0: int((y == 0).sum() * self.oversample_all_factor), 1: int((y == 1).sum() * self.oversample_all_factor)}
+            x = random_over_sample(x, y, want, self.sampling_rng)
+        self.set_kfold_indexes(x)
 
     @classmethod
     def with_derived_scaling(cls, windows, targets, indices=None, device='cuda'):

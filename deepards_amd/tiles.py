@@ -156,3 +156,39 @@ def patient_map_to_loc(patients, selected):
     for pt in selected:
         locs.extend(np.nonzero(patients == pt)[0].tolist())
     return locs
+
+
+def random_over_sample(x, y, sampling_strategy=None, rng=None):
+    """``imblearn.over_sampling.RandomOverSampler(sampling_strategy).fit_resample(x.reshape(-1, 1), y)[0].ravel()``
+    as the reference calls it (dataset.py:571-572, 580-581), restated from the published algorithm of imbalanced-learn
+    0.4.x (``RandomOverSampler._fit_resample``): the output is the input followed, class by class in ascending label
+    order, by ``n_extra`` items of that class drawn with replacement -- ``rng.randint(0, n_class, n_extra)`` indexes the
+    class's positions in input order.  ``sampling_strategy`` None ('auto' = 'not majority'): every class but the
+    largest grows to the largest's size; a dict {label: wanted count}: each class grows to its count (never shrinks).
+    ``rng``: np.random.RandomState; None uses numpy's global one like ``random_state=None`` does.
+    The package is not installable here, so this restatement is NOT pinned against it (parity unpinned); the tests pin
+    the rules above."""
+    x, y = np.asarray(x), np.asarray(y)
+    if x.shape != y.shape or x.ndim != 1:
+        raise ValueError('x and y must be (n,) arrays')
+    rng = np.random if rng is None else rng
+    classes, counts = np.unique(y, return_counts=True)
+    stats = dict(zip(classes.tolist(), counts.tolist()))
+    if sampling_strategy is None:
+        n_max = max(stats.values())
+        majority = max(stats, key=stats.get)
+        extra = {c: n_max - n for c, n in stats.items() if c != majority}
+    else:
+        extra = {}
+        for c, want in sampling_strategy.items():
+            if c not in stats:
+                raise ValueError('class %r is not in y' % (c,))
+            if want < stats[c]:
+                raise ValueError('over-sampling cannot shrink class %r from %d to %d' % (c, stats[c], want))
+            extra[c] = want - stats[c]
+    idx = np.arange(len(x))
+    for c in sorted(extra):
+        where = np.flatnonzero(y == c)
+        draw = rng.randint(low=0, high=stats[c], size=extra[c])
+        idx = np.append(idx, where[draw])
+    return x[idx]

@@ -204,6 +204,8 @@ class _Tape(object):
         self.g = {}
         self.R = rows_per_window
         self.stats = {}
+        self.decisions = {}          # name -> dict(kind, ...): every ReLU mask / max-pool argmax of the forward, mutable
+        self.order = []              # decision names in forward order
 
     def acc(self, name, g):
         self.g[name] = self.g.get(name, 0) + g
@@ -252,18 +254,29 @@ def _bn(t, x, prefix):
     return y, bwd
 
 
-def _relu(x):
+def _relu(t, x, name):
+    """ReLU whose backward mask lives on the tape (t.decisions[name]['mask']) and is read when the backward RUNS, so a
+    test can re-run the backward under another admissible decision of an element whose pre-activation is within fp32
+    noise of zero (``rebackward``)."""
     y = relu(x)
-    return y, (lambda dy: dy * (y > 0))
+    d = t.decisions[name] = dict(kind='relu', pre=x, mask=y > 0)
+    t.order.append(name)
+    return y, (lambda dy: dy * d['mask'])
+
+
+def _maxpool(t, x, name):
+    y, idx = maxpool3s2p1_fwd(x)
+    d = t.decisions[name] = dict(kind='maxpool', x=x, idx=idx)
+    t.order.append(name)
+    return y, (lambda dy: maxpool3s2p1_bwd(dy, d['idx'], x.shape[2]))
 
 
 def _stem(t, x, conv, bn, pool_type='max'):
     y0, b_conv = _conv(t, x, conv, 2, 3, need_dx=False)
     y1, b_bn = _bn(t, y0, bn)
-    y2, b_relu = _relu(y1)
+    y2, b_relu = _relu(t, y1, bn + '.relu')
     if pool_type == 'max':
-        y3, idx = maxpool3s2p1_fwd(y2)
-        b_pool = lambda d: maxpool3s2p1_bwd(d, idx, y2.shape[2])
+        y3, b_pool = _maxpool(t, y2, bn + '.maxpool')
     else:
         y3 = avgpool3s2p1_fwd(y2)
         b_pool = lambda d: avgpool3s2p1_bwd(d, y2.shape[2])
@@ -288,7 +301,7 @@ def resnet18_features(t, x, prefix='breath_block.', first_pool_type='max', layer
             xin = h
             o, b1 = _conv(t, xin, bp + 'conv1.weight', stride, 1)
             o, b2 = _bn(t, o, bp + 'bn1')
-            o, b3 = _relu(o)
+            o, b3 = _relu(t, o, bp + 'relu1')
             o, b4 = _conv(t, o, bp + 'conv2.weight', 1, 1)
             o, b5 = _bn(t, o, bp + 'bn2')
             if stride != 1 or inpl != planes:
@@ -298,7 +311,7 @@ def resnet18_features(t, x, prefix='breath_block.', first_pool_type='max', layer
             else:
                 r = xin
                 b_res = lambda d: d
-            h, b6 = _relu(o + r)
+            h, b6 = _relu(t, o + r, bp + 'relu2')
 
             def blk_bwd(d, b1=b1, b2=b2, b3=b3, b4=b4, b5=b5, b6=b6, b_res=b_res):
                 dz = b6(d)
@@ -331,10 +344,10 @@ def densenet18_features(t, x, prefix='breath_block.', drop_masks=None, block_con
             lp = '%sdenseblock%d.denselayer%d.' % (fp, bi, li)
             xin = h
             o, b1 = _bn(t, xin, lp + 'norm1')
-            o, b2 = _relu(o)
+            o, b2 = _relu(t, o, lp + 'relu1')
             o, b3 = _conv(t, o, lp + 'conv1.weight', 1, 0)
             o, b4 = _bn(t, o, lp + 'norm2')
-            o, b5 = _relu(o)
+            o, b5 = _relu(t, o, lp + 'relu2')
             o, b6 = _conv(t, o, lp + 'conv2.weight', 1, 1)
             mask = None if drop_masks is None else drop_masks.get((bi, li))
             if mask is not None:
@@ -351,13 +364,13 @@ def densenet18_features(t, x, prefix='breath_block.', drop_masks=None, block_con
         if bi != 4:
             tp = '%stransition%d.' % (fp, bi)
             o, b1 = _bn(t, h, tp + 'norm')
-            o, b2 = _relu(o)
+            o, b2 = _relu(t, o, tp + 'relu')
             o, b3 = _conv(t, o, tp + 'conv.weight', 1, 0)
             lin = o.shape[2]
             h = avgpool_fwd(o, 2, 2)
             backs.append((lambda b1, b2, b3, lin: (lambda d: b1(b2(b3(avgpool_bwd(d, 2, 2, lin))))))(b1, b2, b3, lin))
     o, b1 = _bn(t, h, fp + 'norm5')
-    o, b2 = _relu(o)
+    o, b2 = _relu(t, o, fp + 'relu5')
     lh = o.shape[2]
     feat = avgpool_fwd(o, 7, 1)
     n = x.shape[0]
@@ -369,6 +382,47 @@ def densenet18_features(t, x, prefix='breath_block.', drop_masks=None, block_con
             d = b(d)
         return d
     return out, bwd
+
+
+def ambiguous_decisions(t, tol):
+    """Activation decisions of the forward that an fp32 implementation may legitimately take the other way: ReLU
+    elements with |pre-activation| < tol, max-pool windows whose best and second-best candidates (at different
+    positions, best > 0) are closer than tol.  -> [(name, flat index, margin)] in forward order."""
+    out = []
+    for name in t.order:
+        d = t.decisions[name]
+        if d['kind'] == 'relu':
+            for i in np.flatnonzero(np.abs(d['pre']) < tol):
+                out.append((name, int(i), float(abs(d['pre'].flat[i]))))
+        else:
+            x = d['x']
+            n, c, l = x.shape
+            lo = d['idx'].shape[2]
+            xp = np.full((n, c, l + 2), -np.inf)
+            xp[:, :, 1:l + 1] = x
+            cand = np.stack([xp[:, :, k:k + (lo - 1) * 2 + 1:2] for k in range(3)], axis=-1)
+            srt = np.sort(cand, axis=-1)
+            gap = srt[..., 2] - srt[..., 1]
+            for i in np.flatnonzero((gap < tol) & (srt[..., 2] > 0)):
+                out.append((name, int(i), float(gap.flat[i])))
+    return out
+
+
+def _apply_flip(t, name, i):
+    d = t.decisions[name]
+    if d['kind'] == 'relu':
+        d['mask'] = d['mask'].copy()
+        d['mask'].flat[i] = ~d['mask'].flat[i]
+    else:                                                     # route the gradient to the runner-up position instead
+        x = d['x']
+        n, c, l = x.shape
+        lo = d['idx'].shape[2]
+        ni, ci, j = np.unravel_index(i, (n, c, lo))
+        best = int(d['idx'][ni, ci, j])
+        pos = [q for q in (2 * j - 1, 2 * j, 2 * j + 1) if 0 <= q < l and q != best]
+        other = max(pos, key=lambda q: x[ni, ci, q])
+        d['idx'] = d['idx'].copy()
+        d['idx'][ni, ci, j] = other
 
 
 HEADS = ('linear', 'to_mean', 'compr_to_rf', 'single_breath', 'double_linear', 'lstm')
@@ -487,7 +541,9 @@ def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_ba
     else:
         loss, dl = bce_with_logits(logits, target)
     out['loss'] = loss
-    if need_grads:
+
+    def run_backward():
+        t.g = {}
         t.acc('linear_final.weight', dl.T @ flat)
         t.acc('linear_final.bias', dl.sum(axis=0))
         dflat = dl @ w
@@ -514,5 +570,25 @@ def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_ba
             t.acc('linear_intermediate.bias', dinter.sum(axis=0))
             dfeat = dinter @ wi
         fbwd(dfeat)
-        out['grads'] = t.g
+        return t.g
+
+    def rebackward(flips):
+        """Gradients with the listed decisions [(name, flat index)] taken the OTHER way (forward values unchanged: the
+        elements are within fp32 noise of the decision boundary).  The tape's decisions are restored afterwards."""
+        saved = {}
+        for name, i in flips:
+            d = t.decisions[name]
+            key = 'mask' if d['kind'] == 'relu' else 'idx'
+            saved.setdefault(name, (key, d[key]))
+            _apply_flip(t, name, i)
+        try:
+            return dict(run_backward())
+        finally:
+            for name, (key, val) in saved.items():
+                t.decisions[name][key] = val
+
+    if need_grads:
+        out['grads'] = dict(run_backward())
+        out['tape'] = t
+        out['rebackward'] = rebackward
     return out

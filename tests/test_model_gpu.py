@@ -4,6 +4,7 @@
 Bar (BASELINE.json north_star): logits / gradients within 1e-4 (fp32) of the reference CPU path."""
 import glob
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -55,17 +56,25 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
+from decision_match import decision_matched_gradients as _dmg      # noqa: E402
+
+
+def decision_matched_gradients(ref, ours, log_tag=''):
+    return _dmg(ref, ours, log_tag, log=log)
+
+
 @pytest.mark.parametrize('path', GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
 def test_logits_and_grads_match_reference_golden(M, path):
-    """Logits: 1e-4 absolute (north star), every golden.
-    Gradients: an fp32 forward differs from the fp64 one by ~1e-5, enough to flip a ReLU / max-pool
-    decision on the few elements whose pre-activation is that close to zero; ONE flip changes the
-    gradient of everything upstream by ~1e-3 relative.  The reference does it to itself: its own
-    fp32 vs fp64 gradients differ by up to 6e-2 abs / 3e-2 rel-l2 on the b4_flow goldens (measured,
-    DESIGN.md).  So elementwise 1e-4 gradient parity is only well-posed where no decision can flip:
-      * goldens '*_active' (every ReLU active, avg first pool): strict, err <= 1e-4 * max(1, max|ref|)
-      * the other goldens: flip-tolerant bound rel-l2 <= 5e-2 per parameter
-    and with IDENTICAL inputs per unit in tests/test_functions_gpu.py (strict, 2e-5)."""
+    """Logits: 1e-4 absolute (north star), every golden, against the reference's fp64 capture.
+    Gradients, every parameter, every golden: within 1e-4 (rel-l2 <= 1e-4, or max abs err <= 1e-4 * max(1, max|ref|))
+    of the EXACT gradients -- the numpy oracle's, which tests/test_oracle_golden.py pins to the reference's captured
+    fp64 gradients at 1e-10 -- under the activation decisions this run took (``decision_matched_gradients``: an fp32
+    forward legitimately takes the other branch of a ReLU whose pre-activation is within ~1e-6 of zero; the flips
+    adopted are logged, each must be an element the oracle itself lists as within 3e-5 of the boundary, and there may
+    be only a handful).  '*_active' goldens (every ReLU active, avg first pool) have no decision to flip.
+    The reference's own fp32 capture (grad32/) is held to the same yardstick for scale: its rel-l2 against grad64/ is
+    logged next to ours."""
     g = _gold(path)
     backbone = str(g['backbone'])
     shift = float(g['bn_bias_shift'])
@@ -84,28 +93,37 @@ def test_logits_and_grads_match_reference_golden(M, path):
         (err, ref32, float(loss), float(g['loss64'])))
     assert err < 1e-4
     assert abs(float(loss) - float(g['loss64'])) < 1e-5
-    worst = 0.0
-    bad = []
+    params64 = {k: v.astype(np.float64) for k, v in seeded_params(backbone, int(g['seed']), bn_bias_shift=shift).items()}
+    ref = np_ref.cnn_linear_forward_backward(params64, g['x'].astype(np.float64), g['target'].astype(np.float64),
+                                             backbone=backbone, first_pool_type=str(g['first_pool_type']))
+    ours = {}
     for n, p in model.named_parameters():
         key = 'grad64/' + n
         if key not in g:
             assert p.grad is None, n
             continue
-        d = digest(p.grad.cpu().numpy())
-        e = np.abs(d - g[key])
-        # digest tail (sum, abs-sum, sq-sum) scales with the tensor size: compare relatively there
-        body = slice(None) if p.numel() <= 1024 else slice(0, -3)   # drop the [sum, abs-sum, sq-sum] tail
-        abs_err = e[body].max()
-        rl2 = rel_l2(d[body], g[key][body])
-        worst = max(worst, abs_err)
-        log('   grad %-60s max abs err %.3e rel-l2 %.3e max|ref| %.3e' % (n, abs_err, rl2, np.abs(g[key][body]).max()))
-        scale = max(1.0, np.abs(g[key][body]).max())
-        if strict:
-            if not abs_err <= 1e-4 * scale:
-                bad.append((n, abs_err, scale))
-        elif not (rl2 <= 5e-2 or abs_err <= 1e-4 * scale):
+        ours[n] = p.grad.cpu().numpy().astype(np.float64)
+        d = digest(ref['grads'][n])                                     # the oracle IS the reference's fp64 capture
+        body = slice(None) if p.numel() <= 1024 else slice(0, -3)
+        assert np.abs(d - g[key])[body].max() <= 1e-9 * max(1.0, np.abs(g[key][body]).max()), n
+    matched, flips, ncand = decision_matched_gradients(ref, ours, os.path.basename(path))
+    if strict:
+        assert not flips, flips
+    assert len(flips) <= 12, flips
+    worst, bad = 0.0, []
+    for n in ours:
+        abs_err = float(np.abs(ours[n] - matched[n]).max())
+        rl2 = rel_l2(ours[n], matched[n])
+        rl2_exact = rel_l2(ours[n], ref['grads'][n])
+        body = slice(None) if ours[n].size <= 1024 else slice(0, -3)
+        ref32_rl2 = rel_l2(g['grad32/' + n][body], g['grad64/' + n][body])
+        worst = max(worst, rl2)
+        log('   grad %-60s max abs err %.3e rel-l2 %.3e (no matching: %.3e; reference fp32 vs fp64: %.3e)' %
+            (n, abs_err, rl2, rl2_exact, ref32_rl2))
+        scale = max(1.0, float(np.abs(matched[n]).max()))
+        if not (rl2 <= 1e-4 or abs_err <= 1e-4 * scale):
             bad.append((n, abs_err, rl2))
-    log('   worst grad abs err %.3e' % worst)
+    log('   worst grad rel-l2 %.3e with %d flips of %d candidates' % (worst, len(flips), ncand))
     assert not bad, bad
 
 
@@ -930,3 +948,226 @@ def test_driver_mirror_kfolds_on_device_store():
     mu, std = train.scaling_factors[1]
     ref = ((wins[test.get_kfold_indexes_for_fold(1)[0]] - mu) / std).astype(np.float32)
     assert np.array_equal(x.cpu().numpy()[0], ref)
+
+
+def test_cli_main_runs_config_c1_on_the_ingested_fixture(tmp_path):
+    """``python -m deepards_amd.train_ards_detector -co <the C1 experiment file> --train-from-pickle <fixture> ...``
+    (train_ards_detector.py:1579-1590): configuration merge, dataset ingest (the .npz `python -m deepards_amd.ingest`
+    made from the reference's pickled fixture), patient-wise k-folds with minority oversampling, a fresh model per fold,
+    per-patient votes over the fixture's 12 (anonymised) patients, reference-style checkpoint names."""
+    from deepards_amd import train_ards_detector as T
+    from deepards_amd import checkpoint as C
+    from deepards_amd import ingest
+    gold = os.path.join(os.path.dirname(__file__), 'golden', 'test_dataset.npz')
+    exp = os.path.join(os.path.dirname(os.path.dirname(__file__)), 'deepards_amd', 'experiment_files',
+                       'unpadded_centered_nb20_cnn_linear.yml')
+    cls, res = T.main(['-co', exp, '--train-from-pickle', gold, '--kfolds', '2', '-e', '2', '-b', '4', '--base-network',
+                       'resnet18', '--seed', '5', '--save-model', 'runs/c1.pth', '--save-model-per-epoch',
+                       '--saved-models-dir', str(tmp_path)])
+    a = cls.args
+    assert (a.network, a.clip_grad, a.cuda_no_dp, a.oversample_minority, a.kfolds, a.batch_size) == \
+        ('cnn_linear', True, True, True, 2, 4)                   # experiment file + CLI over defaults.yml
+    ds = ingest.load_npz(gold)
+    labels = ds.targets.argmax(1)
+    all_test = []
+    for fold in (0, 1):
+        losses = res.get_meter('loss', fold)
+        assert len(losses) >= 4 and np.isfinite(losses).all()
+        r = res.patient_results[(fold, 2)]
+        assert r['votes'].shape == (12, 2)                      # the fixture's 12 patients
+        test_windows = sorted(set(r['window_abs_index'].tolist()))
+        voted = set(np.nonzero(r['votes'].sum(axis=1))[0].tolist())
+        assert voted == set(ds.patient_slot[test_windows].tolist())
+        assert r['votes'].sum() == len(test_windows) == len(r['window_pred'])
+        for p in voted:                                         # every patient's votes = its windows' predictions
+            w = [i for i in test_windows if ds.patient_slot[i] == p]
+            pred = {int(i): int(q) for i, q in zip(r['window_abs_index'], r['window_pred'])}
+            assert r['votes'][p].tolist() == [sum(pred[i] == 0 for i in w), sum(pred[i] == 1 for i in w)]
+        all_test += test_windows
+        for ep in (1, 2):
+            assert os.path.exists(os.path.join(str(tmp_path), 'c1-epoch%d-fold%d.pth' % (ep, fold)))
+        assert os.path.exists(os.path.join(str(tmp_path), 'c1-fold%d.pth' % fold))
+    assert sorted(all_test) == list(range(20))                  # the two test folds partition the windows
+    assert cls.pred_idx == res.patient_results[(1, 2)]['window_abs_index'].tolist()     # absolute indices (obs_idx)
+    # the train fold was oversampled to class parity (dataset.py:561-573)
+    tr = cls.args.train_store if cls.args.train_store is not None else None
+    assert tr is None                                           # stores came from the pickle, not from the caller
+    # the last fold's checkpoint is this package's own whole module: loads back bit-identical
+    back = C.load_model_weights(os.path.join(str(tmp_path), 'c1-fold1.pth'), lambda: None)
+    for (k, p), (_, q) in zip(cls.model.state_dict().items(), back.state_dict().items()):
+        assert torch.equal(p.cpu(), q.cpu()), k
+    # --no-train --load-checkpoint: inference over the same folds with the saved model (evaluate.py's use)
+    cls2, res2 = T.main(['--cuda-no-dp', '--train-from-pickle', gold, '--kfolds', '2', '-e', '1', '-b', '4',
+                         '--base-network', 'resnet18', '--no-train', '--only-fold', '1', '--load-checkpoint',
+                         os.path.join(str(tmp_path), 'c1-fold1.pth')])
+    assert (1, 1) in res2.patient_results and (0, 1) not in res2.patient_results
+    assert res2.patient_results[(1, 1)]['votes'].sum() == res.patient_results[(1, 2)]['votes'].sum()
+
+
+def test_cli_main_holdout_with_test_pickle_and_foreign_base_network(tmp_path):
+    """Holdout run (no k-folds): --test-from-pickle gets the TRAIN set's scaling factors (train_ards_detector.py:285);
+    --load-base-network takes the breath block out of a checkpoint saved under the REFERENCE's class paths, read
+    without unpickling (:383-388)."""
+    from deepards_amd import train_ards_detector as T
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'tools'))
+    from ref_paths import as_reference_classes as _as_reference_classes
+    gold = os.path.join(os.path.dirname(__file__), 'golden', 'test_dataset.npz')
+    path = str(tmp_path / 'ref_model.pth')
+
+    def save(M):
+        torch.manual_seed(11)
+        m = M.CNNLinearNetwork(M.densenet18(), 20, 0)
+        torch.save(m, path, _use_new_zipfile_serialization=False)          # the pytorch-1.0 format of the reference's env
+        return m
+    ref = _as_reference_classes(save)
+    cls, res = T.main(['--cuda-no-dp', '--train-from-pickle', gold, '--test-from-pickle', gold, '-e', '1', '-b', '6',
+                       '--base-network', 'resnet18', '--load-base-network', path, '--freeze-base-network', '--seed', '1'])
+    assert cls.model.breath_block.network_name == 'densenet18'             # the file's backbone, not --base-network
+    r = res.patient_results[(0, 1)]
+    assert r['votes'].sum() == 20 and r['votes'].shape == (12, 2)
+    # frozen base network: only linear_final moved (get_base_network :411-413)
+    for (k, p), (_, q) in zip(cls.model.breath_block.state_dict().items(), ref.breath_block.state_dict().items()):
+        assert torch.equal(p.cpu(), q), k
+    assert len(res.get_meter('loss', 0)) == 4                              # 20 windows, batches of 6: 6 + 6 + 6 + 2
+
+
+# ---- the bench shape (BASELINE configs[1]: B = 64 windows of (20, 1, 224)) --------------------------------------------
+def _set_fast_paths(on):
+    """Toggle every fast path at once: Winograd forward / data / weight gradients, split-K tail tiles, paired stride-2
+    launches, ReLU bit masks -- off = the plain direct kernels."""
+    from deepards_amd import _lib, functional as F_, hip_ops as H_
+    F_._WINOGRAD, F_._PAIR_S2, F_._BN_MASK, H_.WINOGRAD_WGRAD = on, on, on, on
+    _lib.lib().da_debug_set(3, 1 if on else 0)
+    _lib.lib().da_wino_debug_tail(1 if on else 0)
+
+
+@pytest.mark.parametrize('backbone', ['resnet18', 'densenet18'])
+def test_bench_shape_b64_windows_vs_oracle_and_independence(M, backbone):
+    """At the size the metric is quoted on every batched path is live (split-K tail tiles, F(4,3), XCD-chunked block
+    order, 16-channel BatchNorm blocks).  (i) window independence: model(x64)[i] vs model(x64[i:i+1])[0] for all 64
+    windows.  Not bit-for-bit BY DESIGN: the tile a window's rows land in (full tile or split-K half tile) and the
+    BatchNorm block geometry (32- or 16-channel blocks, chosen from the window count) change the fp32 summation ORDER
+    with the batch size, never the operands -- bound 4e-6, three orders below the north-star tolerance.  (ii) the
+    logits of 4 windows spread over the batch, and their loss terms, against the numpy oracle run on those 4 windows
+    alone (windows are independent, SURVEY finding 3) within 1e-4."""
+    model = build(M, backbone, 4)
+    x, t = seeded_batch(64, 20, 64)
+    xt = torch.from_numpy(x).cuda()
+    with torch.no_grad():
+        full = model(xt, None).cpu().numpy().astype(np.float64)
+        single = np.concatenate([model(xt[i:i + 1], None).cpu().numpy() for i in range(64)]).astype(np.float64)
+    dev = np.abs(full - single).max()
+    log(backbone, 'B=64 window independence: max |model(x64)[i] - model(x64[i:i+1])[0]| = %.3e' % dev)
+    assert dev < 4e-6 * max(1.0, np.abs(full).max())
+    pick = [0, 21, 42, 63]
+    params = {k: v.astype(np.float64) for k, v in seeded_params(backbone, 4).items()}
+    ref = np_ref.cnn_linear_forward_backward(params, x[pick].astype(np.float64), t[pick].astype(np.float64),
+                                             backbone=backbone, need_grads=False)
+    err = np.abs(full[pick] - ref['logits']).max()
+    log(backbone, 'B=64: logits of windows %s vs oracle: %.3e' % (pick, err))
+    assert err < 1e-4
+    bce = lambda z, y: np.maximum(z, 0) - z * y + np.log1p(np.exp(-np.abs(z)))
+    assert np.abs(bce(full[pick], t[pick]) - bce(ref['logits'], t[pick])).max() < 1e-5
+
+
+@pytest.mark.parametrize('backbone', ['resnet18', 'densenet18'])
+def test_bench_shape_b64_gradients_are_the_mean_of_its_shards(M, backbone):
+    """Linearity at full size (the oracle would need minutes for 64 windows): the loss is a mean over windows and
+    BatchNorm never crosses windows, so the B=64 gradient is the mean of the gradients of its eight 8-window shards.
+    The B=64 run takes the batched paths (one weight-gradient launch over 1280 rows with split-K slabs, tail tiles),
+    the shards other tile shapes and split counts: agreement pins the batching logic, not the arithmetic (that is the
+    goldens' job).  Bound: rel-l2 2e-5 per parameter (summation order only)."""
+    from deepards_amd.functional import bce_with_logits
+    x, t = seeded_batch(64, 20, 65)
+    xt, tt = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+
+    def grads(xs, ts):
+        model = build(M, backbone, 4)
+        bce_with_logits(model(xs, None), ts).backward()
+        return {n: p.grad.double() for n, p in model.named_parameters() if p.grad is not None}
+    full = grads(xt, tt)
+    acc = None
+    for s0 in range(0, 64, 8):
+        g = grads(xt[s0:s0 + 8].contiguous(), tt[s0:s0 + 8].contiguous())
+        acc = g if acc is None else {n: acc[n] + g[n] for n in g}
+    worst = 0.0
+    for n in full:
+        r = float((full[n] - acc[n] / 8).norm() / (full[n].norm() + 1e-30))
+        worst = max(worst, r)
+        assert r < 2e-5, (n, r)
+    log(backbone, 'B=64 gradient vs mean of 8 shard gradients: worst rel-l2 %.3e' % worst)
+
+
+@pytest.mark.parametrize('backbone', ['resnet18', 'densenet18'])
+def test_fast_paths_against_the_direct_kernels(M, backbone):
+    """Second check, not the only one: the fast paths (Winograd F(2,3) / F(4,3) forward, data and weight gradients,
+    split-K tail tiles, paired stride-2 launches, ReLU bit masks) against the plain direct kernels of the same build,
+    whole model, at batch sizes around the tile / round boundaries including the bench shape.  Logits within 2e-5;
+    parameter gradients within 1e-4 rel-l2 unless an activation decision differs between the two runs (then a looser
+    3e-2: both runs are fp32, neither is exact -- exactness is pinned by the goldens above)."""
+    from deepards_amd.functional import bce_with_logits
+    res = {}
+    try:
+        for fast in (True, False):
+            _set_fast_paths(fast)
+            for b in (1, 3, 16, 64, 65):
+                model = build(M, backbone, 1)
+                x, t = seeded_batch(b, 20, b)
+                o = model(torch.from_numpy(x).cuda(), None)
+                bce_with_logits(o, torch.from_numpy(t).cuda()).backward()
+                res[(fast, b)] = (o.detach().double().cpu().numpy(),
+                                  {n: p.grad.double().cpu().numpy() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        _set_fast_paths(True)
+    for b in (1, 3, 16, 64, 65):
+        (la, ga), (lb, gb) = res[(True, b)], res[(False, b)]
+        e = np.abs(la - lb).max()
+        worst = max(rel_l2(ga[n], gb[n]) for n in ga)
+        tight = sum(rel_l2(ga[n], gb[n]) < 1e-4 for n in ga)
+        log(backbone, 'fast vs direct kernels B=%d: logits %.2e, worst grad rel-l2 %.2e (%d of %d parameters < 1e-4)' %
+            (b, e, worst, tight, len(ga)))
+        assert e < 2e-5 and worst < 3e-2
+        assert rel_l2(ga['linear_final.weight'], gb['linear_final.weight']) < 1e-5      # behind no decision at all
+
+
+def test_densenet_dropout_on_against_the_oracle_with_the_device_masks(M):
+    """DenseNet with drop_rate 0.2 ACTIVE (the reference never leaves train mode, SURVEY finding 4) against
+    np_ref.densenet18_features(drop_masks=...): the device's counter-based keep masks are exported by running the same
+    generator (da_dropout, same seed / salt / rate) over a tensor of ones, handed to the oracle as explicit masks, and
+    logits / loss / every parameter gradient must agree like the dropout-free goldens do (1e-4; decision-matched)."""
+    from deepards_amd import hip_ops as H_
+    from deepards_amd.functional import bce_with_logits
+    model = build(M, 'densenet18', 2, drop_rate=0.2)
+    feats = model.breath_block.features
+    x, t = seeded_batch(3, 20, 9)
+    xt, tt = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    seed_used = feats._drop_seed.clone() + (0x9E3779B97F4A7C15 >> 1)        # forward bumps the seed, then uses it
+    out = model(xt, None)
+    assert torch.equal(feats._drop_seed, seed_used)
+    loss = bce_with_logits(out, tt)
+    loss.backward()
+    masks, salt = {}, 0
+    for bi, l in ((1, 56), (2, 28), (3, 14), (4, 7)):
+        for li in (1, 2):
+            salt += 1
+            m = H_.dropout(torch.ones(60, l, 32, device='cuda'), seed_used, salt, 0.2)      # RLC keep mask / (1 - p)
+            masks[(bi, li)] = m.permute(0, 2, 1).cpu().numpy().astype(np.float64)           # oracle layout (N, C, L)
+            vals = np.unique(masks[(bi, li)])
+            assert set(np.round(vals, 6).tolist()) <= {0.0, 1.25}
+    kept = np.mean([m.mean() / 1.25 for m in masks.values()])
+    assert abs(kept - 0.8) < 0.01                                                            # the rate is the rate
+    params = {k: v.astype(np.float64) for k, v in seeded_params('densenet18', 2).items()}
+    ref = np_ref.cnn_linear_forward_backward(params, x.astype(np.float64), t.astype(np.float64), backbone='densenet18',
+                                             drop_masks=masks)
+    err = np.abs(out.detach().cpu().numpy() - ref['logits']).max()
+    log('densenet18 dropout ON vs oracle with the device masks: logits %.3e loss %.8f vs %.8f' % (err, float(loss), ref['loss']))
+    assert err < 1e-4 and abs(float(loss) - ref['loss']) < 1e-5
+    ours = {n: p.grad.cpu().numpy().astype(np.float64) for n, p in model.named_parameters() if p.grad is not None}
+    matched, flips, _ = decision_matched_gradients(ref, ours, 'densenet18 dropout on')
+    assert len(flips) <= 6
+    for n in ours:
+        assert rel_l2(ours[n], matched[n]) <= 1e-4 or np.abs(ours[n] - matched[n]).max() <= 1e-4, n
+    nodrop = np_ref.cnn_linear_forward_backward(params, x.astype(np.float64), t.astype(np.float64), backbone='densenet18',
+                                                need_grads=False)
+    assert np.abs(nodrop['logits'] - ref['logits']).max() > 1e-3                             # the masks do matter
