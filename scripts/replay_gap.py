@@ -17,12 +17,12 @@ def timeit(fn, n=50):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 print('train_step        %.4f ms' % timeit(lambda: tr.train_step(x, t)))
-print('bare graph replay %.4f ms' % timeit(lambda: tr._graph.replay()))
+print('bare graph replay %.4f ms' % timeit(lambda: tr._graph[0].replay()))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(50): tr._graph.replay()
+for _ in range(50): tr._graph[0].replay()
 e1.record(); torch.cuda.synchronize()
 print('bare replay (events) %.4f ms' % (e0.elapsed_time(e1) / 50))
 t0 = time.perf_counter()
-for _ in range(50): tr._graph.replay()
+for _ in range(50): tr._graph[0].replay()
 print('cpu time per replay call %.4f ms' % ((time.perf_counter() - t0) / 50 * 1e3)); torch.cuda.synchronize()

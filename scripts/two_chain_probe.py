@@ -20,12 +20,12 @@ def timeit(fn, n=40):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-t1 = timeit(lambda: one._graph.replay())
-th = timeit(lambda: a._graph.replay())
+t1 = timeit(lambda: one._graph[0].replay())
+th = timeit(lambda: a._graph[0].replay())
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 def both():
-    with torch.cuda.stream(s1): a._graph.replay()
-    with torch.cuda.stream(s2): b._graph.replay()
+    with torch.cuda.stream(s1): a._graph[0].replay()
+    with torch.cuda.stream(s2): b._graph[0].replay()
 t2 = timeit(both)
 print('one B=64 chain      %.3f ms  -> %.0f breath-seq/s' % (t1, 1280 / t1 * 1e3))
 print('one B=32 chain      %.3f ms  -> %.0f' % (th, 640 / th * 1e3))

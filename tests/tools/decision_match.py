@@ -19,7 +19,9 @@ def decision_matched_gradients(ref, ours, log_tag='', tols=(1e-5, 3e-5), log=pri
     taken by the caller on the full tensors.  Returns (gradients, flips adopted, number of candidates)."""
     base = ref['grads']
     names = [n for n in base if n in ours]
-    scale = {n: float(np.linalg.norm(base[n])) + 1e-30 for n in names}
+    # gradients that are analytically zero (a conv in front of a BatchNorm when every ReLU is active) get a unit
+    # scale: their error is judged absolutely, not relative to a norm of ~1e-17
+    scale = {n: (float(np.linalg.norm(base[n])) if float(np.linalg.norm(base[n])) > 1e-9 else 1.0) for n in names}
     if max(np.linalg.norm(ours[n] - base[n]) / scale[n] for n in names) < 2e-5:
         return base, [], 0
     rng = np.random.RandomState(0)
