@@ -27,8 +27,10 @@ sys.path.insert(0, ROOT)
 
 # algorithmic work per breath-sequence: FLOPs train, activation bytes train fp32, #params
 WORK = {
-    'resnet18': dict(flops=228.665e6, act_bytes=1421.1e3, params=3864386),
-    'densenet18': dict(flops=33.404e6, act_bytes=1052.8e3, params=214850),
+    'resnet18': dict(flops=228.665e6, act_bytes=1421.1e3, act_bytes_bf16=710.5e3, params=3864386),
+    'densenet18': dict(flops=33.404e6, act_bytes=1052.8e3, act_bytes_bf16=526.4e3, params=214850),
+    # BASELINE configs[4]'s tile shape (NB 40, L 512; head 5120*40 -> 2): SURVEY 8d row 3
+    ('resnet18', 40, 512): dict(flops=522.711e6, act_bytes=3248.1e3, act_bytes_bf16=1624.1e3, params=3864386 - 20482 + 2 * 5120 * 40 + 2),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), headline sparsity figure NOT used
@@ -40,7 +42,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--backbone', default='resnet18', choices=sorted(WORK))
+    ap.add_argument('--backbone', default='resnet18', choices=['resnet18', 'densenet18'])
+    ap.add_argument('--nb', type=int, default=20, help='sub-batch rows per window (BASELINE configs[4]: 40)')
+    ap.add_argument('--seq-len', type=int, default=224, help='samples per row (BASELINE configs[4]: 512)')
     ap.add_argument('--batch', type=int, default=64, help='windows per GPU (BASELINE configs[1]: B=64)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -301,10 +305,33 @@ def main():
     F_.set_conv_dtype(args.dtype)
     torch.manual_seed(0)                                 # same init on every rank (replicas start identical)
     bb = M.resnet18() if args.backbone == 'resnet18' else M.densenet18()
-    model = M.CNNLinearNetwork(bb, 20, 0).to(dev)
+    NB, SL = args.nb, args.seq_len
+    c5_shape = (NB, SL) != (20, 224)
+    if c5_shape:
+        # BASELINE configs[4]'s tile shape.  The reference cannot run it (CNNLinearNetwork refuses seq_len != 224 and
+        # never concatenates the 9 metadata inputs, SURVEY finding 8), so the model around the tile is STATED here, not
+        # mirrored: the breath block on (B*NB, 1, L) rows with per-window BatchNorm, its features (AvgPool1d(7,1) leaves
+        # L/32 - 6 positions per channel) flattened per window like view(-1), one Linear(F*NB, 2) head, no metadata.
+        if (args.backbone, NB, SL) not in WORK:
+            raise SystemExit('no algorithmic-work row for %s NB=%d L=%d (SURVEY 8d has resnet18 40 x 512)' % (args.backbone, NB, SL))
+
+        class BreathBlockLinear(torch.nn.Module):
+            def __init__(self, breath_block, nb, seq_len):
+                super().__init__()
+                self.breath_block, self.nb = breath_block, nb
+                feat = breath_block.n_out_filters * (seq_len // 32 - 6)
+                self.linear_final = torch.nn.Linear(feat * nb, 2)
+
+            def forward(self, x, metadata):
+                b, nb, c, l = x.shape
+                feat = self.breath_block.forward_windows(x.reshape(b * nb, c, l), nb)
+                return F_.Linear2Function.apply(feat.view(b, -1), self.linear_final.weight, self.linear_final.bias)
+        model = BreathBlockLinear(bb, NB, SL).to(dev)
+    else:
+        model = M.CNNLinearNetwork(bb, 20, 0).to(dev)
     B = args.batch
     g = torch.Generator().manual_seed(1000 + rank)       # each rank its own shard of the global batch
-    x = torch.randn(B, 20, 1, 224, generator=g).to(dev)
+    x = torch.randn(B, NB, 1, SL, generator=g).to(dev)
     t = torch.zeros(B, 2)
     t[torch.arange(B), torch.randint(0, 2, (B,), generator=g)] = 1
     t = t.to(dev)
@@ -356,20 +383,25 @@ def main():
     say('timed region done: %d rounds of %d steps, median %.3f ms/step (min %.3f, max %.3f)' %
         (len(rounds), args.steps, 1e3 * dt / args.steps, 1e3 * srt[0] / args.steps, 1e3 * srt[-1] / args.steps))
 
-    seqs = world * B * 20 * args.steps
+    seqs = world * B * NB * args.steps
     value = seqs / dt
-    w = WORK[args.backbone]
+    w = WORK[(args.backbone, NB, SL)] if c5_shape else WORK[args.backbone]
     out = {
-        'metric': 'breath-sequences/sec (train step) cnn_linear nb20 seq224',
+        'metric': ('breath-sequences/sec (train step) cnn_linear nb20 seq224' if not c5_shape else
+                   'breath-sequences/sec (train step) %s breath block + linear head nb%d seq%d' % (args.backbone, NB, SL)),
         'value': round(value, 1), 'unit': 'breath-sequences/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-        'config': {'workload': ('cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) fp32 train step (BASELINE configs[1])'
-                                if args.dtype == 'f32' else
-                                'cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) train step, bf16 operands / fp32 sums in the '
-                                'residual-block convs (forward, data and weight gradient), everything else fp32 (BASELINE configs[2])') % (args.backbone, B),
-                   'backbone': args.backbone, 'batch_per_gpu': B, 'global_batch': B * world, 'n_sub_batches': 20,
-                   'seq_len': 224, 'optimizer': 'sgd-nesterov+clamp', 'parallelism': 'dp%d' % world,
+        'config': {'workload': (('%s breath block + Linear(F*NB, 2) head (stated, not mirrored: the reference cannot run this shape), '
+                                 'synthetic (B=%d per GPU, %d, 1, %d) train step, %s (tile shape of BASELINE configs[4])' %
+                                 (args.backbone, B, NB, SL, 'fp32' if args.dtype == 'f32' else 'bf16 operands / fp32 sums in the residual-block convs'))
+                                if c5_shape else
+                                ('cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) fp32 train step (BASELINE configs[1])'
+                                 if args.dtype == 'f32' else
+                                 'cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) train step, bf16 operands / fp32 sums in the '
+                                 'residual-block convs (forward, data and weight gradient), everything else fp32 (BASELINE configs[2])') % (args.backbone, B)),
+                   'backbone': args.backbone, 'batch_per_gpu': B, 'global_batch': B * world, 'n_sub_batches': NB,
+                   'seq_len': SL, 'optimizer': 'sgd-nesterov+clamp', 'parallelism': 'dp%d' % world,
                    'hipgraph': not args.no_graph},
         'final_loss': round(loss, 6),
         'timing': {'rounds': len(rounds), 'steps_per_round': args.steps, 'reported': 'median round',
@@ -394,14 +426,27 @@ def main():
         out['allreduce_exposed'] = True            # issued between the two captured graphs, not overlapped with backward
     if rehearse:
         out['rehearsal'] = 'gloo: %d ranks sharing %d GPU(s); throughput is NOT a measurement' % (world, torch.cuda.device_count())
-    step_flops = w['flops'] * B * 20
-    step_bytes = (w['act_bytes'] * B * 20) + 8 * 4 * w['params']
+    step_flops = w['flops'] * B * NB
+    step_bytes = (w['act_bytes'] * B * NB) + 8 * 4 * w['params']
     per_gpu_dt = dt / args.steps
-    out['step_roofline'] = {
-        'alg_tflops': round(step_flops / per_gpu_dt / 1e12, 2), 'peak_tflops_fp32_mfma': PEAK_FP32_MFMA_TFLOPS,
-        'frac_compute': round(step_flops / per_gpu_dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-        'alg_gbs': round(step_bytes / per_gpu_dt / 1e9, 1), 'peak_gbs': PEAK_HBM_GBS,
-        'frac_hbm': round(step_bytes / per_gpu_dt / 1e9 / PEAK_HBM_GBS, 4), 'binding': 'compute(fp32 mfma)'}
+    if args.dtype == 'f32':
+        out['step_roofline'] = {
+            'alg_tflops': round(step_flops / per_gpu_dt / 1e12, 2), 'peak_tflops_fp32_mfma': PEAK_FP32_MFMA_TFLOPS,
+            'frac_compute': round(step_flops / per_gpu_dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            'alg_gbs': round(step_bytes / per_gpu_dt / 1e9, 1), 'peak_gbs': PEAK_HBM_GBS,
+            'frac_hbm': round(step_bytes / per_gpu_dt / 1e9 / PEAK_HBM_GBS, 4), 'binding': 'compute(fp32 mfma)'}
+    else:
+        # bf16 arithmetic makes the step memory-bound: price it against HBM with the ALGORITHMIC bytes of
+        # a bf16-storage step (what the path should move), next to the bytes the current storage really implies
+        bf16_bytes = (w['act_bytes_bf16'] * B * NB) + 8 * 4 * w['params']
+        out['step_roofline'] = {
+            'bound': 'hbm', 'alg_bytes_bf16_storage': int(bf16_bytes),
+            'alg_gbs': round(bf16_bytes / per_gpu_dt / 1e9, 1), 'peak_gbs': PEAK_HBM_GBS,
+            'frac_hbm': round(bf16_bytes / per_gpu_dt / 1e9 / PEAK_HBM_GBS, 4),
+            'storage_now': F_.storage_dtype() if hasattr(F_, 'storage_dtype') else 'f32',
+            'alg_bytes_at_current_storage': int(step_bytes if not hasattr(F_, 'storage_dtype') or F_.storage_dtype() == 'f32' else bf16_bytes),
+            'alg_tflops': round(step_flops / per_gpu_dt / 1e12, 2), 'peak_tflops_bf16_mfma': PEAK_BF16_MFMA_TFLOPS,
+            'frac_compute': round(step_flops / per_gpu_dt / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4), 'binding': 'hbm'}
 
     if rank == 0 and not args.no_roofline:
         # instrumented EAGER steps: HIP events around every C-ABI launch, on the launch stream
@@ -481,7 +526,7 @@ def main():
             out['wgrad_tflops'] = round(wg['flops'] / (wg['total_ms'] * 1e-3) / 1e12, 2)
         out['eager_kernel_ms_per_step'] = round(tot / nprof, 3)
 
-    if world == 1 and not args.no_extra:
+    if world == 1 and not args.no_extra and not c5_shape:
         # forward-only (run_test_epoch step: no_grad train-mode forward + loss + argmax), same batch, graph replayed
         for _ in range(3):
             tr.test_step(x, t)
@@ -491,12 +536,12 @@ def main():
             tr.test_step(x, t)
         torch.cuda.synchronize()
         d1 = (time.perf_counter() - t1) / args.steps
-        out.setdefault('extra', {})['inference'] = {'value': round(B * 20 / d1, 1), 'unit': 'breath-sequences/s',
+        out.setdefault('extra', {})['inference'] = {'value': round(B * NB / d1, 1), 'unit': 'breath-sequences/s',
                                                      'ms_per_step': round(1e3 * d1, 4),
                                                      'note': 'forward-only test step of %s, B=%d' % (args.backbone, B)}
         say('inference extra done')
 
-    if world == 1 and not args.no_extra and args.backbone == 'resnet18':
+    if world == 1 and not args.no_extra and args.backbone == 'resnet18' and not c5_shape:
         # secondary figure: the reference's DEFAULT backbone (defaults.yml:18), same step definition, dropout active
         torch.manual_seed(0)
         m2 = M.CNNLinearNetwork(M.densenet18(), 20, 0).to(dev)
@@ -517,7 +562,7 @@ def main():
             'note': 'cnn_linear+densenet18 (reference default backbone), drop_rate 0.2 active'}
         say('densenet18 extra done')
 
-    if world == 1 and not args.no_extra and args.backbone == 'resnet18' and args.dtype == 'f32':
+    if world == 1 and not args.no_extra and args.backbone == 'resnet18' and args.dtype == 'f32' and not c5_shape:
         # BASELINE configs[2] ("resnet18-1D ... bf16"): same step with bf16 operands in the k3 s1 conv forward / data gradient
         F_.set_conv_dtype('bf16')
         try:
@@ -542,7 +587,7 @@ def main():
             F_.set_conv_dtype('f32')
         say('bf16 extra done')
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not c5_shape:      # the reference's CPU path cannot run the C5 shape
         say('cpu baseline ...')
         out['cpu_baseline'] = cpu_baseline(args.backbone, B, args.cpu_seconds)
         out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
