@@ -53,6 +53,9 @@ def parse():
     ap.add_argument('--min-seconds', type=float, default=1.0, help='repeat the K-step timed bracket until this much timed work')
     ap.add_argument('--max-rounds', type=int, default=200)
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary densenet18 measurement')
+    ap.add_argument('--storage', default=None, choices=['f32', 'bf16'],
+                    help='activation storage under --dtype bf16: bf16 (default: BASELINE configs[2] / [4], bf16 storage with '
+                         'fp32 statistics and accumulators) or f32 (round 1: bf16 operands only)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="arithmetic of the k3 s1 convs' forward / data gradient: f32 (the headline, BASELINE configs[1]) or "
                          "bf16 operands with fp32 sums (BASELINE configs[2])")
@@ -303,6 +306,12 @@ def main():
 
     from deepards_amd import functional as F_
     F_.set_conv_dtype(args.dtype)
+    storage = args.storage or args.dtype
+    if args.dtype == 'f32' and storage != 'f32':
+        raise SystemExit('--storage bf16 needs --dtype bf16')
+    if args.backbone != 'resnet18':
+        storage = 'f32'                                  # no bf16-storage DenseNet (96-channel convs)
+    F_.set_storage_dtype(storage)
     torch.manual_seed(0)                                 # same init on every rank (replicas start identical)
     bb = M.resnet18() if args.backbone == 'resnet18' else M.densenet18()
     NB, SL = args.nb, args.seq_len
@@ -394,12 +403,13 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': (('%s breath block + Linear(F*NB, 2) head (stated, not mirrored: the reference cannot run this shape), '
                                  'synthetic (B=%d per GPU, %d, 1, %d) train step, %s (tile shape of BASELINE configs[4])' %
-                                 (args.backbone, B, NB, SL, 'fp32' if args.dtype == 'f32' else 'bf16 operands / fp32 sums in the residual-block convs'))
+                                 (args.backbone, B, NB, SL, 'fp32' if args.dtype == 'f32' else 'bf16 MFMA operands / fp32 sums in the residual-block convs, %s activation storage, fp32 statistics' % storage))
                                 if c5_shape else
                                 ('cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) fp32 train step (BASELINE configs[1])'
                                  if args.dtype == 'f32' else
-                                 'cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) train step, bf16 operands / fp32 sums in the '
-                                 'residual-block convs (forward, data and weight gradient), everything else fp32 (BASELINE configs[2])') % (args.backbone, B)),
+                                 'cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) train step, bf16 MFMA operands / fp32 sums in the '
+                                 'residual-block convs (forward, data and weight gradient), ' + storage + ' activation storage, fp32 '
+                                 'statistics / optimizer (BASELINE configs[2])') % (args.backbone, B)),
                    'backbone': args.backbone, 'batch_per_gpu': B, 'global_batch': B * world, 'n_sub_batches': NB,
                    'seq_len': SL, 'optimizer': 'sgd-nesterov+clamp', 'parallelism': 'dp%d' % world,
                    'hipgraph': not args.no_graph},
@@ -443,8 +453,8 @@ def main():
             'bound': 'hbm', 'alg_bytes_bf16_storage': int(bf16_bytes),
             'alg_gbs': round(bf16_bytes / per_gpu_dt / 1e9, 1), 'peak_gbs': PEAK_HBM_GBS,
             'frac_hbm': round(bf16_bytes / per_gpu_dt / 1e9 / PEAK_HBM_GBS, 4),
-            'storage_now': F_.storage_dtype() if hasattr(F_, 'storage_dtype') else 'f32',
-            'alg_bytes_at_current_storage': int(step_bytes if not hasattr(F_, 'storage_dtype') or F_.storage_dtype() == 'f32' else bf16_bytes),
+            'storage_now': F_.storage_dtype(),
+            'alg_bytes_at_current_storage': int(step_bytes if F_.storage_dtype() == 'f32' else bf16_bytes),
             'alg_tflops': round(step_flops / per_gpu_dt / 1e12, 2), 'peak_tflops_bf16_mfma': PEAK_BF16_MFMA_TFLOPS,
             'frac_compute': round(step_flops / per_gpu_dt / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4), 'binding': 'hbm'}
 
@@ -565,6 +575,7 @@ def main():
     if world == 1 and not args.no_extra and args.backbone == 'resnet18' and args.dtype == 'f32' and not c5_shape:
         # BASELINE configs[2] ("resnet18-1D ... bf16"): same step with bf16 operands in the k3 s1 conv forward / data gradient
         F_.set_conv_dtype('bf16')
+        F_.set_storage_dtype('bf16')
         try:
             torch.manual_seed(0)
             m3 = M.CNNLinearNetwork(M.resnet18(), 20, 0).to(dev)
@@ -577,12 +588,12 @@ def main():
                 l3 = tr3.train_step(x, t)
             torch.cuda.synchronize()
             d3 = (time.perf_counter() - t1) / args.steps
-            out.setdefault('extra', {})['resnet18_bf16_convs'] = {
+            out.setdefault('extra', {})['resnet18_bf16'] = {
                 'value': round(B * 20 / d3, 1), 'ms_per_step': round(1e3 * d3, 4), 'dtype': 'bf16',
                 'final_loss': round(float(l3), 6),
-                'note': 'cnn_linear+resnet18, k3 s1 conv forward, data gradient and weight gradient on '
-                        'v_mfma_f32_32x32x16_bf16 (operands rounded to bf16, fp32 sums), the stride-2 / 1x1 convs too; storage, '
-                        'statistics, stem and optimizer fp32'}
+                'note': 'cnn_linear+resnet18 (BASELINE configs[2]): every residual-block conv (forward, data and weight gradient) on '
+                        'v_mfma_f32_32x32x16_bf16 with fp32 sums, activations and activation gradients STORED in bf16, '
+                        'statistics / parameters / optimizer fp32'}
         finally:
             F_.set_conv_dtype('f32')
         say('bf16 extra done')

@@ -51,6 +51,8 @@ class RepackDesc(ctypes.Structure):
 # name -> (restype, argtypes); must list exactly the symbols the header declares (tests check it)
 SIGNATURES = {
     'da_version': (_I, []),
+    'da_set_act_dtype': (_I, [_I]),
+    'da_get_act_dtype': (_I, []),
     'da_abi_sizes': (None, [ctypes.POINTER(_I)]),
     'da_sizeof_wgrad_reduce_desc': (_I, []),
     'da_sizeof_bn_running_desc': (_I, []),
@@ -100,6 +102,8 @@ SIGNATURES = {
     'da_avgpool_bwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'da_avgpool_slide_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     'da_avgpool_slide_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    'da_global_avgpool_fwd': (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    'da_global_avgpool_bwd': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'da_linear2_fwd': (_I, [_P, _P, _P, _P, _I, _I, _P]),
     'da_bce_logits': (_I, [_P, _P, _I, _F, _P, _P, _P]),
     'da_linear2_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -36,16 +36,17 @@ __device__ __forceinline__ void block_fold(float (&v)[4], float* red, int slot, 
 // 32-channel group) would leave most CUs idle on the wide early layers):
 //   stage 1  grid (W, C/32, P): chunk-local mean and centred M2 over <= `chunk` positions
 //   stage 2  bn_stats_merge: Chan's pairwise update over the P chunks in order -> mean, invstd
-__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, int ld, int Wn, int C,
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const AT* __restrict__ x, int ld, int Wn, int C,
                                                                int chunk, float* __restrict__ part) {
   __shared__ float red[(SLOTS + 1) * CG];
   const int w = blockIdx.x, cg = blockIdx.y, pc = blockIdx.z, P = gridDim.z;
   const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
   const int p_beg = pc * chunk, p_end = min(Wn, p_beg + chunk);
-  const float* base = x + (size_t)w * Wn * ld + cg * CG + q * 4;
+  const AT* base = x + (size_t)w * Wn * ld + cg * CG + q * 4;
   float s[4] = {0.f, 0.f, 0.f, 0.f}, m[4];
   for (int p = p_beg + slot; p < p_end; p += SLOTS) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * ld);
+    f32x4 v = Act<AT>::ld4(base + (size_t)p * ld);
 #pragma unroll
     for (int e = 0; e < 4; ++e) s[e] += v[e];
   }
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   for (int e = 0; e < 4; ++e) m[e] *= inv_n;
   float s2[4] = {0.f, 0.f, 0.f, 0.f}, m2[4];
   for (int p = p_beg + slot; p < p_end; p += SLOTS) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * ld);
+    f32x4 v = Act<AT>::ld4(base + (size_t)p * ld);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float d = v[e] - m[e];
@@ -153,8 +154,9 @@ __global__ __launch_bounds__(256) void bn_running_multi_kernel(BnRunningTable t)
 }
 
 // out = act( (x-mean)*invstd*gamma + beta (+ res) )
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ res,
-                                                       int ldr, float* __restrict__ out, int ldo, int Wn, int C,
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const AT* __restrict__ x, int ldx, const AT* __restrict__ res,
+                                                       int ldr, AT* __restrict__ out, int ldo, int Wn, int C,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int relu, int chunk, const float* __restrict__ part, int P,
@@ -186,12 +188,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   const int p_end = min(Wn, p_beg + chunk);
   for (int p = p_beg + slot; p < p_end; p += SLOTS) {
     size_t pos = (size_t)w * Wn + p;
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + pos * ldx + c0);
+    f32x4 v = Act<AT>::ld4(x + pos * ldx + c0);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (v[e] - mu[e]) * is[e] * ga[e] + be[e];
     if (res) {
-      f32x4 r = *reinterpret_cast<const f32x4*>(res + pos * ldr + c0);
+      f32x4 r = Act<AT>::ld4(res + pos * ldr + c0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] += r[e];
     }
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
     }
-    *reinterpret_cast<f32x4*>(out + pos * ldo + c0) = o;
+    Act<AT>::st4(out + pos * ldo + c0, o);
   }
 }
 
@@ -210,22 +212,24 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 //   reduce: part[w][p][{s1,s2}][C] = sum over the chunk of g, g*xhat
 //   apply : dx = gamma*invstd*(g - mean_w(g) - xhat*mean_w(g*xhat));  gout (optional) = g;
 //           chunk 0 also stores the window totals ds1/ds2 for dbeta/dgamma.
+template <typename AT>
 __device__ __forceinline__ f32x4 bn_masked_g(f32x4 g, const f32x4& xh, const f32x4& ga, const f32x4& be, int mask_mode,
-                                             const float* __restrict__ outp, size_t off) {
+                                             const AT* __restrict__ outp, size_t off) {
   if (mask_mode == 1) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) g[e] = (xh[e] * ga[e] + be[e] > 0.f) ? g[e] : 0.f;
   } else if (mask_mode == 2) {
-    f32x4 o = *reinterpret_cast<const f32x4*>(outp + off);
+    f32x4 o = Act<AT>::ld4(outp + off);
 #pragma unroll
     for (int e = 0; e < 4; ++e) g[e] = (o[e] > 0.f) ? g[e] : 0.f;
   }
   return g;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dout, int ldd,
-                                                            const float* __restrict__ x, int ldx,
-                                                            const float* __restrict__ outp, int ldo, int Wn, int C,
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const AT* __restrict__ dout, int ldd,
+                                                            const AT* __restrict__ x, int ldx,
+                                                            const AT* __restrict__ outp, int ldo, int Wn, int C,
                                                             int chunk, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
@@ -243,8 +247,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   for (int p = p_beg + slot; p < p_end; p += SLOTS) {
     size_t pos = (size_t)w * Wn + p;
-    f32x4 g = *reinterpret_cast<const f32x4*>(dout + pos * ldd + c0);
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + pos * ldx + c0);
+    f32x4 g = Act<AT>::ld4(dout + pos * ldd + c0);
+    f32x4 v = Act<AT>::ld4(x + pos * ldx + c0);
     f32x4 xh;
 #pragma unroll
     for (int e = 0; e < 4; ++e) xh[e] = (v[e] - mu[e]) * is[e];
@@ -268,17 +272,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, int ldd,
-                                                           const float* __restrict__ x, int ldx,
-                                                           const float* __restrict__ outp, int ldo,
-                                                           float* __restrict__ dx, int lddx, float* __restrict__ gout,
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const AT* __restrict__ dout, int ldd,
+                                                           const AT* __restrict__ x, int ldx,
+                                                           const AT* __restrict__ outp, int ldo,
+                                                           AT* __restrict__ dx, int lddx, AT* __restrict__ gout,
                                                            int ldg, int Wn, int C, int chunk,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int mask_mode,
                                                            const float* __restrict__ part, float* __restrict__ ds1,
-                                                           float* __restrict__ ds2, const float* __restrict__ add,
+                                                           float* __restrict__ ds2, const AT* __restrict__ add,
                                                            int ldadd) {
   const int w = blockIdx.x, cg = blockIdx.y, pc = blockIdx.z, P = gridDim.z;
   const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
@@ -306,8 +311,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const int p_beg = pc * chunk, p_end = min(Wn, p_beg + chunk);
   for (int p = p_beg + slot; p < p_end; p += SLOTS) {
     size_t pos = (size_t)w * Wn + p;
-    f32x4 g = *reinterpret_cast<const f32x4*>(dout + pos * ldd + c0);
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + pos * ldx + c0);
+    f32x4 g = Act<AT>::ld4(dout + pos * ldd + c0);
+    f32x4 v = Act<AT>::ld4(x + pos * ldx + c0);
     f32x4 xh, d;
 #pragma unroll
     for (int e = 0; e < 4; ++e) xh[e] = (v[e] - mu[e]) * is[e];
@@ -315,12 +320,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < 4; ++e) d[e] = ga[e] * is[e] * (g[e] - t1[e] * inv_n - xh[e] * t2[e] * inv_n);
     if (add) {
-      const f32x4 av = *reinterpret_cast<const f32x4*>(add + pos * ldadd + c0);
+      const f32x4 av = Act<AT>::ld4(add + pos * ldadd + c0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] += av[e];
     }
-    *reinterpret_cast<f32x4*>(dx + pos * lddx + c0) = d;
-    if (gout) *reinterpret_cast<f32x4*>(gout + pos * ldg + c0) = g;
+    Act<AT>::st4(dx + pos * lddx + c0, d);
+    if (gout) Act<AT>::st4(gout + pos * ldg + c0, g);
   }
 }
 
@@ -370,10 +375,10 @@ __device__ __forceinline__ void quad_block_sum(f32x4 (&v)[NV], float* red) {
 }
 
 // mean / invstd of the window (two-pass from registers), published, and out = act(bn(x) (+res))
-template <int NPOS, int QB>
-__global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const float* __restrict__ x, int ldx,
-                                                            const float* __restrict__ res, int ldr,
-                                                            float* __restrict__ out, int ldo, int Wn, int C,
+template <typename AT, int NPOS, int QB>
+__global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const AT* __restrict__ x, int ldx,
+                                                            const AT* __restrict__ res, int ldr,
+                                                            AT* __restrict__ out, int ldo, int Wn, int C,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int relu, float eps,
                                                             float* __restrict__ mean_out,
@@ -385,15 +390,15 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const float* __restr
   const int q = threadIdx.x & (NQ - 1), slot = threadIdx.x >> QB;
   const int c0 = cg * CGB + q * 4;
   const size_t base = (size_t)w * Wn;
-  const float* xb = x + base * ldx + cg * CGB;      // wave-uniform bases + 32-bit lane offsets
-  const float* rb = res ? res + base * ldr + cg * CGB : nullptr;
-  float* ob = out + base * ldo + cg * CGB;
+  const AT* xb = x + base * ldx + cg * CGB;      // wave-uniform bases + 32-bit lane offsets
+  const AT* rb = res ? res + base * ldr + cg * CGB : nullptr;
+  AT* ob = out + base * ldo + cg * CGB;
   f32x4 v[NPOS];
 #pragma unroll
   for (int k = 0; k < NPOS; ++k) {
     const int p = slot + k * P;
     v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p < Wn) v[k] = *reinterpret_cast<const f32x4*>(xb + (uint32_t)(p * ldx + q * 4));
+    if (p < Wn) v[k] = Act<AT>::ld4(xb + (uint32_t)(p * ldx + q * 4));
   }
   f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const float* __restr
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mu[e]) * is[e] * ga[e] + be[e];
       if (rb) {
-        f32x4 r = *reinterpret_cast<const f32x4*>(rb + (uint32_t)(p * ldr + q * 4));
+        f32x4 r = Act<AT>::ld4(rb + (uint32_t)(p * ldr + q * 4));
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] += r[e];
       }
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const float* __restr
           o[e] = fmaxf(o[e], 0.f);
         }
       }
-      *reinterpret_cast<f32x4*>(ob + (uint32_t)(p * ldo + q * 4)) = o;
+      Act<AT>::st4(ob + (uint32_t)(p * ldo + q * 4), o);
     }
   }
   // ReLU decisions of this thread's 4 x NPOS elements: the backward kernel (same geometry, same thread -> element map)
@@ -455,17 +460,17 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const float* __restr
 }
 
 // same arithmetic as bn_bwd_reduce_kernel + bn_bwd_apply_kernel with the slab held in registers
-template <int NPOS, int QB>
-__global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restrict__ dout, int ldd,
-                                                            const float* __restrict__ x, int ldx,
-                                                            const float* __restrict__ outp, int ldo,
-                                                            float* __restrict__ dx, int lddx, float* __restrict__ gout,
+template <typename AT, int NPOS, int QB>
+__global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict__ dout, int ldd,
+                                                            const AT* __restrict__ x, int ldx,
+                                                            const AT* __restrict__ outp, int ldo,
+                                                            AT* __restrict__ dx, int lddx, AT* __restrict__ gout,
                                                             int ldg, int Wn, int C, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int mask_mode,
                                                             float* __restrict__ ds1, float* __restrict__ ds2,
-                                                            const float* __restrict__ add, int ldadd,
+                                                            const AT* __restrict__ add, int ldadd,
                                                             const unsigned long long* __restrict__ mask) {
   __shared__ float red[16 * 2 * CG];
   constexpr int NQ = 1 << QB, CGB = 4 * NQ;            // channel quads / channels per block (32 or 16)
@@ -474,12 +479,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restr
   const int c0 = cg * CGB + q * 4;
   // wave-uniform slab bases + 32-bit lane offsets (one SGPR pair + one VGPR per access instead of a 64-bit VGPR pair)
   const size_t base = (size_t)w * Wn;
-  const float* db = dout + base * ldd + cg * CGB;
-  const float* xb = x + base * ldx + cg * CGB;
-  const float* ob = outp ? outp + base * ldo + cg * CGB : nullptr;
-  float* dxb = dx + base * lddx + cg * CGB;
-  float* gb = gout ? gout + base * ldg + cg * CGB : nullptr;
-  const float* ab = add ? add + base * ldadd + cg * CGB : nullptr;       // dx = bn_bwd(...) + add (pass-through gradient)
+  const AT* db = dout + base * ldd + cg * CGB;
+  const AT* xb = x + base * ldx + cg * CGB;
+  const AT* ob = outp ? outp + base * ldo + cg * CGB : nullptr;
+  AT* dxb = dx + base * lddx + cg * CGB;
+  AT* gb = gout ? gout + base * ldg + cg * CGB : nullptr;
+  const AT* ab = add ? add + base * ldadd + cg * CGB : nullptr;       // dx = bn_bwd(...) + add (pass-through gradient)
   const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
   const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * C + c0);
   const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
@@ -491,8 +496,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restr
     g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     xh[k] = mu;
     if (p < Wn) {
-      g[k] = *reinterpret_cast<const f32x4*>(db + (uint32_t)(p * ldd + q * 4));
-      xh[k] = *reinterpret_cast<const f32x4*>(xb + (uint32_t)(p * ldx + q * 4));
+      g[k] = Act<AT>::ld4(db + (uint32_t)(p * ldd + q * 4));
+      xh[k] = Act<AT>::ld4(xb + (uint32_t)(p * ldx + q * 4));
     }
   }
   f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -530,12 +535,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restr
       for (int e = 0; e < 4; ++e)
         d[e] = ga[e] * is[e] * (g[k][e] - acc[0][e] * inv_n - xh[k][e] * acc[1][e] * inv_n);
       if (ab) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ab + (uint32_t)(p * ldadd + q * 4));
+        const f32x4 av = Act<AT>::ld4(ab + (uint32_t)(p * ldadd + q * 4));
 #pragma unroll
         for (int e = 0; e < 4; ++e) d[e] += av[e];
       }
-      *reinterpret_cast<f32x4*>(dxb + (uint32_t)(p * lddx + q * 4)) = d;
-      if (gb) *reinterpret_cast<f32x4*>(gb + (uint32_t)(p * ldg + q * 4)) = g[k];
+      Act<AT>::st4(dxb + (uint32_t)(p * lddx + q * 4), d);
+      if (gb) Act<AT>::st4(gb + (uint32_t)(p * ldg + q * 4), g[k]);
     }
   }
 }
@@ -643,13 +648,14 @@ size_t da_bn_workspace(int W, int Wn, int C) {
 }
 
 // stage 1 of the statistics: part[w][p][{mean,M2}][C] chunk records (da_bn_workspace() bytes).
-int da_bn_stats_partial(const float* x, int ld, int W, int Wn, int C, float* part, hipStream_t stream) {
+int da_bn_stats_partial(const void* x, int ld, int W, int Wn, int C, float* part, hipStream_t stream) {
   DA_ENTER();
   if (!x || !part || C % CG || ld % 4 || Wn < 1) return DA_EINVAL;
   if (W == 0) return DA_OK;
   int P, chunk;
   bn_chunks(W, Wn, C, &P, &chunk);
-  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(W, C / CG, P), dim3(256), 0, stream, x, ld, Wn, C, chunk, part);
+  DA_ACT_DISPATCH(hipLaunchKernelGGL(bn_stats_partial_kernel<AT>, dim3(W, C / CG, P), dim3(256), 0, stream, (const AT*)x, ld,
+                                     Wn, C, chunk, part));
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -708,7 +714,7 @@ int da_bn_param_grad_multi(const da_bn_pgrad_desc* descs, int n, int accumulate,
 
 // out = act(bn(x) (+res)).  Statistics either as mean/invstd [W][C], or (part != NULL) as the chunk
 // records of da_bn_stats_partial: they are merged on the fly and mean/invstd are WRITTEN as a by-product.
-int da_bn_apply(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
+int da_bn_apply(const void* x, int ldx, const void* res, int ldr, void* out, int ldo, int W, int Wn, int C,
                 float* mean, float* invstd, const float* gamma, const float* beta, int relu, const float* part,
                 float eps, hipStream_t stream) {
   DA_ENTER();
@@ -719,8 +725,9 @@ int da_bn_apply(const float* x, int ldx, const float* res, int ldr, float* out, 
   int nz = (Wn + chunk - 1) / chunk;
   int P, schunk;
   bn_chunks(W, Wn, C, &P, &schunk);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(W, C / CG, nz), dim3(256), 0, stream, x, ldx, res, ldr, out, ldo, Wn, C,
-                     mean, invstd, gamma, beta, relu, chunk, part, P, schunk, eps, mean, invstd);
+  DA_ACT_DISPATCH(hipLaunchKernelGGL(bn_apply_kernel<AT>, dim3(W, C / CG, nz), dim3(256), 0, stream, (const AT*)x, ldx,
+                                     (const AT*)res, ldr, (AT*)out, ldo, Wn, C, mean, invstd, gamma, beta, relu, chunk, part,
+                                     P, schunk, eps, mean, invstd));
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -728,7 +735,7 @@ int da_bn_apply(const float* x, int ldx, const float* res, int ldr, float* out, 
 // Statistics + normalisation in one call: mean/invstd [W][C] are OUTPUTS, out = act(bn(x) (+res)).
 // One single-pass kernel when a window slab fits a block's registers (Wn <= 1280), otherwise
 // da_bn_stats_partial + da_bn_apply.  scratch: da_bn_workspace() bytes.
-static int bn_fwd_impl(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
+static int bn_fwd_impl(const void* x, int ldx, const void* res, int ldr, void* out, int ldo, int W, int Wn, int C,
                        float* mean, float* invstd, const float* gamma, const float* beta, int relu, float eps,
                        float* scratch, unsigned long long* mask, hipStream_t stream) {
   DA_ENTER();
@@ -738,15 +745,14 @@ static int bn_fwd_impl(const float* x, int ldx, const float* res, int ldr, float
   if (W == 0) return DA_OK;
   int cgb = 0;
   if (int threads = bn_fused_geometry(W, Wn, C, &cgb)) {
-    if (cgb == 32)
-      hipLaunchKernelGGL((bn_fwd_fused_kernel<FUSED_NPOS, 3>), dim3(W, C / 32), dim3(threads), 0, stream, x, ldx, res,
-                         ldr, out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd, mask);
-    else if (cgb == 16)
-      hipLaunchKernelGGL((bn_fwd_fused_kernel<FUSED_NPOS, 2>), dim3(W, C / 16), dim3(threads), 0, stream, x, ldx, res,
-                         ldr, out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd, mask);
-    else
-      hipLaunchKernelGGL((bn_fwd_fused_kernel<FUSED_NPOS, 1>), dim3(W, C / 8), dim3(threads), 0, stream, x, ldx, res,
-                         ldr, out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd, mask);
+#define BN_FWD_LAUNCH(QB, CH)                                                                                        \
+  DA_ACT_DISPATCH(hipLaunchKernelGGL((bn_fwd_fused_kernel<AT, FUSED_NPOS, QB>), dim3(W, C / CH), dim3(threads), 0, stream, \
+                                     (const AT*)x, ldx, (const AT*)res, ldr, (AT*)out, ldo, Wn, C, gamma, beta, relu, eps,   \
+                                     mean, invstd, mask))
+    if (cgb == 32) BN_FWD_LAUNCH(3, 32);
+    else if (cgb == 16) BN_FWD_LAUNCH(2, 16);
+    else BN_FWD_LAUNCH(1, 8);
+#undef BN_FWD_LAUNCH
     DA_CHECK_LAUNCH();
     return DA_OK;
   }
@@ -756,7 +762,7 @@ static int bn_fwd_impl(const float* x, int ldx, const float* res, int ldr, float
   return da_bn_apply(x, ldx, res, ldr, out, ldo, W, Wn, C, mean, invstd, gamma, beta, relu, scratch, eps, stream);
 }
 
-int da_bn_fwd(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
+int da_bn_fwd(const void* x, int ldx, const void* res, int ldr, void* out, int ldo, int W, int Wn, int C,
               float* mean, float* invstd, const float* gamma, const float* beta, int relu, float eps, float* scratch,
               hipStream_t stream) {
   return bn_fwd_impl(x, ldx, res, ldr, out, ldo, W, Wn, C, mean, invstd, gamma, beta, relu, eps, scratch, nullptr, stream);
@@ -778,10 +784,10 @@ int da_bn_debug_target_blocks(int blocks) {
 // scratch: da_bn_workspace() bytes.  ds: [2][W][C] per-window totals (sum g, sum g*xhat), always written.
 // dgamma/dbeta: [C]; when both are non-NULL they are computed here (accumulated when accumulate != 0),
 // when NULL the caller folds ds later with da_bn_param_grad_multi.
-static int bn_bwd_impl(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
-                       float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd,
+static int bn_bwd_impl(const void* dout, int ldd, const void* x, int ldx, const void* out, int ldo, void* dx, int lddx,
+                       void* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma,
-                       float* dbeta, int accumulate, const float* add, int ldadd, const unsigned long long* mask,
+                       float* dbeta, int accumulate, const void* add, int ldadd, const unsigned long long* mask,
                        hipStream_t stream) {
   DA_ENTER();
   if (mask) mask_mode = 3;
@@ -798,24 +804,25 @@ static int bn_bwd_impl(const float* dout, int ldd, const float* x, int ldx, cons
   float* s2 = ds + (size_t)W * C;
   int cgb = 0;
   if (int threads = bn_fused_geometry(W, Wn, C, &cgb)) {
-    if (cgb == 32)
-      hipLaunchKernelGGL((bn_bwd_fused_kernel<FUSED_NPOS, 3>), dim3(W, C / 32), dim3(threads), 0, stream, dout, ldd, x,
-                         ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2, add, ldadd, mask);
-    else if (cgb == 16)
-      hipLaunchKernelGGL((bn_bwd_fused_kernel<FUSED_NPOS, 2>), dim3(W, C / 16), dim3(threads), 0, stream, dout, ldd, x,
-                         ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2, add, ldadd, mask);
-    else
-      hipLaunchKernelGGL((bn_bwd_fused_kernel<FUSED_NPOS, 1>), dim3(W, C / 8), dim3(threads), 0, stream, dout, ldd, x,
-                         ldx, out, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2, add, ldadd, mask);
+#define BN_BWD_LAUNCH(QB, CH)                                                                                         \
+  DA_ACT_DISPATCH(hipLaunchKernelGGL((bn_bwd_fused_kernel<AT, FUSED_NPOS, QB>), dim3(W, C / CH), dim3(threads), 0, stream,  \
+                                     (const AT*)dout, ldd, (const AT*)x, ldx, (const AT*)out, ldo, (AT*)dx, lddx, (AT*)gout,  \
+                                     ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2, (const AT*)add, ldadd, mask))
+    if (cgb == 32) BN_BWD_LAUNCH(3, 32);
+    else if (cgb == 16) BN_BWD_LAUNCH(2, 16);
+    else BN_BWD_LAUNCH(1, 8);
+#undef BN_BWD_LAUNCH
     DA_CHECK_LAUNCH();
   } else {
-  if (mask) return DA_EINVAL;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(W, C / CG, P), dim3(256), 0, stream, dout, ldd, x, ldx, out, ldo, Wn, C,
-                     chunk, mean, invstd, gamma, beta, mask_mode, scratch);
-  DA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(W, C / CG, P), dim3(256), 0, stream, dout, ldd, x, ldx, out, ldo, dx,
-                     lddx, gout, ldg, Wn, C, chunk, mean, invstd, gamma, beta, mask_mode, scratch, s1, s2, add, ldadd);
-  DA_CHECK_LAUNCH();
+    if (mask) return DA_EINVAL;
+    DA_ACT_DISPATCH(hipLaunchKernelGGL(bn_bwd_reduce_kernel<AT>, dim3(W, C / CG, P), dim3(256), 0, stream, (const AT*)dout, ldd,
+                                       (const AT*)x, ldx, (const AT*)out, ldo, Wn, C, chunk, mean, invstd, gamma, beta,
+                                       mask_mode, scratch));
+    DA_CHECK_LAUNCH();
+    DA_ACT_DISPATCH(hipLaunchKernelGGL(bn_bwd_apply_kernel<AT>, dim3(W, C / CG, P), dim3(256), 0, stream, (const AT*)dout, ldd,
+                                       (const AT*)x, ldx, (const AT*)out, ldo, (AT*)dx, lddx, (AT*)gout, ldg, Wn, C, chunk,
+                                       mean, invstd, gamma, beta, mask_mode, scratch, s1, s2, (const AT*)add, ldadd));
+    DA_CHECK_LAUNCH();
   }
   if (dgamma) {
     BnPgradTable t;
@@ -826,8 +833,8 @@ static int bn_bwd_impl(const float* dout, int ldd, const float* x, int ldx, cons
   return DA_OK;
 }
 
-int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
-              float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd, const float* gamma,
+int da_bn_bwd(const void* dout, int ldd, const void* x, int ldx, const void* out, int ldo, void* dx, int lddx,
+              void* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd, const float* gamma,
               const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma, float* dbeta, int accumulate,
               hipStream_t stream) {
   return bn_bwd_impl(dout, ldd, x, ldx, out, ldo, dx, lddx, gout, ldg, W, Wn, C, mean, invstd, gamma, beta, mask_mode,
@@ -843,7 +850,7 @@ size_t da_bn_mask_words(int W, int Wn, int C) {
 }
 
 // da_bn_fwd (relu != 0) that also records the ReLU decisions, 1 bit per element (da_bn_mask_words() words).
-int da_bn_fwd_mask(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
+int da_bn_fwd_mask(const void* x, int ldx, const void* res, int ldr, void* out, int ldo, int W, int Wn, int C,
                    float* mean, float* invstd, const float* gamma, const float* beta, float eps, float* scratch,
                    unsigned long long* mask, hipStream_t stream) {
   if (!mask) return DA_EINVAL;
@@ -852,7 +859,7 @@ int da_bn_fwd_mask(const float* x, int ldx, const float* res, int ldr, float* ou
 
 // da_bn_bwd of act = ReLU whose decisions come from the mask of da_bn_fwd_mask instead of the output tensor
 // (mask_mode 2 reads `out`, 18 MB per layer at B = 64, only for its sign).
-int da_bn_bwd_mask(const float* dout, int ldd, const float* x, int ldx, float* dx, int lddx, float* gout, int ldg, int W,
+int da_bn_bwd_mask(const void* dout, int ldd, const void* x, int ldx, void* dx, int lddx, void* gout, int ldg, int W,
                    int Wn, int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
                    float* scratch, float* ds, float* dgamma, float* dbeta, int accumulate,
                    const unsigned long long* mask, hipStream_t stream) {
@@ -863,10 +870,10 @@ int da_bn_bwd_mask(const float* dout, int ldd, const float* x, int ldx, float* d
 
 // da_bn_bwd with dx = (BatchNorm input gradient) + add[pos][0:C] (pitch ldadd): the pass-through gradient of a
 // concatenation (densenet.py:41 torch.cat) joins in the same pass instead of a separate add kernel.
-int da_bn_bwd_add(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
-                  float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd, const float* gamma,
+int da_bn_bwd_add(const void* dout, int ldd, const void* x, int ldx, const void* out, int ldo, void* dx, int lddx,
+                  void* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd, const float* gamma,
                   const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma, float* dbeta,
-                  int accumulate, const float* add, int ldadd, hipStream_t stream) {
+                  int accumulate, const void* add, int ldadd, hipStream_t stream) {
   if (!add) return DA_EINVAL;
   return bn_bwd_impl(dout, ldd, x, ldx, out, ldo, dx, lddx, gout, ldg, W, Wn, C, mean, invstd, gamma, beta, mask_mode,
                      scratch, ds, dgamma, dbeta, accumulate, add, ldadd, nullptr, stream);

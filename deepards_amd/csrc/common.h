@@ -13,8 +13,49 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+
 #define DA_OK 0
 #define DA_EINVAL (-1)
+
+// Activation storage type.  Every RLC activation / activation-gradient tensor that crosses a kernel boundary is either
+// float (default) or bf16 (da_set_act_dtype(1): BASELINE's bf16 configs; statistics, sums, parameters and their
+// gradients stay float).  Kernels that touch activations are templated on AT and launched through DA_ACT_DISPATCH;
+// all arithmetic is fp32 either way -- bf16 is a storage format (round-to-nearest-even on store, exact widening on load).
+template <typename T> struct Act;
+template <> struct Act<float> {
+  static __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+  static __device__ __forceinline__ float ld1(const float* p) { return *p; }
+  static __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+};
+template <> struct Act<__bf16> {
+  static __device__ __forceinline__ f32x4 ld4(const __bf16* p) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                 __uint_as_float(r.y & 0xffff0000u)};
+  }
+  static __device__ __forceinline__ void st4(__bf16* p, const f32x4& v) {
+    const f32x2v lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    const bf16x2v a = __builtin_convertvector(lo, bf16x2v), b = __builtin_convertvector(hi, bf16x2v);   // v_cvt_pk_bf16_f32
+    *reinterpret_cast<f32x2v*>(p) = f32x2v{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)};
+  }
+  static __device__ __forceinline__ float ld1(const __bf16* p) { return (float)*p; }
+  static __device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
+};
+extern int g_act_bf16;                 // head_optim.hip; set by da_set_act_dtype
+// run STMT once with `AT` = the current activation storage type
+#define DA_ACT_DISPATCH(STMT)  \
+  do {                         \
+    if (g_act_bf16) {          \
+      typedef __bf16 AT;       \
+      STMT;                    \
+    } else {                   \
+      typedef float AT;        \
+      STMT;                    \
+    }                          \
+  } while (0)
 
 // hipGetLastError() is sticky per thread: clear whatever an earlier runtime call (ours or PyTorch's)
 // left behind before judging our own launches.

@@ -14,7 +14,6 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 // block id -> work item so that CONSECUTIVE work items share an XCD (blocks are dealt to the 8 XCDs round-robin): the
 // channel tiles of one position tile, which read the same activation panel, then hit the same L2 (conv_gemm.hip)
@@ -25,9 +24,9 @@ __device__ __forceinline__ int xcd_chunked_bf(int id, int total) {
 }
 
 struct ConvBf16Args {
-  const float* x;       // [M][ldx] fp32, first C channels
+  const void* x;        // [M][ldx] activations (float or bf16: template AT), first C channels
   const __bf16* w;      // [3][N][C] bf16 taps
-  float* y;             // [M][ldy] fp32, first N channels
+  void* y;              // [M][ldy] activations, first N channels
   int M, L, ldx, C, ldy, N, accumulate;
   FastDiv divL;
 };
@@ -44,8 +43,28 @@ __device__ __forceinline__ f32x2v cvt4_bf16(const f32x4& v) {       // 4 bf16 (n
   return f32x2v{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)};
 }
 
+// Four channels of one position on their way global memory -> registers -> LDS image (bf16 bits).  float activations
+// are rounded while being staged (v_cvt_pk_bf16_f32); bf16 activations (da_set_act_dtype(1)) are already the image's
+// format: 8-byte loads, no conversion -- half the bytes through the load path.
+template <typename AT> struct Stage;
+template <> struct Stage<float> {
+  typedef f32x4 reg;
+  static __device__ __forceinline__ reg zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ reg ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ f32x2v bits(const reg& v) { return cvt4_bf16(v); }
+};
+template <> struct Stage<__bf16> {
+  typedef f32x2v reg;
+  static __device__ __forceinline__ reg zero() { return f32x2v{0.f, 0.f}; }
+  static __device__ __forceinline__ reg ld(const __bf16* p) { return *reinterpret_cast<const f32x2v*>(p); }
+  static __device__ __forceinline__ f32x2v bits(const reg& v) { return v; }
+};
+
+template <typename AT>
 __global__ __launch_bounds__(256) void conv3_bf16_kernel(ConvBf16Args a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[CB_LDS_BYTES];
+  const AT* ax = reinterpret_cast<const AT*>(a.x);
+  AT* ay = reinterpret_cast<AT*>(a.y);
   unsigned char* Xs = lds;                            // [130][80 B]: positions P0-1 .. P0+128
   unsigned char* Ws = lds + CB_XROWS * CB_PITCH;      // [3][64][80 B]
 
@@ -74,7 +93,7 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(ConvBf16Args a) {
   const __bf16* wsrc = a.w + (size_t)(n_blk + wrow) * a.C + ws * 8;
   const size_t wtap = (size_t)a.N * a.C;
 
-  f32x4 rx[NXP];
+  typename Stage<AT>::reg rx[NXP];
   f32x4 rw[3];                                        // 8 bf16 each, as bits
   auto gload = [&](int ks) {
     const int c0 = ks << 5;
@@ -82,8 +101,8 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(ConvBf16Args a) {
     for (int t = 0; t < 3; ++t) rw[t] = *reinterpret_cast<const f32x4*>(wsrc + t * wtap + c0);
 #pragma unroll
     for (int p = 0; p < NXP; ++p) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (xok[p]) v = *reinterpret_cast<const f32x4*>(a.x + xoff[p] + c0);
+      typename Stage<AT>::reg v = Stage<AT>::zero();
+      if (xok[p]) v = Stage<AT>::ld(ax + xoff[p] + c0);
       rx[p] = v;
     }
   };
@@ -116,7 +135,7 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(ConvBf16Args a) {
 #pragma unroll
     for (int p = 0; p < NXP; ++p) {
       const int r = p * 32 + xrow;
-      if (r < CB_XROWS) *reinterpret_cast<f32x2v*>(Xs + r * CB_PITCH + xq * 8) = cvt4_bf16(rx[p]);
+      if (r < CB_XROWS) *reinterpret_cast<f32x2v*>(Xs + r * CB_PITCH + xq * 8) = Stage<AT>::bits(rx[p]);
     }
 #pragma unroll
     for (int t = 0; t < 3; ++t) *reinterpret_cast<f32x4*>(Ws + (t * CB_TN + wrow) * CB_PITCH + ws * 16) = rw[t];
@@ -145,10 +164,10 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(ConvBf16Args a) {
     for (int r = 0; r < 16; ++r) {
       const long P = (long)P0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
       if (P < a.M) {
-        float* o = a.y + P * a.ldy + n_blk + wn * 32 + frow;
+        AT* o = ay + P * a.ldy + n_blk + wn * 32 + frow;
         float v = acc[mt][r];
-        if (a.accumulate) v += *o;
-        *o = v;
+        if (a.accumulate) v += Act<AT>::ld1(o);
+        Act<AT>::st1(o, v);
       }
     }
 }
@@ -162,17 +181,19 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(ConvBf16Args a) {
 // tap needs are then unit-stride in m (conflict-free ds_read_b128), whatever the tap's parity.
 // ---------------------------------------------------------------------------------------------
 struct ConvBf16GenArgs {
-  const float* x;
+  const void* x;        // activations (template AT)
   const __bf16* w;      // [taps][N][C]
-  float* y;
+  void* y;
   int M, Lm, Lsrc, ldx, C, Ldst, ldy, N, dst_stride, dst_off, ntaps, accumulate;
   int src_off[3], wtap[3];
   long Msrc;            // rows * Lsrc
   FastDiv divLm;
 };
 
-template <int SS>
+template <int SS, typename AT>
 __device__ __forceinline__ void conv_bf16_gen_body(const ConvBf16GenArgs& a, const int tile, unsigned char* lds) {
+  const AT* ax = reinterpret_cast<const AT*>(a.x);
+  AT* ay = reinterpret_cast<AT*>(a.y);
   constexpr int HROWS = CB_TM + 1;                               // rows per parity half (SS = 2)
   constexpr int NR = SS * (CB_TM - 1) + 3;                       // panel rows at most (span of the taps <= 2)
   constexpr int XBYTES = (SS == 2 ? 2 * HROWS : NR) * CB_PITCH;
@@ -206,7 +227,8 @@ __device__ __forceinline__ void conv_bf16_gen_body(const ConvBf16GenArgs& a, con
   const size_t wtapsz = (size_t)a.N * a.C;
   const __bf16* wsrc = a.w + (size_t)(n_blk + wrow) * a.C + ws * 8;
 
-  f32x4 rx[NXP], rw[3];
+  typename Stage<AT>::reg rx[NXP];
+  f32x4 rw[3];
   auto gload = [&](int ks) {
     const int c0 = ks << 5;
 #pragma unroll
@@ -214,8 +236,8 @@ __device__ __forceinline__ void conv_bf16_gen_body(const ConvBf16GenArgs& a, con
       if (t < a.ntaps) rw[t] = *reinterpret_cast<const f32x4*>(wsrc + a.wtap[t] * wtapsz + c0);
 #pragma unroll
     for (int p = 0; p < NXP; ++p) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (xok[p]) v = *reinterpret_cast<const f32x4*>(a.x + xoff[p] + c0);
+      typename Stage<AT>::reg v = Stage<AT>::zero();
+      if (xok[p]) v = Stage<AT>::ld(ax + xoff[p] + c0);
       rx[p] = v;
     }
   };
@@ -258,7 +280,7 @@ __device__ __forceinline__ void conv_bf16_gen_body(const ConvBf16GenArgs& a, con
       const int r = p * 32 + xrow;
       if (r < NR) {
         const int off = SS == 1 ? r * CB_PITCH : (r & 1) * HROWS * CB_PITCH + (r >> 1) * CB_PITCH;
-        *reinterpret_cast<f32x2v*>(Xs + off + xq * 8) = cvt4_bf16(rx[p]);
+        *reinterpret_cast<f32x2v*>(Xs + off + xq * 8) = Stage<AT>::bits(rx[p]);
       }
     }
 #pragma unroll
@@ -292,10 +314,10 @@ __device__ __forceinline__ void conv_bf16_gen_body(const ConvBf16GenArgs& a, con
       if (m < a.M) {
         const uint32_t rq = fdiv((uint32_t)m, a.divLm);
         const int j = (int)((uint32_t)m - rq * (uint32_t)a.Lm);
-        float* o = a.y + ((size_t)rq * a.Ldst + (size_t)j * a.dst_stride + a.dst_off) * a.ldy + n_blk + wn * 32 + frow;
+        AT* o = ay + ((size_t)rq * a.Ldst + (size_t)j * a.dst_stride + a.dst_off) * a.ldy + n_blk + wn * 32 + frow;
         float v = acc[mt][r];
-        if (a.accumulate) v += *o;
-        *o = v;
+        if (a.accumulate) v += Act<AT>::ld1(o);
+        Act<AT>::st1(o, v);
       }
     }
 }
@@ -309,13 +331,13 @@ struct ConvBf16GenTable {
   int n;
 };
 
-template <int SS>
+template <int SS, typename AT>
 __global__ __launch_bounds__(256) void conv_bf16_gen_kernel(ConvBf16GenTable t) {
   constexpr int XBYTES = (SS == 2 ? 2 * (CB_TM + 1) : SS * (CB_TM - 1) + 3) * CB_PITCH;
   __shared__ __attribute__((aligned(16))) unsigned char lds[XBYTES + 3 * CB_TN * CB_PITCH];
   int i = 0;
   while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
-  conv_bf16_gen_body<SS>(t.d[i], xcd_chunked_bf(blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i]), lds);
+  conv_bf16_gen_body<SS, AT>(t.d[i], xcd_chunked_bf(blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i]), lds);
 }
 
 // wf[t][co][ci] = bf16(w[co][ci][t]) (forward taps), wd[t][ci][co] = bf16(w[co][ci][2 - t]) (data-gradient taps)
@@ -346,8 +368,8 @@ __global__ __launch_bounds__(256) void pack_conv3_bf16_kernel(const float* __res
 // Image rows are 192 bytes (128 data + 64 pad): the 4 rows of a transposed read fall on disjoint bank ranges.
 // ---------------------------------------------------------------------------------------------
 struct WgradBf16Args {
-  const float* dy;
-  const float* x;
+  const void* dy;       // activations (template AT)
+  const void* x;
   float* slab;
   int rows, L, Kpad, lddy, N, ldx, C, pchunk;
   FastDiv divL1;        // by L + 1
@@ -367,7 +389,10 @@ __device__ __forceinline__ f32x2v ds_read_tr16(const unsigned char* p) {
   return v;
 }
 
+template <typename AT>
 __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const int block_id, unsigned char* lds) {
+  const AT* ady = reinterpret_cast<const AT*>(a.dy);
+  const AT* axx = reinterpret_cast<const AT*>(a.x);
   unsigned char* Ys = lds;                              // [64][192 B]  dY at padded positions k0 .. k0+63
   unsigned char* Xs = lds + WB_KP * WB_PITCH;           // [66][192 B]  X at padded positions k0-1 .. k0+64
 
@@ -379,7 +404,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const in
   const int L1 = a.L + 1;
 
   const int lq = tid & 15, lr = tid >> 4;               // loader: 16 rows x 16 channel quads per pass
-  f32x4 ry[4], rx[5];
+  typename Stage<AT>::reg ry[4], rx[5];
   auto gload = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -388,8 +413,8 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const in
       const uint32_t sq = fdiv((uint32_t)(ok ? Pp : 0), a.divL1);
       const int l = (ok ? Pp : 0) - (int)sq * L1;
       ok = ok && l < a.L;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)sq * a.L + l) * a.lddy + n_blk + lq * 4);
+      typename Stage<AT>::reg v = Stage<AT>::zero();
+      if (ok) v = Stage<AT>::ld(ady + ((size_t)sq * a.L + l) * a.lddy + n_blk + lq * 4);
       ry[p] = v;
     }
 #pragma unroll
@@ -400,8 +425,8 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const in
       const uint32_t sq = fdiv((uint32_t)(ok ? Pp : 0), a.divL1);
       const int l = (ok ? Pp : 0) - (int)sq * L1;
       ok = ok && l < a.L;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)sq * a.L + l) * a.ldx + c_blk + lq * 4);
+      typename Stage<AT>::reg v = Stage<AT>::zero();
+      if (ok) v = Stage<AT>::ld(axx + ((size_t)sq * a.L + l) * a.ldx + c_blk + lq * 4);
       rx[p] = v;
     }
   };
@@ -424,10 +449,10 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const in
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      *reinterpret_cast<f32x2v*>(Ys + (lr + 16 * p) * WB_PITCH + lq * 8) = cvt4_bf16(ry[p]);
-      *reinterpret_cast<f32x2v*>(Xs + (lr + 16 * p) * WB_PITCH + lq * 8) = cvt4_bf16(rx[p]);
+      *reinterpret_cast<f32x2v*>(Ys + (lr + 16 * p) * WB_PITCH + lq * 8) = Stage<AT>::bits(ry[p]);
+      *reinterpret_cast<f32x2v*>(Xs + (lr + 16 * p) * WB_PITCH + lq * 8) = Stage<AT>::bits(rx[p]);
     }
-    if (tid < 32) *reinterpret_cast<f32x2v*>(Xs + (64 + lr) * WB_PITCH + lq * 8) = cvt4_bf16(rx[4]);
+    if (tid < 32) *reinterpret_cast<f32x2v*>(Xs + (64 + lr) * WB_PITCH + lq * 8) = Stage<AT>::bits(rx[4]);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     if (k0 + WB_KP < k_end) gload(k0 + WB_KP);
@@ -473,8 +498,10 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const in
 // (slot 0 and slot Lx + 1 zero) the input slot of (P', t) is Q' = 2 P' + t -- linear, so the X image of a K step is the
 // contiguous range Q' = 2 k0 .. 2 k0 + 130 and a transposed read takes rows 2 apart (160-byte rows keep its 4 rows on
 // disjoint banks).
-template <int NTAPS>
+template <int NTAPS, typename AT>
 __device__ __forceinline__ void wgrad_bf16_s2_body(const WgradBf16Args& a, const int block_id, unsigned char* lds) {
+  const AT* ady = reinterpret_cast<const AT*>(a.dy);
+  const AT* axx = reinterpret_cast<const AT*>(a.x);
   unsigned char* Ys = lds;                              // [64][192 B]
   unsigned char* Xs = lds + WB_KP * WB_PITCH;           // [131][160 B]: input slots 2 k0 .. 2 k0 + 130
 
@@ -487,7 +514,7 @@ __device__ __forceinline__ void wgrad_bf16_s2_body(const WgradBf16Args& a, const
 
   const int lq = tid & 15, lr = tid >> 4;
   constexpr int NXP = (WB_X2ROWS + 15) / 16;            // 9 passes of 16 rows, the last one 3 rows
-  f32x4 ry[4], rx[NXP];
+  typename Stage<AT>::reg ry[4], rx[NXP];
   auto gload = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -496,8 +523,8 @@ __device__ __forceinline__ void wgrad_bf16_s2_body(const WgradBf16Args& a, const
       const uint32_t sq = fdiv((uint32_t)(ok ? Pp : 0), a.divL1);
       const int j = (ok ? Pp : 0) - (int)sq * L1;
       ok = ok && j < a.L;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)sq * a.L + j) * a.lddy + n_blk + lq * 4);
+      typename Stage<AT>::reg v = Stage<AT>::zero();
+      if (ok) v = Stage<AT>::ld(ady + ((size_t)sq * a.L + j) * a.lddy + n_blk + lq * 4);
       ry[p] = v;
     }
 #pragma unroll
@@ -508,8 +535,8 @@ __device__ __forceinline__ void wgrad_bf16_s2_body(const WgradBf16Args& a, const
       const uint32_t sq = fdiv((uint32_t)(ok ? Qp : 0), a.divLx2);
       const int sl = (int)((ok ? Qp : 0) - (long)sq * Lx2);
       ok = ok && sl >= 1 && sl <= Lx;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)sq * Lx + (sl - 1)) * a.ldx + c_blk + lq * 4);
+      typename Stage<AT>::reg v = Stage<AT>::zero();
+      if (ok) v = Stage<AT>::ld(axx + ((size_t)sq * Lx + (sl - 1)) * a.ldx + c_blk + lq * 4);
       rx[p] = v;
     }
   };
@@ -529,11 +556,11 @@ __device__ __forceinline__ void wgrad_bf16_s2_body(const WgradBf16Args& a, const
   for (int k0 = k_beg; k0 < k_end; k0 += WB_KP) {
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x2v*>(Ys + (lr + 16 * p) * WB_PITCH + lq * 8) = cvt4_bf16(ry[p]);
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x2v*>(Ys + (lr + 16 * p) * WB_PITCH + lq * 8) = Stage<AT>::bits(ry[p]);
 #pragma unroll
     for (int p = 0; p < NXP; ++p) {
       const int r = lr + 16 * p;
-      if (r < WB_X2ROWS) *reinterpret_cast<f32x2v*>(Xs + r * WB_XPITCH2 + lq * 8) = cvt4_bf16(rx[p]);
+      if (r < WB_X2ROWS) *reinterpret_cast<f32x2v*>(Xs + r * WB_XPITCH2 + lq * 8) = Stage<AT>::bits(rx[p]);
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
@@ -585,14 +612,15 @@ struct WgradBf16Table {
   int n;
 };
 
+template <typename AT>
 __global__ __launch_bounds__(256) void wgrad_bf16_multi_kernel(WgradBf16Table t) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[WB_LDS_BYTES];
   int i = 0;
   while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
   const int b = xcd_chunked_bf(blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i]);   // a split's tiles share an XCD
-  if (t.d[i].mode == 0) wgrad_bf16_body(t.d[i], b, lds);
-  else if (t.d[i].mode == 1) wgrad_bf16_s2_body<3>(t.d[i], b, lds);
-  else wgrad_bf16_s2_body<1>(t.d[i], b, lds);
+  if (t.d[i].mode == 0) wgrad_bf16_body<AT>(t.d[i], b, lds);
+  else if (t.d[i].mode == 1) wgrad_bf16_s2_body<3, AT>(t.d[i], b, lds);
+  else wgrad_bf16_s2_body<1, AT>(t.d[i], b, lds);
 }
 
 // jobs the bf16 kernels take: channel counts multiples of 64 and  k3 s1 p1 | k3 s2 p1 | k1 s2 p0 (even input length)
@@ -625,7 +653,7 @@ int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s) {
     if (!cnt) return DA_OK;
     t.n = cnt;
     t.first_block[cnt] = blocks;
-    hipLaunchKernelGGL(wgrad_bf16_multi_kernel, dim3(blocks), dim3(256), 0, s, t);
+    DA_ACT_DISPATCH(hipLaunchKernelGGL(wgrad_bf16_multi_kernel<AT>, dim3(blocks), dim3(256), 0, s, t));
     DA_CHECK_LAUNCH();
     cnt = 0;
     blocks = 0;
@@ -658,7 +686,7 @@ extern "C" {
 // y (+)= conv1d(x, k = 3, stride 1, pad 1) per row of L positions, bf16 products / fp32 sums.  x: [rows][L][ldx] fp32
 // (first C channels), wpk: [3][N][C] bf16 from da_pack_conv3_bf16, y: [rows][L][ldy] fp32 (first N channels).
 // C % 32 == 0, N % 64 == 0.  replaces reference models/resnet.py:5-8 (conv2x2) under dtype bf16
-int da_conv3_bf16(const float* x, const void* wpk, float* y, int rows, int L, int ldx, int C, int ldy, int N,
+int da_conv3_bf16(const void* x, const void* wpk, void* y, int rows, int L, int ldx, int C, int ldy, int N,
                   int accumulate, hipStream_t stream) {
   DA_ENTER();
   if (!x || !wpk || !y || rows < 0 || L < 1 || C % 32 || N % CB_TN || C < 32 || N < CB_TN || ldx % 4 || ldx < C || ldy < N)
@@ -672,7 +700,7 @@ int da_conv3_bf16(const float* x, const void* wpk, float* y, int rows, int L, in
   a.divL = make_fastdiv((uint32_t)L);
   const long tiles = ((M + CB_TM - 1) / CB_TM) * (N / CB_TN);
   if (tiles > 0x7fffffffl) return DA_EINVAL;
-  hipLaunchKernelGGL(conv3_bf16_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, a);
+  DA_ACT_DISPATCH(hipLaunchKernelGGL(conv3_bf16_kernel<AT>, dim3((unsigned)tiles), dim3(256), 0, stream, a));
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -724,8 +752,8 @@ int da_conv_bf16_multi(const da_conv_job* jobs, int n, hipStream_t stream) {
     if (!cnt) continue;
     t.n = cnt;
     t.first_block[cnt] = blocks;
-    if (ss == 1) hipLaunchKernelGGL(conv_bf16_gen_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, t);
-    else hipLaunchKernelGGL(conv_bf16_gen_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, t);
+    if (ss == 1) DA_ACT_DISPATCH(hipLaunchKernelGGL((conv_bf16_gen_kernel<1, AT>), dim3((unsigned)blocks), dim3(256), 0, stream, t));
+    else DA_ACT_DISPATCH(hipLaunchKernelGGL((conv_bf16_gen_kernel<2, AT>), dim3((unsigned)blocks), dim3(256), 0, stream, t));
     DA_CHECK_LAUNCH();
   }
   return DA_OK;

@@ -925,6 +925,7 @@ int da_conv_gemm(const float* x, const float* w, float* y, int rows, int Lm, int
                  int ldy, int N, int dst_stride, int dst_off, int src_stride, int ntaps, const int* src_off,
                  const int* wtap, int accumulate, hipStream_t stream) {
   DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;              // float activations only
   if (!x || !w || !y || rows < 0 || Lm < 1 || ntaps < 1 || ntaps > 3) return DA_EINVAL;
   ConvGemmArgs a;
   a.x = x; a.w = w; a.y = y;
@@ -944,6 +945,7 @@ int da_conv_gemm(const float* x, const float* w, float* y, int rows, int Lm, int
 // The problems must not write the same output elements.
 int da_conv_gemm_multi(const da_conv_job* jobs, int n, hipStream_t stream) {
   DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;              // float activations only
   if (n < 1 || n > 4 || !jobs) return DA_EINVAL;
   ConvGemmArgs a[4];
   for (int i = 0; i < n; ++i) {
@@ -983,6 +985,7 @@ int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
     if (!j.dy || !j.x || !j.workspace || j.ntaps < 1 || j.ntaps > 3 || j.C % 32 || j.N % 32 || j.lddy % 4 || j.ldx % 4)
       return DA_EINVAL;
     if ((uint64_t)j.rows * j.Lm * (uint64_t)j.Lm >= 0xffffffffull) return DA_EINVAL;
+    if (g_act_bf16 && j.winograd != 16) return DA_EINVAL;     // bf16 activations: only the bf16-operand kernels read them
     if (j.winograd == 16 ? !bf16_wgrad_eligible(j)
                          : (j.winograd ? !wino_wgrad_eligible(j) : !wgrad_plan(j.rows * j.Lm, j.N, j.C, j.ntaps).tn))
       return DA_EINVAL;
@@ -1055,6 +1058,7 @@ int da_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, 
                   int N, int Lx, int ldx, int C, int dy_stride, int dy_off, int src_stride, int ntaps,
                   const int* src_off, int accumulate, hipStream_t stream) {
   DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;              // float activations only
   if (!dy || !x || !workspace || ntaps < 1 || ntaps > 3) return DA_EINVAL;
   if (C % 32 || N % 32 || lddy % 4 || ldx % 4) return DA_EINVAL;
   WgradArgs a;

@@ -874,6 +874,7 @@ extern "C" {
 int da_conv3_winograd4(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
                        int accumulate, hipStream_t stream) {
   DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;              // float activations only
   if (!x || !u || !y || rows < 0 || L < 1 || C % 32 || N % 32 || C < 32 || N < 32 || ldx % 4 || ldx < C || ldy < N)
     return DA_EINVAL;
   if (rows == 0) return DA_OK;
@@ -915,6 +916,7 @@ int da_wino4_weights(const float* w, float* u, int co, int ci, int transpose, hi
 int da_conv3_winograd(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
                       int accumulate, hipStream_t stream) {
   DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;              // float activations only
   if (!x || !u || !y || rows < 0 || L < 1 || C % 32 || N % 32 || C < 32 || N < 32 || ldx % 4 || ldx < C || ldy < N)
     return DA_EINVAL;
   if (rows == 0) return DA_OK;

@@ -607,9 +607,22 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
   }
 }
 
+int g_act_bf16 = 0;       // da_set_act_dtype
+
 extern "C" {
 
-int da_version(void) { return 100; }
+int da_version(void) { return 200; }
+
+// Activation storage type of every RLC activation / activation-gradient tensor that crosses the ABI from here on:
+// 0 = float (default), 1 = bf16 (BASELINE's bf16 configs; needs the bf16-operand conv kernels).  Process-wide and
+// not thread-safe: set it once, before the step is built (a captured graph keeps the kernels it was captured with).
+// Entry points whose kernels exist only for float activations return DA_EINVAL while it is 1.
+int da_set_act_dtype(int bf16) {
+  if (bf16 != 0 && bf16 != 1) return DA_EINVAL;
+  g_act_bf16 = bf16;
+  return DA_OK;
+}
+int da_get_act_dtype(void) { return g_act_bf16; }
 
 
 
@@ -838,6 +851,7 @@ int da_repack_multi(const da_repack_desc* descs, int n, hipStream_t stream) {
 int da_concat2(const float* a, int lda, int C1, const float* b, int ldb, int C2, float* out, int ldo, size_t npos,
                hipStream_t stream) {
   DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;              // float activations only
   if (!a || !b || !out || C1 % 4 || C2 % 4 || lda % 4 || ldb % 4 || ldo % 4) return DA_EINVAL;
   if (npos == 0) return DA_OK;
   hipLaunchKernelGGL(concat2_kernel, dim3(grid_for(npos * ((C1 + C2) / 4), 256, 8192)), dim3(256), 0, stream, a, lda,
@@ -849,6 +863,7 @@ int da_concat2(const float* a, int lda, int C1, const float* b, int ldb, int C2,
 int da_slice_copy(const float* src, int lds, int off, float* dst, int ldd, int C, size_t npos, int accumulate,
                   hipStream_t stream) {
   DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;              // float activations only
   if (!src || !dst || C % 4 || lds % 4 || ldd % 4 || off % 4) return DA_EINVAL;
   if (npos == 0) return DA_OK;
   hipLaunchKernelGGL(slice_copy_kernel, dim3(grid_for(npos * (C / 4), 256, 8192)), dim3(256), 0, stream, src, lds, off,
@@ -861,6 +876,7 @@ int da_slice_copy(const float* src, int lds, int off, float* dst, int ldd, int C
 int da_concat2_dropout(const float* a, int lda, int C1, const float* b, int ldb, int C2, float* out, int ldo, size_t npos,
                        const int64_t* seed, unsigned salt, float p, hipStream_t stream) {
   DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;              // float activations only
   if (!a || !b || !out || !seed || C1 % 4 || C2 % 4 || lda % 4 || ldb % 4 || ldo % 4 || p < 0.f || p >= 1.f) return DA_EINVAL;
   if (npos == 0) return DA_OK;
   hipLaunchKernelGGL(concat2_dropout_kernel, dim3(grid_for(npos * ((C1 + C2) / 4), 256, 8192)), dim3(256), 0, stream, a, lda,
@@ -873,6 +889,7 @@ int da_concat2_dropout(const float* a, int lda, int C1, const float* b, int ldb,
 int da_slice_dropout(const float* src, int lds, int off, float* dst, int ldd, int C, size_t npos, const int64_t* seed,
                      unsigned salt, float p, hipStream_t stream) {
   DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;              // float activations only
   if (!src || !dst || !seed || C % 4 || lds % 4 || ldd % 4 || off % 4 || p < 0.f || p >= 1.f) return DA_EINVAL;
   if (npos == 0) return DA_OK;
   hipLaunchKernelGGL(slice_dropout_kernel, dim3(grid_for(npos * (C / 4), 256, 8192)), dim3(256), 0, stream, src, lds, off,
@@ -884,6 +901,7 @@ int da_slice_dropout(const float* src, int lds, int off, float* dst, int ldd, in
 // y = dropout(x) with keep-prob 1-p; the same (seed, salt) reproduces the mask (used by backward).
 int da_dropout(const float* x, float* y, size_t n, const int64_t* seed, unsigned salt, float p, hipStream_t stream) {
   DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;              // float activations only
   if (!x || !y || !seed || p < 0.f || p >= 1.f) return DA_EINVAL;
   if (n == 0) return DA_OK;
   hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, stream, x, y, n, seed, salt, p);

@@ -10,8 +10,9 @@
 #include "common.h"
 
 // y[row][l][co] = sum_k w[co][k] * x[row][2l + k - 3];  block = one waveform row.
+template <typename AT>
 __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            float* __restrict__ y, int Lin, int Lout, int C0, int ldy) {
+                                                            AT* __restrict__ y, int Lin, int Lout, int C0, int ldy) {
   extern __shared__ float xs[];  // Lin + 6
   const int row = blockIdx.x;
   for (int i = threadIdx.x; i < Lin + 6; i += blockDim.x) {
@@ -28,12 +29,13 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < 7; ++k) acc = fmaf(wk[k], xs[2 * l + k], acc);
-    y[((size_t)row * Lout + l) * ldy + co] = acc;
+    Act<AT>::st1(y + ((size_t)row * Lout + l) * ldy + co, acc);
   }
 }
 
 // partial[blk][co][k] = sum over this block's rows, positions of dy[row][l][co] * x[row][2l+k-3]
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ dy, int lddy,
+template <typename AT>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const AT* __restrict__ dy, int lddy,
                                                          const float* __restrict__ x, float* __restrict__ partial,
                                                          int rows, int Lin, int Lout, int C0) {
   extern __shared__ float sm[];  // xs[Lin+6] then red[nslots][C0*7]
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     __syncthreads();
     if (slot < nslots) {
       for (int l = slot; l < Lout; l += nslots) {
-        float g = dy[((size_t)row * Lout + l) * lddy + co];
+        float g = Act<AT>::ld1(dy + ((size_t)row * Lout + l) * lddy + co);
 #pragma unroll
         for (int k = 0; k < 7; ++k) acc[k] = fmaf(g, xs[2 * l + k], acc[k]);
       }
@@ -90,8 +92,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
 
 // out[row][j][c] = pool_{l in {2j-1,2j,2j+1}} relu(bn(y[row][l][c]));  pool_mode 0 = max (-inf pad),
 // 1 = avg (count_include_pad, zeros).  One thread per (output position, channel quad).
-__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ y, int ldy,
-                                                               float* __restrict__ out, int ldo, int rows, int R,
+template <typename AT>
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const AT* __restrict__ y, int ldy,
+                                                               AT* __restrict__ out, int ldo, int rows, int R,
                                                                int Lin, int Lout, int C, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd,
                                                                const float* __restrict__ gamma,
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
   for (int t = 0; t < 3; ++t) {
     int l = 2 * j - 1 + t;
     if (l < 0 || l >= Lin) continue;
-    f32x4 v = *reinterpret_cast<const f32x4*>(y + ((size_t)row * Lin + l) * ldy + c0);
+    f32x4 v = Act<AT>::ld4(y + ((size_t)row * Lin + l) * ldy + c0);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float z = fmaxf((v[e] - mu[e]) * is[e] * ga[e] + be[e], 0.f);
@@ -128,15 +131,16 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] *= (1.0f / 3.0f);
   }
-  *reinterpret_cast<f32x4*>(out + po * ldo + c0) = o;
+  Act<AT>::st4(out + po * ldo + c0, o);
 }
 
 // Gradient w.r.t. the ReLU output at stem resolution: dz[row][l][c] = sum over the (<= 2) pooling
 // windows j that contain l of [argmax_j == l] * dout[row][j][c]  (max; first maximum wins, as ATen)
 // or dout[row][j][c]/3 (avg).  The ReLU mask and BN backward are applied afterwards by da_bn_bwd
 // (mask_mode 1), so no index tensor is ever stored: the argmax is recomputed from y.
-__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dout, int ldd,
-                                                       const float* __restrict__ y, int ldy, float* __restrict__ dz,
+template <typename AT>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const AT* __restrict__ dout, int ldd,
+                                                       const AT* __restrict__ y, int ldy, AT* __restrict__ dz,
                                                        int lddz, int rows, int R, int Lin, int Lout, int C,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
   if (pool_mode == 1) {
     for (int j = j_lo; j <= j_hi; ++j) {
       if (j >= Lout) continue;
-      f32x4 g = *reinterpret_cast<const f32x4*>(dout + ((size_t)row * Lout + j) * ldd + c0);
+      f32x4 g = Act<AT>::ld4(dout + ((size_t)row * Lout + j) * ldd + c0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[e] += g[e] * (1.0f / 3.0f);
     }
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
       for (int t = 0; t < 3; ++t) {
         int ll = 2 * j - 1 + t;
         if (ll < 0 || ll >= Lin) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(y + ((size_t)row * Lin + ll) * ldy + c0);
+        f32x4 v = Act<AT>::ld4(y + ((size_t)row * Lin + ll) * ldy + c0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float z = fmaxf((v[e] - mu[e]) * is[e] * ga[e] + be[e], 0.f);
@@ -186,17 +190,18 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
           }
         }
       }
-      f32x4 g = *reinterpret_cast<const f32x4*>(dout + ((size_t)row * Lout + j) * ldd + c0);
+      f32x4 g = Act<AT>::ld4(dout + ((size_t)row * Lout + j) * ldd + c0);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (barg[e] == l) acc[e] += g[e];
     }
   }
-  *reinterpret_cast<f32x4*>(dz + pi * lddz + c0) = acc;
+  Act<AT>::st4(dz + pi * lddz + c0, acc);
 }
 
 // generic AvgPool1d(k, stride=k) (k=2 transition) and AvgPool1d(L, 1) on an L-long row (k = L -> 1).
-__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out,
+template <typename IT, typename OT>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const IT* __restrict__ x, int ldx, OT* __restrict__ out,
                                                           int ldo, int rows, int Lin, int Lout, int k, int C) {
   const int nq = C >> 2;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -208,17 +213,18 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restric
   int row = (int)(po / Lout);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int t = 0; t < k; ++t) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)row * Lin + j * k + t) * ldx + q * 4);
+    f32x4 v = Act<IT>::ld4(x + ((size_t)row * Lin + j * k + t) * ldx + q * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] += v[e];
   }
   const float inv = 1.0f / (float)k;
 #pragma unroll
   for (int e = 0; e < 4; ++e) acc[e] *= inv;
-  *reinterpret_cast<f32x4*>(out + po * ldo + q * 4) = acc;
+  Act<OT>::st4(out + po * ldo + q * 4, acc);
 }
 
-__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dout, int ldd, float* __restrict__ dx,
+template <typename IT, typename OT>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const IT* __restrict__ dout, int ldd, OT* __restrict__ dx,
                                                           int lddx, int rows, int Lin, int Lout, int k, int C) {
   const int nq = C >> 2;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -231,17 +237,18 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
   int j = l / k;
   f32x4 g = {0.f, 0.f, 0.f, 0.f};
   if (j < Lout) {
-    g = *reinterpret_cast<const f32x4*>(dout + ((size_t)row * Lout + j) * ldd + q * 4);
+    g = Act<IT>::ld4(dout + ((size_t)row * Lout + j) * ldd + q * 4);
     const float inv = 1.0f / (float)k;
 #pragma unroll
     for (int e = 0; e < 4; ++e) g[e] *= inv;
   }
-  *reinterpret_cast<f32x4*>(dx + pi * lddx + q * 4) = g;
+  Act<OT>::st4(dx + pi * lddx + q * 4, g);
 }
 
 // AvgPool1d(k, stride=1) on a map longer than k, flattened the way `x.view(x.size(0), -1)` flattens (N, C, Lout):
 // feature index c * Lout + j (resnet.py:159-160 / densenet.py:183-184 on seq_len > 224, e.g. BASELINE config C5's 512).
-__global__ __launch_bounds__(256) void avgpool_slide_fwd_kernel(const float* __restrict__ x, int ldx,
+template <typename AT>
+__global__ __launch_bounds__(256) void avgpool_slide_fwd_kernel(const AT* __restrict__ x, int ldx,
                                                                 float* __restrict__ feat, int rows, int Lin, int Lout,
                                                                 int k, int C) {
   const int nq = C >> 2;
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256) void avgpool_slide_fwd_kernel(const float* __r
   int row = (int)(po / Lout);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int t = 0; t < k; ++t) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)row * Lin + j + t) * ldx + q * 4);
+    f32x4 v = Act<AT>::ld4(x + ((size_t)row * Lin + j + t) * ldx + q * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] += v[e];
   }
@@ -264,7 +271,8 @@ __global__ __launch_bounds__(256) void avgpool_slide_fwd_kernel(const float* __r
   for (int e = 0; e < 4; ++e) o[(size_t)e * Lout] = acc[e] * inv;
 }
 
-__global__ __launch_bounds__(256) void avgpool_slide_bwd_kernel(const float* __restrict__ dfeat, float* __restrict__ dx,
+template <typename AT>
+__global__ __launch_bounds__(256) void avgpool_slide_bwd_kernel(const float* __restrict__ dfeat, AT* __restrict__ dx,
                                                                 int lddx, int rows, int Lin, int Lout, int k, int C) {
   const int nq = C >> 2;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256) void avgpool_slide_bwd_kernel(const float* __r
   const float inv = 1.0f / (float)k;
 #pragma unroll
   for (int e = 0; e < 4; ++e) g[e] *= inv;
-  *reinterpret_cast<f32x4*>(dx + pi * lddx + q * 4) = g;
+  Act<AT>::st4(dx + pi * lddx + q * 4, g);
 }
 
 static inline int grid1d(size_t total, int bs) { return (int)((total + bs - 1) / bs); }
@@ -293,13 +301,13 @@ static inline int grid1d(size_t total, int bs) { return (int)((total + bs - 1) /
 extern "C" {
 
 // x: [rows][Lin] raw waveform (C_in = 1).  w: [C0][1][7] (torch layout).  y: [rows][Lin/2][ldy].
-int da_stem_conv_fwd(const float* x, const float* w, float* y, int rows, int Lin, int C0, int ldy,
+int da_stem_conv_fwd(const float* x, const float* w, void* y, int rows, int Lin, int C0, int ldy,
                      hipStream_t stream) {
   DA_ENTER();
   if (!x || !w || !y || Lin < 2 || Lin % 2 || C0 < 1 || C0 > 256 || 256 % C0) return DA_EINVAL;
   if (rows == 0) return DA_OK;
-  hipLaunchKernelGGL(stem_conv_fwd_kernel, dim3(rows), dim3(256), (Lin + 6) * sizeof(float), stream, x, w, y, Lin,
-                     Lin / 2, C0, ldy);
+  DA_ACT_DISPATCH(hipLaunchKernelGGL(stem_conv_fwd_kernel<AT>, dim3(rows), dim3(256), (Lin + 6) * sizeof(float), stream, x, w,
+                                     (AT*)y, Lin, Lin / 2, C0, ldy));
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -309,7 +317,7 @@ size_t da_stem_wgrad_workspace(int rows, int C0) {
   return (size_t)nblk * C0 * 7 * sizeof(float);
 }
 
-int da_stem_conv_wgrad(const float* dy, int lddy, const float* x, float* dw, float* workspace, int rows, int Lin,
+int da_stem_conv_wgrad(const void* dy, int lddy, const float* x, float* dw, float* workspace, int rows, int Lin,
                        int C0, int accumulate, hipStream_t stream) {
   DA_ENTER();
   if (!dy || !x || !dw || !workspace || Lin % 2 || C0 < 1 || C0 > 256 || 256 % C0) return DA_EINVAL;
@@ -317,8 +325,8 @@ int da_stem_conv_wgrad(const float* dy, int lddy, const float* x, float* dw, flo
   int nblk = rows < 512 ? rows : 512;
   int nslots = 256 / C0;
   size_t shm = ((Lin + 6) + (size_t)nslots * C0 * 7) * sizeof(float);
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), shm, stream, dy, lddy, x, workspace, rows, Lin, Lin / 2,
-                     C0);
+  DA_ACT_DISPATCH(hipLaunchKernelGGL(stem_wgrad_kernel<AT>, dim3(nblk), dim3(256), shm, stream, (const AT*)dy, lddy, x,
+                                     workspace, rows, Lin, Lin / 2, C0));
   DA_CHECK_LAUNCH();
   int n = C0 * 7;
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((n + 7) / 8), dim3(256), 0, stream, workspace, nblk, n, dw,
@@ -328,7 +336,7 @@ int da_stem_conv_wgrad(const float* dy, int lddy, const float* x, float* dw, flo
 }
 
 // Lout = (Lin + 2 - 3)/2 + 1.  R = rows per BN window.  pool_mode 0 max / 1 avg.
-int da_bn_relu_pool_fwd(const float* y, int ldy, float* out, int ldo, int rows, int R, int Lin, int C,
+int da_bn_relu_pool_fwd(const void* y, int ldy, void* out, int ldo, int rows, int R, int Lin, int C,
                         const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode,
                         hipStream_t stream) {
   DA_ENTER();
@@ -336,13 +344,13 @@ int da_bn_relu_pool_fwd(const float* y, int ldy, float* out, int ldo, int rows, 
   if (rows == 0) return DA_OK;
   int Lout = (Lin - 1) / 2 + 1;
   size_t total = (size_t)rows * Lout * (C / 4);
-  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, stream, y, ldy, out, ldo, rows, R,
-                     Lin, Lout, C, mean, invstd, gamma, beta, pool_mode);
+  DA_ACT_DISPATCH(hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<AT>, dim3(grid1d(total, 256)), dim3(256), 0, stream, (const AT*)y,
+                                     ldy, (AT*)out, ldo, rows, R, Lin, Lout, C, mean, invstd, gamma, beta, pool_mode));
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
 
-int da_pool_bwd(const float* dout, int ldd, const float* y, int ldy, float* dz, int lddz, int rows, int R, int Lin,
+int da_pool_bwd(const void* dout, int ldd, const void* y, int ldy, void* dz, int lddz, int rows, int R, int Lin,
                 int C, const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode,
                 hipStream_t stream) {
   DA_ENTER();
@@ -350,8 +358,9 @@ int da_pool_bwd(const float* dout, int ldd, const float* y, int ldy, float* dz, 
   if (rows == 0) return DA_OK;
   int Lout = (Lin - 1) / 2 + 1;
   size_t total = (size_t)rows * Lin * (C / 4);
-  hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, stream, dout, ldd, y, ldy, dz, lddz, rows,
-                     R, Lin, Lout, C, mean, invstd, gamma, beta, pool_mode);
+  DA_ACT_DISPATCH(hipLaunchKernelGGL(pool_bwd_kernel<AT>, dim3(grid1d(total, 256)), dim3(256), 0, stream, (const AT*)dout, ldd,
+                                     (const AT*)y, ldy, (AT*)dz, lddz, rows, R, Lin, Lout, C, mean, invstd, gamma, beta,
+                                     pool_mode));
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -364,34 +373,34 @@ int da_avgpool_fwd(const float* x, int ldx, float* out, int ldo, int rows, int L
   if (rows == 0) return DA_OK;
   int Lout = Lin / k;
   size_t total = (size_t)rows * Lout * (C / 4);
-  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, stream, x, ldx, out, ldo, rows, Lin,
-                     Lout, k, C);
+  hipLaunchKernelGGL((avgpool_fwd_kernel<float, float>), dim3(grid1d(total, 256)), dim3(256), 0, stream, x, ldx, out, ldo,
+                     rows, Lin, Lout, k, C);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
 
 // AvgPool1d(k, stride 1) + view(rows, -1): feat is (rows, C * (Lin - k + 1)) with the channel index slowest.
-int da_avgpool_slide_fwd(const float* x, int ldx, float* feat, int rows, int Lin, int k, int C, hipStream_t stream) {
+int da_avgpool_slide_fwd(const void* x, int ldx, float* feat, int rows, int Lin, int k, int C, hipStream_t stream) {
   DA_ENTER();
   if (!x || !feat || C % 4 || ldx % 4 || k < 1 || k > Lin) return DA_EINVAL;
   if (rows == 0) return DA_OK;
   int Lout = Lin - k + 1;
   size_t total = (size_t)rows * Lout * (C / 4);
-  hipLaunchKernelGGL(avgpool_slide_fwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, stream, x, ldx, feat, rows, Lin,
-                     Lout, k, C);
+  DA_ACT_DISPATCH(hipLaunchKernelGGL(avgpool_slide_fwd_kernel<AT>, dim3(grid1d(total, 256)), dim3(256), 0, stream, (const AT*)x,
+                                     ldx, feat, rows, Lin, Lout, k, C));
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
 
-int da_avgpool_slide_bwd(const float* dfeat, float* dx, int lddx, int rows, int Lin, int k, int C,
+int da_avgpool_slide_bwd(const float* dfeat, void* dx, int lddx, int rows, int Lin, int k, int C,
                          hipStream_t stream) {
   DA_ENTER();
   if (!dfeat || !dx || C % 4 || lddx % 4 || k < 1 || k > Lin) return DA_EINVAL;
   if (rows == 0) return DA_OK;
   int Lout = Lin - k + 1;
   size_t total = (size_t)rows * Lin * (C / 4);
-  hipLaunchKernelGGL(avgpool_slide_bwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, stream, dfeat, dx, lddx, rows,
-                     Lin, Lout, k, C);
+  DA_ACT_DISPATCH(hipLaunchKernelGGL(avgpool_slide_bwd_kernel<AT>, dim3(grid1d(total, 256)), dim3(256), 0, stream, dfeat,
+                                     (AT*)dx, lddx, rows, Lin, Lout, k, C));
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -403,8 +412,32 @@ int da_avgpool_bwd(const float* dout, int ldd, float* dx, int lddx, int rows, in
   if (rows == 0) return DA_OK;
   int Lout = Lin / k;
   size_t total = (size_t)rows * Lin * (C / 4);
-  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid1d(total, 256)), dim3(256), 0, stream, dout, ldd, dx, lddx, rows, Lin,
-                     Lout, k, C);
+  hipLaunchKernelGGL((avgpool_bwd_kernel<float, float>), dim3(grid1d(total, 256)), dim3(256), 0, stream, dout, ldd, dx, lddx,
+                     rows, Lin, Lout, k, C);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// The activation -> feature boundary: AvgPool1d(L, stride 1) on an L-long map + view, x in the activation storage type,
+// features always float (and back).  replaces reference models/resnet.py:112,159-160 / densenet.py:167,183-184
+int da_global_avgpool_fwd(const void* x, int ldx, float* feat, int rows, int L, int C, hipStream_t stream) {
+  DA_ENTER();
+  if (!x || !feat || C % 4 || ldx % 4 || L < 1) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  size_t total = (size_t)rows * (C / 4);
+  DA_ACT_DISPATCH(hipLaunchKernelGGL((avgpool_fwd_kernel<AT, float>), dim3(grid1d(total, 256)), dim3(256), 0, stream,
+                                     (const AT*)x, ldx, feat, C, rows, L, 1, L, C));
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+int da_global_avgpool_bwd(const float* dfeat, void* dx, int lddx, int rows, int L, int C, hipStream_t stream) {
+  DA_ENTER();
+  if (!dfeat || !dx || C % 4 || lddx % 4 || L < 1) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  size_t total = (size_t)rows * L * (C / 4);
+  DA_ACT_DISPATCH(hipLaunchKernelGGL((avgpool_bwd_kernel<float, AT>), dim3(grid1d(total, 256)), dim3(256), 0, stream, dfeat, C,
+                                     (AT*)dx, lddx, rows, L, 1, L, C));
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

@@ -123,12 +123,28 @@ def set_conv_dtype(name):
     global _CONV_DTYPE
     if name not in ('f32', 'bf16'):
         raise ValueError("conv dtype must be 'f32' or 'bf16'")
+    if name == 'f32' and H.act_dtype() == 'bf16':
+        H.set_act_dtype('f32')                     # fp32 convs read fp32 activations
     _CONV_DTYPE = name
     H.WGRAD_BF16 = name == 'bf16' and os.environ.get('DA_WGRAD_BF16', '1') != '0'
 
 
 def conv_dtype():
     return _CONV_DTYPE
+
+
+def set_storage_dtype(name):
+    """'f32' or 'bf16': storage of every activation / activation-gradient tensor between two kernels (BASELINE's bf16
+    configs C3 / C5: bf16 storage with fp32 statistics and accumulators).  bf16 storage needs conv dtype 'bf16' and a
+    network whose convs all have bf16 kernels (the ResNets: channel counts multiples of 64, even lengths at the
+    stride-2 heads); captured steps keep the storage they were captured with."""
+    if name == 'bf16' and _CONV_DTYPE != 'bf16':
+        raise ValueError("bf16 storage needs conv dtype 'bf16' (set_conv_dtype('bf16') first)")
+    H.set_act_dtype(name)
+
+
+def storage_dtype():
+    return H.act_dtype()
 
 
 set_conv_dtype(_CONV_DTYPE)
@@ -162,10 +178,17 @@ def _pack(w, code):
     return e
 
 
+def _need_bf16_kernel(code, w, stride, pad):
+    if code != 16 and H.act_dtype() == 'bf16':
+        raise NotImplementedError('bf16 activation storage: the conv %s stride %d pad %d has no bf16 kernel (channel counts '
+                                  'must be multiples of 64, stride-2 inputs of even length)' % (tuple(w.shape), stride, pad))
+
+
 def _conv_fwd(x, w, stride, pad):
     code = _is_wino(w, stride, pad)
     if code == 16 and stride == 2 and x.shape[1] % 2:
         code = 0                                    # odd length: the fp32 kernel
+    _need_bf16_kernel(code, w, stride, pad)
     if code == 16:
         return H.conv3_bf16(x, _pack(w, code)[2]) if stride == 1 else H.conv_fwd_bf16_s2(x, _pack(w, code)[2])
     if code:
@@ -177,6 +200,7 @@ def _conv_dgrad(dy, w, stride, pad, l_in, out=None, accumulate=False):
     code = _is_wino(w, stride, pad)
     if code == 16 and stride == 2 and l_in % 2:
         code = 0
+    _need_bf16_kernel(code, w, stride, pad)
     if code == 16:
         if stride == 2:
             return H.conv_dgrad_bf16_s2(dy, _pack(w, code)[3], l_in, out=out, accumulate=accumulate)
@@ -271,6 +295,11 @@ def _wgrad(dy, x, k, stride, pad, tw):
     if tw is not None and _STEP['on']:
         _STEP['wgrad'].append((dy, x, k, stride, pad, tw))     # launched with all the others by flush_backward()
         return None
+    if H.WGRAD_BF16 or H.act_dtype() == 'bf16':            # the bf16-operand kernels exist in the batched form only
+        (slab,) = H.conv_wgrad_multi([(dy, x, k, stride, pad)])
+        dw = tw if tw is not None else torch.empty((dy.shape[2], x.shape[2], k), device=x.device, dtype=torch.float32)
+        H.wgrad_reduce_multi([(slab, dw)], accumulate=tw is not None)
+        return None if tw is not None else dw
     dw = H.conv_wgrad(dy, x, k, stride, pad, out=tw, accumulate=tw is not None)
     return None if tw is not None else dw
 
@@ -441,14 +470,13 @@ class GlobalAvgPoolFunction(Function):
         ctx.lin, ctx.c = x.shape[1], x.shape[2]
         if ctx.lin > 7:             # seq_len > 224: sliding window, flattened channel-major like view(N, -1)
             return H.avgpool_slide_fwd(x, 7)
-        return H.avgpool_fwd(x, x.shape[1]).view(x.shape[0], x.shape[2])
+        return H.global_avgpool_fwd(x)
 
     @staticmethod
     def backward(ctx, dfeat):
         if ctx.lin > 7:
             return H.avgpool_slide_bwd(dfeat.contiguous(), ctx.lin, 7, ctx.c)
-        d = dfeat.contiguous().view(dfeat.shape[0], 1, dfeat.shape[1])
-        return H.avgpool_bwd(d, ctx.lin, ctx.lin)
+        return H.global_avgpool_bwd(dfeat.contiguous(), ctx.lin)
 
 
 class Linear2Function(Function):

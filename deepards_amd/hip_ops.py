@@ -34,10 +34,29 @@ def _chk(rc, name):
         torch.cuda.synchronize()
 
 
+# Storage type of the RLC activation / activation-gradient tensors (include/deepards_hip.h, da_act_t): float32, or
+# bfloat16 after set_act_dtype('bf16') (BASELINE's bf16 configs).  Features, statistics, parameters stay float32.
+ACT = torch.float32
+
+
+def set_act_dtype(name):
+    """'f32' or 'bf16': how every activation tensor between two kernels is stored from now on (process-wide; the
+    library dispatches its activation kernels on it, the wrappers allocate with it)."""
+    global ACT
+    if name not in ('f32', 'bf16'):
+        raise ValueError("activation dtype must be 'f32' or 'bf16'")
+    _chk(_lib.lib().da_set_act_dtype(1 if name == 'bf16' else 0), 'da_set_act_dtype')
+    ACT = torch.bfloat16 if name == 'bf16' else torch.float32
+
+
+def act_dtype():
+    return 'bf16' if ACT == torch.bfloat16 else 'f32'
+
+
 def _rlc(t, name='tensor'):
-    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.is_contiguous()):
-        raise ValueError('%s must be a contiguous float32 CUDA (rows, L, C) tensor, got %s %s %s' %
-                         (name, tuple(t.shape), t.dtype, t.device))
+    if not (t.is_cuda and t.dtype == ACT and t.dim() == 3 and t.is_contiguous()):
+        raise ValueError('%s must be a contiguous %s CUDA (rows, L, C) tensor, got %s %s %s' %
+                         (name, ACT, tuple(t.shape), t.dtype, t.device))
     return t
 
 
@@ -140,7 +159,7 @@ def conv3_bf16(x, wpk, out=None, accumulate=False):
     if out is None:
         if accumulate:
             raise ValueError('accumulate needs out')
-        out = torch.empty((rows, l, n), device=x.device, dtype=torch.float32)
+        out = torch.empty((rows, l, n), device=x.device, dtype=ACT)
     elif tuple(out.shape) != (rows, l, n):
         raise ValueError('conv3_bf16: bad out shape')
     _chk(_lib.lib().da_conv3_bf16(_p(x), _p(wpk), _p(out), rows, l, c, c, n, n, 1 if accumulate else 0, _stream()),
@@ -175,7 +194,7 @@ def conv_fwd_bf16_s2(x, *packs):
     jobs, outs = [], []
     for wf16 in packs:
         k, n = _check_bf16_pack(x, wf16, 'conv_fwd_bf16_s2')
-        out = torch.empty((rows, l // 2, n), device=x.device, dtype=torch.float32)
+        out = torch.empty((rows, l // 2, n), device=x.device, dtype=ACT)
         so, wt = ([-1, 0, 1], [0, 1, 2]) if k == 3 else ([0], [0])
         jobs.append((x, wf16, out, l // 2, l, l // 2, 1, 0, 2, so, wt, False))
         outs.append(out)
@@ -195,7 +214,7 @@ def conv_dgrad_bf16_s2(dy, wd16, l_in, out=None, accumulate=False):
     if out is None:
         if accumulate:
             raise ValueError('accumulate needs out')
-        out = (torch.zeros if k == 1 else torch.empty)((rows, l_in, ci), device=dy.device, dtype=torch.float32)
+        out = (torch.zeros if k == 1 else torch.empty)((rows, l_in, ci), device=dy.device, dtype=ACT)
     elif tuple(out.shape) != (rows, l_in, ci):
         raise ValueError('conv_dgrad_bf16_s2: bad out shape')
     elif k == 1 and not accumulate:
@@ -412,7 +431,7 @@ def stem_conv_fwd(x, w):
     c0 = w.shape[0]
     if tuple(w.shape[1:]) != (1, 7):
         raise ValueError('stem conv expects (C0,1,7) weights (in_channels=1)')
-    y = torch.empty((rows, lin // 2, c0), device=x.device, dtype=torch.float32)
+    y = torch.empty((rows, lin // 2, c0), device=x.device, dtype=ACT)
     _chk(_lib.lib().da_stem_conv_fwd(_p(x), _p(w), _p(y), rows, lin, c0, c0, _stream()), 'da_stem_conv_fwd')
     return y
 
@@ -588,7 +607,7 @@ def bn_relu_pool_fwd(y, R, mean, invstd, gamma, beta, pool_mode):
     _rlc(y, 'y')
     rows, lin, c = y.shape
     lout = (lin - 1) // 2 + 1
-    out = torch.empty((rows, lout, c), device=y.device, dtype=torch.float32)
+    out = torch.empty((rows, lout, c), device=y.device, dtype=ACT)
     _chk(_lib.lib().da_bn_relu_pool_fwd(_p(y), c, _p(out), c, rows, R, lin, c, _p(mean), _p(invstd), _p(gamma),
                                         _p(beta), pool_mode, _stream()), 'da_bn_relu_pool_fwd')
     return out
@@ -604,8 +623,36 @@ def pool_bwd(dout, y, R, mean, invstd, gamma, beta, pool_mode):
     return dz
 
 
-def avgpool_fwd(x, k):
+def _rlc32(t, name='tensor'):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.is_contiguous()):
+        raise ValueError('%s must be a contiguous float32 CUDA (rows, L, C) tensor, got %s %s %s' %
+                         (name, tuple(t.shape), t.dtype, t.device))
+    return t
+
+
+def global_avgpool_fwd(x):
+    """AvgPool1d(L, stride 1) on an L-long map + view: x (rows, L, C) in the activation storage type -> (rows, C)
+    float32 features (the activation -> feature boundary)."""
     _rlc(x, 'x')
+    rows, lin, c = x.shape
+    feat = torch.empty((rows, c), device=x.device, dtype=torch.float32)
+    _chk(_lib.lib().da_global_avgpool_fwd(_p(x), c, _p(feat), rows, lin, c, _stream()), 'da_global_avgpool_fwd')
+    return feat
+
+
+def global_avgpool_bwd(dfeat, lin):
+    """dfeat (rows, C) float32 -> dx (rows, L, C) in the activation storage type."""
+    _f32(dfeat, 'dfeat')
+    rows, c = dfeat.shape
+    dx = torch.empty((rows, lin, c), device=dfeat.device, dtype=ACT)
+    _chk(_lib.lib().da_global_avgpool_bwd(_p(dfeat), _p(dx), c, rows, lin, c, _stream()), 'da_global_avgpool_bwd')
+    return dx
+
+
+def avgpool_fwd(x, k):
+    """float32 tensors only (pools inside fp32 networks and over features); the activation -> feature boundary is
+    global_avgpool_fwd."""
+    _rlc32(x, 'x')
     rows, lin, c = x.shape
     out = torch.empty((rows, lin // k, c), device=x.device, dtype=torch.float32)
     _chk(_lib.lib().da_avgpool_fwd(_p(x), c, _p(out), c, rows, lin, k, c, _stream()), 'da_avgpool_fwd')
@@ -613,7 +660,7 @@ def avgpool_fwd(x, k):
 
 
 def avgpool_bwd(dout, lin, k):
-    _rlc(dout, 'dout')
+    _rlc32(dout, 'dout')
     rows, lout, c = dout.shape
     dx = torch.empty((rows, lin, c), device=dout.device, dtype=torch.float32)
     _chk(_lib.lib().da_avgpool_bwd(_p(dout), c, _p(dx), c, rows, lin, k, c, _stream()), 'da_avgpool_bwd')
@@ -634,7 +681,7 @@ def avgpool_slide_bwd(dfeat, lin, k, c):
     rows = dfeat.shape[0]
     if dfeat.shape[1] != c * (lin - k + 1):
         raise ValueError('dfeat must be (rows, C * (L - k + 1))')
-    dx = torch.empty((rows, lin, c), device=dfeat.device, dtype=torch.float32)
+    dx = torch.empty((rows, lin, c), device=dfeat.device, dtype=ACT)
     _chk(_lib.lib().da_avgpool_slide_bwd(_p(dfeat), _p(dx), c, rows, lin, k, c, _stream()), 'da_avgpool_slide_bwd')
     return dx
 

@@ -44,7 +44,7 @@ saved_models_default_dir = os.path.join(os.path.dirname(os.path.abspath(__file__
 # Knobs this build adds below defaults.yml (the reference has none of them) + the store_true switches of build_parser,
 # which must not live in defaults.yml (defaults.yml:9) and read as off / None when nobody set them.
 BUILD_DEFAULTS = dict(
-    train_store=None, test_store=None, test_patient_slot=None, use_graph=True, seed=None, conv_dtype=None,
+    train_store=None, test_store=None, test_patient_slot=None, use_graph=True, seed=None, conv_dtype=None, act_dtype=None,
     cuda=None, cuda_no_dp=None, no_print_progress=None, print_progress=None, no_test_after_epochs=None, debug=None,
     save_model_per_epoch=None, no_train=None, resnet_double_conv=None, bm_to_linear=None, unshuffled=None,
     oversample_minority=None, reshuffle_oversample_per_epoch=None, freeze_base_network=None, stop_on_loss=None,
@@ -68,7 +68,7 @@ DEFAULTS = dict(
     oversample_minority=False, oversample_all_factor=1.0, reshuffle_oversample_per_epoch=False,
     undersample_factor=-1, train_pt_frac=1.0, train_from_pickle=None, test_from_pickle=None, train_to_pickle=None,
     test_to_pickle=None, stop_on_loss=False, stop_thresh=1.5, stop_after_epoch=1,
-    train_store=None, test_store=None, test_patient_slot=None, use_graph=True, seed=None, conv_dtype=None,
+    train_store=None, test_store=None, test_patient_slot=None, use_graph=True, seed=None, conv_dtype=None, act_dtype=None,
 )
 
 
@@ -127,6 +127,10 @@ class BaseTraining(object):
         if _flag(args, 'conv_dtype', None):
             from . import functional as F_
             F_.set_conv_dtype(args.conv_dtype)
+            # BASELINE's bf16 configs: bf16 storage too where the network has bf16 kernels throughout (the ResNets)
+            if args.conv_dtype == 'bf16' and str(args.base_network).startswith('resnet') and \
+                    getattr(args, 'act_dtype', None) != 'f32':
+                F_.set_storage_dtype('bf16')
         self.results = Results()
         self.preds, self.pred_idx = [], []
 
@@ -482,6 +486,7 @@ def build_parser():
     parser.add_argument('--seed', type=int, help='seed of the initialisation, the shuffles and the oversampler')
     parser.add_argument('--no-graph', dest='use_graph', action='store_false', default=None, help='run the step eagerly')
     parser.add_argument('--conv-dtype', choices=['f32', 'bf16'], help='arithmetic of the residual-block convs')
+    parser.add_argument('--act-dtype', choices=['f32', 'bf16'], help='activation storage under --conv-dtype bf16 (default bf16 for ResNets)')
     return parser
 
 

@@ -28,6 +28,16 @@ extern "C" {
 typedef struct ihipStream_t* da_stream_t; /* == hipStream_t */
 
 int da_version(void);
+
+/* Activation storage type.  `da_act_t*` parameters below are RLC activation / activation-gradient tensors whose element
+   type is float (default) or bf16 (after da_set_act_dtype(1): BASELINE's bf16 configs -- every tensor between two
+   kernels of the breath block is then stored in bf16; statistics, sums, features, parameters and their gradients stay
+   float, all arithmetic is fp32 or bf16-MFMA with fp32 accumulation).  Pitches (`ld*`) count ELEMENTS.  The setting is
+   process-wide and not thread-safe: set it before the step is built.  Entry points that take `float*` activations
+   (the fp32 conv kernels, concat / slice / dropout) return -1 while bf16 is selected. */
+typedef void da_act_t;
+int da_set_act_dtype(int bf16);
+int da_get_act_dtype(void);
 /* sizeof of {da_wgrad_job, da_conv_job, da_wgrad_reduce_desc, da_repack_desc, da_bn_running_desc, da_bn_pgrad_desc} as the
    library was built (ABI drift check for bindings) */
 void da_abi_sizes(int* out);
@@ -91,21 +101,21 @@ int da_wino4_weights(const float* w, float* u, int co, int ci, int transpose, da
  * (nearest-even) on the way into LDS, bf16 taps wpk [3][N][C] from da_pack_conv3_bf16, v_mfma_f32_32x32x16_bf16 with
  * fp32 accumulation.  C % 32 == 0, N % 64 == 0.  wf [3][Co][Ci] forward taps, wd [3][Ci][Co] data-gradient taps
  * (reversed); either may be NULL. */
-int da_conv3_bf16(const float* x, const void* wpk, float* y, int rows, int L, int ldx, int C, int ldy, int N,
+int da_conv3_bf16(const da_act_t* x, const void* wpk, da_act_t* y, int rows, int L, int ldx, int C, int ldy, int N,
                   int accumulate, da_stream_t stream);
 int da_pack_conv3_bf16(const float* w, void* wf, void* wd, int co, int ci, da_stream_t stream);
 /* da_conv_gemm_multi's contract with bf16 operands for the stride-2 block heads and 1x1 downsamples
  * (resnet.py:5-8,126-128), forward and data gradient: per job Lsrc == src_stride * Lm, source offsets within a span of
  * 2, x2 == NULL, w = bf16 [taps][N][C] (da_repack_desc.points = 16 emits them for K = 1 and K = 3); the jobs of a call
  * share src_stride (1 or 2); up to 4 per launch. */
-int da_conv_bf16_multi(const da_conv_job* jobs, int n, da_stream_t stream);
+int da_conv_bf16_multi(const da_conv_job* jobs, int n, da_stream_t stream);   /* jobs[].x / .y are da_act_t tensors here */
 /* all weight-gradient GEMMs of a step in one launch per tile shape (jobs: HOST array); slabs only, reduce afterwards */
 typedef struct {
   const float* dy; const float* x; float* workspace;
   int rows, Lm, Ldy, lddy, N, Lx, ldx, C, dy_stride, dy_off, src_stride, ntaps; int src_off[3];
   int winograd;   /* != 0: k3 s1 p1 job (N, C multiples of 64) in Winograd F(2,3) form; plan with winograd = 1 */
 } da_wgrad_job;
-int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, da_stream_t stream);
+int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, da_stream_t stream);  /* winograd == 16 jobs: dy / x are da_act_t tensors (the only kind accepted while bf16 is selected) */
 /* deferred slab reduction: da_conv_wgrad with dw == NULL leaves da_conv_wgrad_splits() slabs in the workspace */
 int da_conv_wgrad_splits(int rows, int Lm, int N, int C, int ntaps);
 /* host only: out[4] = {tile_n, tile_c, splits, positions per split} the plan of da_conv_wgrad and
@@ -123,10 +133,10 @@ typedef struct { const float* W; float* Wf; float* Wd; float* Uf; float* Ud; int
 int da_repack_multi(const da_repack_desc* descs, int n, da_stream_t stream);
 
 /* ---- stem: Conv1d(1, C0, k7, s2, p3)  resnet.py:86-87,142 ; densenet.py:118-119 ----------- */
-int da_stem_conv_fwd(const float* x, const float* w, float* y, int rows, int Lin, int C0, int ldy,
+int da_stem_conv_fwd(const float* x, const float* w, da_act_t* y, int rows, int Lin, int C0, int ldy,
                      da_stream_t stream);
 size_t da_stem_wgrad_workspace(int rows, int C0);
-int da_stem_conv_wgrad(const float* dy, int lddy, const float* x, float* dw, float* workspace, int rows, int Lin,
+int da_stem_conv_wgrad(const da_act_t* dy, int lddy, const float* x, float* dw, float* workspace, int rows, int Lin,
                        int C0, int accumulate, da_stream_t stream);
 
 /* ---- window-grouped train-mode BatchNorm1d (+ReLU, +residual) ------------------------------
@@ -142,19 +152,19 @@ typedef struct { const float* s1; const float* s2; float* dgamma; float* dbeta; 
 /* two-stage statistics: P chunks of `chunk` positions per window so that W*C/32*P blocks fill the chip */
 void da_bn_chunks(int W, int Wn, int C, int* P, int* chunk);
 size_t da_bn_workspace(int W, int Wn, int C);      /* bytes of part[w][p][{mean,M2}][C] / backward scratch */
-int da_bn_stats_partial(const float* x, int ld, int W, int Wn, int C, float* part, da_stream_t stream);
+int da_bn_stats_partial(const da_act_t* x, int ld, int W, int Wn, int C, float* part, da_stream_t stream);
 int da_bn_stats_merge(const float* part, int W, int Wn, int C, float eps, float* mean, float* invstd,
                       da_stream_t stream);
 /* the reference's W sequential momentum-0.1 updates per BatchNorm in closed form; num_batches_tracked += W */
 int da_bn_running_multi(const da_bn_running_desc* descs, int n, da_stream_t stream);
 /* out = act(bn(x) (+res)); with part != NULL the chunk records are merged on the fly and mean/invstd WRITTEN */
-int da_bn_apply(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
+int da_bn_apply(const da_act_t* x, int ldx, const da_act_t* res, int ldr, da_act_t* out, int ldo, int W, int Wn, int C,
                 float* mean, float* invstd, const float* gamma, const float* beta, int relu, const float* part,
                 float eps, da_stream_t stream);
 /* statistics + normalisation in one call (mean/invstd [W][C] are OUTPUTS): one single-pass kernel when a window
    slab fits a block's registers (Wn <= 1280), else da_bn_stats_partial + da_bn_apply.  scratch: da_bn_workspace().
    replaces nn.BatchNorm1d(+ReLU)(+residual) forward, reference models/resnet.py:27-38, models/densenet.py:23-29 */
-int da_bn_fwd(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
+int da_bn_fwd(const da_act_t* x, int ldx, const da_act_t* res, int ldr, da_act_t* out, int ldo, int W, int Wn, int C,
               float* mean, float* invstd, const float* gamma, const float* beta, int relu, float eps, float* scratch,
               da_stream_t stream);
 /* tests: on != 0 forces the two-stage kernels in da_bn_fwd / da_bn_bwd (both paths are checked against the oracle) */
@@ -165,35 +175,35 @@ int da_bn_debug_target_blocks(int blocks);
 /* mask_mode 0: no ReLU; 1: ReLU, mask recomputed from bn(x); 2: ReLU, mask from `out` (residual).
  * scratch: da_bn_workspace() bytes.  ds: [2][W][C] per-window totals, always written.  dgamma/dbeta NULL:
  * fold ds later with da_bn_param_grad_multi. */
-int da_bn_bwd(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
-              float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd,
+int da_bn_bwd(const da_act_t* dout, int ldd, const da_act_t* x, int ldx, const da_act_t* out, int ldo, da_act_t* dx, int lddx,
+              da_act_t* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd,
               const float* gamma, const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma,
               float* dbeta, int accumulate, da_stream_t stream);
 /* ReLU decisions as a bit mask, 64 bits per thread of the single-pass kernels (da_bn_mask_words() words; 0 = this shape
    takes the two-stage kernels, no mask form): da_bn_fwd_mask = da_bn_fwd(relu) + mask; da_bn_bwd_mask = da_bn_bwd of a
    ReLU'd BatchNorm(+residual) that reads the mask instead of the output tensor (mask_mode 2 reads `out` only for its sign) */
 size_t da_bn_mask_words(int W, int Wn, int C);
-int da_bn_fwd_mask(const float* x, int ldx, const float* res, int ldr, float* out, int ldo, int W, int Wn, int C,
+int da_bn_fwd_mask(const da_act_t* x, int ldx, const da_act_t* res, int ldr, da_act_t* out, int ldo, int W, int Wn, int C,
                    float* mean, float* invstd, const float* gamma, const float* beta, float eps, float* scratch,
                    unsigned long long* mask, da_stream_t stream);
-int da_bn_bwd_mask(const float* dout, int ldd, const float* x, int ldx, float* dx, int lddx, float* gout, int ldg, int W,
+int da_bn_bwd_mask(const da_act_t* dout, int ldd, const da_act_t* x, int ldx, da_act_t* dx, int lddx, da_act_t* gout, int ldg, int W,
                    int Wn, int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
                    float* scratch, float* ds, float* dgamma, float* dbeta, int accumulate,
                    const unsigned long long* mask, da_stream_t stream);
 /* da_bn_bwd with dx = input gradient + add[pos][0:C] (pitch ldadd): a concatenation's pass-through gradient
    (densenet.py:41) joins in the same pass */
-int da_bn_bwd_add(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
-                  float* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd, const float* gamma,
+int da_bn_bwd_add(const da_act_t* dout, int ldd, const da_act_t* x, int ldx, const da_act_t* out, int ldo, da_act_t* dx, int lddx,
+                  da_act_t* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd, const float* gamma,
                   const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma, float* dbeta,
-                  int accumulate, const float* add, int ldadd, da_stream_t stream);
+                  int accumulate, const da_act_t* add, int ldadd, da_stream_t stream);
 int da_bn_param_grad_multi(const da_bn_pgrad_desc* descs, int n, int accumulate, da_stream_t stream);
 
 /* ---- pools ------------------------------------------------------------------------------
  * stem BN+ReLU+{Max,Avg}Pool1d(3,2,1): resnet.py:100-104,152-153 ; densenet.py:120-123 */
-int da_bn_relu_pool_fwd(const float* y, int ldy, float* out, int ldo, int rows, int R, int Lin, int C,
+int da_bn_relu_pool_fwd(const da_act_t* y, int ldy, da_act_t* out, int ldo, int rows, int R, int Lin, int C,
                         const float* mean, const float* invstd, const float* gamma, const float* beta,
                         int pool_mode, da_stream_t stream);
-int da_pool_bwd(const float* dout, int ldd, const float* y, int ldy, float* dz, int lddz, int rows, int R, int Lin,
+int da_pool_bwd(const da_act_t* dout, int ldd, const da_act_t* y, int ldy, da_act_t* dz, int lddz, int rows, int R, int Lin,
                 int C, const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode,
                 da_stream_t stream);
 /* AvgPool1d(k, stride k): densenet.py:79 (k=2) ; AvgPool1d(7,1) on L=7: resnet.py:112,159, densenet.py:167,183 */
@@ -203,9 +213,14 @@ int da_avgpool_bwd(const float* dout, int ldd, float* dx, int lddx, int rows, in
                    da_stream_t stream);
 /* AvgPool1d(k, stride 1) on a map longer than k followed by x.view(x.size(0), -1) (resnet.py:159-160,
  * densenet.py:183-184 when seq_len > 224): feat[row][c * Lout + j], Lout = Lin - k + 1. */
-int da_avgpool_slide_fwd(const float* x, int ldx, float* feat, int rows, int Lin, int k, int C, da_stream_t stream);
-int da_avgpool_slide_bwd(const float* dfeat, float* dx, int lddx, int rows, int Lin, int k, int C,
+int da_avgpool_slide_fwd(const da_act_t* x, int ldx, float* feat, int rows, int Lin, int k, int C, da_stream_t stream);
+int da_avgpool_slide_bwd(const float* dfeat, da_act_t* dx, int lddx, int rows, int Lin, int k, int C,
                          da_stream_t stream);
+/* The activation -> feature boundary, AvgPool1d(L, stride 1) on an L-long map + view (resnet.py:112,159-160,
+ * densenet.py:167,183-184): x in the activation storage type, feat[row][c] always float; and its backward. */
+int da_global_avgpool_fwd(const da_act_t* x, int ldx, float* feat, int rows, int L, int C, da_stream_t stream);
+int da_global_avgpool_bwd(const float* dfeat, da_act_t* dx, int lddx, int rows, int L, int C, da_stream_t stream);
+
 
 /* ---- head + loss ---------------------------------------------------------------------------
  * linear_final on view(-1) of the (NB,F) block: torch_cnn_linear_network.py:102,110-112 ;

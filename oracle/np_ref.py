@@ -204,11 +204,17 @@ class _Tape(object):
         self.g = {}
         self.R = rows_per_window
         self.stats = {}
+        self.bf16_storage = False    # BASELINE configs C3 / C5 (build-side, not in the reference): every activation and
+                                     # activation gradient that crosses a kernel boundary on the device is rounded to bf16
         self.decisions = {}          # name -> dict(kind, ...): every ReLU mask / max-pool argmax of the forward, mutable
         self.order = []              # decision names in forward order
 
     def acc(self, name, g):
         self.g[name] = self.g.get(name, 0) + g
+
+    def rs(self, a):
+        """A tensor as the device stores it between two kernels: bf16-rounded under bf16 storage, else unchanged."""
+        return round_bf16(a) if self.bf16_storage else a
 
 
 def round_bf16(a):
@@ -229,6 +235,7 @@ def _conv(t, x, name, stride, pad, need_dx=True):
         (stride == 1 or x.shape[2] % 2 == 0)
     bf_fd = bf_w
     y = conv1d_fwd(round_bf16(x), round_bf16(w), stride, pad) if bf_fd else conv1d_fwd(x, w, stride, pad)
+    y = t.rs(y)
 
     def bwd(dy):
         dx, dw = conv1d_bwd(x, w, dy, stride, pad, need_dx)
@@ -237,49 +244,53 @@ def _conv(t, x, name, stride, pad, need_dx=True):
         if bf_w:                                      # dw from rounded (dy, x)
             _, dw = conv1d_bwd(round_bf16(x), w, round_bf16(dy), stride, pad, False)
         t.acc(name, dw)
-        return dx
+        return t.rs(dx) if dx is not None else dx
     return y, bwd
 
 
-def _bn(t, x, prefix):
+def _bn(t, x, prefix, store=False):
+    """store: the BatchNorm output itself is written to memory (the downsample branch); otherwise it is consumed inside
+    the same kernel by the ReLU / residual add that follows and only THAT result is stored (and rounded, bf16 storage)."""
     gname, bname = prefix + '.weight', prefix + '.bias'
     y, st = bn_window_fwd(x, t.p[gname], t.p[bname], t.R)
     t.stats[prefix] = (st, t.R * x.shape[2])
+    if store:
+        y = t.rs(y)
 
     def bwd(dy):
         dx, dg, db = bn_window_bwd(x, t.p[gname], st, dy, t.R)
         t.acc(gname, dg)
         t.acc(bname, db)
-        return dx
+        return t.rs(dx)
     return y, bwd
 
 
-def _relu(t, x, name):
+def _relu(t, x, name, store=True):
     """ReLU whose backward mask lives on the tape (t.decisions[name]['mask']) and is read when the backward RUNS, so a
     test can re-run the backward under another admissible decision of an element whose pre-activation is within fp32
-    noise of zero (``rebackward``)."""
+    noise of zero (``rebackward``).  store: the result is written to memory (rounded under bf16 storage)."""
     y = relu(x)
     d = t.decisions[name] = dict(kind='relu', pre=x, mask=y > 0)
     t.order.append(name)
-    return y, (lambda dy: dy * d['mask'])
+    return (t.rs(y) if store else y), (lambda dy: dy * d['mask'])
 
 
 def _maxpool(t, x, name):
     y, idx = maxpool3s2p1_fwd(x)
     d = t.decisions[name] = dict(kind='maxpool', x=x, idx=idx)
     t.order.append(name)
-    return y, (lambda dy: maxpool3s2p1_bwd(dy, d['idx'], x.shape[2]))
+    return t.rs(y), (lambda dy: t.rs(maxpool3s2p1_bwd(dy, d['idx'], x.shape[2])))
 
 
 def _stem(t, x, conv, bn, pool_type='max'):
     y0, b_conv = _conv(t, x, conv, 2, 3, need_dx=False)
     y1, b_bn = _bn(t, y0, bn)
-    y2, b_relu = _relu(t, y1, bn + '.relu')
+    y2, b_relu = _relu(t, y1, bn + '.relu', store=False)       # relu -> pool inside one kernel
     if pool_type == 'max':
         y3, b_pool = _maxpool(t, y2, bn + '.maxpool')
     else:
-        y3 = avgpool3s2p1_fwd(y2)
-        b_pool = lambda d: avgpool3s2p1_bwd(d, y2.shape[2])
+        y3 = t.rs(avgpool3s2p1_fwd(y2))
+        b_pool = lambda d: t.rs(avgpool3s2p1_bwd(d, y2.shape[2]))
     return y3, (lambda d: b_conv(b_bn(b_relu(b_pool(d)))))
 
 
@@ -306,7 +317,7 @@ def resnet18_features(t, x, prefix='breath_block.', first_pool_type='max', layer
             o, b5 = _bn(t, o, bp + 'bn2')
             if stride != 1 or inpl != planes:
                 r, d1 = _conv(t, xin, bp + 'downsample.0.weight', stride, 0)
-                r, d2 = _bn(t, r, bp + 'downsample.1')
+                r, d2 = _bn(t, r, bp + 'downsample.1', store=True)
                 b_res = (lambda d1, d2: (lambda d: d1(d2(d))))(d1, d2)
             else:
                 r = xin
@@ -315,7 +326,7 @@ def resnet18_features(t, x, prefix='breath_block.', first_pool_type='max', layer
 
             def blk_bwd(d, b1=b1, b2=b2, b3=b3, b4=b4, b5=b5, b6=b6, b_res=b_res):
                 dz = b6(d)
-                return b1(b2(b3(b4(b5(dz))))) + b_res(dz)
+                return t.rs(b1(b2(b3(b4(b5(dz))))) + b_res(dz))
             backs.append(blk_bwd)
             inpl = planes
     feat = avgpool_fwd(h, 7, 1)
@@ -324,7 +335,7 @@ def resnet18_features(t, x, prefix='breath_block.', first_pool_type='max', layer
     out = feat.reshape(n, -1)
 
     def bwd(dout):
-        d = avgpool_bwd(dout.reshape(feat.shape), 7, 1, lh)
+        d = t.rs(avgpool_bwd(dout.reshape(feat.shape), 7, 1, lh))
         for b in reversed(backs):
             d = b(d)
         return d
@@ -479,7 +490,7 @@ def lstm_bwd(x, w_ih, w_hh, tape, dh_all):
 
 def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_batches=20,
                                 first_pool_type='max', drop_masks=None, need_grads=True, head='linear',
-                                bf16_convs=False):
+                                bf16_convs=False, bf16_storage=False):
     """CNNLinearNetwork.forward over a batch (torch_cnn_linear_network.py:104-113) + BCE loss
     (train_ards_detector.py:929-930) + backward.  x (B,NB,C,224); target (B,2) one-hot.
     params: dict name -> ndarray with the reference's state_dict keys.
@@ -501,6 +512,7 @@ def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_ba
     b, nb, c, l = x.shape
     t = _Tape(params, nb)
     t.bf16_convs = bf16_convs
+    t.bf16_storage = bf16_storage            # resnets only (the device has no bf16-storage DenseNet)
     rows = x.reshape(b * nb, c, l)
     if backbone in RESNET_LAYERS:
         feat, fbwd = resnet18_features(t, rows, first_pool_type=first_pool_type, layers=RESNET_LAYERS[backbone])

@@ -1,0 +1,292 @@
+"""bf16 ACTIVATION STORAGE (BASELINE configs C3 / C5: "bf16 storage with fp32 accumulate / statistics").
+
+The reference is fp32-only (SURVEY finding 8): there is no bf16 reference, so every bound in this file is builder-stated
+-- **parity unpinned**.  What IS pinned:
+
+* kernel level, differentially: each activation kernel run with bf16 storage equals the SAME kernel run with fp32
+  storage (which tests/test_hip_ops_gpu.py pins to the numpy oracle) on inputs that are exactly representable in bf16,
+  up to the one rounding of its outputs to bf16 (|a - b| <= 2^-7 |b|: one bf16 ulp, a value on a rounding boundary may
+  land on either side when the fp32 sums differ in their last bits);
+* model level: logits / loss / gradients against the numpy oracle run with the same rounding model
+  (np_ref ... bf16_convs=True, bf16_storage=True: operands of the residual-block convs AND every stored activation /
+  activation gradient rounded to bf16), and a training run whose loss goes down.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ref
+from oracle.weights import seeded_params, seeded_batch
+
+pytestmark = pytest.mark.gpu
+LOG = os.path.join(os.path.dirname(os.path.dirname(__file__)), 'gpurun_out', 'parity_model.log')
+
+
+def log(*a):
+    os.makedirs(os.path.dirname(LOG), exist_ok=True)
+    with open(LOG, 'a') as f:
+        f.write(' '.join(str(x) for x in a) + '\n')
+
+
+@pytest.fixture(scope='module')
+def H():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from deepards_amd import hip_ops
+    return hip_ops
+
+
+class storage(object):
+    """with storage(H, 'bf16'): ... -- activation storage switched for the block, fp32 restored afterwards."""
+
+    def __init__(self, H, name):
+        self.H, self.name = H, name
+
+    def __enter__(self):
+        self.H.set_act_dtype(self.name)
+
+    def __exit__(self, *exc):
+        self.H.set_act_dtype('f32')
+
+
+def bf(t):
+    """float32 tensor with bf16-representable values."""
+    return t.bfloat16().float()
+
+
+def one_ulp(a16, ref32, name, slack=1.0):
+    """a16 (bf16 tensor) == ref32 rounded to bf16, up to one bf16 ulp of the reference."""
+    a, r = a16.float(), ref32.float()
+    tol = slack * (2.0 ** -7) * r.abs() + 1e-30
+    bad = (a - r).abs() > tol + 1e-6 * r.abs().max()
+    assert not bool(bad.any()), '%s: %d of %d elements beyond one bf16 ulp, worst %.3e' % (
+        name, int(bad.sum()), bad.numel(), float(((a - r).abs() / (r.abs() + 1e-20))[bad].max()))
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return bf(torch.randn(shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize('C,L,R,W', [(64, 56, 20, 4), (128, 28, 20, 3), (512, 7, 20, 5), (64, 128, 40, 2), (64, 112, 20, 2)])
+def test_batchnorm_kernels_bf16_storage(H, C, L, R, W):
+    """bn_fwd (+ReLU, +residual, +mask) and bn_bwd (all mask modes) -- single-pass and two-stage geometries."""
+    rows = R * W
+    x, res, dout = rnd((rows, L, C), 1, 2.0), rnd((rows, L, C), 2), rnd((rows, L, C), 3)
+    gamma = (torch.rand(C, generator=torch.Generator().manual_seed(4)) + 0.5).cuda()
+    beta = (torch.randn(C, generator=torch.Generator().manual_seed(5)) * 0.3).cuda()
+    for relu, use_res in ((True, False), (False, False), (True, True)):
+        o32, m32, i32 = H.bn_fwd(x, R, gamma, beta, relu=relu, res=res if use_res else None)
+        with storage(H, 'bf16'):
+            o16, m16, i16 = H.bn_fwd(x.bfloat16(), R, gamma, beta, relu=relu, res=res.bfloat16() if use_res else None)
+        assert o16.dtype == torch.bfloat16 and m16.dtype == torch.float32
+        assert torch.allclose(m16, m32, rtol=1e-6, atol=1e-7) and torch.allclose(i16, i32, rtol=1e-6)
+        one_ulp(o16, o32, 'bn_fwd relu=%s res=%s' % (relu, use_res))
+    # backward, mask recomputed (mode 1) / no relu (mode 0) / from the output (mode 2) / from the bit mask
+    o32, m32, i32, mask32 = H.bn_fwd(x, R, gamma, beta, relu=True, res=res, want_mask=True)
+    with storage(H, 'bf16'):
+        o16, m16, i16, mask16 = H.bn_fwd(x.bfloat16(), R, gamma, beta, relu=True, res=res.bfloat16(), want_mask=True)
+    for mode in (0, 1, 2):
+        kw = dict(out=o32) if mode == 2 else {}
+        dx32, dg32, db32, g32, ds32 = H.bn_bwd(dout, x, R, m32, i32, gamma, beta, mode, want_g=True, **kw)
+        with storage(H, 'bf16'):
+            kw16 = dict(out=o16) if mode == 2 else {}
+            dx16, dg16, db16, g16, ds16 = H.bn_bwd(dout.bfloat16(), x.bfloat16(), R, m16, i16, gamma, beta, mode,
+                                                   want_g=True, **kw16)
+        if mode != 2:                       # mode 2's mask comes from the ROUNDED output: identical unless out == 0 exactly
+            assert torch.allclose(ds16, ds32, rtol=2e-5, atol=1e-4), 'sums differ, mode %d' % mode
+            one_ulp(dx16, dx32, 'bn_bwd dx mode %d' % mode, slack=1.5)
+            one_ulp(g16, g32, 'bn_bwd g mode %d' % mode)
+            assert torch.allclose(dg16, dg32, rtol=2e-5, atol=1e-3) and torch.allclose(db16, db32, rtol=2e-5, atol=1e-3)
+        else:
+            assert float((dx16.float() - dx32).norm() / dx32.norm()) < 1e-2
+    if mask32 is not None:
+        dx32, _, _, g32, _ = H.bn_bwd(dout, x, R, m32, i32, gamma, beta, 2, want_g=True, mask=mask32)
+        with storage(H, 'bf16'):
+            dx16, _, _, g16, _ = H.bn_bwd(dout.bfloat16(), x.bfloat16(), R, m16, i16, gamma, beta, 2, want_g=True, mask=mask16)
+        one_ulp(dx16, dx32, 'bn_bwd dx bit mask', slack=1.5)
+        one_ulp(g16, g32, 'bn_bwd g bit mask')
+
+
+@pytest.mark.parametrize('rows,lin,R,pool', [(40, 224, 20, 0), (40, 224, 20, 1), (80, 512, 40, 0)])
+def test_stem_and_pool_kernels_bf16_storage(H, rows, lin, R, pool):
+    g = torch.Generator().manual_seed(rows + lin)
+    x2d = torch.randn(rows, lin, generator=g).cuda()                       # the network input stays float32
+    w = (torch.randn(64, 1, 7, generator=g) * 0.3).cuda()
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.3).cuda()
+    y32 = H.stem_conv_fwd(x2d, w)
+    with storage(H, 'bf16'):
+        y16 = H.stem_conv_fwd(x2d, w)
+    assert y16.dtype == torch.bfloat16
+    one_ulp(y16, y32, 'stem conv')
+    yb = y16.float()                                                        # continue both paths from the SAME stored tensor
+    m32, i32 = H.bn_stats(yb, R)
+    p32 = H.bn_relu_pool_fwd(yb, R, m32, i32, gamma, beta, pool)
+    dout = rnd(tuple(p32.shape), 7)
+    dz32 = H.pool_bwd(dout, yb, R, m32, i32, gamma, beta, pool)
+    dy32, _, _, _, _ = H.bn_bwd(dz32.bfloat16().float(), yb, R, m32, i32, gamma, beta, 1)
+    dw32 = H.stem_conv_wgrad(dy32.bfloat16().float(), x2d)
+    with storage(H, 'bf16'):
+        m16, i16 = H.bn_stats(y16, R)
+        p16 = H.bn_relu_pool_fwd(y16, R, m16, i16, gamma, beta, pool)
+        dz16 = H.pool_bwd(dout.bfloat16(), y16, R, m16, i16, gamma, beta, pool)
+        dy16, _, _, _, _ = H.bn_bwd(dz16, y16, R, m16, i16, gamma, beta, 1)
+        dw16 = H.stem_conv_wgrad(dy16, x2d)
+    assert torch.allclose(m16, m32, rtol=1e-6, atol=1e-7) and torch.allclose(i16, i32, rtol=1e-6)
+    one_ulp(p16, p32, 'bn_relu_pool')
+    one_ulp(dz16, dz32, 'pool_bwd')
+    one_ulp(dy16, dy32, 'stem bn_bwd', slack=2.0)
+    assert float((dw16 - dw32).norm() / dw32.norm()) < 2e-2 and dw16.dtype == torch.float32
+
+
+@pytest.mark.parametrize('ci,co,L,rows', [(64, 64, 56, 40), (128, 128, 28, 23), (512, 512, 7, 40), (64, 64, 128, 9)])
+def test_conv_kernels_bf16_storage(H, ci, co, L, rows):
+    """k3 s1 conv forward / data gradient (+accumulate), the stride-2 pair, and all three weight-gradient forms with bf16
+    activations in and out: equal to the float-storage kernels on the same (bf16-representable) inputs, outputs rounded."""
+    g = torch.Generator().manual_seed(ci + L)
+    x, dy = rnd((rows, L, ci), 11), rnd((rows, L, co), 12)
+    w = (torch.randn(co, ci, 3, generator=g) * np.sqrt(2.0 / (3 * co))).cuda()
+    wf, wd = H.pack_conv3_bf16(w)
+    y32 = H.conv3_bf16(x, wf)
+    dx32 = H.conv3_bf16(dy, wd)
+    base = rnd((rows, L, ci), 13)
+    acc32 = H.conv3_bf16(dy, wd, out=base.clone(), accumulate=True)
+    with storage(H, 'bf16'):
+        y16 = H.conv3_bf16(x.bfloat16(), wf)
+        dx16 = H.conv3_bf16(dy.bfloat16(), wd)
+        acc16 = H.conv3_bf16(dy.bfloat16(), wd, out=base.bfloat16(), accumulate=True)
+    assert y16.dtype == torch.bfloat16
+    one_ulp(y16, y32, 'conv3 fwd')
+    one_ulp(dx16, dx32, 'conv3 dgrad')
+    one_ulp(acc16, acc32, 'conv3 dgrad accumulate')
+    # weight gradients: float slabs either way
+    jobs32 = [(dy, x, 3, 1, 1)]
+    H.WGRAD_BF16 = True
+    try:
+        (slab32,) = H.conv_wgrad_multi(jobs32)
+        dw32 = torch.zeros(co, ci, 3, device='cuda')
+        H.wgrad_reduce_multi([(slab32, dw32)], accumulate=False)
+        with storage(H, 'bf16'):
+            (slab16,) = H.conv_wgrad_multi([(dy.bfloat16(), x.bfloat16(), 3, 1, 1)])
+            dw16 = torch.zeros(co, ci, 3, device='cuda')
+            H.wgrad_reduce_multi([(slab16, dw16)], accumulate=False)
+    finally:
+        H.WGRAD_BF16 = False
+    assert torch.allclose(dw16, dw32, rtol=1e-5, atol=1e-4 * float(dw32.abs().max()))
+    if L % 2 == 0 and co == 2 * ci or (ci, co) == (64, 64):
+        # stride-2 block head (k3 s2 p1) + 1x1 downsample sharing one launch, and their data / weight gradients
+        co2 = 2 * ci
+        w1 = (torch.randn(co2, ci, 3, generator=g) * 0.05).cuda()
+        wdn = (torch.randn(co2, ci, 1, generator=g) * 0.05).cuda()
+        (_, _, f1, d1), (_, _, fd, dd) = H.repack_multi([w1, wdn], [16, 16])
+        dy2 = rnd((rows, L // 2, co2), 14)
+        a32, b32 = H.conv_fwd_bf16_s2(x, f1, fd)
+        g32 = H.conv_dgrad_bf16_s2(dy2, d1, L)
+        H.conv_dgrad_bf16_s2(dy2, dd, L, out=g32, accumulate=True)
+        H.WGRAD_BF16 = True
+        try:
+            s32 = H.conv_wgrad_multi([(dy2, x, 3, 2, 1), (dy2, x, 1, 2, 0)])
+            with storage(H, 'bf16'):
+                a16, b16 = H.conv_fwd_bf16_s2(x.bfloat16(), f1, fd)
+                g16 = H.conv_dgrad_bf16_s2(dy2.bfloat16(), d1, L)
+                g16_first = g16.clone()
+                H.conv_dgrad_bf16_s2(dy2.bfloat16(), dd, L, out=g16, accumulate=True)
+                s16 = H.conv_wgrad_multi([(dy2.bfloat16(), x.bfloat16(), 3, 2, 1), (dy2.bfloat16(), x.bfloat16(), 1, 2, 0)])
+        finally:
+            H.WGRAD_BF16 = False
+        one_ulp(a16, a32, 'stride-2 conv fwd')
+        one_ulp(b16, b32, 'downsample fwd')
+        # the accumulate form rounds twice under bf16 storage (the first launch stores bf16, the second adds to it): the
+        # error is one ulp of the FIRST term plus one of the sum -- judged against both (the sum may cancel)
+        assert g16_first.dtype == torch.bfloat16
+        err = (g16.float() - g32).abs()
+        tol = 1.5 * 2.0 ** -7 * (g16_first.float().abs() + g32.abs()) + 1e-6 * g32.abs().max()
+        assert not bool((err > tol).any()), 'stride-2 dgrad pair: %d elements beyond two roundings' % int((err > tol).sum())
+        for (sl16, *_), (sl32, *_) in zip(s16, s32):
+            assert torch.allclose(sl16, sl32, rtol=1e-5, atol=1e-4 * float(sl32.abs().max()) + 1e-6)
+
+
+def test_feature_boundary_and_refusals_bf16_storage(H):
+    x = rnd((40, 7, 512), 21)
+    f32 = H.global_avgpool_fwd(x)
+    d = torch.randn(40, 512, generator=torch.Generator().manual_seed(3)).cuda()
+    dx32 = H.global_avgpool_bwd(d, 7)
+    xl = rnd((40, 16, 512), 22)
+    s32 = H.avgpool_slide_fwd(xl, 7)
+    ds = torch.randn(tuple(s32.shape), generator=torch.Generator().manual_seed(4)).cuda()
+    dxl32 = H.avgpool_slide_bwd(ds, 16, 7, 512)
+    with storage(H, 'bf16'):
+        f16 = H.global_avgpool_fwd(x.bfloat16())
+        dx16 = H.global_avgpool_bwd(d, 7)
+        s16 = H.avgpool_slide_fwd(xl.bfloat16(), 7)
+        dxl16 = H.avgpool_slide_bwd(ds, 16, 7, 512)
+        assert f16.dtype == torch.float32 and torch.allclose(f16, f32, rtol=1e-6, atol=1e-6)     # features stay float
+        assert torch.allclose(s16, s32, rtol=1e-6, atol=1e-6)
+        one_ulp(dx16, dx32, 'global pool bwd')
+        one_ulp(dxl16, dxl32, 'sliding pool bwd')
+        # the float-activation kernels refuse to run on bf16 storage instead of misreading it
+        u = H.wino_weights(torch.randn(64, 64, 3).cuda())
+        with pytest.raises(H.HipError):
+            H.conv3_winograd(rnd((20, 56, 64), 5).bfloat16(), u)
+        with pytest.raises(H.HipError):
+            H.concat2(rnd((20, 56, 64), 5).bfloat16(), rnd((20, 56, 32), 6).bfloat16())
+        with pytest.raises(ValueError):
+            H.bn_fwd(rnd((20, 56, 64), 5), 20, torch.ones(64).cuda(), torch.zeros(64).cuda())   # float tensor, bf16 mode
+    assert H.act_dtype() == 'f32'
+
+
+def test_resnet18_bf16_storage_vs_rounding_oracle_and_training(H):
+    """cnn_linear + resnet18 with bf16 convs AND bf16 storage against the oracle with the same rounding model.  bf16 keeps
+    8 significant bits and every stored tensor is rounded: an element near a rounding boundary lands on either side
+    depending on the last bits of an fp32 sum, so agreement is statistical, not elementwise -- bounds (builder-stated,
+    parity unpinned): logits within 3e-2 of the same-rounding oracle and 5e-2 of the exact one, loss within 2e-2, every
+    parameter gradient rel-l2 < 0.6 (measured in the log); 12 SGD steps bring the loss down; DenseNet is refused."""
+    import deepards_amd.models as M
+    from deepards_amd import functional as F_
+    from deepards_amd.functional import bce_with_logits
+    from deepards_amd.train import HotPathTrainer
+    x, t = seeded_batch(3, 20, 11)
+    xt, tt = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    params = {k: v.astype(np.float64) for k, v in seeded_params('resnet18', 6).items()}
+    exact = np_ref.cnn_linear_forward_backward(params, x.astype(np.float64), t.astype(np.float64), need_grads=False)
+    ref = np_ref.cnn_linear_forward_backward(params, x.astype(np.float64), t.astype(np.float64), bf16_convs=True,
+                                             bf16_storage=True)
+
+    def build():
+        model = M.CNNLinearNetwork(M.resnet18(), 20, 0)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_params('resnet18', 6).items()}, strict=False)
+        return model.cuda().train()
+    F_.set_conv_dtype('bf16')
+    try:
+        F_.set_storage_dtype('bf16')
+        assert F_.storage_dtype() == 'bf16'
+        model = build()
+        out = model(xt, None)
+        assert out.dtype == torch.float32
+        loss = bce_with_logits(out, tt)
+        loss.backward()
+        logits = out.detach().cpu().numpy()
+        e_same, e_exact = np.abs(logits - ref['logits']).max(), np.abs(logits - exact['logits']).max()
+        worst = 0.0
+        for n, p in model.named_parameters():
+            if n in ref['grads']:
+                r = float(np.linalg.norm(p.grad.cpu().numpy() - ref['grads'][n]) / (np.linalg.norm(ref['grads'][n]) + 1e-30))
+                worst = max(worst, r)
+        log('resnet18 bf16 storage: logits vs same-rounding oracle %.3e, vs exact %.3e; loss %.5f vs %.5f; worst gradient '
+            'rel-l2 vs same-rounding oracle %.3e' % (e_same, e_exact, float(loss), ref['loss'], worst))
+        assert e_same < 3e-2 and e_exact < 5e-2 and abs(float(loss) - ref['loss']) < 2e-2 and worst < 0.6
+        tr = HotPathTrainer(build(), use_graph=True)
+        losses = [float(tr.train_step(xt, tt)) for _ in range(12)]
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+        loss_t, logits_t, pred = tr.test_step(xt, tt)
+        assert np.isfinite(float(loss_t)) and pred.shape == (3,)
+        dn = M.CNNLinearNetwork(M.densenet18(drop_rate=0.0), 20, 0).cuda().train()
+        with pytest.raises((NotImplementedError, H.HipError)):
+            dn(xt, None)                                    # no bf16-storage DenseNet (96-channel convs, concat kernels)
+    finally:
+        F_.set_conv_dtype('f32')
+    assert F_.storage_dtype() == 'f32' and F_.conv_dtype() == 'f32'
+    with torch.no_grad():                                   # the fp32 path is untouched by the excursion
+        assert np.abs(build()(xt, None).cpu().numpy() - exact['logits']).max() < 1e-4
