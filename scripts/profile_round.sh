@@ -7,7 +7,7 @@
 #   3. PMC passes FETCH_SIZE / WRITE_SIZE (separate runs)   -> gpurun_out/<tag>_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv, <tag>_traffic.json
 # Copy what should be judged from gpurun_out/ into profiles/.
 set -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 R=$(pwd)
 out=$R/gpurun_out
 mkdir -p $out
@@ -29,3 +29,13 @@ timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUS
 cd $R
 python scripts/pmc_mfma_busy.py $out/prof_mfma > $out/${tag}_pmc_mfma_busy.json
 rm -rf $out/prof_mfma
+# 5. the bf16 configuration (BASELINE configs[2]): bench line + kernel stats of `bench.py --dtype bf16`
+timeout -k 10 300 python bench.py --dtype bf16 --no-extra --no-cpu-baseline > $out/${tag}_bench_bf16.json 2> $out/${tag}_bench_bf16.err || { tail -5 $out/${tag}_bench_bf16.err; exit 1; }
+cd /tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_bf16 -- python3 $R/bench.py --dtype bf16 --no-extra --no-cpu-baseline > $out/${tag}_bench_bf16_under_rocprof.json 2> $out/prof_bf16.err || { tail -5 $out/prof_bf16.err; exit 1; }
+cp $(find $out/prof_bf16 -name '*kernel_stats.csv' | head -1) $out/${tag}_bf16_mode_kernel_stats.csv
+rm -rf $out/prof_bf16
+cd $R
+# 6. the C5 tile shape (BASELINE configs[4]: NB 40, L 512), fp32 and bf16
+timeout -k 10 300 python bench.py --nb 40 --seq-len 512 --no-cpu-baseline > $out/${tag}_bench_c5_f32.json 2> /dev/null
+timeout -k 10 300 python bench.py --nb 40 --seq-len 512 --dtype bf16 --no-cpu-baseline > $out/${tag}_bench_c5_bf16.json 2> /dev/null

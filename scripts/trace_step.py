@@ -4,7 +4,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-idx = [i for i, n in enumerate(names) if n.startswith('stem_conv_fwd')]
+idx = [i for i, n in enumerate(names) if 'stem_conv_fwd' in n]
 last = rows[idx[-1] - 2:]
 t0 = int(last[0]['Start_Timestamp'])
 agg, prev_end = {}, None
