@@ -160,6 +160,7 @@ class HotPathTrainer(object):
         self.last_logits = None
         self.allreduce_calls = 0
         self._synced = False
+        self._graph_opt_shared = None      # the captured update (data parallel): independent of the batch shape
 
     # ---- replicas ----------------------------------------------------------------------------
     def sync_replicas(self):
@@ -275,8 +276,6 @@ class HotPathTrainer(object):
                 self._graph_opt_shared = graph_opt
         ent = self._graphs[tuple(inputs.shape)] = (graph, static, static_out, graph_opt)
         return ent
-
-    _graph_opt_shared = None
 
     def _eager_single_gpu_parts(self, inputs, target):
         self.bucket.zero_grad()
