@@ -1,0 +1,36 @@
+"""RCCL smoke on ONE GPU: a world-size-1 'nccl' process group carries every collective the data-parallel path issues
+(flat fp32 / int64 broadcasts of sync_replicas, the seed broadcast of shared_generator, the sum all-reduce of the 15.5 MB
+gradient bucket between two graph replays, the float64 MAX all-reduce and the barrier of bench.py).  World size 1 moves no
+data between GPUs -- this only proves that the calls, dtypes and stream ordering are accepted by RCCL on this stack."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+os.environ.setdefault('MASTER_PORT', '29577')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+import deepards_amd.models as M
+from deepards_amd.train import HotPathTrainer, shared_generator
+model = M.CNNLinearNetwork(M.resnet18(), 20, 0).cuda()
+tr = HotPathTrainer(model, world_size=1, use_graph=True)
+tr.world_size = 2                       # take the data-parallel code paths (a lone rank "sums" its own gradients: x1)
+tr._synced = False
+tr.sync_replicas()
+g = shared_generator(tr, None)
+print('shared generator seed ok', torch.randperm(5, generator=g).tolist())
+x = torch.randn(8, 20, 1, 224, device='cuda'); t = torch.zeros(8, 2, device='cuda'); t[:, 0] = 1
+losses = [float(tr.train_step(x, t)) for _ in range(4)]
+print('losses', losses, 'allreduce calls', tr.allreduce_calls, 'graphs', len(tr._graphs))
+tt = torch.tensor([1.5], device='cuda', dtype=torch.float64)
+dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    tr.bucket.allreduce()
+torch.cuda.synchronize()
+print('all-reduce of %d bytes on a 1-rank RCCL group: %.3f ms each' % (tr.bucket.numel * 4, (time.perf_counter() - t0) / 20 * 1e3))
+assert all(l == l for l in losses) and tr.allreduce_calls == 4
+dist.destroy_process_group()
+print('rccl world-1 probe ok')

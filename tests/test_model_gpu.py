@@ -1191,3 +1191,21 @@ def test_densenet_dropout_on_against_the_oracle_with_the_device_masks(M):
     nodrop = np_ref.cnn_linear_forward_backward(params, x.astype(np.float64), t.astype(np.float64), backbone='densenet18',
                                                 need_grads=False)
     assert np.abs(nodrop['logits'] - ref['logits']).max() > 1e-3                             # the masks do matter
+
+
+def test_rccl_accepts_the_data_parallel_collectives_on_one_gpu():
+    """RCCL itself (backend 'nccl'), as far as ONE GPU can show it: a fresh process with a world-size-1 process group
+    issues every collective of the data-parallel path -- the fp32 / int64 broadcasts of sync_replicas, the seed broadcast
+    of shared_generator, the sum all-reduce of the flat gradient bucket between the two captured graphs, bench.py's
+    float64 MAX all-reduce and barrier (scripts/rccl_world1_probe.py).  No data crosses GPUs at world size 1; the
+    2-process tests above carry the real exchange over gloo.  What stays unmeasured until a multi-GPU node runs it is
+    RCCL's inter-GPU transport."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29600 + os.getpid() % 300))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'rccl_world1_probe.py')], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0 and 'rccl world-1 probe ok' in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
