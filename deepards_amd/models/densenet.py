@@ -7,29 +7,31 @@ module names (state_dict keys match), ``avgpool``, ``n_out_filters``, ``network_
 dropout stays active whenever the module is in training mode -- which is always on this path
 (SURVEY.md finding 4).  Compute runs in the HIP kernels via ``deepards_amd.functional``.
 """
-import math
 from collections import OrderedDict
 
 import torch
 import torch.nn as nn
 
 from .. import functional as F_
-from .resnet import _require_cuda
+from .resnet import _require_cuda, conv1d, init_like_reference
+
+
+def _bn(c):
+    return nn.BatchNorm1d(c, track_running_stats=False)        # densenet.py:107: always batch statistics
 
 
 class _DenseLayer(nn.Sequential):
+    """norm1 -> relu1 -> conv1 (1x1, to bn_size * growth) -> norm2 -> relu2 -> conv2 (k3, to growth) -> dropout -> cat:
+    the child names are the state_dict contract (reference models/densenet.py:18-33)."""
     num_layers = 2
 
-    def __init__(self, num_input_features, growth_rate, bn_size, drop_rate, track_running_stats):
+    def __init__(self, num_input_features, growth_rate, bn_size, drop_rate, track_running_stats=False):
         super(_DenseLayer, self).__init__()
-        self.add_module('norm1', nn.BatchNorm1d(num_input_features, track_running_stats=track_running_stats))
-        self.add_module('relu1', nn.ReLU(inplace=True))
-        self.add_module('conv1', nn.Conv1d(num_input_features, bn_size * growth_rate, kernel_size=1, stride=1,
-                                           bias=False))
-        self.add_module('norm2', nn.BatchNorm1d(bn_size * growth_rate, track_running_stats=track_running_stats))
-        self.add_module('relu2', nn.ReLU(inplace=True))
-        self.add_module('conv2', nn.Conv1d(bn_size * growth_rate, growth_rate, kernel_size=3, stride=1, padding=1,
-                                           bias=False))
+        mid = bn_size * growth_rate
+        for name, mod in (('norm1', _bn(num_input_features)), ('relu1', nn.ReLU(inplace=True)),
+                          ('conv1', conv1d(num_input_features, mid, 1)), ('norm2', _bn(mid)), ('relu2', nn.ReLU(inplace=True)),
+                          ('conv2', conv1d(mid, growth_rate, 3))):
+            self.add_module(name, mod)
         self.drop_rate = float(drop_rate)
 
     def conv_info(self):
@@ -44,34 +46,45 @@ class _DenseLayer(nn.Sequential):
 
 
 class _DenseBlock(nn.Sequential):
-    def __init__(self, num_layers, num_input_features, bn_size, growth_rate, drop_rate, track_running_stats):
+    def __init__(self, num_layers, num_input_features, bn_size, growth_rate, drop_rate, track_running_stats=False):
         super(_DenseBlock, self).__init__()
-        self.kernel_sizes, self.strides, self.paddings = [], [], []
         self.track_running_stats = track_running_stats
         for i in range(num_layers):
-            layer = _DenseLayer(num_input_features + i * growth_rate, growth_rate, bn_size, drop_rate,
-                                track_running_stats)
-            lks, ls, lp = layer.conv_info()
-            self.kernel_sizes.extend(lks)
-            self.strides.extend(ls)
-            self.paddings.extend(lp)
-            self.add_module('denselayer%d' % (i + 1), layer)
+            self.add_module('denselayer%d' % (i + 1),
+                            _DenseLayer(num_input_features + i * growth_rate, growth_rate, bn_size, drop_rate))
         self.num_layers = _DenseLayer.num_layers * num_layers
 
     def conv_info(self):
-        return self.kernel_sizes, self.strides, self.paddings
+        """(kernel sizes, strides, paddings) of the block's convs in order (protopnet's receptive-field bookkeeping)."""
+        ks, st, pd = [], [], []
+        for layer in self.children():
+            a, b, c = layer.conv_info()
+            ks, st, pd = ks + a, st + b, pd + c
+        return ks, st, pd
+
+    @property
+    def kernel_sizes(self):
+        return self.conv_info()[0]
+
+    @property
+    def strides(self):
+        return self.conv_info()[1]
+
+    @property
+    def paddings(self):
+        return self.conv_info()[2]
 
 
 class _Transition(nn.Sequential):
+    """norm -> relu -> conv (1x1, halves the channels) -> pool (AvgPool1d(2, 2)); reference models/densenet.py:68-79."""
     num_layers = 1
 
-    def __init__(self, num_input_features, num_output_features, track_running_stats):
+    def __init__(self, num_input_features, num_output_features, track_running_stats=False):
         super(_Transition, self).__init__()
-        self.add_module('norm', nn.BatchNorm1d(num_input_features, track_running_stats=track_running_stats))
-        self.add_module('relu', nn.ReLU(inplace=True))
-        self.add_module('conv', nn.Conv1d(num_input_features, num_output_features, kernel_size=1, stride=1,
-                                          bias=False))
-        self.add_module('pool', nn.AvgPool1d(kernel_size=2, stride=2))
+        for name, mod in (('norm', _bn(num_input_features)), ('relu', nn.ReLU(inplace=True)),
+                          ('conv', conv1d(num_input_features, num_output_features, 1)),
+                          ('pool', nn.AvgPool1d(kernel_size=2, stride=2))):
+            self.add_module(name, mod)
 
     def conv_info(self):
         return [1, 2], [1, 2], [0, 0]
@@ -115,6 +128,10 @@ class _Features(nn.Sequential):
 
 
 class DenseNet(nn.Module):
+    """DenseNet-BC on 1-D windows: stem (conv0 k7 s2, norm0, relu0, pool0), `block_config` dense blocks of growth-rate
+    layers with halving transitions between them, norm5.  Module names / order / shapes are the reference's
+    (densenet.py:83-166): 64 state_dict keys for cnn_linear + densenet18."""
+
     def __init__(self, growth_rate=32, block_config=(6, 12, 24, 16), num_init_features=64, bn_size=4,
                  drop_rate=0.2, num_classes=1000, with_fft=False, only_fft=False, fft_real_only=False):
         super(DenseNet, self).__init__()
@@ -122,56 +139,37 @@ class DenseNet(nn.Module):
             raise NotImplementedError('FFT input channels are outside the accelerated hot path (in_channels=1)')
         if growth_rate % 32 or (bn_size * growth_rate) % 32 or num_init_features % 32 or 256 % num_init_features:
             raise NotImplementedError('channel counts must be multiples of 32')
-        self.kernel_sizes, self.strides, self.paddings = [], [], []
-        self.n_layers = 0
-        self.inplanes = num_init_features
         self.drop_rate = drop_rate
-        track_running_stats = False
-        self.features = _Features(OrderedDict([
-            ('conv0', nn.Conv1d(1, num_init_features, kernel_size=7, stride=2, padding=3, bias=False)),
-            ('norm0', nn.BatchNorm1d(num_init_features, track_running_stats=track_running_stats)),
-            ('relu0', nn.ReLU(inplace=True)),
-            ('pool0', nn.MaxPool1d(kernel_size=3, stride=2, padding=1)),
-        ]))
-        self.kernel_sizes.extend([7, 3])
-        self.strides.extend([2, 2])
-        self.paddings.extend([3, 1])
-        num_features = num_init_features
-        for i, num_layers in enumerate(block_config):
-            block = _DenseBlock(num_layers=num_layers, num_input_features=num_features, bn_size=bn_size,
-                                growth_rate=growth_rate, drop_rate=drop_rate,
-                                track_running_stats=track_running_stats)
-            self.update_conv_info(block)
+        self.features = _Features(OrderedDict((
+            ('conv0', conv1d(1, num_init_features, 7, 2)), ('norm0', _bn(num_init_features)),
+            ('relu0', nn.ReLU(inplace=True)), ('pool0', nn.MaxPool1d(kernel_size=3, stride=2, padding=1)))))
+        width, self.n_layers = num_init_features, 0
+        for i, n in enumerate(block_config):
+            block = _DenseBlock(n, width, bn_size, growth_rate, drop_rate)
             self.features.add_module('denseblock%d' % (i + 1), block)
-            num_features = num_features + num_layers * growth_rate
-            if i != len(block_config) - 1:
-                trans = _Transition(num_input_features=num_features, num_output_features=num_features // 2,
-                                    track_running_stats=track_running_stats)
-                self.update_conv_info(trans)
-                self.n_layers += trans.num_layers
-                self.features.add_module('transition%d' % (i + 1), trans)
-                num_features = num_features // 2
-        self.features.add_module('norm5', nn.BatchNorm1d(num_features, track_running_stats=track_running_stats))
-        for m in self.modules():
-            if isinstance(m, nn.Conv1d):
-                n = m.kernel_size[0] * m.out_channels
-                m.weight.data.normal_(0, math.sqrt(2. / n))
-            elif isinstance(m, nn.BatchNorm1d):
-                nn.init.constant_(m.weight, 1)
-                nn.init.constant_(m.bias, 0)
-        self.n_out_filters = num_features
+            self.n_layers += block.num_layers
+            width += n * growth_rate
+            if i + 1 < len(block_config):                            # a transition halves the width between blocks
+                self.features.add_module('transition%d' % (i + 1), _Transition(width, width // 2))
+                self.n_layers += 2 * _Transition.num_layers          # the reference counts a transition twice (:137-140)
+                width //= 2
+        self.features.add_module('norm5', _bn(width))
+        init_like_reference(self)
+        self.inplanes = num_init_features
+        self.n_out_filters = width
         self.avgpool = nn.AvgPool1d(7, stride=1)
+        # the stem's (kernel, stride, padding) then every block's / transition's, as conv_info() reports them
+        self.kernel_sizes, self.strides, self.paddings = [7, 3], [2, 2], [3, 1]
+        for mod in self.features.children():
+            if isinstance(mod, (_DenseBlock, _Transition)):
+                ks, st, pd = mod.conv_info()
+                self.kernel_sizes += ks
+                self.strides += st
+                self.paddings += pd
         # device-resident dropout seed: bumped on the device each forward so a captured graph replays
         # with fresh masks
         self.features.drop_rate = drop_rate
         self.features.register_buffer('_drop_seed', torch.zeros(1, dtype=torch.int64), persistent=False)
-
-    def update_conv_info(self, obj):
-        bks, bs, bp = obj.conv_info()
-        self.n_layers += obj.num_layers
-        self.kernel_sizes.extend(bks)
-        self.strides.extend(bs)
-        self.paddings.extend(bp)
 
     def conv_info(self):
         return self.kernel_sizes, self.strides, self.paddings

@@ -20,33 +20,52 @@ def _require_cuda(x, what):
                            'CPU fallback' % (what, x.device))
 
 
+def conv1d(cin, cout, k, stride=1):
+    """Bias-free Conv1d with 'same'-style padding k // 2 (every conv of both backbones: k7 p3, k3 p1, k1 p0)."""
+    return nn.Conv1d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False)
+
+
+def init_like_reference(net):
+    """The reference's initialisation (resnet.py:115-121, densenet.py:155-164): conv weights N(0, sqrt(2 / (k * C_out))),
+    BatchNorm gamma 1 / beta 0."""
+    for m in net.modules():
+        if isinstance(m, nn.Conv1d):
+            m.weight.data.normal_(0, math.sqrt(2.0 / (m.kernel_size[0] * m.out_channels)))
+        elif isinstance(m, nn.BatchNorm1d):
+            m.weight.data.fill_(1)
+            m.bias.data.zero_()
+
+
 class BasicBlock(nn.Module):
+    """Parameter container of one residual block; child names and their order are the state_dict contract
+    (conv1, bn1, relu, conv2, bn2, downsample -- reference models/resnet.py:14-22)."""
     expansion = 1
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super(BasicBlock, self).__init__()
-        self.conv1 = nn.Conv1d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
-        self.bn1 = nn.BatchNorm1d(planes)
-        self.relu = nn.ReLU(inplace=True)
-        self.conv2 = nn.Conv1d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
-        self.bn2 = nn.BatchNorm1d(planes)
-        self.downsample = downsample
-        self.stride = stride
+        children = (('conv1', conv1d(inplanes, planes, 3, stride)), ('bn1', nn.BatchNorm1d(planes)),
+                    ('relu', nn.ReLU(inplace=True)), ('conv2', conv1d(planes, planes, 3)), ('bn2', nn.BatchNorm1d(planes)))
+        for name, mod in children:
+            self.add_module(name, mod)
+        self.downsample, self.stride = downsample, stride
 
     def forward_rlc(self, x, R):
         """x: (rows, L, C) channels-last; R rows per BatchNorm window."""
         ds = self.downsample
+        dsw = (None, None, None, None) if ds is None else (ds[0].weight, ds[1].weight, ds[1].bias, F_.BNState(ds[1]))
         return F_.BasicBlockFunction.apply(
-            x, self.conv1.weight, self.bn1.weight, self.bn1.bias,
-            self.conv2.weight, self.bn2.weight, self.bn2.bias,
-            None if ds is None else ds[0].weight,
-            None if ds is None else ds[1].weight,
-            None if ds is None else ds[1].bias,
-            self.stride, R, F_.BNState(self.bn1), F_.BNState(self.bn2),
-            None if ds is None else F_.BNState(ds[1]))
+            x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias,
+            dsw[0], dsw[1], dsw[2], self.stride, R, F_.BNState(self.bn1), F_.BNState(self.bn2), dsw[3])
+
+
+_POOLS = {'max': nn.MaxPool1d, 'avg': nn.AvgPool1d}
 
 
 class ResNet(nn.Module):
+    """Four stages of BasicBlocks behind a k7 s2 stem.  The module tree (names, order, shapes -- including the stem's
+    unused conv1_alt / conv2 / bn2, SURVEY finding 6) is the reference's (resnet.py:81-135): 129 state_dict keys for
+    cnn_linear + resnet18."""
+
     def __init__(self, block, layers, initial_planes=64, first_pool_type='max', double_conv_first=False):
         super(ResNet, self).__init__()
         if block is not BasicBlock:
@@ -55,47 +74,29 @@ class ResNet(nn.Module):
             raise NotImplementedError('double_conv_first is outside the accelerated hot path')
         if initial_planes not in (64, 128, 256):
             raise NotImplementedError('initial_planes must be 64, 128 or 256 on the accelerated path')
-        self.inplanes = initial_planes
-        self.expansion = block.expansion
-        self.conv1 = nn.Conv1d(1, self.inplanes, kernel_size=7, stride=2, padding=3, bias=False)
-        self.conv1_alt = nn.Conv1d(1, self.inplanes, kernel_size=3, stride=1, padding=1, bias=False)
-        self.bn1 = nn.BatchNorm1d(self.inplanes)
-        self.conv2 = nn.Conv1d(self.inplanes, self.inplanes, kernel_size=7, stride=2, padding=3, bias=False)
-        self.bn2 = nn.BatchNorm1d(self.inplanes)
-        self.double_conv_first = double_conv_first
-        self.relu = nn.ReLU(inplace=True)
-        if first_pool_type == 'max':
-            self.first_pool = nn.MaxPool1d(kernel_size=3, stride=2, padding=1)
-        elif first_pool_type == 'avg':
-            self.first_pool = nn.AvgPool1d(kernel_size=3, stride=2, padding=1)
-        else:
+        if first_pool_type not in _POOLS:
             raise ValueError('first_pool_type must be "max" or "avg"')
-        self.first_pool_type = first_pool_type
-        self.layer1 = self._make_layer(block, initial_planes, layers[0])
-        self.layer2 = self._make_layer(block, initial_planes * 2, layers[1], stride=2)
-        self.layer3 = self._make_layer(block, initial_planes * 4, layers[2], stride=2)
-        self.layer4 = self._make_layer(block, initial_planes * 8, layers[3], stride=2)
+        p = initial_planes
+        self.expansion, self.double_conv_first, self.first_pool_type = block.expansion, double_conv_first, first_pool_type
+        stem = (('conv1', conv1d(1, p, 7, 2)), ('conv1_alt', conv1d(1, p, 3)), ('bn1', nn.BatchNorm1d(p)),
+                ('conv2', conv1d(p, p, 7, 2)), ('bn2', nn.BatchNorm1d(p)), ('relu', nn.ReLU(inplace=True)),
+                ('first_pool', _POOLS[first_pool_type](kernel_size=3, stride=2, padding=1)))
+        for name, mod in stem:
+            self.add_module(name, mod)
+        width = p
+        for i, n_blocks in enumerate(layers):                       # stage i: p * 2^i planes, stride 2 from stage 2 on
+            planes, stride = p << i, (1 if i == 0 else 2)
+            out = planes * block.expansion
+            shortcut = None
+            if stride != 1 or width != out:
+                shortcut = nn.Sequential(conv1d(width, out, 1, stride), nn.BatchNorm1d(out))
+            stage = [block(width, planes, stride, shortcut)] + [block(out, planes) for _ in range(n_blocks - 1)]
+            self.add_module('layer%d' % (i + 1), nn.Sequential(*stage))
+            width = out
+        self.inplanes = width
         self.avgpool = nn.AvgPool1d(7, stride=1)
-        for m in self.modules():
-            if isinstance(m, nn.Conv1d):
-                n = m.kernel_size[0] * m.out_channels
-                m.weight.data.normal_(0, math.sqrt(2. / n))
-            elif isinstance(m, nn.BatchNorm1d):
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
-        self.n_out_filters = self.inplanes * block.expansion
-
-    def _make_layer(self, block, planes, blocks, stride=1):
-        downsample = None
-        if stride != 1 or self.inplanes != planes * block.expansion:
-            downsample = nn.Sequential(
-                nn.Conv1d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
-                nn.BatchNorm1d(planes * block.expansion))
-        layers = [block(self.inplanes, planes, stride, downsample)]
-        self.inplanes = planes * block.expansion
-        for _ in range(1, blocks):
-            layers.append(block(self.inplanes, planes))
-        return nn.Sequential(*layers)
+        init_like_reference(self)
+        self.n_out_filters = width
 
     def forward_windows(self, x, rows_per_window):
         """x: (rows, 1, L) with rows = windows * rows_per_window; BatchNorm statistics are taken per

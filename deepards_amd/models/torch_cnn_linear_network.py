@@ -17,110 +17,108 @@ import torch.nn as nn
 from .. import functional as F_
 
 
-class CNNLinearNetwork(nn.Module):
-    def __init__(self, breath_block, sequence_size, metadata_features):
-        super(CNNLinearNetwork, self).__init__()
-        self.seq_size = 224
-        self.breath_block = breath_block
-        self.n_sub_batches = sequence_size
-        self.metadata_features = metadata_features
-        self.linear_final = nn.Linear(self.breath_block.n_out_filters * sequence_size + metadata_features, 2)
+SEQ_LEN = 224                 # ARDSRawDataset.seq_len (dataset.py:345): the only row length the reference's heads accept
 
-    def forward(self, x, metadata):
-        # input should be in shape: (batches, breaths in seq, chans, 224)
-        if x.shape[-1] != 224:
-            raise Exception('input breaths must have sequence length of 224')
+
+class _WindowHead(nn.Module):
+    """What every head of the reference file shares: ``seq_size``, the ``breath_block`` child, a ``linear_final`` child
+    (attribute and state_dict names are the contract), the 224-sample check and the batched breath-block pass."""
+
+    def __init__(self, breath_block, head_inputs):
+        nn.Module.__init__(self)
+        self.seq_size = SEQ_LEN
+        self.breath_block = breath_block
+        self.linear_final = nn.Linear(head_inputs, 2)
+
+    def _features(self, x):
+        """x (B, NB, C, 224) -> (B, NB, features (B * NB, F)): all windows in one pass, BatchNorm still per window."""
+        if x.shape[-1] != SEQ_LEN:
+            raise Exception('input breaths must have sequence length of 224')        # the reference's message (:106-107)
         if x.shape[0] == 0:           # the reference indexes x[0] first (torch_cnn_linear_network.py:110)
             raise IndexError('index 0 is out of bounds for dimension 0 with size 0')
-        if self.metadata_features:
+        b, nb, c, l = x.shape
+        return b, nb, self.breath_block.forward_windows(x.reshape(b * nb, c, l), nb)
+
+    def _head(self, flat, layer=None):
+        layer = self.linear_final if layer is None else layer
+        return F_.Linear2Function.apply(flat, layer.weight, layer.bias)
+
+    @staticmethod
+    def _no_metadata(metadata_features):
+        if metadata_features:
             # the reference builds the head wider but never concatenates metadata -> shape error there too
             raise NotImplementedError('metadata_features > 0 is not runnable in the reference either '
                                       '(SURVEY.md finding 8)')
-        b, nb, c, l = x.shape
-        feat = self.breath_block.forward_windows(x.reshape(b * nb, c, l), nb)        # (B*NB, F)
-        flat = feat.view(b, nb * feat.shape[1])                                     # == view(-1) per window
-        return F_.Linear2Function.apply(flat, self.linear_final.weight, self.linear_final.bias)
+
+
+class CNNLinearNetwork(_WindowHead):
+    def __init__(self, breath_block, sequence_size, metadata_features):
+        _WindowHead.__init__(self, breath_block, breath_block.n_out_filters * sequence_size + metadata_features)
+        self.n_sub_batches, self.metadata_features = sequence_size, metadata_features
+
+    def forward(self, x, metadata):
+        b, nb, feat = self._features(x)
+        self._no_metadata(self.metadata_features)
+        return self._head(feat.view(b, nb * feat.shape[1]))                           # == view(-1) per window
 
 
 def _windows(model, x):
-    # input should be in shape: (batches, breaths in seq, chans, 224)
-    if x.shape[-1] != 224:
-        raise Exception('input breaths must have sequence length of 224')
-    if x.shape[0] == 0:           # the reference indexes x[0] first (torch_cnn_linear_network.py:110)
-        raise IndexError('index 0 is out of bounds for dimension 0 with size 0')
-    b, nb, c, l = x.shape
-    return b, nb, model.breath_block.forward_windows(x.reshape(b * nb, c, l), nb)    # (B*NB, F)
+    return model._features(x)
 
 
-class CNNLinearToMean(nn.Module):
+class CNNLinearToMean(_WindowHead):
     def __init__(self, breath_block):
-        super(CNNLinearToMean, self).__init__()
-        self.seq_size = 224
-        self.breath_block = breath_block
-        self.linear_final = nn.Linear(self.breath_block.n_out_filters, 2)
+        _WindowHead.__init__(self, breath_block, breath_block.n_out_filters)
 
     def forward(self, x, metadata):
-        b, nb, feat = _windows(self, x)
-        return F_.Linear2Function.apply(F_.WindowMeanFunction.apply(feat, nb), self.linear_final.weight,
-                                        self.linear_final.bias)
+        b, nb, feat = self._features(x)
+        return self._head(F_.WindowMeanFunction.apply(feat, nb))
 
 
-class CNNLinearComprToRF(nn.Module):
+class CNNLinearComprToRF(_WindowHead):
     def __init__(self, breath_block):
-        super(CNNLinearComprToRF, self).__init__()
-        self.seq_size = 224
-        self.breath_block = breath_block
-        self.linear_final = nn.Linear(self.breath_block.n_out_filters, 2)
+        _WindowHead.__init__(self, breath_block, breath_block.n_out_filters)
 
     def forward(self, x, metadata):
-        b, nb, feat = _windows(self, x)
-        return F_.Linear2Function.apply(F_.WindowMedianFunction.apply(feat, nb), self.linear_final.weight,
-                                        self.linear_final.bias)
+        b, nb, feat = self._features(x)
+        return self._head(F_.WindowMedianFunction.apply(feat, nb))
 
 
-class CNNSingleBreathLinearNetwork(nn.Module):
+class CNNSingleBreathLinearNetwork(_WindowHead):
     def __init__(self, breath_block):
-        super(CNNSingleBreathLinearNetwork, self).__init__()
-        self.seq_size = 224
-        self.breath_block = breath_block
-        self.linear_final = nn.Linear(self.breath_block.n_out_filters, 2)
+        _WindowHead.__init__(self, breath_block, breath_block.n_out_filters)
 
     def forward(self, x, metadata):
-        b, nb, feat = _windows(self, x)
-        return F_.Linear2Function.apply(feat, self.linear_final.weight, self.linear_final.bias).view(b, nb, 2)
+        b, nb, feat = self._features(x)
+        return self._head(feat).view(b, nb, 2)
 
 
-class CNNDoubleLinearNetwork(nn.Module):
+class CNNDoubleLinearNetwork(_WindowHead):
     def __init__(self, breath_block, sequence_size, metadata_features):
-        super(CNNDoubleLinearNetwork, self).__init__()
-        self.seq_size = 224
-        self.breath_block = breath_block
-        self.metadata_features = metadata_features
-        self.linear_intermediate = nn.Linear(self.breath_block.n_out_filters, 2)
+        nn.Module.__init__(self)
+        self.seq_size, self.breath_block, self.metadata_features = SEQ_LEN, breath_block, metadata_features
+        self.linear_intermediate = nn.Linear(breath_block.n_out_filters, 2)       # registered before linear_final (:79-80)
         self.linear_final = nn.Linear(2 * sequence_size + metadata_features, 2)
 
     def forward(self, x, metadata):
-        if self.metadata_features:
-            raise NotImplementedError('metadata_features > 0 is not runnable in the reference either '
-                                      '(SURVEY.md finding 8)')
-        b, nb, feat = _windows(self, x)
-        inter = F_.Linear2Function.apply(feat, self.linear_intermediate.weight, self.linear_intermediate.bias)
-        return F_.Linear2Function.apply(inter.view(b, nb * 2), self.linear_final.weight, self.linear_final.bias)
+        self._no_metadata(self.metadata_features)
+        b, nb, feat = self._features(x)
+        inter = self._head(feat, self.linear_intermediate)
+        return self._head(inter.view(b, nb * 2))
 
 
-class CNNLSTMNetwork(nn.Module):
+class CNNLSTMNetwork(_WindowHead):
     """reference models/torch_cnn_lstm_combo.py:6-50: breath block -> nn.LSTM over the NB breaths -> Linear(H, 2) per
     breath; returns (logits (B, NB, 2), (hx, cx)).  Metadata features are not on the accelerated path (NaN metadata =
     none, as the reference's default run)."""
 
     def __init__(self, breath_block, metadata_features, bm_to_linear, lstm_hidden_units):
-        super(CNNLSTMNetwork, self).__init__()
+        nn.Module.__init__(self)
         if metadata_features:
             raise NotImplementedError('metadata features are outside the accelerated path')
         if lstm_hidden_units % 8 or not 8 <= lstm_hidden_units <= 64:
             raise NotImplementedError('lstm_hidden_units must be a multiple of 8 in [8, 64] (defaults.yml: 16)')
-        self.seq_size = 224
-        self.breath_block = breath_block
+        self.seq_size, self.breath_block = SEQ_LEN, breath_block
         self.lstm_hidden_units = lstm_hidden_units
         self.lstm_layers = 1
         self.bm_to_linear = bm_to_linear
@@ -128,7 +126,7 @@ class CNNLSTMNetwork(nn.Module):
         self.linear_final = nn.Linear(lstm_hidden_units, 2)
 
     def forward(self, x, metadata, hx_cx=None):
-        b, nb, feat = _windows(self, x)
+        b, nb, feat = self._features(x)
         h0 = c0 = None
         if hx_cx is not None:
             h0 = hx_cx[0].detach().reshape(b, -1).contiguous()
