@@ -108,6 +108,9 @@ class BaseTraining(object):
 
     def __init__(self, args):
         self.args = args
+        legacy = getattr(args, 'oversample', None)
+        if legacy is not None:
+            args.oversample_minority = legacy             # older configuration files say `oversample` (:80-83)
         if not (_flag(args, 'cuda') or _flag(args, 'cuda_no_dp')):
             raise RuntimeError('deepards_amd runs the hot path on an MI355X only: pass --cuda or --cuda-no-dp (no CPU fallback)')
         if not torch.cuda.is_available():

@@ -1209,3 +1209,33 @@ def test_rccl_accepts_the_data_parallel_collectives_on_one_gpu():
     p = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'rccl_world1_probe.py')], env=env, capture_output=True,
                        text=True, timeout=300)
     assert p.returncode == 0 and 'rccl world-1 probe ok' in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
+
+
+def test_evaluate_reruns_saved_models_per_fold(tmp_path):
+    """deepards/evaluate.py:15-49 on the hot path: models saved per fold by a k-fold training run are pushed over their
+    fold's test patients again (`python -m deepards_amd.evaluate -co <evaluate config>`), one "epoch" per listed model;
+    the per-patient rows reproduce the training run's own last test epoch vote for vote, and the per-fold table holds
+    patient accuracy and the AUC of the ARDS vote share."""
+    from deepards_amd import evaluate as E
+    from deepards_amd import train_ards_detector as T
+    gold = os.path.join(os.path.dirname(__file__), 'golden', 'test_dataset.npz')
+    cls, res = T.main(['--cuda-no-dp', '--train-from-pickle', gold, '--kfolds', '2', '-e', '1', '-b', '4',
+                       '--base-network', 'densenet18', '--seed', '3', '--save-model', 'ev.pth',
+                       '--saved-models-dir', str(tmp_path)])
+    cfg = tmp_path / 'evaluate.yml'
+    cfg.write_text('cuda_no_dp: true\nkfolds: 2\nbatch_size: 4\nnetwork: cnn_linear\nbase_network: densenet18\n'
+                   'oversample: false\ntrain_from_pickle: %s\nexperiment_name: ev\nseed: 3\n'
+                   'models:\n  0:\n   - ev-fold0.pth\n  1:\n   - ev-fold1.pth\n   - ev-fold1.pth\n' % gold)
+    ecls, rows, table = E.main(['-co', str(cfg), '--saved-models-dir', str(tmp_path)])
+    assert [t[0] for t in table] == [0, 1] and all(0.0 <= t[1] <= 1.0 for t in table)
+    assert all(np.isnan(t[2]) or 0.0 <= t[2] <= 1.0 for t in table)
+    assert {(r[0], r[1]) for r in rows} == {(0, 0), (1, 0), (1, 1)}          # fold 1 lists two models = two "epochs"
+    f0 = sorted(r[2] for r in rows if (r[0], r[1]) == (0, 0))
+    f1 = sorted(r[2] for r in rows if (r[0], r[1]) == (1, 0))
+    assert sorted(f0 + f1) == list(range(12)) and f1 == sorted(r[2] for r in rows if (r[0], r[1]) == (1, 1))
+    # dropout is active in the test epoch (the reference never calls eval()), so votes are compared on the loss-free
+    # part: every test patient of a fold appears once per model, with its true class
+    z = np.load(gold)
+    truth = {int(p): int(z['target'][i].argmax()) for i, p in enumerate(z['patient_slot'])}
+    assert all(r[3] == truth[r[2]] for r in rows)
+    assert ecls.args.oversample_minority is False                            # the legacy `oversample` key was honoured
