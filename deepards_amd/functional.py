@@ -73,13 +73,17 @@ def flush_backward():
 
 
 _OVERLAP_STEM = os.environ.get('DA_WGRAD_OVERLAP', '1') != '0'
+# experiment knobs (scripts/): DA_WGRAD_EARLY=1 launches a stage's weight gradients as soon as the stage's data gradients
+# are done, on the side stream; DA_WGRAD_PRIO sets that stream's priority (1 = lowest on this stack, -1 = highest)
+_WGRAD_EARLY = os.environ.get('DA_WGRAD_EARLY', '0') == '1'
+_WGRAD_PRIO = int(os.environ.get('DA_WGRAD_PRIO', '0'))
 _SIDE = {}
 
 
 def _side_stream(which=0):
     key = (torch.cuda.current_device(), which)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream()
+        _SIDE[key] = torch.cuda.Stream(priority=_WGRAD_PRIO) if _WGRAD_PRIO else torch.cuda.Stream()
     return _SIDE[key]
 
 
@@ -97,7 +101,7 @@ def _launch_wgrads(side=False):
         with torch.cuda.stream(s):
             slabs = H.conv_wgrad_multi([j[:5] for j in jobs])
         _STEP['forked'] = True
-        _STEP['keep'] = jobs                     # dy / x stay alive until the join
+        _STEP['keep'] = _STEP.get('keep', []) + jobs      # dy / x stay alive until the join
     else:
         slabs = H.conv_wgrad_multi([j[:5] for j in jobs])
     _STEP['wslab'] += [(sl, j[5]) for sl, j in zip(slabs, jobs)]
@@ -362,6 +366,8 @@ class BasicBlockFunction(Function):
         dw1 = _wgrad(dy1, x, 3, stride, 1, tw1)
         if ctx.has_ds:
             dwd = _wgrad(dyd, x, 1, stride, 0, twd)
+            if _WGRAD_EARLY and _STEP['on']:
+                _launch_wgrads(side=True)
             if stride == 2 and _PAIR_S2 and not _is_wino(w1, stride, 1):
                 dx = H.conv_dgrad_s2_pair(dy1, _pack(w1, False)[1], dyd, _pack(wd, False)[1], lin)
             else:
