@@ -40,8 +40,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--backbone', default='resnet18', choices=['resnet18', 'densenet18'])
     ap.add_argument('--nb', type=int, default=20, help='sub-batch rows per window (BASELINE configs[4]: 40)')
     ap.add_argument('--seq-len', type=int, default=224, help='samples per row (BASELINE configs[4]: 512)')
