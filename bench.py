@@ -68,8 +68,8 @@ class KernelTimer(object):
     REPEAT = 8                              # launches per bracket in the repeated measurement
     REPEATED = ('da_conv3_winograd', 'da_conv3_winograd4', 'da_conv3_bf16')     # x,u,y,rows,L,ldx,C,ldy,N,accumulate,stream
 
-    def __init__(self, lib, torch):
-        self.lib, self.torch = lib, torch
+    def __init__(self, lib, torch, act_bytes=4.0):
+        self.lib, self.torch, self.act_bytes = lib, torch, act_bytes
         self.records = {}
         self.rep_records = {}
         self.orig = {}
@@ -101,7 +101,7 @@ class KernelTimer(object):
         """(algorithmic FLOPs, algorithmic HBM bytes) of one launch of C-ABI entry point `name` with ctypes args `a`.
         GEMM entries: the direct convolution's FLOPs and input + output + weights; bandwidth entries: every tensor
         they read or write, once."""
-        f = 4.0                                                               # bytes per element (fp32 storage)
+        f = self.act_bytes                                                    # bytes per activation element (storage)
         if name == 'da_conv_gemm':       # x,w,y,rows,Lm,Lsrc,ldx,C,Ldst,ldy,N,...,ntaps at index 14
             return (2.0 * a[3] * a[4] * a[7] * a[10] * a[14],
                     f * (a[3] * a[5] * a[7] + a[3] * a[4] * a[10] + a[14] * a[7] * a[10]))
@@ -238,13 +238,13 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(entry):
+def pmc_traffic(entry, mode=''):
     """HBM bytes per launch of the dominant kernel (C-ABI entry point `entry`) from the newest committed rocprofv3
     PMC passes (profiles/rNN_traffic.json), or None.  bench.py cannot run the profiler on itself
     (scripts/profile_round.sh re-collects them); the file carries the sha of the kernel sources it was profiled at,
     and the figure is dropped (null) when the sources have changed since or it is about another kernel."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic%s.json' % ('_' + mode if mode else ''))), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
@@ -257,7 +257,7 @@ def pmc_traffic(entry):
                 os.path.basename(path), d.get('csrc_sha16'), csrc_sha16())
         return ent['hbm_bytes_per_launch'], '%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, sources %s)' % (
             os.path.basename(path), d.get('csrc_sha16'))
-    return None, 'no profiles/r*_traffic.json'
+    return None, 'no profiles/r*_traffic%s.json' % ('_' + mode if mode else '')
 
 
 def np_isfinite(v):
@@ -460,7 +460,7 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         # instrumented EAGER steps: HIP events around every C-ABI launch, on the launch stream
-        kt = KernelTimer(lib, torch)
+        kt = KernelTimer(lib, torch, act_bytes=2.0 if F_.storage_dtype() == 'bf16' else 4.0)
         names = [n for n in _lib.SIGNATURES if n not in ('da_version', 'da_conv_wgrad_workspace', 'da_stem_wgrad_workspace', 'da_bn_workspace', 'da_debug_set', 'da_bn_chunks', 'da_conv_wgrad_splits', 'da_conv_wgrad_plan', 'da_bn_debug_two_stage', 'da_bn_debug_target_blocks', 'da_abi_sizes', 'da_wino_debug_tail', 'da_wino_debug_pchunk', 'da_wino_weights', 'da_wino4_weights',
                                                           'da_hip_runtime_symbol')]
         tr_e = HotPathTrainer(model, optimizer='sgd', use_graph=False)
@@ -506,13 +506,13 @@ def main():
         single_us = dom['avg_us']
         if 'rep_total_ms' in dom:                 # per-launch time from the 8-launch brackets (see KernelTimer._repeat)
             dom = dict(dom, total_ms=dom['rep_total_ms'], avg_us=dom['rep_avg_us'])
-        if dom['flops']:
+        if dom['flops'] and args.dtype == 'f32':
             ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
             peak, bound, unit = PEAK.get(dname, PEAK_FP32_MFMA_TFLOPS), 'mfma', 'TFLOP/s'
-        else:
+        else:                                     # bf16 arithmetic: every kernel of the step is priced against HBM
             ach = dom['bytes'] / (dom['total_ms'] * 1e-3) / 1e9
             peak, bound, unit = PEAK_HBM_GBS, 'hbm', 'GB/s'
-        traffic, traffic_note = pmc_traffic(dname)
+        traffic, traffic_note = pmc_traffic(dname, ('bf16' if F_.storage_dtype() == 'bf16' else 'bf16_f32storage') if args.dtype == 'bf16' else '')
         out['roofline'] = {'bound': bound, 'kernel': KERNEL_OF[dname], 'entry': dname,
                            'achieved': round(ach, 2), 'peak': peak, 'unit': unit,
                            'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_note,
@@ -524,7 +524,7 @@ def main():
         for k in cands:                           # every single-kernel entry against ITS roofline (eager, single brackets)
             v = summ[k]
             ms = v.get('rep_total_ms', v['total_ms'])
-            if v['flops']:
+            if v['flops'] and args.dtype == 'f32':
                 out['kernel_roofline'][k] = {'tflops': round(v['flops'] / ms / 1e9, 1),
                                              'frac': round(v['flops'] / ms / 1e9 / PEAK.get(k, PEAK_FP32_MFMA_TFLOPS), 3)}
             else:
@@ -551,7 +551,8 @@ def main():
                                                      'note': 'forward-only test step of %s, B=%d' % (args.backbone, B)}
         say('inference extra done')
 
-    if world == 1 and not args.no_extra and args.backbone == 'resnet18' and not c5_shape:
+    if world == 1 and not args.no_extra and args.backbone == 'resnet18' and args.dtype == 'f32' and not c5_shape:
+        # (fp32 only: densenet's 64+32k channel counts have no bf16 kernels)
         # secondary figure: the reference's DEFAULT backbone (defaults.yml:18), same step definition, dropout active
         torch.manual_seed(0)
         m2 = M.CNNLinearNetwork(M.densenet18(), 20, 0).to(dev)

@@ -3,7 +3,7 @@ FETCH_SIZE is doubled (gfx950 tallies 128-B read requests at 64 B, MI355X_MICROA
 WRITE_SIZE is taken as reported; both are in KiB.  Writes gpurun_out/<tag>_traffic.json: one record per C-ABI entry
 point that launches exactly one kernel (what bench.py's `roofline.traffic` looks up), stamped with the sha of the
 kernel sources it was measured at (bench.py drops the figure when the sources have changed since)."""
-import csv, glob, json, os, sys, collections
+import csv, glob, json, os, re, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,8 +14,17 @@ tag, fdir, wdir = sys.argv[1], sys.argv[2], sys.argv[3]
 ENTRY_KERNEL = {'da_conv3_winograd': ('conv3_wino_kernel', 'conv3_wino_bn_kernel'),
                 'da_conv3_winograd4': ('conv3_wino4k_kernel',),
                 'da_conv_gemm_multi': ('conv_gemm_multi_kernel',), 'da_conv3_bf16': ('conv3_bf16_kernel',),
+                'da_conv_bf16_multi': ('conv_bf16_gen_kernel',),
                 'da_pool_bwd': ('pool_bwd_kernel',), 'da_bn_fwd': ('bn_fwd_fused_kernel',),
                 'da_bn_bwd': ('bn_bwd_fused_kernel',)}
+
+
+def plain_name(n):
+    """Kernel name without signature; template instantiations arrive Itanium-mangled (_Z<len><name>I...) in this CSV."""
+    m = re.match(r'_Z(\d+)', n)
+    if m:
+        return n[m.end():m.end() + int(m.group(1))]
+    return n.split('(')[0].replace('void ', '')
 
 
 def per_kernel(d, counter):
@@ -23,14 +32,14 @@ def per_kernel(d, counter):
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] == counter:
-                acc[r['Kernel_Name'].split('(')[0].replace('void ', '')].append(float(r['Counter_Value']))
+                acc[plain_name(r['Kernel_Name'])].append(float(r['Counter_Value']))
     return acc
 
 
 acc = {}
 for counter, d in (('FETCH_SIZE', fdir), ('WRITE_SIZE', wdir)):
     acc[counter] = per_kernel(d, counter)
-    with open('gpurun_out/%s_pmc_%s_per_kernel.csv' % (tag, counter), 'w') as f:
+    with open('gpurun_out/%s_pmc_%s_per_kernel%s.csv' % (tag, counter, sys.argv[4] if len(sys.argv) > 4 else ''), 'w') as f:
         f.write('kernel,launches,mean_%s_kb_raw,total_kb_raw\n' % counter)
         for k, v in sorted(acc[counter].items(), key=lambda kv: -sum(kv[1])):
             f.write('"%s",%d,%.1f,%.1f\n' % (k, len(v), sum(v) / len(v), sum(v)))
@@ -49,5 +58,7 @@ res = {'csrc_sha16': csrc_sha16(), 'kernels': kernels,
               '--warmup 2 --no-graph --no-cpu-baseline --no-extra --no-roofline; FETCH_SIZE doubled per MI355X_MICROARCH.md '
               '(gfx950 reports half the bytes of 16-B/lane coalesced reads), WRITE_SIZE as reported; KB = 1024 B; per-launch '
               'means over all launches of the kernel in those runs'}
-json.dump(res, open('gpurun_out/%s_traffic.json' % tag, 'w'), indent=1)
+suffix = sys.argv[4] if len(sys.argv) > 4 else ''          # '_bf16': the passes ran `bench.py --dtype bf16`
+res['how'] = res['how'].replace('--no-roofline;', '--no-roofline%s;' % (' --dtype bf16' if suffix else ''))
+json.dump(res, open('gpurun_out/%s_traffic%s.json' % (tag, suffix), 'w'), indent=1)
 print(json.dumps(res))

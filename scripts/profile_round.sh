@@ -39,3 +39,11 @@ cd $R
 # 6. the C5 tile shape (BASELINE configs[4]: NB 40, L 512), fp32 and bf16
 timeout -k 10 300 python bench.py --nb 40 --seq-len 512 --no-cpu-baseline > $out/${tag}_bench_c5_f32.json 2> /dev/null
 timeout -k 10 300 python bench.py --nb 40 --seq-len 512 --dtype bf16 --no-cpu-baseline > $out/${tag}_bench_c5_bf16.json 2> /dev/null
+# 7. PMC traffic of the bf16 configuration (the dominant kernel there is conv3_bf16_kernel) -> <tag>_traffic_bf16.json
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/prof16_$c -- python3 $R/bench.py --dtype bf16 --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-extra --no-roofline --min-seconds 0 > $out/prof16_$c.log 2>&1 || { tail -5 $out/prof16_$c.log; exit 1; }
+done
+cd $R
+python scripts/pmc_traffic.py $tag $out/prof16_FETCH_SIZE $out/prof16_WRITE_SIZE _bf16
+rm -rf $out/prof16_FETCH_SIZE $out/prof16_WRITE_SIZE
