@@ -56,7 +56,7 @@ def parse():
     ap.add_argument('--storage', default=None, choices=['f32', 'bf16'],
                     help='activation storage under --dtype bf16: bf16 (default: BASELINE configs[2] / [4], bf16 storage with '
                          'fp32 statistics and accumulators) or f32 (round 1: bf16 operands only)')
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f32x3'],
                     help="arithmetic of the k3 s1 convs' forward / data gradient: f32 (the headline, BASELINE configs[1]) or "
                          "bf16 operands with fp32 sums (BASELINE configs[2])")
     return ap.parse_args()
@@ -66,7 +66,7 @@ class KernelTimer(object):
     """Wraps C-ABI entry points with HIP events recorded on the launch stream (eager mode only)."""
 
     REPEAT = 8                              # launches per bracket in the repeated measurement
-    REPEATED = ('da_conv3_winograd', 'da_conv3_winograd4', 'da_conv3_bf16')     # x,u,y,rows,L,ldx,C,ldy,N,accumulate,stream
+    REPEATED = ('da_conv3_winograd', 'da_conv3_winograd4', 'da_conv3_bf16', 'da_conv3_x3')     # x,u,y,rows,L,ldx,C,ldy,N,accumulate,stream
 
     def __init__(self, lib, torch, act_bytes=4.0):
         self.lib, self.torch, self.act_bytes = lib, torch, act_bytes
@@ -108,8 +108,8 @@ class KernelTimer(object):
         if name == 'da_conv_wgrad':      # dy,x,dw,ws,rows,Lm,Ldy,lddy,N,Lx,ldx,C,...,ntaps at index 15
             return (2.0 * a[4] * a[5] * a[8] * a[11] * a[15],
                     f * (a[4] * a[6] * a[8] + a[4] * a[9] * a[11] + a[15] * a[8] * a[11]))
-        if name in ('da_conv3_winograd', 'da_conv3_winograd4', 'da_conv3_bf16'):  # x,u,y,rows,L,ldx,C,ldy,N,accumulate
-            pts = {'da_conv3_winograd': 4, 'da_conv3_winograd4': 6, 'da_conv3_bf16': 1.5}[name]
+        if name in ('da_conv3_winograd', 'da_conv3_winograd4', 'da_conv3_bf16', 'da_conv3_x3'):  # x,u,y,rows,L,ldx,C,ldy,N,accumulate
+            pts = {'da_conv3_winograd': 4, 'da_conv3_winograd4': 6, 'da_conv3_bf16': 1.5, 'da_conv3_x3': 4.5}[name]
             return (2.0 * a[3] * a[4] * a[6] * a[8] * 3,
                     f * (a[3] * a[4] * a[6] + a[3] * a[4] * a[8] * (2 if a[9] else 1) + pts * a[6] * a[8]))
         if name == 'da_conv_wgrad_multi':   # jobs (host array of da_wgrad_job), n
@@ -306,8 +306,9 @@ def main():
 
     from deepards_amd import functional as F_
     F_.set_conv_dtype(args.dtype)
-    storage = args.storage or args.dtype
-    if args.dtype == 'f32' and storage != 'f32':
+    fp32like = args.dtype in ('f32', 'f32x3')            # f32x3: fp32-equivalent products on the bf16 pipe (opt-in)
+    storage = args.storage or ('f32' if fp32like else args.dtype)
+    if fp32like and storage != 'f32':
         raise SystemExit('--storage bf16 needs --dtype bf16')
     if args.backbone != 'resnet18':
         storage = 'f32'                                  # no bf16-storage DenseNet (96-channel convs)
@@ -403,10 +404,14 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': (('%s breath block + Linear(F*NB, 2) head (stated, not mirrored: the reference cannot run this shape), '
                                  'synthetic (B=%d per GPU, %d, 1, %d) train step, %s (tile shape of BASELINE configs[4])' %
-                                 (args.backbone, B, NB, SL, 'fp32' if args.dtype == 'f32' else 'bf16 MFMA operands / fp32 sums in the residual-block convs, %s activation storage, fp32 statistics' % storage))
+                                 (args.backbone, B, NB, SL, 'fp32' if args.dtype == 'f32' else 'fp32 via three-term bf16 splits (opt-in)' if args.dtype == 'f32x3' else 'bf16 MFMA operands / fp32 sums in the residual-block convs, %s activation storage, fp32 statistics' % storage))
                                 if c5_shape else
                                 ('cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) fp32 train step (BASELINE configs[1])'
                                  if args.dtype == 'f32' else
+                                 'cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) fp32 train step (BASELINE configs[1]); OPT-IN arithmetic: '
+                                 'the residual-block conv products as exact three-term bf16 splits (six bf16 MFMA products per multiply, '
+                                 'fp32 sums, fp32 storage) -- not the default path'
+                                 if args.dtype == 'f32x3' else
                                  'cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) train step, bf16 MFMA operands / fp32 sums in the '
                                  'residual-block convs (forward, data and weight gradient), ' + storage + ' activation storage, fp32 '
                                  'statistics / optimizer (BASELINE configs[2])') % (args.backbone, B)),
@@ -439,7 +444,7 @@ def main():
     step_flops = w['flops'] * B * NB
     step_bytes = (w['act_bytes'] * B * NB) + 8 * 4 * w['params']
     per_gpu_dt = dt / args.steps
-    if args.dtype == 'f32':
+    if fp32like:
         out['step_roofline'] = {
             'alg_tflops': round(step_flops / per_gpu_dt / 1e12, 2), 'peak_tflops_fp32_mfma': PEAK_FP32_MFMA_TFLOPS,
             'frac_compute': round(step_flops / per_gpu_dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -491,6 +496,8 @@ def main():
             'da_conv_gemm': 'conv_gemm_tailed_kernel<*> / conv_gemm_kernel<*> (conv fwd + dgrad implicit GEMM, v_mfma_f32_32x32x2_f32)',
             'da_conv_gemm_multi': 'conv_gemm_multi_kernel (stride-2 block heads + 1x1 downsamples, fwd + dgrad, v_mfma_f32_32x32x2_f32)',
             'da_conv3_bf16': 'conv3_bf16_kernel (k3 s1 conv forward + data gradient, v_mfma_f32_32x32x16_bf16)',
+            'da_conv3_x3': 'conv3_x3_kernel (k3 s1 conv forward + data gradient, fp32 products as six v_mfma_f32_32x32x16_bf16 of '
+                           'three-term splits; peak = the bf16 MFMA peak / 6)',
             'da_conv_bf16_multi': 'conv_bf16_gen_kernel<*> (stride-2 / 1x1 convs, bf16 operands)',
             'da_bn_fwd': 'bn_fwd_fused_kernel<*> (per-window BatchNorm (+ReLU)(+residual) forward, single pass)',
             'da_bn_fwd_mask': 'bn_fwd_fused_kernel<*> (block-output BatchNorm + residual + ReLU forward, ReLU bit mask)',
@@ -499,14 +506,15 @@ def main():
             'da_bn_bwd_add': 'bn_bwd_fused_kernel<*> (BatchNorm backward + concat pass-through)',
             'da_pool_bwd': 'pool_bwd_kernel (stem max/avg pool + ReLU backward)',
         }
-        PEAK = {'da_conv3_bf16': PEAK_BF16_MFMA_TFLOPS, 'da_conv_bf16_multi': PEAK_BF16_MFMA_TFLOPS}
+        PEAK = {'da_conv3_bf16': PEAK_BF16_MFMA_TFLOPS, 'da_conv_bf16_multi': PEAK_BF16_MFMA_TFLOPS,
+                'da_conv3_x3': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)}
         cands = [k for k in summ if k in KERNEL_OF and (summ[k]['flops'] or summ[k]['bytes'])]
         dname = max(cands, key=lambda k: summ[k].get('rep_total_ms', summ[k]['total_ms']))   # argmax over all of them
         dom = summ[dname]
         single_us = dom['avg_us']
         if 'rep_total_ms' in dom:                 # per-launch time from the 8-launch brackets (see KernelTimer._repeat)
             dom = dict(dom, total_ms=dom['rep_total_ms'], avg_us=dom['rep_avg_us'])
-        if dom['flops'] and args.dtype == 'f32':
+        if dom['flops'] and fp32like:
             ach = dom['flops'] / (dom['total_ms'] * 1e-3) / 1e12
             peak, bound, unit = PEAK.get(dname, PEAK_FP32_MFMA_TFLOPS), 'mfma', 'TFLOP/s'
         else:                                     # bf16 arithmetic: every kernel of the step is priced against HBM
@@ -524,7 +532,7 @@ def main():
         for k in cands:                           # every single-kernel entry against ITS roofline (eager, single brackets)
             v = summ[k]
             ms = v.get('rep_total_ms', v['total_ms'])
-            if v['flops'] and args.dtype == 'f32':
+            if v['flops'] and fp32like:
                 out['kernel_roofline'][k] = {'tflops': round(v['flops'] / ms / 1e9, 1),
                                              'frac': round(v['flops'] / ms / 1e9 / PEAK.get(k, PEAK_FP32_MFMA_TFLOPS), 3)}
             else:

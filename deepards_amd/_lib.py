@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libdeepards_hip.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'deepards_hip.h')
-SOURCES = ['conv_gemm.hip', 'conv_wino.hip', 'conv_bf16.hip', 'bn.hip', 'stem_pool.hip', 'head_optim.hip']
+SOURCES = ['conv_gemm.hip', 'conv_wino.hip', 'conv_bf16.hip', 'conv_x3.hip', 'bn.hip', 'stem_pool.hip', 'head_optim.hip']
 
 _P, _I, _F, _Z, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_uint
 _IP = ctypes.POINTER(ctypes.c_int)
@@ -88,6 +88,8 @@ SIGNATURES = {
     'da_conv3_winograd4': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'da_conv3_bf16': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'da_pack_conv3_bf16': (_I, [_P, _P, _P, _I, _I, _P]),
+    'da_conv3_x3': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'da_pack_conv3_x3': (_I, [_P, _P, _P, _I, _I, _P]),
     'da_conv_bf16_multi': (_I, [ctypes.POINTER(ConvJob), _I, _P]),
     'da_wino_debug_tail': (_I, [_I]),
     'da_wino_debug_pchunk': (_I, [_I]),

@@ -377,11 +377,52 @@ struct WgradBf16Args {
   FastDiv divLx2;       // modes 1 / 2: by 2 L + 2
 };
 
-#define WB_KP 64
-#define WB_PITCH 192
-#define WB_XPITCH2 160                                 // stride-2 X image: rows 2 apart per transposed read
-#define WB_X2ROWS (2 * WB_KP + 3)
-#define WB_LDS_BYTES (WB_KP * WB_PITCH + WB_X2ROWS * WB_XPITCH2)      // >= the stride-1 images
+// NS = 1: operands rounded to bf16 (conv dtype 'bf16').  NS = 3: fp32-equivalent products ("f32x3", conv_x3.hip): every
+// operand is split exactly into three bf16 terms kept in three channel planes of the image row, and a product is the six
+// MFMA products h h' + h m' + m h' + h l' + l h' + m m' (the dropped ones are below one fp32 rounding).  The K step is
+// 64 positions for NS = 1 and 32 for NS = 3 (three times the image bytes per position).
+template <int NS> struct WB {
+  static constexpr int KP = NS == 1 ? 64 : 32;
+  static constexpr int PITCH = NS * 128 + 64;            // 192 / 448: = 192 mod 256, the 4 rows of a transposed read fall on disjoint bank ranges
+  static constexpr int XPITCH2 = NS * 128 + 32;          // 160 / 416: stride-2 X image, rows 2 apart per transposed read
+  static constexpr int X2ROWS = 2 * KP + 3;
+  static constexpr int LDS_BYTES = KP * PITCH + ((KP + 2) * PITCH > X2ROWS * XPITCH2 ? (KP + 2) * PITCH : X2ROWS * XPITCH2);
+};
+
+// the NS bf16 terms of 4 channels (as bits), written to the planes of an image row at d
+template <typename AT, int NS> struct WBStage;
+template <typename AT> struct WBStage<AT, 1> {
+  static __device__ __forceinline__ void put(unsigned char* d, const typename Stage<AT>::reg& v) {
+    *reinterpret_cast<f32x2v*>(d) = Stage<AT>::bits(v);
+  }
+};
+template <> struct WBStage<float, 3> {
+  static __device__ __forceinline__ f32x4 widen(const f32x2v& b) {
+    const uint32_t u0 = __float_as_uint(b[0]), u1 = __float_as_uint(b[1]);
+    return f32x4{__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 << 16),
+                 __uint_as_float(u1 & 0xffff0000u)};
+  }
+  static __device__ __forceinline__ void put(unsigned char* d, const f32x4& v) {
+    const f32x2v h = cvt4_bf16(v);
+    const f32x4 r1 = v - widen(h);
+    const f32x2v m = cvt4_bf16(r1);
+    const f32x4 r2 = r1 - widen(m);
+    *reinterpret_cast<f32x2v*>(d) = h;
+    *reinterpret_cast<f32x2v*>(d + 128) = m;
+    *reinterpret_cast<f32x2v*>(d + 256) = cvt4_bf16(r2);
+  }
+};
+
+// acc += A B over the NS x NS split terms that matter (small terms first)
+template <int NS>
+__device__ __forceinline__ void wb_mfma(f32x16& acc, const f32x4* a, const f32x4* b) {
+#define WB_M(i, j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc, 0, 0, 0)
+  if (NS == 3) {
+    WB_M(2, 0); WB_M(0, 2); WB_M(1, 1); WB_M(1, 0); WB_M(0, 1);
+  }
+  WB_M(0, 0);
+#undef WB_M
+}
 
 __device__ __forceinline__ f32x2v ds_read_tr16(const unsigned char* p) {
   f32x2v v;
@@ -389,12 +430,13 @@ __device__ __forceinline__ f32x2v ds_read_tr16(const unsigned char* p) {
   return v;
 }
 
-template <typename AT>
+template <typename AT, int NS>
 __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const int block_id, unsigned char* lds) {
+  constexpr int KP = WB<NS>::KP, PITCH = WB<NS>::PITCH, NP = KP / 16;
   const AT* ady = reinterpret_cast<const AT*>(a.dy);
   const AT* axx = reinterpret_cast<const AT*>(a.x);
-  unsigned char* Ys = lds;                              // [64][192 B]  dY at padded positions k0 .. k0+63
-  unsigned char* Xs = lds + WB_KP * WB_PITCH;           // [66][192 B]  X at padded positions k0-1 .. k0+64
+  unsigned char* Ys = lds;                              // [KP][PITCH]      dY at padded positions k0 .. k0+KP-1
+  unsigned char* Xs = lds + KP * PITCH;                 // [KP + 2][PITCH]  X at padded positions k0-1 .. k0+KP
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntc = a.C >> 6, tiles = (a.N >> 6) * ntc;
@@ -404,10 +446,10 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const in
   const int L1 = a.L + 1;
 
   const int lq = tid & 15, lr = tid >> 4;               // loader: 16 rows x 16 channel quads per pass
-  typename Stage<AT>::reg ry[4], rx[5];
+  typename Stage<AT>::reg ry[NP], rx[NP + 1];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int Pp = k0 + lr + 16 * p;                  // padded position of dY row
       bool ok = Pp < k_end;
       const uint32_t sq = fdiv((uint32_t)(ok ? Pp : 0), a.divL1);
@@ -418,10 +460,10 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const in
       ry[p] = v;
     }
 #pragma unroll
-    for (int p = 0; p < 5; ++p) {
-      const int r = p < 4 ? lr + 16 * p : 64 + lr;      // image row; rows 64, 65 by the first 32 threads
+    for (int p = 0; p < NP + 1; ++p) {
+      const int r = p < NP ? lr + 16 * p : KP + lr;     // image row; rows KP, KP+1 by the first 32 threads
       const int Pp = k0 - 1 + r;
-      bool ok = Pp >= 0 && Pp < a.Kpad && (p < 4 || tid < 32);
+      bool ok = Pp >= 0 && Pp < a.Kpad && (p < NP || tid < 32);
       const uint32_t sq = fdiv((uint32_t)(ok ? Pp : 0), a.divL1);
       const int l = (ok ? Pp : 0) - (int)sq * L1;
       ok = ok && l < a.L;
@@ -435,8 +477,8 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const in
   // lane 4q + p of the group supplies the address of position row q, channels 4p .. 4p + 3
   const int wn = wave >> 1, wc = wave & 1;
   const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
-  const unsigned char* yfrag = Ys + (8 * (g >> 1) + tq) * WB_PITCH + (wn * 32 + 16 * (g & 1) + 4 * tp) * 2;
-  const unsigned char* xfrag = Xs + (8 * (g >> 1) + tq) * WB_PITCH + (wc * 32 + 16 * (g & 1) + 4 * tp) * 2;
+  const unsigned char* yfrag = Ys + (8 * (g >> 1) + tq) * PITCH + (wn * 32 + 16 * (g & 1) + 4 * tp) * 2;
+  const unsigned char* xfrag = Xs + (8 * (g >> 1) + tq) * PITCH + (wc * 32 + 16 * (g & 1) + 4 * tp) * 2;
 
   f32x16 acc[3];
 #pragma unroll
@@ -445,37 +487,70 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const in
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   if (k_beg < k_end) gload(k_beg);
-  for (int k0 = k_beg; k0 < k_end; k0 += WB_KP) {
+  for (int k0 = k_beg; k0 < k_end; k0 += KP) {
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      *reinterpret_cast<f32x2v*>(Ys + (lr + 16 * p) * WB_PITCH + lq * 8) = Stage<AT>::bits(ry[p]);
-      *reinterpret_cast<f32x2v*>(Xs + (lr + 16 * p) * WB_PITCH + lq * 8) = Stage<AT>::bits(rx[p]);
+    for (int p = 0; p < NP; ++p) {
+      WBStage<AT, NS>::put(Ys + (lr + 16 * p) * PITCH + lq * 8, ry[p]);
+      WBStage<AT, NS>::put(Xs + (lr + 16 * p) * PITCH + lq * 8, rx[p]);
     }
-    if (tid < 32) *reinterpret_cast<f32x2v*>(Xs + (64 + lr) * WB_PITCH + lq * 8) = Stage<AT>::bits(rx[4]);
+    if (tid < 32) WBStage<AT, NS>::put(Xs + (KP + lr) * PITCH + lq * 8, rx[NP]);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    if (k0 + WB_KP < k_end) gload(k0 + WB_KP);
+    if (k0 + KP < k_end) gload(k0 + KP);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kk = 0; kk < WB_KP / 16; ++kk) {
-      const unsigned char* yp = yfrag + kk * 16 * WB_PITCH;
-      const unsigned char* xp = xfrag + kk * 16 * WB_PITCH;
-      f32x2v y0 = ds_read_tr16(yp), y1 = ds_read_tr16(yp + 4 * WB_PITCH);
-      f32x2v b0[3], b1[3];
+    for (int kk = 0; kk < (NS == 1 ? KP / 16 : 0); ++kk) {
+      const unsigned char* yp = yfrag + kk * 16 * PITCH;
+      const unsigned char* xp = xfrag + kk * 16 * PITCH;
+      {
+        f32x2v y0 = ds_read_tr16(yp), y1 = ds_read_tr16(yp + 4 * PITCH);
+        f32x2v b0[3], b1[3];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {                     // X image row j + t holds the position dY row j meets at tap t
-        b0[t] = ds_read_tr16(xp + t * WB_PITCH);
-        b1[t] = ds_read_tr16(xp + (t + 4) * WB_PITCH);
+        for (int t = 0; t < 3; ++t) {                   // X image row j + t holds the position dY row j meets at tap t
+          b0[t] = ds_read_tr16(xp + t * PITCH);
+          b1[t] = ds_read_tr16(xp + (t + 4) * PITCH);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(y0), "+v"(y1), "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]), "+v"(b1[2]));
+        const f32x4 av = {y0[0], y0[1], y1[0], y1[1]};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const f32x4 bv = {b0[t][0], b0[t][1], b1[t][0], b1[t][1]};
+          wb_mfma<1>(acc[t], &av, &bv);
+        }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(y0), "+v"(y1), "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]), "+v"(b1[2]));
-      const f32x4 av = {y0[0], y0[1], y1[0], y1[1]};
+    }
+    if constexpr (NS > 1) {
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const f32x4 bv = {b0[t][0], b0[t][1], b1[t][0], b1[t][1]};
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
-                                                         acc[t], 0, 0, 0);
+      for (int kk = 0; kk < KP / 16; ++kk) {
+        const unsigned char* yp = yfrag + kk * 16 * PITCH;
+        const unsigned char* xp = xfrag + kk * 16 * PITCH;
+        f32x2v y0[NS], y1[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          y0[s] = ds_read_tr16(yp + s * 128);
+          y1[s] = ds_read_tr16(yp + 4 * PITCH + s * 128);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          f32x2v b0[NS], b1[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            b0[s] = ds_read_tr16(xp + t * PITCH + s * 128);
+            b1[s] = ds_read_tr16(xp + (t + 4) * PITCH + s * 128);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(y0[0]), "+v"(y1[0]), "+v"(y0[NS / 2]), "+v"(y1[NS / 2]), "+v"(y0[NS - 1]), "+v"(y1[NS - 1]),
+                         "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[NS / 2]), "+v"(b1[NS / 2]), "+v"(b0[NS - 1]), "+v"(b1[NS - 1]));
+          f32x4 av[NS], bv[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            av[s] = f32x4{y0[s][0], y0[s][1], y1[s][0], y1[s][1]};
+            bv[s] = f32x4{b0[s][0], b0[s][1], b1[s][0], b1[s][1]};
+          }
+          wb_mfma<NS>(acc[t], av, bv);
+        }
       }
     }
   }
@@ -498,12 +573,13 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const in
 // (slot 0 and slot Lx + 1 zero) the input slot of (P', t) is Q' = 2 P' + t -- linear, so the X image of a K step is the
 // contiguous range Q' = 2 k0 .. 2 k0 + 130 and a transposed read takes rows 2 apart (160-byte rows keep its 4 rows on
 // disjoint banks).
-template <int NTAPS, typename AT>
+template <int NTAPS, typename AT, int NS>
 __device__ __forceinline__ void wgrad_bf16_s2_body(const WgradBf16Args& a, const int block_id, unsigned char* lds) {
+  constexpr int KP = WB<NS>::KP, PITCH = WB<NS>::PITCH, XPITCH2 = WB<NS>::XPITCH2, X2ROWS = WB<NS>::X2ROWS, NP = KP / 16;
   const AT* ady = reinterpret_cast<const AT*>(a.dy);
   const AT* axx = reinterpret_cast<const AT*>(a.x);
-  unsigned char* Ys = lds;                              // [64][192 B]
-  unsigned char* Xs = lds + WB_KP * WB_PITCH;           // [131][160 B]: input slots 2 k0 .. 2 k0 + 130
+  unsigned char* Ys = lds;                              // [KP][PITCH]
+  unsigned char* Xs = lds + KP * PITCH;                 // [2 KP + 3][XPITCH2]: input slots 2 k0 .. 2 k0 + 2 KP + 2
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntc = a.C >> 6, tiles = (a.N >> 6) * ntc;
@@ -513,11 +589,11 @@ __device__ __forceinline__ void wgrad_bf16_s2_body(const WgradBf16Args& a, const
   const int L1 = a.L + 1, Lx = 2 * a.L, Lx2 = Lx + 2;
 
   const int lq = tid & 15, lr = tid >> 4;
-  constexpr int NXP = (WB_X2ROWS + 15) / 16;            // 9 passes of 16 rows, the last one 3 rows
-  typename Stage<AT>::reg ry[4], rx[NXP];
+  constexpr int NXP = (X2ROWS + 15) / 16;               // passes of 16 rows, the last one 3 rows
+  typename Stage<AT>::reg ry[NP], rx[NXP];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int Pp = k0 + lr + 16 * p;
       bool ok = Pp < k_end;
       const uint32_t sq = fdiv((uint32_t)(ok ? Pp : 0), a.divL1);
@@ -531,7 +607,7 @@ __device__ __forceinline__ void wgrad_bf16_s2_body(const WgradBf16Args& a, const
     for (int p = 0; p < NXP; ++p) {
       const int r = lr + 16 * p;
       const long Qp = 2l * k0 + r;                      // padded input slot
-      bool ok = r < WB_X2ROWS && Qp < 2l * a.Kpad;
+      bool ok = r < X2ROWS && Qp < 2l * a.Kpad;
       const uint32_t sq = fdiv((uint32_t)(ok ? Qp : 0), a.divLx2);
       const int sl = (int)((ok ? Qp : 0) - (long)sq * Lx2);
       ok = ok && sl >= 1 && sl <= Lx;
@@ -543,8 +619,8 @@ __device__ __forceinline__ void wgrad_bf16_s2_body(const WgradBf16Args& a, const
 
   const int wn = wave >> 1, wc = wave & 1;
   const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
-  const unsigned char* yfrag = Ys + (8 * (g >> 1) + tq) * WB_PITCH + (wn * 32 + 16 * (g & 1) + 4 * tp) * 2;
-  const unsigned char* xfrag = Xs + 2 * (8 * (g >> 1) + tq) * WB_XPITCH2 + (wc * 32 + 16 * (g & 1) + 4 * tp) * 2;
+  const unsigned char* yfrag = Ys + (8 * (g >> 1) + tq) * PITCH + (wn * 32 + 16 * (g & 1) + 4 * tp) * 2;
+  const unsigned char* xfrag = Xs + 2 * (8 * (g >> 1) + tq) * XPITCH2 + (wc * 32 + 16 * (g & 1) + 4 * tp) * 2;
 
   f32x16 acc[NTAPS];
 #pragma unroll
@@ -553,43 +629,77 @@ __device__ __forceinline__ void wgrad_bf16_s2_body(const WgradBf16Args& a, const
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   if (k_beg < k_end) gload(k_beg);
-  for (int k0 = k_beg; k0 < k_end; k0 += WB_KP) {
+  for (int k0 = k_beg; k0 < k_end; k0 += KP) {
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x2v*>(Ys + (lr + 16 * p) * WB_PITCH + lq * 8) = Stage<AT>::bits(ry[p]);
+    for (int p = 0; p < NP; ++p) WBStage<AT, NS>::put(Ys + (lr + 16 * p) * PITCH + lq * 8, ry[p]);
 #pragma unroll
     for (int p = 0; p < NXP; ++p) {
       const int r = lr + 16 * p;
-      if (r < WB_X2ROWS) *reinterpret_cast<f32x2v*>(Xs + r * WB_XPITCH2 + lq * 8) = Stage<AT>::bits(rx[p]);
+      if (r < X2ROWS) WBStage<AT, NS>::put(Xs + r * XPITCH2 + lq * 8, rx[p]);
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    if (k0 + WB_KP < k_end) gload(k0 + WB_KP);
+    if (k0 + KP < k_end) gload(k0 + KP);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kk = 0; kk < WB_KP / 16; ++kk) {
-      const unsigned char* yp = yfrag + kk * 16 * WB_PITCH;
-      const unsigned char* xp = xfrag + kk * 32 * WB_XPITCH2;
-      f32x2v y0 = ds_read_tr16(yp), y1 = ds_read_tr16(yp + 4 * WB_PITCH);
-      f32x2v b0[NTAPS], b1[NTAPS];
+    for (int kk = 0; kk < (NS == 1 ? KP / 16 : 0); ++kk) {
+      const unsigned char* yp = yfrag + kk * 16 * PITCH;
+      const unsigned char* xp = xfrag + kk * 32 * XPITCH2;
+      {
+        f32x2v y0 = ds_read_tr16(yp), y1 = ds_read_tr16(yp + 4 * PITCH);
+        f32x2v b0[NTAPS], b1[NTAPS];
 #pragma unroll
-      for (int t = 0; t < NTAPS; ++t) {                 // input slot of (output row j, tap t) = 2 j + t (k1: t = 1)
-        const int tt = NTAPS == 1 ? 1 : t;
-        b0[t] = ds_read_tr16(xp + tt * WB_XPITCH2);
-        b1[t] = ds_read_tr16(xp + (tt + 8) * WB_XPITCH2);
+        for (int t = 0; t < NTAPS; ++t) {               // input slot of (output row j, tap t) = 2 j + t (k1: t = 1)
+          const int tt = NTAPS == 1 ? 1 : t;
+          b0[t] = ds_read_tr16(xp + tt * XPITCH2);
+          b1[t] = ds_read_tr16(xp + (tt + 8) * XPITCH2);
+        }
+        if (NTAPS == 3)
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(y0), "+v"(y1), "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[NTAPS - 1]), "+v"(b1[NTAPS - 1]),
+                         "+v"(b0[NTAPS / 2]), "+v"(b1[NTAPS / 2]));
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y0), "+v"(y1), "+v"(b0[0]), "+v"(b1[0]));
+        const f32x4 av = {y0[0], y0[1], y1[0], y1[1]};
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+          const f32x4 bv = {b0[t][0], b0[t][1], b1[t][0], b1[t][1]};
+          wb_mfma<1>(acc[t], &av, &bv);
+        }
       }
-      if (NTAPS == 3)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(y0), "+v"(y1), "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[NTAPS - 1]), "+v"(b1[NTAPS - 1]),
-                       "+v"(b0[NTAPS / 2]), "+v"(b1[NTAPS / 2]));
-      else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y0), "+v"(y1), "+v"(b0[0]), "+v"(b1[0]));
-      const f32x4 av = {y0[0], y0[1], y1[0], y1[1]};
+    }
+    if constexpr (NS > 1) {
 #pragma unroll
-      for (int t = 0; t < NTAPS; ++t) {
-        const f32x4 bv = {b0[t][0], b0[t][1], b1[t][0], b1[t][1]};
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
-                                                         acc[t], 0, 0, 0);
+      for (int kk = 0; kk < KP / 16; ++kk) {
+        const unsigned char* yp = yfrag + kk * 16 * PITCH;
+        const unsigned char* xp = xfrag + kk * 32 * XPITCH2;
+        f32x2v y0[NS], y1[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          y0[s] = ds_read_tr16(yp + s * 128);
+          y1[s] = ds_read_tr16(yp + 4 * PITCH + s * 128);
+        }
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+          const int tt = NTAPS == 1 ? 1 : t;       // input slot of (output row j, tap t) = 2 j + t (k1: t = 1)
+          f32x2v b0[NS], b1[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            b0[s] = ds_read_tr16(xp + tt * XPITCH2 + s * 128);
+            b1[s] = ds_read_tr16(xp + (tt + 8) * XPITCH2 + s * 128);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(y0[0]), "+v"(y1[0]), "+v"(y0[NS / 2]), "+v"(y1[NS / 2]), "+v"(y0[NS - 1]), "+v"(y1[NS - 1]),
+                         "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[NS / 2]), "+v"(b1[NS / 2]), "+v"(b0[NS - 1]), "+v"(b1[NS - 1]));
+          f32x4 av[NS], bv[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            av[s] = f32x4{y0[s][0], y0[s][1], y1[s][0], y1[s][1]};
+            bv[s] = f32x4{b0[s][0], b0[s][1], b1[s][0], b1[s][1]};
+          }
+          wb_mfma<NS>(acc[t], av, bv);
+        }
       }
     }
   }
@@ -612,15 +722,15 @@ struct WgradBf16Table {
   int n;
 };
 
-template <typename AT>
+template <typename AT, int NS>
 __global__ __launch_bounds__(256) void wgrad_bf16_multi_kernel(WgradBf16Table t) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[WB_LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[WB<NS>::LDS_BYTES];
   int i = 0;
   while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
   const int b = xcd_chunked_bf(blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i]);   // a split's tiles share an XCD
-  if (t.d[i].mode == 0) wgrad_bf16_body<AT>(t.d[i], b, lds);
-  else if (t.d[i].mode == 1) wgrad_bf16_s2_body<3, AT>(t.d[i], b, lds);
-  else wgrad_bf16_s2_body<1, AT>(t.d[i], b, lds);
+  if (t.d[i].mode == 0) wgrad_bf16_body<AT, NS>(t.d[i], b, lds);
+  else if (t.d[i].mode == 1) wgrad_bf16_s2_body<3, AT, NS>(t.d[i], b, lds);
+  else wgrad_bf16_s2_body<1, AT, NS>(t.d[i], b, lds);
 }
 
 // jobs the bf16 kernels take: channel counts multiples of 64 and  k3 s1 p1 | k3 s2 p1 | k1 s2 p0 (even input length)
@@ -640,20 +750,22 @@ void bf16_wgrad_plan(int rows, int L, int* splits, int* pchunk) {
   const long K = (long)rows * (L + 1);
   long sp = (K + g_wb_pchunk - 1) / g_wb_pchunk;
   if (sp < 1) sp = 1;
-  long pc = ((K + sp - 1) / sp + WB_KP - 1) / WB_KP * WB_KP;
-  if (pc < WB_KP) pc = WB_KP;
+  long pc = ((K + sp - 1) / sp + 63) / 64 * 64;          // a multiple of both K steps (64 / 32 positions)
+  if (pc < 64) pc = 64;
   *splits = (int)((K + pc - 1) / pc > 0 ? (K + pc - 1) / pc : 1);
   *pchunk = (int)pc;
 }
 
-int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s) {
+// jobs flagged `code` (16: bf16 operands; 48: fp32-equivalent split-bf16 products, fp32 activations only)
+int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, int code, hipStream_t s) {
   WgradBf16Table t;
   int cnt = 0, blocks = 0;
   auto flush = [&]() -> int {
     if (!cnt) return DA_OK;
     t.n = cnt;
     t.first_block[cnt] = blocks;
-    DA_ACT_DISPATCH(hipLaunchKernelGGL(wgrad_bf16_multi_kernel<AT>, dim3(blocks), dim3(256), 0, s, t));
+    if (code == 48) hipLaunchKernelGGL((wgrad_bf16_multi_kernel<float, 3>), dim3(blocks), dim3(256), 0, s, t);
+    else DA_ACT_DISPATCH(hipLaunchKernelGGL((wgrad_bf16_multi_kernel<AT, 1>), dim3(blocks), dim3(256), 0, s, t));
     DA_CHECK_LAUNCH();
     cnt = 0;
     blocks = 0;
@@ -661,7 +773,8 @@ int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s) {
   };
   for (int i = 0; i < n; ++i) {
     const da_wgrad_job& j = jobs[i];
-    if (j.winograd != 16) continue;
+    if (j.winograd != code) continue;
+    if (code == 48 && g_act_bf16) return DA_EINVAL;      // the split kernels read fp32 activations
     int splits, pchunk;
     bf16_wgrad_plan(j.rows, j.Lm, &splits, &pchunk);
     WgradBf16Args& a = t.d[cnt];

@@ -117,20 +117,22 @@ _WINO4_MIN_C = int(os.environ.get('DA_WINO4_MINC', '512'))   # channels from whi
 
 
 # Arithmetic of the k3 s1 p1 convs' forward / data gradient: 'f32' (default: Winograd on the fp32 matrix cores, the
-# path every 1e-4 parity claim is about) or 'bf16' (BASELINE config C3: operands rounded to bf16, fp32 sums, conv_bf16.hip;
-# also the k3 s1 weight gradients unless DA_WGRAD_BF16=0).
+# path every 1e-4 parity claim is about), 'bf16' (BASELINE config C3: operands rounded to bf16, fp32 sums, conv_bf16.hip;
+# also the k3 s1 weight gradients unless DA_WGRAD_BF16=0) or 'f32x3' (fp32-equivalent products from exact three-term
+# bf16 splits on the bf16 matrix cores, conv_x3.hip; the weight gradients too with DA_WGRAD_X3=1).
 _CONV_DTYPE = os.environ.get('DA_CONV_DTYPE', 'f32')
 
 
 def set_conv_dtype(name):
-    """'f32' or 'bf16' (see _CONV_DTYPE); captured steps keep the arithmetic they were captured with."""
+    """'f32', 'bf16' or 'f32x3' (see _CONV_DTYPE); captured steps keep the arithmetic they were captured with."""
     global _CONV_DTYPE
-    if name not in ('f32', 'bf16'):
-        raise ValueError("conv dtype must be 'f32' or 'bf16'")
-    if name == 'f32' and H.act_dtype() == 'bf16':
+    if name not in ('f32', 'bf16', 'f32x3'):
+        raise ValueError("conv dtype must be 'f32', 'bf16' or 'f32x3'")
+    if name != 'bf16' and H.act_dtype() == 'bf16':
         H.set_act_dtype('f32')                     # fp32 convs read fp32 activations
     _CONV_DTYPE = name
     H.WGRAD_BF16 = name == 'bf16' and os.environ.get('DA_WGRAD_BF16', '1') != '0'
+    H.WGRAD_X3 = name == 'f32x3' and os.environ.get('DA_WGRAD_X3', '0') != '0'
 
 
 def conv_dtype():
@@ -164,6 +166,8 @@ def _is_wino(w, stride, pad):
         return 16                                   # also the stride-2 block heads and 1x1 downsamples (even lengths)
     if not (w.shape[2] == 3 and stride == 1 and pad == 1 and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0):
         return 0
+    if _CONV_DTYPE == 'f32x3' and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
+        return 48                                   # split-bf16 products, direct form (conv_x3.hip)
     if not _WINOGRAD:
         return 0
     return 6 if min(w.shape[0], w.shape[1]) >= _WINO4_MIN_C else 4
@@ -173,9 +177,10 @@ def _pack(w, code):
     """(wf, wd, uf, ud) of a conv weight: direct packs (code 0), Winograd taps or bf16 tap packs (in the uf / ud
     places), repacked once per step."""
     e = _STEP['pack'].get(w.data_ptr()) if _STEP['on'] else None
-    want = w.shape[2] if code == 16 else (code if code else 0)
+    want = w.shape[2] if code in (16, 48) else (code if code else 0)
     if e is None or (e[2] is None if code else e[0] is None) or \
-            (code and (e[2].shape[0] != want or (e[2].dtype == torch.bfloat16) != (code == 16))):
+            (code and (e[2].shape[0] != want or (e[2].dtype == torch.bfloat16) != (code in (16, 48)) or
+                      (e[2].dim() == 6) != (code == 48))):
         e = H.repack_multi([w], [code])[0]
         if _STEP['on']:
             _STEP['pack'][w.data_ptr()] = e
@@ -195,6 +200,8 @@ def _conv_fwd(x, w, stride, pad):
     _need_bf16_kernel(code, w, stride, pad)
     if code == 16:
         return H.conv3_bf16(x, _pack(w, code)[2]) if stride == 1 else H.conv_fwd_bf16_s2(x, _pack(w, code)[2])
+    if code == 48:
+        return H.conv3_x3(x, _pack(w, code)[2])
     if code:
         return H.conv3_winograd(x, _pack(w, code)[2])
     return H.conv_fwd(x, _pack(w, 0)[0], stride, pad)
@@ -209,6 +216,8 @@ def _conv_dgrad(dy, w, stride, pad, l_in, out=None, accumulate=False):
         if stride == 2:
             return H.conv_dgrad_bf16_s2(dy, _pack(w, code)[3], l_in, out=out, accumulate=accumulate)
         return H.conv3_bf16(dy, _pack(w, code)[3], out=out, accumulate=accumulate)
+    if code == 48:
+        return H.conv3_x3(dy, _pack(w, code)[3], out=out, accumulate=accumulate)
     if code:
         return H.conv3_winograd(dy, _pack(w, code)[3], out=out, accumulate=accumulate)
     return H.conv_dgrad(dy, _pack(w, 0)[1], stride, pad, l_in, out=out, accumulate=accumulate)
@@ -295,7 +304,7 @@ def _wgrad(dy, x, k, stride, pad, tw):
     if tw is not None and _STEP['on']:
         _STEP['wgrad'].append((dy, x, k, stride, pad, tw))     # launched with all the others by flush_backward()
         return None
-    if H.WGRAD_BF16 or H.act_dtype() == 'bf16':            # the bf16-operand kernels exist in the batched form only
+    if H.WGRAD_BF16 or H.WGRAD_X3 or H.act_dtype() == 'bf16':   # the bf16-pipe kernels exist in the batched form only
         (slab,) = H.conv_wgrad_multi([(dy, x, k, stride, pad)])
         dw = tw if tw is not None else torch.empty((dy.shape[2], x.shape[2], k), device=x.device, dtype=torch.float32)
         H.wgrad_reduce_multi([(slab, dw)], accumulate=tw is not None)

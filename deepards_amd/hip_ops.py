@@ -167,6 +167,39 @@ def conv3_bf16(x, wpk, out=None, accumulate=False):
     return out
 
 
+def pack_conv3_x3(w):
+    """(Co, Ci, 3) fp32 conv weight -> fragment-major split-bf16 packs (wf, wd) for conv3_x3: flat bf16 buffers of
+    3 * 3 * Co * Ci elements, tagged with their (N, C)."""
+    _f32(w, 'w')
+    co, ci, k = w.shape
+    if k != 3 or co % 32 or ci % 32:
+        raise ValueError('pack_conv3_x3: (Co, Ci, 3) weight with Co, Ci multiples of 32 expected')
+    wf = torch.empty((3, co // 32, ci // 16, 3, 64, 8), device=w.device, dtype=torch.bfloat16)
+    wd = torch.empty((3, ci // 32, co // 16, 3, 64, 8), device=w.device, dtype=torch.bfloat16)
+    _chk(_lib.lib().da_pack_conv3_x3(_p(w), _p(wf), _p(wd), co, ci, _stream()), 'da_pack_conv3_x3')
+    return wf, wd
+
+
+def conv3_x3(x, wpk, out=None, accumulate=False):
+    """k3 s1 p1 conv of x (rows, L, C) fp32 with the split-bf16 packs wpk (3, N/32, C/16, 3, 64, 8) of pack_conv3_x3:
+    fp32-equivalent products on the bf16 matrix cores, fp32 sums -> (rows, L, N)."""
+    _rlc32(x, 'x')
+    rows, l, c = x.shape
+    if wpk.dim() != 6 or wpk.shape[0] != 3 or wpk.shape[2] * 16 != c or tuple(wpk.shape[3:]) != (3, 64, 8) or \
+            wpk.shape[1] % 2 or c % 32 or wpk.dtype != torch.bfloat16 or not wpk.is_contiguous():
+        raise ValueError('conv3_x3: unsupported shape x%s w%s' % (tuple(x.shape), tuple(wpk.shape)))
+    n = wpk.shape[1] * 32
+    if out is None:
+        if accumulate:
+            raise ValueError('accumulate needs out')
+        out = torch.empty((rows, l, n), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (rows, l, n) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError('conv3_x3: bad out')
+    _chk(_lib.lib().da_conv3_x3(_p(x), _p(wpk), _p(out), rows, l, c, c, n, n, 1 if accumulate else 0, _stream()),
+         'da_conv3_x3')
+    return out
+
+
 def _conv_bf16_multi(jobs):
     """jobs: [(x, wpk, out, lm, lsrc, ldst, dst_stride, dst_off, src_stride, src_off, wtap, accumulate)] in one call."""
     arr = (_lib.ConvJob * len(jobs))()
@@ -342,6 +375,7 @@ def conv_wgrad(dy, x, k, stride, pad, out=None, accumulate=False, defer=False):
 
 WINOGRAD_WGRAD = os.environ.get('DA_WINOGRAD_WGRAD', '1') != '0'
 WGRAD_BF16 = False        # set by functional.set_conv_dtype('bf16'): k3 s1 weight gradients on the bf16 matrix cores
+WGRAD_X3 = False          # fp32-equivalent split-bf16 products ("f32x3") for the same jobs the bf16 kernels take
 
 
 def conv_wgrad_multi(jobs):
@@ -366,6 +400,10 @@ def conv_wgrad_multi(jobs):
                 (k == 3 and stride == 1 and pad == 1) or
                 (stride == 2 and l % 2 == 0 and ((k == 3 and pad == 1) or (k == 1 and pad == 0)))):
             wino = 16                                # bf16 operands / fp32 sums (conv dtype bf16)
+        elif WGRAD_X3 and ACT == torch.float32 and co % 64 == 0 and ci % 64 == 0 and (
+                (k == 3 and stride == 1 and pad == 1) or
+                (stride == 2 and l % 2 == 0 and ((k == 3 and pad == 1) or (k == 1 and pad == 0)))):
+            wino = 48                                # three-term bf16 splits, six products: fp32-equivalent
         _chk(L.da_conv_wgrad_plan(rows, lo, co, ci, k, wino, plan), 'da_conv_wgrad_plan')
         ws = torch.empty((plan[2] * k * co * ci,), device=x.device, dtype=torch.float32)
         d.dy, d.x, d.workspace = dy.data_ptr(), x.data_ptr(), ws.data_ptr()
@@ -394,7 +432,8 @@ def wgrad_reduce_multi(items, accumulate=True):
 def repack_multi(weights, winograd=None):
     """[(Co,Ci,K) weights] -> [(wf, wd, uf, ud)] with one launch per 32 weights.  winograd[i] (K == 3; True / 4:
     F(2,3), 6: F(4,3)): emit the Winograd taps uf (points,Co,Ci) / ud (points,Ci,Co) INSTEAD of the direct packs
-    wf / wd (None in the tuple); 16: bf16 tap packs of conv3_bf16 in the uf / ud places."""
+    wf / wd (None in the tuple); 16: bf16 tap packs of conv3_bf16 in the uf / ud places; 48: the split-bf16 fragment
+    packs of conv3_x3 there."""
     outs, descs = [], []
     for n, w in enumerate(weights):
         _f32(w, 'w')
@@ -403,7 +442,7 @@ def repack_multi(weights, winograd=None):
         wino = bool(code)
         if wino and k != 3 and not (code == 16 and k == 1):
             raise ValueError('winograd taps need a 3-tap weight')
-        pts = code if wino and code in (6, 16) else 4
+        pts = code if wino and code in (6, 16, 48) else 4
         mk = lambda *shape: torch.empty(shape, device=w.device, dtype=torch.float32)
         wf, wd = (None, None) if wino else (mk(k, co, ci), mk(k, ci, co))
         if pts == 16:                                # bf16 tap packs (3, Co, Ci) / (3, Ci, Co)
@@ -411,6 +450,11 @@ def repack_multi(weights, winograd=None):
                 raise ValueError('bf16 tap packs need channel counts that are multiples of 32')
             uf = torch.empty((k, co, ci), device=w.device, dtype=torch.bfloat16)
             ud = torch.empty((k, ci, co), device=w.device, dtype=torch.bfloat16)
+        elif pts == 48:                              # split-bf16 fragment packs of conv3_x3 (pack_conv3_x3f's layout)
+            if co % 32 or ci % 32:
+                raise ValueError('split-bf16 packs need channel counts that are multiples of 32')
+            uf = torch.empty((3, co // 32, ci // 16, 3, 64, 8), device=w.device, dtype=torch.bfloat16)
+            ud = torch.empty((3, ci // 32, co // 16, 3, 64, 8), device=w.device, dtype=torch.bfloat16)
         else:
             uf, ud = (mk(pts, co, ci), mk(pts, ci, co)) if wino else (None, None)
         descs.append((w.data_ptr(), _p(wf), _p(wd), _p(uf), _p(ud), co, ci, k, pts))

@@ -104,6 +104,14 @@ int da_wino4_weights(const float* w, float* u, int co, int ci, int transpose, da
 int da_conv3_bf16(const da_act_t* x, const void* wpk, da_act_t* y, int rows, int L, int ldx, int C, int ldy, int N,
                   int accumulate, da_stream_t stream);
 int da_pack_conv3_bf16(const float* w, void* wf, void* wd, int co, int ci, da_stream_t stream);
+/* ---- fp32 convolutions on the bf16 matrix cores ("f32x3", conv_x3.hip; opt-in arithmetic) ------
+ * same nn.Conv1d calls again (resnet.py:5-8,27-38), fp32 in / out / sums: every operand is split exactly into three
+ * bf16 terms and a product taken as six bf16 MFMA products (the dropped ones are below one fp32 rounding); direct
+ * 3-tap form.  wpk: fragment-major packs [3][N/32][C/16][3][64][8] bf16 from da_pack_conv3_x3 (wf forward, wd data
+ * gradient, either may be NULL; da_repack_desc.points = 48 emits the same).  C % 32 == 0, N % 64 == 0. */
+int da_conv3_x3(const float* x, const void* wpk, float* y, int rows, int L, int ldx, int C, int ldy, int N,
+                int accumulate, da_stream_t stream);
+int da_pack_conv3_x3(const float* w, void* wf, void* wd, int co, int ci, da_stream_t stream);
 /* da_conv_gemm_multi's contract with bf16 operands for the stride-2 block heads and 1x1 downsamples
  * (resnet.py:5-8,126-128), forward and data gradient: per job Lsrc == src_stride * Lm, source offsets within a span of
  * 2, x2 == NULL, w = bf16 [taps][N][C] (da_repack_desc.points = 16 emits them for K = 1 and K = 3); the jobs of a call
