@@ -520,7 +520,11 @@ def main():
         else:                                     # bf16 arithmetic: every kernel of the step is priced against HBM
             ach = dom['bytes'] / (dom['total_ms'] * 1e-3) / 1e9
             peak, bound, unit = PEAK_HBM_GBS, 'hbm', 'GB/s'
-        traffic, traffic_note = pmc_traffic(dname, ('bf16' if F_.storage_dtype() == 'bf16' else 'bf16_f32storage') if args.dtype == 'bf16' else '')
+        if c5_shape or B != 64:
+            traffic, traffic_note = None, 'the PMC passes under profiles/ ran the default workload (B=64, nb20, seq224) only'
+        else:
+            traffic, traffic_note = pmc_traffic(dname, ('bf16' if F_.storage_dtype() == 'bf16' else 'bf16_f32storage') if args.dtype == 'bf16' else
+                                                ('f32x3' if args.dtype == 'f32x3' else ''))
         out['roofline'] = {'bound': bound, 'kernel': KERNEL_OF[dname], 'entry': dname,
                            'achieved': round(ach, 2), 'peak': peak, 'unit': unit,
                            'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_note,
@@ -528,6 +532,11 @@ def main():
                            'avg_launch_us_single_bracket': round(single_us, 2),
                            'alg_flops_per_launch': round(dom['flops'] / dom['calls'], 1),
                            'alg_bytes_per_launch': round(dom['bytes'] / dom['calls'], 1)}
+        executed = {'da_conv3_winograd': 2.0 / 3.0, 'da_conv3_winograd4': 0.5}.get(dname)
+        if executed and bound == 'mfma':          # Winograd: `achieved` counts the direct convolution's FLOPs (the contract's
+            # ALGORITHMIC work), the matrix pipe executes fewer -- the fraction of the pipe's peak it really runs at:
+            out['roofline']['executed_flops_per_alg_flop'] = round(executed, 4)
+            out['roofline']['frac_of_peak_executed'] = round(ach * executed / peak, 4)
         out['kernel_roofline'] = {}
         for k in cands:                           # every single-kernel entry against ITS roofline (eager, single brackets)
             v = summ[k]
@@ -606,6 +615,36 @@ def main():
         finally:
             F_.set_conv_dtype('f32')
         say('bf16 extra done')
+
+    if world == 1 and not args.no_extra and args.backbone == 'resnet18' and args.dtype == 'f32' and not c5_shape and not args.no_graph:
+        # two k-fold replicas side by side on this GPU (train_ards_detector --folds-in-flight 2): each its own model,
+        # optimizer, captured step and stream, replayed round-robin; aggregate rate of the pair
+        reps = []
+        fold_streams = [torch.cuda.Stream() for _ in range(2)]      # created back to back: consecutive HIP streams sit on different hardware queues
+        for r in range(2):
+            torch.manual_seed(100 + r)
+            mr = M.CNNLinearNetwork(M.resnet18(), 20, 0).to(dev)
+            trr = HotPathTrainer(mr, optimizer='sgd', use_graph=True)
+            sr = fold_streams[r]
+            with torch.cuda.stream(sr):
+                for _ in range(3):
+                    trr.train_step(x, t)
+            torch.cuda.synchronize()
+            reps.append((trr, sr, trr.static_batch()))
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            for trr, sr, st in reps:
+                with torch.cuda.stream(sr):
+                    trr.train_step(st[0], st[1])
+        torch.cuda.synchronize()
+        d4 = (time.perf_counter() - t1) / args.steps
+        out.setdefault('extra', {})['two_folds_in_flight'] = {
+            'value': round(2 * B * 20 / d4, 1), 'ms_per_round': round(1e3 * d4, 4), 'vs_one_after_the_other': round(2 * B * 20 / d4 / value, 3),
+            'note': 'two independent cnn_linear+resnet18 training replicas (two k-folds) of B=%d each on one GPU, own streams; '
+                    'aggregate breath-sequences/s of the pair -- NOT the headline workload (one model)' % B}
+        for trr, _, _ in reps:
+            trr.release_graphs()
+        say('two-fold extra done')
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not c5_shape:      # the reference's CPU path cannot run the C5 shape
         say('cpu baseline ...')

@@ -51,7 +51,7 @@ BUILD_DEFAULTS = dict(
     clip_grad=None, with_fft=None, only_fft=None, fft_real_only=None, random_kfold=None, bootstrap=None,
     kfolds=None, only_fold=None, load_checkpoint=None, load_base_network=None, save_model=None, saved_models_dir=None,
     train_from_pickle=None, train_to_pickle=None, test_from_pickle=None, test_to_pickle=None,
-    experiment_name='deepards_amd', config_override=None,
+    experiment_name='deepards_amd', config_override=None, folds_in_flight=1,
 )
 
 # make_args(): the merged view with every reference default, for callers that build ``args`` in Python
@@ -238,12 +238,21 @@ class BaseTraining(object):
         train_dataset, test_dataset = self.get_base_datasets()
         for i in range(self.n_kfolds):
             if self.args.kfolds is not None:
+                self._seed_fold_sampler(train_dataset, i)
                 for ds in (train_dataset, test_dataset):
                     if hasattr(ds, 'set_kfold_indexes_for_fold'):
                         ds.set_kfold_indexes_for_fold(i)
             shuffle = not _flag(self.args, 'unshuffled')
             yield (train_dataset, (train_dataset, self.args.batch_size, shuffle),
                    test_dataset, (test_dataset, self.args.batch_size, shuffle))
+
+    def _seed_fold_sampler(self, store, fold_num):
+        """Each fold's oversampling draws come from a generator of their own (seeded from --seed and the fold; numpy's
+        global RNG without a seed, like the reference's RandomOverSampler()): a fold then draws the same windows
+        whether the folds run one after the other or side by side (--folds-in-flight)."""
+        if hasattr(store, 'sampling_rng') and self.args.seed is not None:
+            import numpy as np
+            store.sampling_rng = np.random.RandomState(self.args.seed + 7919 * (fold_num + 1))
 
     # ---- epochs --------------------------------------------------------------------------------------------------
     def run_train_epoch(self, model, train_loader, optimizer, epoch_num, fold_num):
@@ -293,6 +302,9 @@ class BaseTraining(object):
         from .checkpoint import model_save_path
         a = self.args
         saved_models_dir = a.saved_models_dir if getattr(a, 'saved_models_dir', None) else saved_models_default_dir
+        n_flight = int(getattr(a, 'folds_in_flight', 1) or 1)
+        if n_flight > 1 and self.n_kfolds > 1 and a.kfolds is not None:
+            return self._train_and_test_folds_in_flight(n_flight, saved_models_dir)
         for fold_num, (train_dataset, train_loader, test_dataset, test_loader) in enumerate(self.get_splits()):
             if a.only_fold and fold_num != a.only_fold:
                 continue
@@ -310,6 +322,80 @@ class BaseTraining(object):
             if a.save_model:
                 self._save(model, model_save_path(a.save_model, saved_models_dir, self.n_kfolds, fold_num))
             self.model, self.optimizer = model, optimizer
+        return self.results
+
+    def _train_and_test_folds_in_flight(self, n_flight, saved_models_dir):
+        """The fold loop of ``train_and_test`` with ``n_flight`` folds side by side on this GPU: every fold has its own
+        view of the tile store (fold indices, scaling factors, oversampling draws), model, trainer (captured step) and
+        HIP stream; the host walks the folds' batches round-robin, so the step kernels of different folds overlap on the
+        chip (independent launches fill the ramp / drain / latency gaps a B <= 64 step leaves: +12 % aggregate at B = 64
+        with two folds, +17 % at B = 16 with four, scripts/two_fold_probe.py).  Within a fold nothing changes -- same
+        kernels in the same order on one stream -- so its losses, predictions and weights are those of the sequential
+        loop bit for bit (tests/test_model_gpu.py)."""
+        import copy
+        from .checkpoint import model_save_path
+        from .train import _epoch_indices, shard_windows, shared_generator
+        a = self.args
+        if self._data_parallel()[0] > 1:
+            raise NotImplementedError('--folds-in-flight with data parallelism: give every rank group its own folds instead')
+        train_dataset, test_dataset = self.get_base_datasets()
+        folds = [f for f in range(self.n_kfolds) if not (a.only_fold and f != a.only_fold)]
+        shuffle = not _flag(a, 'unshuffled')
+        for g0 in range(0, len(folds), n_flight):
+            ctx = []
+            # created back to back: HIP deals consecutive streams onto different hardware queues, and two folds on one
+            # queue would run one after the other
+            streams = [torch.cuda.Stream() for _ in folds[g0:g0 + n_flight]]
+            for fold_num in folds[g0:g0 + n_flight]:
+                tr_ds, te_ds = copy.copy(train_dataset), copy.copy(test_dataset)
+                self._seed_fold_sampler(tr_ds, fold_num)
+                for ds in (tr_ds, te_ds):
+                    ds.set_kfold_indexes_for_fold(fold_num)
+                stream = streams[len(ctx)]
+                with torch.cuda.stream(stream):
+                    model = self.get_model()
+                    optimizer = self.get_optimizer(model, 1, 0, None)
+                ctx.append((fold_num, stream, model, optimizer, tr_ds, te_ds))
+            torch.cuda.synchronize()
+            for epoch_num in range(1, a.epochs + 1):
+                if not _flag(a, 'no_train'):
+                    plans = []
+                    for fold_num, stream, model, optimizer, tr_ds, te_ds in ctx:
+                        gen = None
+                        if a.seed is not None:
+                            gen = torch.Generator().manual_seed(a.seed + 1000 * fold_num + epoch_num)
+                        if shuffle:
+                            gen = shared_generator(optimizer, gen)
+                        plans.append(list(_epoch_indices(tr_ds, a.batch_size, shuffle, gen, 1)))
+                    for b in range(max(len(p) for p in plans)):
+                        for (fold_num, stream, model, optimizer, tr_ds, te_ds), plan in zip(ctx, plans):
+                            if b >= len(plan) or (_flag(a, 'debug') and b > 0):
+                                continue
+                            idx = plan[b][0][shard_windows(len(plan[b][0]), 1, 0)]
+                            with torch.cuda.stream(stream):
+                                static = optimizer.static_batch(len(idx))
+                                x, t = tr_ds.batch(idx, out=static) if static is not None else tr_ds.batch(idx)
+                                loss = optimizer.train_step(x, t).clone()
+                            self.results.update_meter('loss_epoch_{}'.format(epoch_num), fold_num, loss)
+                            self.results.update_meter('loss', fold_num, loss)
+                    torch.cuda.synchronize()                 # the meters are read from the default stream
+                for fold_num, stream, model, optimizer, tr_ds, te_ds in ctx:
+                    if _flag(a, 'reshuffle_oversample_per_epoch'):
+                        tr_ds.set_oversampling_indices()
+                    with torch.cuda.stream(stream):
+                        if not _flag(a, 'no_test_after_epochs') or epoch_num == a.epochs - 1:
+                            self.run_test_epoch(epoch_num, model, te_ds, (te_ds, a.batch_size, shuffle), fold_num, optimizer=optimizer)
+                        stream.synchronize()
+                        if _flag(a, 'save_model_per_epoch'):
+                            self._save(model, model_save_path(a.save_model, saved_models_dir, self.n_kfolds, fold_num, epoch_num))
+            torch.cuda.synchronize()
+            for fold_num, stream, model, optimizer, tr_ds, te_ds in ctx:
+                if a.save_model:
+                    self._save(model, model_save_path(a.save_model, saved_models_dir, self.n_kfolds, fold_num))
+                self.model, self.optimizer = model, optimizer
+            self.fold_models = getattr(self, 'fold_models', {})
+            self.fold_models.update({c[0]: c[2] for c in ctx})
+            a.train_store = ctx[-1][4]
         return self.results
 
     def _save(self, model, path):
@@ -488,7 +574,9 @@ def build_parser():
     # this build's own switches
     parser.add_argument('--seed', type=int, help='seed of the initialisation, the shuffles and the oversampler')
     parser.add_argument('--no-graph', dest='use_graph', action='store_false', default=None, help='run the step eagerly')
-    parser.add_argument('--conv-dtype', choices=['f32', 'bf16'], help='arithmetic of the residual-block convs')
+    parser.add_argument('--conv-dtype', choices=['f32', 'bf16', 'f32x3'], help='arithmetic of the residual-block convs')
+    parser.add_argument('--folds-in-flight', type=int, help='k-folds trained side by side on this GPU, each on its own stream '
+                        '(same per-fold results as one after the other; a B <= 64 step leaves the chip partly idle)')
     parser.add_argument('--act-dtype', choices=['f32', 'bf16'], help='activation storage under --conv-dtype bf16 (default bf16 for ResNets)')
     return parser
 
