@@ -619,8 +619,9 @@ def main():
     if world == 1 and not args.no_extra and args.backbone == 'resnet18' and args.dtype == 'f32' and not c5_shape and not args.no_graph:
         # two k-fold replicas side by side on this GPU (train_ards_detector --folds-in-flight 2): each its own model,
         # optimizer, captured step and stream, replayed round-robin; aggregate rate of the pair
+        from deepards_amd.train import concurrent_streams
         reps = []
-        fold_streams = [torch.cuda.Stream() for _ in range(2)]      # created back to back: consecutive HIP streams sit on different hardware queues
+        fold_streams = concurrent_streams(2)        # two streams on different hardware queues (measured with a spin kernel)
         for r in range(2):
             torch.manual_seed(100 + r)
             mr = M.CNNLinearNetwork(M.resnet18(), 20, 0).to(dev)

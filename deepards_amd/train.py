@@ -392,6 +392,39 @@ def run_train_epoch(trainer, loader, batch_size=None):
     return losses
 
 
+def concurrent_streams(n, spin_cycles=1500000, candidates=None):
+    """``n`` HIP streams whose work really overlaps.  HIP deals streams onto a small number of hardware queues
+    (GPU_MAX_HW_QUEUES, 4 by default) and two streams on ONE queue run their kernels one after the other -- which pair
+    shares a queue depends on every stream the process made before.  Measured, not guessed: a one-block spin kernel
+    (torch.cuda._sleep) on two candidates takes one spin when they overlap and two when they do not.  Falls back to
+    plain new streams when fewer than ``n`` overlapping ones are found."""
+    import time
+    cands = [torch.cuda.Stream() for _ in range(candidates or 3 * n + 2)]
+
+    def spin(streams):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in streams:
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(spin_cycles)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    spin(cands[:1])
+    one = min(spin(cands[:1]) for _ in range(3))
+    chosen = [cands[0]]
+    for c in cands[1:]:
+        if len(chosen) == n:
+            break
+        if all(spin([c, s]) < 1.5 * one for s in chosen):
+            chosen.append(c)
+    for c in cands:
+        if len(chosen) == n:
+            break
+        if c not in chosen:
+            chosen.append(c)
+    return chosen
+
+
 def shared_generator(trainer, generator=None):
     """The generator an epoch's permutation is drawn from.  One GPU: the caller's (None = torch's global RNG, like a
     DataLoader).  Data parallel: rank 0 draws a seed (from its generator or its global RNG), broadcasts it, and every

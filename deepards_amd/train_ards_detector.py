@@ -334,7 +334,7 @@ class BaseTraining(object):
         loop bit for bit (tests/test_model_gpu.py)."""
         import copy
         from .checkpoint import model_save_path
-        from .train import _epoch_indices, shard_windows, shared_generator
+        from .train import _epoch_indices, concurrent_streams, shard_windows, shared_generator
         a = self.args
         if self._data_parallel()[0] > 1:
             raise NotImplementedError('--folds-in-flight with data parallelism: give every rank group its own folds instead')
@@ -343,9 +343,7 @@ class BaseTraining(object):
         shuffle = not _flag(a, 'unshuffled')
         for g0 in range(0, len(folds), n_flight):
             ctx = []
-            # created back to back: HIP deals consecutive streams onto different hardware queues, and two folds on one
-            # queue would run one after the other
-            streams = [torch.cuda.Stream() for _ in folds[g0:g0 + n_flight]]
+            streams = concurrent_streams(len(folds[g0:g0 + n_flight]))     # on different hardware queues (measured)
             for fold_num in folds[g0:g0 + n_flight]:
                 tr_ds, te_ds = copy.copy(train_dataset), copy.copy(test_dataset)
                 self._seed_fold_sampler(tr_ds, fold_num)

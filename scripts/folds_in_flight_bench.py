@@ -28,7 +28,7 @@ for flight in (1, 2, 4, 1):
     dt = time.perf_counter() - t0
     losses = [r.get_meter('loss', f) for f in range(4)]
     steps = sum(len(l) for l in losses)
-    same = res and all(a == b for a, b in zip(losses, res[1][1]))
+    same = bool(res) and all(a == b for a, b in zip(losses, res[1][1]))
     res.setdefault(flight, (dt, losses))
     print('folds in flight %d: %.2f s for %d steps of B=%s (%.0f breath-seq/s incl. set-up / captures); losses equal to the '
           'sequential run: %s' % (flight, dt, steps, BATCH, steps * int(BATCH) * 20 / dt, same if flight != 1 or same else '-'), flush=True)
