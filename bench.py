@@ -632,9 +632,12 @@ def main():
                     trr.train_step(x, t)
             torch.cuda.synchronize()
             reps.append((trr, sr, trr.static_batch()))
+        from deepards_amd.train import place_replicas_on_streams
+        placed = place_replicas_on_streams([r_[0] for r_ in reps])     # measured stream placement (state restored afterwards)
+        torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            for trr, sr, st in reps:
+            for (trr, _, st), sr in zip(reps, placed):
                 with torch.cuda.stream(sr):
                     trr.train_step(st[0], st[1])
         torch.cuda.synchronize()

@@ -316,6 +316,42 @@ class HotPathTrainer(object):
         self.last_loss, self.last_logits = loss, logits
         return loss
 
+    def snapshot(self):
+        """Everything a train / test step changes, copied: parameters (the flat bucket), optimizer state, module buffers
+        (BatchNorm running statistics, dropout seeds), the static batch of every captured graph and the counters.
+        ``restore`` puts it back bit for bit -- replays in between (e.g. to time stream placements) leave no trace."""
+        torch.cuda.synchronize()
+        snap = {'steps': self.steps, 'allreduce_calls': getattr(self, 'allreduce_calls', 0),
+                'buffers': [b.detach().clone() for b in self.model.buffers()],
+                'state': {k: v.detach().clone() for k, v in self.state.items()},
+                'static': {k: tuple(t.clone() for t in e[1]) for k, e in self._graphs.items()}}
+        if self.bucket is not None:
+            snap['p'], snap['g'] = self.bucket.p.clone(), self.bucket.g.clone()
+        else:
+            snap['params'] = [q.detach().clone() for q in self.model.parameters()]
+        return snap
+
+    def restore(self, snap):
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            if self.bucket is not None:
+                self.bucket.p.copy_(snap['p'])
+                self.bucket.g.copy_(snap['g'])
+            else:
+                for q, v in zip(self.model.parameters(), snap['params']):
+                    q.copy_(v)
+            for b, v in zip(self.model.buffers(), snap['buffers']):
+                b.copy_(v)
+            for k, v in snap['state'].items():
+                self.state[k].copy_(v)
+            for k, st in snap['static'].items():
+                for dst, src in zip(self._graphs[k][1], st):
+                    dst.copy_(src)
+        self.steps = snap['steps']
+        if hasattr(self, 'allreduce_calls'):
+            self.allreduce_calls = snap['allreduce_calls']
+        torch.cuda.synchronize()
+
     def release_graphs(self):
         """Drop every captured graph and its static buffers NOW (outside any capture): call before discarding a
         trainer so that its graphs are not left to a later garbage-collection pass."""
@@ -390,6 +426,45 @@ def run_train_epoch(trainer, loader, batch_size=None):
         tgt = target[:n][sl].float().to(dev, non_blocking=True)
         losses.append(trainer.train_step(inputs, tgt).clone())
     return losses
+
+
+def place_replicas_on_streams(trainers, rounds=3, candidates=10):
+    """Streams for ``trainers`` (each with a captured train step) so that their replays overlap best: HIP deals streams
+    -- the ones a graph launch runs on and the ones a graph's forked branches use internally -- onto a few hardware
+    queues, two streams on one queue run one after the other, and which streams share a queue depends on everything the
+    process created before.  So the placement is MEASURED with the real thing: every trainer's state is snapshotted,
+    candidate streams are tried one trainer at a time with a few replays of all the steps, the fastest placement is
+    kept, and the snapshots are restored bit for bit (the trial leaves no trace in parameters, optimizer state,
+    running statistics or static batches)."""
+    import time
+    snaps = [tr.snapshot() for tr in trainers]
+    statics = [tr.static_batch() for tr in trainers]
+    if any(st is None for st in statics):
+        raise ValueError('place_replicas_on_streams: every trainer needs a captured step (run two steps first)')
+
+    def rounds_time(streams):
+        for tr, sn in zip(trainers, snaps):             # every trial from the same state: same kernels, same data
+            tr.restore(sn)
+        t0 = time.perf_counter()
+        for _ in range(rounds):
+            for tr, st, s in zip(trainers, statics, streams):
+                with torch.cuda.stream(s):
+                    tr.train_step(st[0], st[1])
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    streams = [torch.cuda.Stream() for _ in trainers]
+    rounds_time(streams)                                 # warm
+    best = rounds_time(streams)
+    for i in range(1, len(trainers)):                    # trainer 0 keeps its stream; the others try the candidates in turn
+        for _ in range(candidates):
+            trial = list(streams)
+            trial[i] = torch.cuda.Stream()
+            t = rounds_time(trial)
+            if t < best * 0.98:
+                best, streams = t, trial
+    for tr, sn in zip(trainers, snaps):
+        tr.restore(sn)
+    return streams
 
 
 def concurrent_streams(n, spin_cycles=1500000, candidates=None):

@@ -334,7 +334,7 @@ class BaseTraining(object):
         loop bit for bit (tests/test_model_gpu.py)."""
         import copy
         from .checkpoint import model_save_path
-        from .train import _epoch_indices, concurrent_streams, shard_windows, shared_generator
+        from .train import _epoch_indices, concurrent_streams, place_replicas_on_streams, shard_windows, shared_generator
         a = self.args
         if self._data_parallel()[0] > 1:
             raise NotImplementedError('--folds-in-flight with data parallelism: give every rank group its own folds instead')
@@ -355,6 +355,7 @@ class BaseTraining(object):
                     optimizer = self.get_optimizer(model, 1, 0, None)
                 ctx.append((fold_num, stream, model, optimizer, tr_ds, te_ds))
             torch.cuda.synchronize()
+            placed = not _flag(a, 'use_graph', True)
             for epoch_num in range(1, a.epochs + 1):
                 if not _flag(a, 'no_train'):
                     plans = []
@@ -366,6 +367,11 @@ class BaseTraining(object):
                             gen = shared_generator(optimizer, gen)
                         plans.append(list(_epoch_indices(tr_ds, a.batch_size, shuffle, gen, 1)))
                     for b in range(max(len(p) for p in plans)):
+                        if not placed and all(c[3].static_batch() is not None for c in ctx) and len(ctx) > 1:
+                            # every fold has its captured step: measure which streams let them overlap (restores all state)
+                            streams = place_replicas_on_streams([c[3] for c in ctx])
+                            ctx = [(c[0], s) + c[2:] for c, s in zip(ctx, streams)]
+                            placed = True
                         for (fold_num, stream, model, optimizer, tr_ds, te_ds), plan in zip(ctx, plans):
                             if b >= len(plan) or (_flag(a, 'debug') and b > 0):
                                 continue
