@@ -649,6 +649,40 @@ def main():
         for trr, _, _ in reps:
             trr.release_graphs()
         say('two-fold extra done')
+        # the reference's DEFAULT protocol (defaults.yml: densenet18, batch_size 16, 5 folds): five fold replicas of B=16
+        # one after the other vs in flight together
+        x16, t16 = x[:16].contiguous(), t[:16].contiguous()
+        reps = []
+        for r in range(5):
+            torch.manual_seed(200 + r)
+            mr = M.CNNLinearNetwork(M.densenet18(), 20, 0).to(dev)
+            trr = HotPathTrainer(mr, optimizer='sgd', use_graph=True)
+            for _ in range(3):
+                trr.train_step(x16, t16)
+            torch.cuda.synchronize()
+            reps.append((trr, trr.static_batch()))
+
+        def five(streams, n):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                for (trr, st), sr in zip(reps, streams):
+                    with torch.cuda.stream(sr):
+                        trr.train_step(st[0], st[1])
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / n
+        one = torch.cuda.Stream()
+        seq5 = five([one] * 5, args.steps)
+        par5 = five(place_replicas_on_streams([r_[0] for r_ in reps]), args.steps)
+        out['extra']['five_folds_in_flight_reference_defaults'] = {
+            'value': round(5 * 16 * 20 / par5, 1), 'one_after_the_other': round(5 * 16 * 20 / seq5, 1),
+            'ms_per_round': round(1e3 * par5, 4), 'vs_one_after_the_other': round(seq5 / par5, 3),
+            'note': 'five independent cnn_linear+densenet18 replicas (the 5 folds of defaults.yml) of batch_size 16 each on one GPU: '
+                    'aggregate breath-sequences/s with the folds in flight together (own streams) and one after the other -- NOT '
+                    'the headline workload'}
+        for trr, _ in reps:
+            trr.release_graphs()
+        say('five-fold extra done')
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not c5_shape:      # the reference's CPU path cannot run the C5 shape
         say('cpu baseline ...')

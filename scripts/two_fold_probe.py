@@ -1,7 +1,7 @@
 """Two independent training replicas (two k-folds of the reference's 5-fold protocol, each its own model / optimizer /
 captured step) on ONE GPU: replayed back to back on one stream vs concurrently on streams placed by measurement
 (train.place_replicas_on_streams), with and without the stem-backward fork inside the captured step.
-usage: python scripts/two_fold_probe.py [B] [n_replicas]"""
+usage: python scripts/two_fold_probe.py [B] [n_replicas] [resnet18|densenet18]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,15 +11,16 @@ from deepards_amd.train import HotPathTrainer, place_replicas_on_streams
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 NR = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+BB = sys.argv[3] if len(sys.argv) > 3 else 'resnet18'
 torch.manual_seed(0)
 x = torch.randn(B, 20, 1, 224, device='cuda')
 t = torch.zeros(B, 2, device='cuda'); t[torch.arange(B), torch.randint(0, 2, (B,))] = 1
-for fork in (True, False):
+for fork in (True,):
     F_._OVERLAP_STEM = fork
     trs = []
     for r in range(NR):
         torch.manual_seed(r)
-        m = M.CNNLinearNetwork(M.resnet18(), 20, 0).cuda()
+        m = M.CNNLinearNetwork(getattr(M, BB)(), 20, 0).cuda()
         tr = HotPathTrainer(m, optimizer='sgd', use_graph=True)
         for _ in range(3):
             tr.train_step(x, t)
@@ -40,7 +41,7 @@ for fork in (True, False):
     a = min(run([one] * NR) for _ in range(2))
     placed = place_replicas_on_streams(trs)
     b = min(run(placed) for _ in range(2))
-    print('stem fork %-5s %d replicas, B=%d each: one stream %.3f ms per round (%.0f breath-seq/s)   own streams %.3f ms '
-          '(%.0f breath-seq/s)  x%.3f' % (fork, NR, B, a * 1e3, NR * B * 20 / a, b * 1e3, NR * B * 20 / b, a / b), flush=True)
+    print('%s stem fork %-5s %d replicas, B=%d each: one stream %.3f ms per round (%.0f breath-seq/s)   own streams %.3f ms '
+          '(%.0f breath-seq/s)  x%.3f' % (BB, fork, NR, B, a * 1e3, NR * B * 20 / a, b * 1e3, NR * B * 20 / b, a / b), flush=True)
     for tr in trs:
         tr.release_graphs()
