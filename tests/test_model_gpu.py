@@ -1241,17 +1241,19 @@ def test_evaluate_reruns_saved_models_per_fold(tmp_path):
     assert ecls.args.oversample_minority is False                            # the legacy `oversample` key was honoured
 
 
-def test_folds_in_flight_reproduce_the_sequential_fold_loop(tmp_path):
+@pytest.mark.parametrize('backbone', ['resnet18', 'densenet18'])
+def test_folds_in_flight_reproduce_the_sequential_fold_loop(tmp_path, backbone):
     """--folds-in-flight 2: two k-folds side by side on one GPU (own store view, model, captured step and stream each,
     batches walked round-robin) give every fold the losses, votes and weights of the one-after-the-other loop, bit for
-    bit -- with minority oversampling and per-epoch re-draws on (each fold owns its sampler)."""
+    bit -- with minority oversampling and per-epoch re-draws on (each fold owns its sampler), and with densenet18's
+    dropout active (its seed is a module buffer: the stream-placement trial snapshots and restores it)."""
     from deepards_amd import train_ards_detector as T
     gold = os.path.join(os.path.dirname(__file__), 'golden', 'test_dataset.npz')
     exp = os.path.join(os.path.dirname(os.path.dirname(__file__)), 'deepards_amd', 'experiment_files',
                        'unpadded_centered_nb20_cnn_linear.yml')
     runs = {}
     for flight in (1, 2, 3):
-        argv = ['-co', exp, '--train-from-pickle', gold, '--kfolds', '3', '-e', '2', '-b', '4', '--base-network', 'resnet18',
+        argv = ['-co', exp, '--train-from-pickle', gold, '--kfolds', '3', '-e', '2', '-b', '4', '--base-network', backbone,
                 '--seed', '9', '--reshuffle-oversample-per-epoch', '--save-model', 'runs/f.pth', '--saved-models-dir',
                 str(tmp_path / ('flight%d' % flight)), '--folds-in-flight', str(flight)]
         cls, res = T.main(argv)
