@@ -161,6 +161,28 @@ class DeviceTileStore(object):
         ox, ot = out if out is not None else (None, None)
         return H.gather_normalize(self.tiles, idx, self.mu, self.std, out=ox), H.gather_rows(self.targets, idx, out=ot)
 
+    def device_indices(self, rel_idx):
+        """Absolute window indices ON THE DEVICE for a whole list of fold-relative indices (an epoch's permutation): one
+        bounds check and one upload per epoch instead of one per batch -- a per-batch host-to-device copy of the
+        indices makes the host wait on the stream every step.  Slices of the result go to ``batch_from_device``."""
+        idx = torch.as_tensor(rel_idx, dtype=torch.int64)
+        if idx.dim() != 1:
+            raise ValueError('rel_idx must be a 1-D index list')
+        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= len(self)):
+            raise IndexError('window index out of range [0, %d)' % len(self))
+        idx = idx.to(self.tiles.device)
+        if self.kfold_indexes is not None:
+            idx = self.kfold_indexes[idx]
+        return idx.contiguous()
+
+    def batch_from_device(self, abs_idx, out=None):
+        """``batch`` for a contiguous int64 DEVICE tensor of absolute indices from ``device_indices`` (already checked)."""
+        if not (abs_idx.is_cuda and abs_idx.dtype == torch.int64 and abs_idx.dim() == 1 and abs_idx.is_contiguous()):
+            raise ValueError('batch_from_device: a contiguous 1-D int64 device tensor from device_indices() expected')
+        ox, ot = out if out is not None else (None, None)
+        return (H.gather_normalize(self.tiles, abs_idx, self.mu, self.std, out=ox),
+                H.gather_rows(self.targets, abs_idx, out=ot))
+
     def epoch(self, batch_size, shuffle=True, generator=None, drop_odd=True):
         """Iterate one epoch like DataLoader(batch_size, shuffle) + clip_odd_batch_sizes (:146-147,482-494)."""
         n = len(self)

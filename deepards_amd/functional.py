@@ -72,7 +72,14 @@ def flush_backward():
     _STEP['pgrad'], _STEP['wslab'] = [], []
 
 
-_OVERLAP_STEM = os.environ.get('DA_WGRAD_OVERLAP', '1') != '0'
+# The stem's backward chain beside the batched weight gradients, on a forked stream inside the captured step: OFF by default
+# since round 2.  (1) It stopped paying once the weight gradients took the Winograd form: resnet18 3.02 ms either way,
+# densenet18 1.507 (off) against 1.521, the bf16 configuration 1.580 (off) against 1.621.  (2) A captured step with a forked
+# branch makes its hipGraphExec own "parallel streams"; destroying ANOTHER such exec (an earlier fold's trainer collected
+# by the gc pass that precedes every capture) while this one is alive leaves a dangling stream in it and the next replay
+# segfaults in hip::Graph::UpdateStreams (ROCm 7.0 runtime bundled with torch 2.10; rocgdb backtrace in DESIGN.md §5) --
+# a captured step without parallel branches has no such streams.  DA_WGRAD_OVERLAP=1 brings the fork back.
+_OVERLAP_STEM = os.environ.get('DA_WGRAD_OVERLAP', '0') == '1'
 # experiment knobs (scripts/): DA_WGRAD_EARLY=1 launches a stage's weight gradients as soon as the stage's data gradients
 # are done, on the side stream; DA_WGRAD_PRIO sets that stream's priority (1 = lowest on this stack, -1 = highest)
 _WGRAD_EARLY = os.environ.get('DA_WGRAD_EARLY', '0') == '1'

@@ -526,16 +526,26 @@ def run_train_epoch_from_store(trainer, store, batch_size=16, shuffle=True, gene
     losses = []
     if shuffle:
         generator = shared_generator(trainer, generator)
-    for idx, _, _ in _epoch_indices(store, batch_size, shuffle, generator, trainer.world_size):
-        sl = shard_windows(len(idx), trainer.world_size, trainer.rank)
-        mine = idx[sl]
+    for mine in epoch_shards_on_device(store, batch_size, shuffle, generator, trainer.world_size, trainer.rank):
         static = trainer.static_batch(len(mine))
-        if static is not None:
-            x, t = store.batch(mine, out=static)
-        else:
-            x, t = store.batch(mine)
+        x, t = store.batch_from_device(mine, out=static) if static is not None else store.batch_from_device(mine)
         losses.append(trainer.train_step(x, t).clone())
     return losses
+
+
+def epoch_shards_on_device(store, batch_size, shuffle, generator, world_size=1, rank=0):
+    """This rank's window shard of every batch of the epoch, as slices of ONE device tensor of absolute indices (the
+    epoch's batches of ``_epoch_indices`` concatenated, uploaded once): no host-to-device copy and no host wait per step."""
+    batches = [idx for idx, _, _ in _epoch_indices(store, batch_size, shuffle, generator, world_size)]
+    if not batches:
+        return []
+    mine = [idx[shard_windows(len(idx), world_size, rank)] for idx in batches]
+    dev = store.device_indices(torch.cat(mine))
+    out, s = [], 0
+    for m in mine:
+        out.append(dev[s:s + len(m)])
+        s += len(m)
+    return out
 
 
 def _epoch_indices(store, batch_size, shuffle, generator, world_size=1):

@@ -321,6 +321,9 @@ class BaseTraining(object):
                     self._save(model, model_save_path(a.save_model, saved_models_dir, self.n_kfolds, fold_num, epoch_num))
             if a.save_model:
                 self._save(model, model_save_path(a.save_model, saved_models_dir, self.n_kfolds, fold_num))
+            prev = getattr(self, 'optimizer', None)
+            if prev is not None and prev is not optimizer and hasattr(prev, 'release_graphs'):
+                prev.release_graphs()                    # the outgoing fold's captured steps go NOW, not in some later gc pass
             self.model, self.optimizer = model, optimizer
         return self.results
 
@@ -334,7 +337,7 @@ class BaseTraining(object):
         loop bit for bit (tests/test_model_gpu.py)."""
         import copy
         from .checkpoint import model_save_path
-        from .train import _epoch_indices, concurrent_streams, place_replicas_on_streams, shard_windows, shared_generator
+        from .train import concurrent_streams, epoch_shards_on_device, place_replicas_on_streams, shared_generator
         a = self.args
         if self._data_parallel()[0] > 1:
             raise NotImplementedError('--folds-in-flight with data parallelism: give every rank group its own folds instead')
@@ -365,7 +368,8 @@ class BaseTraining(object):
                             gen = torch.Generator().manual_seed(a.seed + 1000 * fold_num + epoch_num)
                         if shuffle:
                             gen = shared_generator(optimizer, gen)
-                        plans.append(list(_epoch_indices(tr_ds, a.batch_size, shuffle, gen, 1)))
+                        with torch.cuda.stream(stream):      # the index upload is ordered before the fold's gathers
+                            plans.append(epoch_shards_on_device(tr_ds, a.batch_size, shuffle, gen, 1, 0))
                     for b in range(max(len(p) for p in plans)):
                         if not placed and all(c[3].static_batch() is not None for c in ctx) and len(ctx) > 1:
                             # every fold has its captured step: measure which streams let them overlap (restores all state)
@@ -375,10 +379,10 @@ class BaseTraining(object):
                         for (fold_num, stream, model, optimizer, tr_ds, te_ds), plan in zip(ctx, plans):
                             if b >= len(plan) or (_flag(a, 'debug') and b > 0):
                                 continue
-                            idx = plan[b][0][shard_windows(len(plan[b][0]), 1, 0)]
+                            idx = plan[b]
                             with torch.cuda.stream(stream):
                                 static = optimizer.static_batch(len(idx))
-                                x, t = tr_ds.batch(idx, out=static) if static is not None else tr_ds.batch(idx)
+                                x, t = tr_ds.batch_from_device(idx, out=static) if static is not None else tr_ds.batch_from_device(idx)
                                 loss = optimizer.train_step(x, t).clone()
                             self.results.update_meter('loss_epoch_{}'.format(epoch_num), fold_num, loss)
                             self.results.update_meter('loss', fold_num, loss)

@@ -56,12 +56,12 @@ def main():
         z = np.load(os.path.join(ROOT, 'tests', 'golden', 'test_dataset_windows.npz'))
         store = DeviceTileStore(z['x'], z['target'], float(z['mu']), float(z['std']))
         seen = []
-        orig = store.batch
+        orig = store.batch_from_device                               # what run_train_epoch_from_store gathers with
 
-        def spy(rel_idx, out=None):
-            seen.append(np.asarray(torch.as_tensor(rel_idx).cpu()).copy())
-            return orig(rel_idx, out=out)
-        store.batch = spy
+        def spy(abs_idx, out=None):                                  # no folds here: absolute == relative indices
+            seen.append(np.asarray(abs_idx.cpu()).copy())
+            return orig(abs_idx, out=out)
+        store.batch_from_device = spy
         torch.manual_seed(777 + 13 * rank)                           # different global RNG per rank, generator=None
         losses = []
         for _ in range(2):
