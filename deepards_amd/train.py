@@ -291,7 +291,8 @@ class HotPathTrainer(object):
         buffer, overwritten by the next step -- ``.clone()`` it to keep it (the epoch functions do)."""
         if not inputs.is_cuda:
             raise RuntimeError('HotPathTrainer needs CUDA (MI355X) tensors; there is no CPU fallback')
-        self.model.train()
+        if not self.model.training:                       # (a recursive walk over every module: 0.26 ms a step when unconditional)
+            self.model.train()
         if self.bucket is None:
             loss, logits = self._first_step(inputs, target)
         elif not self.use_graph:
@@ -385,7 +386,8 @@ class HotPathTrainer(object):
         calls (the next replay overwrites the graph's own output buffers)."""
         if not inputs.is_cuda:
             raise RuntimeError('HotPathTrainer needs CUDA (MI355X) tensors; there is no CPU fallback')
-        self.model.train()
+        if not self.model.training:                       # (a recursive walk over every module: 0.26 ms a step when unconditional)
+            self.model.train()
         if not self.use_graph:
             return self._test_forward(inputs, target)
         key = (tuple(inputs.shape), tuple(target.shape))
@@ -574,11 +576,23 @@ def run_test_epoch(trainer, store, patient_slot, batch_size=16):
     n_pat = int(slot.max()) + 1
     votes = torch.zeros((n_pat, 2), dtype=torch.int32, device=dev)
     preds, losses, order, absolute = [], [], [], []
-    for idx, x, t in store.epoch(batch_size, shuffle=False, drop_odd=trainer_clip_odd_batches(trainer)):
+    # the epoch's batches (DataLoader(batch_size) order, unshuffled, + clip_odd_batch_sizes when the model asks for it);
+    # their absolute indices are uploaded ONCE, the steps take device slices: no host-to-device copy per step
+    n, drop_odd = len(store), trainer_clip_odd_batches(trainer)
+    rel = []
+    for s0 in range(0, n, batch_size):
+        idx = torch.arange(s0, min(n, s0 + batch_size))
+        if drop_odd and batch_size != 1 and len(idx) % 2 == 1:
+            idx = idx[:-1]
+        if len(idx):
+            rel.append(idx)
+    abs_dev = store.device_indices(torch.cat(rel)) if rel else None
+    pos = 0
+    for idx in rel:
+        gidx = abs_dev[pos:pos + len(idx)]
+        pos += len(idx)
+        x, t = store.batch_from_device(gidx)
         loss, logits, _ = trainer.test_step(x, t)
-        gidx = idx.to(dev)
-        if store.kfold_indexes is not None:
-            gidx = store.kfold_indexes[gidx]
         grp = slot[gidx]
         if logits.dim() == 3:                       # per-breath heads: every breath votes for its window's patient
             nb = logits.shape[1]                    # (PerBreathClassifierMixin, train_ards_detector.py:548-555)
