@@ -148,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void conv3_x3_kernel(ConvX3Args a) {
   // re-load and re-stage the last panel) so that the compiler can place all of it between the MFMAs.
   auto step = [&](const unsigned char* cur, unsigned char* nxt, const X3BFrag& bc, X3BFrag& bn, int ks) {
     const int k1 = ks + 1 < kch ? ks + 1 : kch - 1, k2 = ks + 2 < kch ? ks + 2 : kch - 1;
-    gload_b(bn, k1);
-    __builtin_amdgcn_sched_barrier(0);                   // keep the fetch a whole K step ahead of its use
+    gload_b(bn, k1);                                     // (the compiler sinks these loads to the end of the step: 122 registers, 4 waves per SIMD;
+                                                         //  pinning them here -- a whole K step ahead -- costs 158 registers and measured 3 % slower)
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
 #pragma unroll
