@@ -1271,3 +1271,16 @@ def test_folds_in_flight_reproduce_the_sequential_fold_loop(tmp_path, backbone):
             mb = torch.load(str(tmp_path / 'flight1' / ('f-fold%d.pth' % fold)), weights_only=False)
             for (k, p), (_, q) in zip(ma.state_dict().items(), mb.state_dict().items()):
                 assert torch.equal(p, q), (flight, fold, k)
+
+
+def test_folds_in_flight_eager_steps(tmp_path):
+    """--folds-in-flight with --no-graph (eager launches from two streams, no captured step, no placement trial):
+    still the sequential loop's numbers."""
+    from deepards_amd import train_ards_detector as T
+    gold = os.path.join(os.path.dirname(__file__), 'golden', 'test_dataset.npz')
+    out = {}
+    for flight in (1, 2):
+        cls, res = T.main(['--cuda-no-dp', '--train-from-pickle', gold, '--kfolds', '2', '-e', '1', '-b', '6', '--base-network',
+                           'resnet18', '--seed', '4', '--clip-grad', '--no-graph', '--folds-in-flight', str(flight)])
+        out[flight] = [res.get_meter('loss', f) for f in (0, 1)] + [res.patient_results[(f, 1)]['votes'].tolist() for f in (0, 1)]
+    assert out[1] == out[2]
