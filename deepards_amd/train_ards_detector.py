@@ -51,7 +51,7 @@ BUILD_DEFAULTS = dict(
     clip_grad=None, with_fft=None, only_fft=None, fft_real_only=None, random_kfold=None, bootstrap=None,
     kfolds=None, only_fold=None, load_checkpoint=None, load_base_network=None, save_model=None, saved_models_dir=None,
     train_from_pickle=None, train_to_pickle=None, test_from_pickle=None, test_to_pickle=None,
-    experiment_name='deepards_amd', config_override=None, folds_in_flight=1,
+    experiment_name='deepards_amd', config_override=None, folds_in_flight=None,
 )
 
 # make_args(): the merged view with every reference default, for callers that build ``args`` in Python
@@ -302,7 +302,10 @@ class BaseTraining(object):
         from .checkpoint import model_save_path
         a = self.args
         saved_models_dir = a.saved_models_dir if getattr(a, 'saved_models_dir', None) else saved_models_default_dir
-        n_flight = int(getattr(a, 'folds_in_flight', 1) or 1)
+        n_flight = getattr(a, 'folds_in_flight', None)
+        if n_flight is None:                             # default: up to 5 folds side by side on a single GPU (same results)
+            n_flight = min(5, self.n_kfolds) if self._data_parallel()[0] == 1 else 1
+        n_flight = int(n_flight)
         if n_flight > 1 and self.n_kfolds > 1 and a.kfolds is not None:
             return self._train_and_test_folds_in_flight(n_flight, saved_models_dir)
         for fold_num, (train_dataset, train_loader, test_dataset, test_loader) in enumerate(self.get_splits()):
@@ -403,7 +406,10 @@ class BaseTraining(object):
                 self.model, self.optimizer = model, optimizer
             self.fold_models = getattr(self, 'fold_models', {})
             self.fold_models.update({c[0]: c[2] for c in ctx})
-            a.train_store = ctx[-1][4]
+        if folds:                                        # like the sequential loop, leave the caller's stores at the last fold
+            self._seed_fold_sampler(train_dataset, folds[-1])
+            for ds in (train_dataset, test_dataset):
+                ds.set_kfold_indexes_for_fold(folds[-1])
         return self.results
 
     def _save(self, model, path):
@@ -584,7 +590,8 @@ def build_parser():
     parser.add_argument('--no-graph', dest='use_graph', action='store_false', default=None, help='run the step eagerly')
     parser.add_argument('--conv-dtype', choices=['f32', 'bf16', 'f32x3'], help='arithmetic of the residual-block convs')
     parser.add_argument('--folds-in-flight', type=int, help='k-folds trained side by side on this GPU, each on its own stream '
-                        '(same per-fold results as one after the other; a B <= 64 step leaves the chip partly idle)')
+                        '(same per-fold results as one after the other; a B <= 64 step leaves the chip partly idle).  '
+                        'Default: min(5, kfolds) on one GPU, 1 under data parallelism; 1 = the sequential loop')
     parser.add_argument('--act-dtype', choices=['f32', 'bf16'], help='activation storage under --conv-dtype bf16 (default bf16 for ResNets)')
     return parser
 
