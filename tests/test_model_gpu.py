@@ -1284,3 +1284,28 @@ def test_folds_in_flight_eager_steps(tmp_path):
                            'resnet18', '--seed', '4', '--clip-grad', '--no-graph', '--folds-in-flight', str(flight)])
         out[flight] = [res.get_meter('loss', f) for f in (0, 1)] + [res.patient_results[(f, 1)]['votes'].tolist() for f in (0, 1)]
     assert out[1] == out[2]
+
+
+@pytest.mark.parametrize('backbone', ['resnet18', 'densenet18'])
+def test_trainer_snapshot_restore_is_traceless(M, backbone):
+    """HotPathTrainer.snapshot / restore (what the stream-placement trial of --folds-in-flight relies on): steps taken
+    after a snapshot leave no trace once it is restored -- the next steps repeat bit for bit (parameters, momentum,
+    BatchNorm running statistics, densenet's dropout seed, static batches)."""
+    from deepards_amd.train import HotPathTrainer
+    x, t = seeded_batch(4, 20, 3)
+    xt, tt = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+    model = build(M, backbone, 2, drop_rate=0.2) if backbone == 'densenet18' else build(M, backbone, 2)
+    tr = HotPathTrainer(model, use_graph=True)
+    for _ in range(3):
+        tr.train_step(xt, tt)
+    snap = tr.snapshot()
+
+    def three():
+        losses = [float(tr.train_step(xt + 0.1 * i, tt)) for i in range(3)]
+        return losses, {k: v.clone() for k, v in model.state_dict().items()}, tr.steps
+    a = three()
+    tr.restore(snap)
+    b = three()
+    assert a[0] == b[0] and a[2] == b[2]
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k
