@@ -571,44 +571,70 @@ def run_test_epoch(trainer, store, patient_slot, batch_size=16):
     0..P-1 (indexed by the ABSOLUTE window index, like the reference's ground-truth frame).  One host sync at the end.
     Returns dict(votes (P,2), pred_frac (P,), prediction (P,), window_pred, window_index (fold-relative),
     window_abs_index (index into all windows = the reference's obs_idx, dataset.py:1349-1350,1404), mean_loss) mirroring metrics.py:572-604: pred_frac = ARDS votes / all votes, prediction = argmax of the votes."""
-    dev = store.tiles.device
-    slot = torch.as_tensor(patient_slot, dtype=torch.int64, device=dev)
-    n_pat = int(slot.max()) + 1
-    votes = torch.zeros((n_pat, 2), dtype=torch.int32, device=dev)
-    preds, losses, order, absolute = [], [], [], []
-    # the epoch's batches (DataLoader(batch_size) order, unshuffled, + clip_odd_batch_sizes when the model asks for it);
-    # their absolute indices are uploaded ONCE, the steps take device slices: no host-to-device copy per step
-    n, drop_odd = len(store), trainer_clip_odd_batches(trainer)
-    rel = []
-    for s0 in range(0, n, batch_size):
-        idx = torch.arange(s0, min(n, s0 + batch_size))
-        if drop_odd and batch_size != 1 and len(idx) % 2 == 1:
-            idx = idx[:-1]
-        if len(idx):
-            rel.append(idx)
-    abs_dev = store.device_indices(torch.cat(rel)) if rel else None
-    pos = 0
-    for idx in rel:
-        gidx = abs_dev[pos:pos + len(idx)]
-        pos += len(idx)
-        x, t = store.batch_from_device(gidx)
-        loss, logits, _ = trainer.test_step(x, t)
-        grp = slot[gidx]
+    steps = test_epoch_steps(trainer, store, patient_slot, batch_size)
+    for _ in steps:
+        pass
+    return steps.result()
+
+
+class test_epoch_steps(object):
+    """``run_test_epoch`` as an iterator: every ``next`` enqueues ONE test step (gather, forward, loss, vote kernel) on
+    the current stream and returns without a host sync; ``result()`` after the last one reads the reductions back.
+    The fold loop with folds in flight walks several of these round-robin, each under its own stream."""
+
+    def __init__(self, trainer, store, patient_slot, batch_size=16):
+        self.trainer, self.store = trainer, store
+        dev = store.tiles.device
+        host_slot = torch.as_tensor(patient_slot, dtype=torch.int64)
+        n_pat = int(host_slot.max()) + 1 if not host_slot.is_cuda else int(host_slot.max().item()) + 1
+        self.slot = host_slot.to(dev)
+        self.votes = torch.zeros((n_pat, 2), dtype=torch.int32, device=dev)
+        self.preds, self.losses, self.order, self.absolute = [], [], [], []
+        # the epoch's batches (DataLoader(batch_size) order, unshuffled, + clip_odd_batch_sizes when the model asks for
+        # it); their absolute indices are uploaded ONCE, the steps take device slices: no host-to-device copy per step
+        n, drop_odd = len(store), trainer_clip_odd_batches(trainer)
+        self.rel = []
+        for s0 in range(0, n, batch_size):
+            idx = torch.arange(s0, min(n, s0 + batch_size))
+            if drop_odd and batch_size != 1 and len(idx) % 2 == 1:
+                idx = idx[:-1]
+            if len(idx):
+                self.rel.append(idx)
+        self.abs_dev = store.device_indices(torch.cat(self.rel)) if self.rel else None
+        self.pos, self.i = 0, 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.i >= len(self.rel):
+            raise StopIteration
+        idx = self.rel[self.i]
+        self.i += 1
+        gidx = self.abs_dev[self.pos:self.pos + len(idx)]
+        self.pos += len(idx)
+        x, t = self.store.batch_from_device(gidx)
+        loss, logits, _ = self.trainer.test_step(x, t)
+        grp = self.slot[gidx]
         if logits.dim() == 3:                       # per-breath heads: every breath votes for its window's patient
             nb = logits.shape[1]                    # (PerBreathClassifierMixin, train_ards_detector.py:548-555)
             grp = grp.repeat_interleave(nb)
             idx = idx.repeat_interleave(nb)
             gidx = gidx.repeat_interleave(nb)
             logits = logits.reshape(-1, 2)
-        preds.append(H.vote_counts(logits.contiguous(), grp, votes))
-        losses.append(loss.reshape(1))
-        order.append(idx)
-        absolute.append(gidx)
-    v = votes.cpu().numpy()
-    tot = v.sum(axis=1)
-    return dict(votes=v, pred_frac=v[:, 1] / tot.clip(min=1), prediction=v.argmax(axis=1),
-                window_pred=torch.cat(preds).cpu().numpy(), window_index=torch.cat(order).numpy(),
-                window_abs_index=torch.cat(absolute).cpu().numpy(), mean_loss=float(torch.cat(losses).mean()))
+        self.preds.append(H.vote_counts(logits.contiguous(), grp, self.votes))
+        self.losses.append(loss.reshape(1))
+        self.order.append(idx)
+        self.absolute.append(gidx)
+        return self.i
+
+    def result(self):
+        v = self.votes.cpu().numpy()
+        tot = v.sum(axis=1)
+        return dict(votes=v, pred_frac=v[:, 1] / tot.clip(min=1), prediction=v.argmax(axis=1),
+                    window_pred=torch.cat(self.preds).cpu().numpy(), window_index=torch.cat(self.order).numpy(),
+                    window_abs_index=torch.cat(self.absolute).cpu().numpy(),
+                    mean_loss=float(torch.cat(self.losses).mean()))
 
 
 def trainer_clip_odd_batches(trainer):

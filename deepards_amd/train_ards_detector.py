@@ -36,7 +36,7 @@ import torch
 
 from . import models as M
 from .config import Configuration
-from .train import HotPathTrainer, run_test_epoch, run_train_epoch_from_store
+from .train import HotPathTrainer, run_test_epoch, run_train_epoch_from_store, test_epoch_steps
 
 base_networks = M.base_networks
 saved_models_default_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'saved_models')
@@ -279,7 +279,7 @@ class BaseTraining(object):
         self.results.update_meter('loss_epoch_{}'.format(epoch_num), fold_num, loss.clone())
         return loss
 
-    def run_test_epoch(self, epoch_num, model, test_dataset, test_loader, fold_num, optimizer=None):
+    def run_test_epoch(self, epoch_num, model, test_dataset, test_loader, fold_num, optimizer=None, _steps_only=False):
         """:424-465 + record_final_epoch_testing_results (:519-524): no_grad forward with train-mode modules (the
         reference never calls eval()), loss meter, window argmax, per-patient votes -- reduced on the device."""
         store, batch_size, _ = test_loader
@@ -288,9 +288,17 @@ class BaseTraining(object):
         slot = self.args.test_patient_slot
         if slot is None:
             slot = torch.zeros(store.tiles.shape[0], dtype=torch.int64)
-        res = run_test_epoch(trainer, store, slot, batch_size=batch_size)
+        steps = test_epoch_steps(trainer, store, slot, batch_size=batch_size)
+        if _steps_only:                                       # folds in flight: the caller walks the steps and finishes
+            return steps
+        for _ in steps:
+            pass
         if optimizer is None:
             trainer.release_graphs()                          # a throw-away trainer: free its graphs here, not in a GC pass
+        return self._finish_test_epoch(steps, epoch_num, fold_num)
+
+    def _finish_test_epoch(self, steps, epoch_num, fold_num):
+        res = steps.result()
         self.preds, self.pred_idx = res['window_pred'].tolist(), res['window_abs_index'].tolist()   # obs_idx is absolute
         self.results.update_meter('test_loss', fold_num, res['mean_loss'])
         self.results.patient_results[(fold_num, epoch_num)] = res
@@ -393,12 +401,24 @@ class BaseTraining(object):
                 for fold_num, stream, model, optimizer, tr_ds, te_ds in ctx:
                     if _flag(a, 'reshuffle_oversample_per_epoch'):
                         tr_ds.set_oversampling_indices()
-                    with torch.cuda.stream(stream):
-                        if not _flag(a, 'no_test_after_epochs') or epoch_num == a.epochs - 1:
-                            self.run_test_epoch(epoch_num, model, te_ds, (te_ds, a.batch_size, shuffle), fold_num, optimizer=optimizer)
-                        stream.synchronize()
-                        if _flag(a, 'save_model_per_epoch'):
-                            self._save(model, model_save_path(a.save_model, saved_models_dir, self.n_kfolds, fold_num, epoch_num))
+                if not _flag(a, 'no_test_after_epochs') or epoch_num == a.epochs - 1:
+                    walks = []                           # the folds' test epochs, one step of each in turn
+                    for fold_num, stream, model, optimizer, tr_ds, te_ds in ctx:
+                        with torch.cuda.stream(stream):
+                            walks.append(self.run_test_epoch(epoch_num, model, te_ds, (te_ds, a.batch_size, shuffle), fold_num,
+                                                             optimizer=optimizer, _steps_only=True))
+                    live = list(range(len(ctx)))
+                    while live:
+                        for i in list(live):
+                            with torch.cuda.stream(ctx[i][1]):
+                                if next(walks[i], None) is None:
+                                    live.remove(i)
+                    torch.cuda.synchronize()
+                    for (fold_num, stream, model, optimizer, tr_ds, te_ds), steps in zip(ctx, walks):
+                        self._finish_test_epoch(steps, epoch_num, fold_num)
+                for fold_num, stream, model, optimizer, tr_ds, te_ds in ctx:
+                    if _flag(a, 'save_model_per_epoch'):
+                        self._save(model, model_save_path(a.save_model, saved_models_dir, self.n_kfolds, fold_num, epoch_num))
             torch.cuda.synchronize()
             for fold_num, stream, model, optimizer, tr_ds, te_ds in ctx:
                 if a.save_model:
