@@ -470,9 +470,6 @@ def main():
                                                           'da_hip_runtime_symbol')]
         tr_e = HotPathTrainer(model, optimizer='sgd', use_graph=False)
         tr_e.bucket, tr_e.state = tr.bucket, tr.state
-        # the captured step runs the stem's backward chain BESIDE the batched weight gradients (functional._OVERLAP_STEM);
-        # two kernels sharing the chip stretch each other's event brackets, so the instrumented steps run them in sequence
-        overlap, F_._OVERLAP_STEM = F_._OVERLAP_STEM, False
         try:
             tr_e._eager_step(x, t)                       # untimed
             kt.install(names)
@@ -482,7 +479,6 @@ def main():
             summ = kt.summary()
         finally:
             kt.remove()
-            F_._OVERLAP_STEM = overlap
         say('roofline pass done')
         # Which kernel each single-kernel entry point launches (rocprofv3 names).  da_conv_wgrad_multi launches TWO
         # kernels per call (wino_wgrad_multi_kernel + conv_wgrad_multi_kernel<>), so HIP events around it time a pair:

@@ -12,8 +12,11 @@ not be: foreign checkpoints are only ever read with loaders that execute nothing
   storages the stream points at (zip ``data/<key>`` entries, or the raw blobs that follow a pytorch<=1.5 "legacy"
   file -- the reference's environment pins pytorch 1.0), the module tree is flattened to a ``state_dict`` with
   ``nn.Module.state_dict``'s naming, ``nn.DataParallel`` wrappers are unwrapped like train_ards_detector.py:385-386;
-* a whole module pickled by THIS package                 -> ``torch.load(..., weights_only=False)`` (a file our own
-  code wrote); recognised by the class path ``deepards_amd.`` at the head of its pickle.
+* a whole module pickled by THIS package                 -> recognised by the class path ``deepards_amd.`` at the head of its
+  pickle -- which anybody can write there, so these files are NOT unpickled freely either: ``load_own_module`` reads them
+  with torch's restricted unpickler (``weights_only=True``) and an allowlist of exactly the ``nn.Module`` classes of
+  ``deepards_amd.models`` and ``torch.nn``.  A file whose head says ``deepards_amd.models.X`` but whose body carries any
+  other global (``os.system`` in a REDUCE, ...) is refused with ``pickle.UnpicklingError`` before anything runs.
 
 ``state_dict`` keys are the reference's, so the extracted weights load straight into this package's models.
 """
@@ -243,13 +246,37 @@ def checkpoint_kind(path):
     return 'state_dict'
 
 
+def _own_module_classes():
+    """The only classes a whole-module file of this package may name: the nn.Module subclasses defined in
+    deepards_amd.models.* and torch.nn's own module classes (containers, Conv1d / BatchNorm1d / Linear / LSTM ... that
+    the models hold as parameter containers)."""
+    import inspect
+    from .models import densenet, resnet, torch_cnn_linear_network
+    allow = []
+    for mod in (resnet, densenet, torch_cnn_linear_network):
+        allow += [c for c in vars(mod).values()
+                  if inspect.isclass(c) and issubclass(c, torch.nn.Module) and c.__module__ == mod.__name__]
+    allow += [c for c in vars(torch.nn).values() if inspect.isclass(c) and issubclass(c, torch.nn.Module)]
+    return allow
+
+
+def load_own_module(path):
+    """A whole module this package saved (``torch.save(model, path)``), through torch's RESTRICTED unpickler: only the
+    classes of ``_own_module_classes`` (constructed with ``__new__`` + ``__setstate__``, never called), tensors,
+    parameters and plain containers are accepted; any other global in the stream raises ``pickle.UnpicklingError``
+    before it is looked up.  The class path at the head of the file is therefore not trusted for anything."""
+    with torch.serialization.safe_globals(_own_module_classes()):
+        return torch.load(path, weights_only=True, map_location='cpu')
+
+
 def load_model_weights(path, build_model):
-    """Model for ``--load-checkpoint`` (train_ards_detector.py:468-469).  Own whole-module files are unpickled; for
-    everything else ``build_model()`` makes a fresh model of the configured architecture and the file's weights are
-    loaded into it (strict: the keys are the reference's)."""
+    """Model for ``--load-checkpoint`` (train_ards_detector.py:468-469).  Own whole-module files go through
+    ``load_own_module`` (restricted unpickler + class allowlist); for everything else ``build_model()`` makes a fresh
+    model of the configured architecture and the file's weights are loaded into it (strict: the keys are the
+    reference's)."""
     kind = checkpoint_kind(path)
     if kind == 'own':
-        return torch.load(path, weights_only=False, map_location='cpu')
+        return load_own_module(path)
     sd = torch.load(path, weights_only=True, map_location='cpu') if kind == 'state_dict' else \
         read_module_checkpoint(path)['state_dict']
     if any(k.startswith('module.') for k in sd):                          # a DataParallel state_dict
@@ -265,7 +292,7 @@ def load_base_network(path, base_networks, build_args=None):
     ``breath_block.*`` weights."""
     kind = checkpoint_kind(path)
     if kind == 'own':
-        saved = torch.load(path, weights_only=False, map_location='cpu')
+        saved = load_own_module(path)
         if isinstance(saved, torch.nn.DataParallel):
             saved = saved.module
         return saved.breath_block

@@ -118,7 +118,9 @@ class DeviceTileStore(object):
             x = random_over_sample(x, labels[x], None, self.sampling_rng)
         if self.oversample_all_factor > 1.0:
             y = labels[x]
-            want = {0: int((y == 0).sum() * self.oversample_all_factor), 1: int((y == 1).sum() * self.oversample_all_factor)}
+            # (a fold that lacks one class: that class is left out of the request instead of asking for 0 items of a
+            #  class that is not there -- imbalanced-learn raises its own error for the reference in that case)
+            want = {c: int((y == c).sum() * self.oversample_all_factor) for c in (0, 1) if (y == c).any()}
             x = random_over_sample(x, y, want, self.sampling_rng)
         self.set_kfold_indexes(x)
 
@@ -173,12 +175,27 @@ class DeviceTileStore(object):
         idx = idx.to(self.tiles.device)
         if self.kfold_indexes is not None:
             idx = self.kfold_indexes[idx]
-        return idx.contiguous()
+        idx = idx.contiguous()
+        # remember the buffer: batch_from_device only accepts slices of index tensors that were checked here
+        import weakref
+        live = getattr(self, '_checked_idx', None)
+        if live is None:
+            live = self._checked_idx = {}
+        for k in [k for k, r in live.items() if r() is None]:
+            del live[k]
+        live[idx.untyped_storage().data_ptr()] = weakref.ref(idx)
+        return idx
 
     def batch_from_device(self, abs_idx, out=None):
-        """``batch`` for a contiguous int64 DEVICE tensor of absolute indices from ``device_indices`` (already checked)."""
+        """``batch`` for a contiguous int64 DEVICE tensor of absolute indices: a slice of what ``device_indices`` returned
+        (bounds-checked there once per epoch).  The gather kernels read ``tiles[idx]`` unchecked, so any other tensor is
+        refused: the check is on the storage the slice lives in."""
         if not (abs_idx.is_cuda and abs_idx.dtype == torch.int64 and abs_idx.dim() == 1 and abs_idx.is_contiguous()):
             raise ValueError('batch_from_device: a contiguous 1-D int64 device tensor from device_indices() expected')
+        ref = getattr(self, '_checked_idx', {}).get(abs_idx.untyped_storage().data_ptr()) if abs_idx.numel() else True
+        if ref is None or (ref is not True and ref() is None):
+            raise ValueError('batch_from_device: indices must be (a slice of) a tensor returned by device_indices(), which '
+                             'checks them against the store; use batch() for anything else')
         ox, ot = out if out is not None else (None, None)
         return (H.gather_normalize(self.tiles, abs_idx, self.mu, self.std, out=ox),
                 H.gather_rows(self.targets, abs_idx, out=ot))

@@ -68,6 +68,7 @@ def main(argv=None):
                                        lambda: cls.get_network(cls.get_base_network())).to(cls.device)
             res = cls.run_test_epoch(i, model, test_dataset, loader, fold)
             rows += patient_rows(res, test_dataset, fold, i)
+    cls.restore_dtypes()
     table = fold_table(rows)
     print('\nMean Results')
     print('%-6s %-10s %-8s' % ('Fold', 'Accuracy', 'AUC'))

@@ -35,12 +35,12 @@ class BNState(object):
 #   * the ~60 tiny per-layer launches -- BN running statistics, BN dgamma/dbeta folds, split-K slab
 #     reductions of the weight gradients -- are queued and served by three batched launches.
 # Outside it (plain autograd use, tests) everything runs immediately.
-_STEP = {'on': False, 'pack': {}, 'running': [], 'pgrad': [], 'wgrad': [], 'wslab': [], 'forked': False, 'keep': []}
+_STEP = {'on': False, 'pack': {}, 'running': [], 'pgrad': [], 'wgrad': [], 'wslab': []}
 
 
 @contextlib.contextmanager
 def training_step(model=None):
-    _STEP.update(on=True, pack={}, running=[], pgrad=[], wgrad=[], wslab=[], forked=False, keep=[])
+    _STEP.update(on=True, pack={}, running=[], pgrad=[], wgrad=[], wslab=[])
     try:
         if model is not None:
             ms = [m for m in model.modules()
@@ -52,7 +52,7 @@ def training_step(model=None):
                 _STEP['pack'][w.data_ptr()] = e
         yield
     finally:
-        _STEP.update(on=False, pack={}, running=[], pgrad=[], wgrad=[], wslab=[], forked=False, keep=[])
+        _STEP.update(on=False, pack={}, running=[], pgrad=[], wgrad=[], wslab=[])
 
 
 def flush_forward():
@@ -65,52 +65,20 @@ def flush_backward():
     """Run the queued parameter-gradient folds (call after the backward, before the optimiser)."""
     H.bn_param_grad_multi(_STEP['pgrad'], accumulate=True)
     _launch_wgrads()
-    if _STEP.get('forked'):
-        torch.cuda.current_stream().wait_stream(_side_stream())        # join the weight-gradient branch
-        _STEP['forked'], _STEP['keep'] = False, []
     H.wgrad_reduce_multi(_STEP['wslab'], accumulate=True)
     _STEP['pgrad'], _STEP['wslab'] = [], []
 
 
-# The stem's backward chain beside the batched weight gradients, on a forked stream inside the captured step: OFF by default
-# since round 2.  (1) It stopped paying once the weight gradients took the Winograd form: resnet18 3.02 ms either way,
-# densenet18 1.507 (off) against 1.521, the bf16 configuration 1.580 (off) against 1.621.  (2) A captured step with a forked
-# branch makes its hipGraphExec own "parallel streams"; destroying ANOTHER such exec (an earlier fold's trainer collected
-# by the gc pass that precedes every capture) while this one is alive leaves a dangling stream in it and the next replay
-# segfaults in hip::Graph::UpdateStreams (ROCm 7.0 runtime bundled with torch 2.10; rocgdb backtrace in DESIGN.md §5) --
-# a captured step without parallel branches has no such streams.  DA_WGRAD_OVERLAP=1 brings the fork back.
-_OVERLAP_STEM = os.environ.get('DA_WGRAD_OVERLAP', '0') == '1'
-# experiment knobs (scripts/): DA_WGRAD_EARLY=1 launches a stage's weight gradients as soon as the stage's data gradients
-# are done, on the side stream; DA_WGRAD_PRIO sets that stream's priority (1 = lowest on this stack, -1 = highest)
-_WGRAD_EARLY = os.environ.get('DA_WGRAD_EARLY', '0') == '1'
-_WGRAD_PRIO = int(os.environ.get('DA_WGRAD_PRIO', '0'))
-_SIDE = {}
-
-
-def _side_stream(which=0):
-    key = (torch.cuda.current_device(), which)
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(priority=_WGRAD_PRIO) if _WGRAD_PRIO else torch.cuda.Stream()
-    return _SIDE[key]
-
-
-def _launch_wgrads(side=False):
-    """Launch the queued weight-gradient GEMMs ((dy, x, k, stride, pad, target) jobs), all in one batched call.
-    side: on a forked stream (joined by flush_backward) -- used when the stem's backward starts: every residual
-    block has queued its jobs by then, and the stem's bandwidth-bound backward chain (pool, BatchNorm, k7 weight
-    gradient) runs beside the MFMA-bound weight gradients instead of in front of them."""
+# The captured step is ONE chain of kernels on one stream.  Rounds 1-2 could fork the stem's backward (or a stage's weight
+# gradients) onto a side stream inside the capture; that never paid once the weight gradients took the Winograd form
+# (DESIGN.md 7a) and a hipGraphExec with parallel branches owns streams that die with ANOTHER such exec (segfault in
+# hip::Graph::UpdateStreams, DESIGN.md 5) -- so the forked paths and their switches are gone, not just off.
+def _launch_wgrads():
+    """Launch the queued weight-gradient GEMMs ((dy, x, k, stride, pad, target) jobs), all in one batched call."""
     jobs = _STEP['wgrad']
     if not jobs:
         return
-    if side:
-        s = _side_stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            slabs = H.conv_wgrad_multi([j[:5] for j in jobs])
-        _STEP['forked'] = True
-        _STEP['keep'] = _STEP.get('keep', []) + jobs      # dy / x stay alive until the join
-    else:
-        slabs = H.conv_wgrad_multi([j[:5] for j in jobs])
+    slabs = H.conv_wgrad_multi([j[:5] for j in jobs])
     _STEP['wslab'] += [(sl, j[5]) for sl, j in zip(slabs, jobs)]
     _STEP['wgrad'] = []
 
@@ -285,8 +253,6 @@ class StemFunction(Function):
     def backward(ctx, dout):
         x2d, y0, mean, invstd, gamma, beta = ctx.saved_tensors
         tw, tg, tb = ctx.gt
-        if _STEP['on'] and _OVERLAP_STEM:
-            _launch_wgrads(side=True)
         dz = H.pool_bwd(dout.contiguous(), y0, ctx.R, mean, invstd, gamma, beta, ctx.pool_mode)
         dy0, dgamma, dbeta = _bn_bwd(dz, y0, ctx.R, mean, invstd, gamma, beta, 1, tg, tb, dx=dz)
         dw = H.stem_conv_wgrad(dy0, x2d, out=tw, accumulate=tw is not None)
@@ -382,8 +348,6 @@ class BasicBlockFunction(Function):
         dw1 = _wgrad(dy1, x, 3, stride, 1, tw1)
         if ctx.has_ds:
             dwd = _wgrad(dyd, x, 1, stride, 0, twd)
-            if _WGRAD_EARLY and _STEP['on']:
-                _launch_wgrads(side=True)
             if stride == 2 and _PAIR_S2 and not _is_wino(w1, stride, 1):
                 dx = H.conv_dgrad_s2_pair(dy1, _pack(w1, False)[1], dyd, _pack(wd, False)[1], lin)
             else:

@@ -439,12 +439,14 @@ class IngestedDataset(object):
         if self.windows.ndim != 4 or self.targets.shape != (self.windows.shape[0], 2):
             raise ValueError('windows must be (N, NB, C, L) and targets (N, 2)')
         self.patients = None if patients is None else np.asarray(patients).astype(str)
-        if patient_slot is None:
+        if patient_slot is None and self.patients is not None:
             slots, seen = [], {}
             for p in self.patients.tolist():
                 slots.append(seen.setdefault(p, len(seen)))
             patient_slot = np.array(slots, dtype=np.int64)
-        self.patient_slot = np.asarray(patient_slot, dtype=np.int64)
+        # None: an older export without patient information -- usable for plain training / a holdout test over windows,
+        # refused for anything patient-wise (k-folds, vote tables) instead of inventing groups
+        self.patient_slot = None if patient_slot is None else np.asarray(patient_slot, dtype=np.int64)
         self.hours = hours
         self.metadata = metadata
         self.scaling_factors = scaling_factors
@@ -457,14 +459,18 @@ class IngestedDataset(object):
 
     @property
     def n_patients(self):
+        if self.patient_slot is None:
+            return 0
         return int(self.patient_slot.max()) + 1 if len(self.patient_slot) else 0
 
     def save_npz(self, path, anonymise=True):
         """One .npz with everything a training run needs (loads with allow_pickle=False).  anonymise: patient
         identifiers are dropped, only their slots (order of first appearance) are written."""
-        out = dict(x=self.windows, target=self.targets, patient_slot=self.patient_slot, hours=self.hours,
+        out = dict(x=self.windows, target=self.targets, hours=self.hours,
                    n_sub_batches=self.n_sub_batches, dataset_type=str(self.dataset_type), train=self.train,
                    total_kfolds=-1 if self.total_kfolds is None else self.total_kfolds)
+        if self.patient_slot is not None:
+            out['patient_slot'] = self.patient_slot
         for k, (mu, std) in self.scaling_factors.items():
             tag = 'none' if k is None else str(int(k))
             out['mu/' + tag], out['std/' + tag] = np.asarray(mu, dtype=np.float64), np.asarray(std, dtype=np.float64)
@@ -498,6 +504,10 @@ class IngestedDataset(object):
         store.patient_slot = self.patient_slot
         store.train = self.train
         if self.total_kfolds is not None:
+            if self.patient_slot is None:
+                raise ValueError('k-fold splits are patient-wise (dataset.py:765-830) and this dataset file carries no '
+                                 'patient information (an export without patient_slot): re-export it with '
+                                 'python -m deepards_amd.ingest <dataset.pkl> <out.npz>')
             factors = {k: (float(np.ravel(m)[0]), float(np.ravel(s)[0])) for k, (m, s) in self.scaling_factors.items()
                        if k is not None} or None
             store.enable_kfolds(self.patient_slot, self.total_kfolds, train=self.train, random_kfold=random_kfold,
@@ -619,7 +629,7 @@ def load_npz(path):
         str(z['dataset_type']) if 'dataset_type' in files else 'unpadded_centered_sequences',
         train=bool(z['train']) if 'train' in files else True, total_kfolds=None if total < 0 else total,
         kfold_patient_splits=splits or None, metadata=z['metadata'] if 'metadata' in files else None,
-        patient_slot=z['patient_slot'] if 'patient_slot' in files else np.arange(n) % 6)
+        patient_slot=z['patient_slot'] if 'patient_slot' in files else None)
 
 
 def load_dataset(path):

@@ -564,14 +564,14 @@ def _epoch_indices(store, batch_size, shuffle, generator, world_size=1):
             yield idx, None, None
 
 
-def run_test_epoch(trainer, store, patient_slot, batch_size=16):
+def run_test_epoch(trainer, store, patient_slot, batch_size=16, shuffle=False, generator=None):
     """BaseTraining.run_test_epoch (:424-465) + record_final_epoch_testing_results (:519-524) with the reductions on
     the device: no_grad forward in train mode, BCE loss, window argmax, per-patient vote table.  ``store`` is a
     DeviceTileStore, ``patient_slot`` an int64 tensor (len(store),) mapping every window to a patient slot
     0..P-1 (indexed by the ABSOLUTE window index, like the reference's ground-truth frame).  One host sync at the end.
     Returns dict(votes (P,2), pred_frac (P,), prediction (P,), window_pred, window_index (fold-relative),
     window_abs_index (index into all windows = the reference's obs_idx, dataset.py:1349-1350,1404), mean_loss) mirroring metrics.py:572-604: pred_frac = ARDS votes / all votes, prediction = argmax of the votes."""
-    steps = test_epoch_steps(trainer, store, patient_slot, batch_size)
+    steps = test_epoch_steps(trainer, store, patient_slot, batch_size, shuffle=shuffle, generator=generator)
     for _ in steps:
         pass
     return steps.result()
@@ -580,9 +580,18 @@ def run_test_epoch(trainer, store, patient_slot, batch_size=16):
 class test_epoch_steps(object):
     """``run_test_epoch`` as an iterator: every ``next`` enqueues ONE test step (gather, forward, loss, vote kernel) on
     the current stream and returns without a host sync; ``result()`` after the last one reads the reductions back.
-    The fold loop with folds in flight walks several of these round-robin, each under its own stream."""
+    The fold loop with folds in flight walks several of these round-robin, each under its own stream.
 
-    def __init__(self, trainer, store, patient_slot, batch_size=16):
+    ``shuffle``: the reference builds the TEST DataLoader with ``shuffle=True`` too unless ``--unshuffled``
+    (train_ards_detector.py:333-338; evaluate.py: ``DataLoader(test_dataset, 16, True)``), so its test batches mix
+    patients; with shuffle the epoch walks one permutation (``generator``, or torch's global RNG like a DataLoader; under
+    data parallelism rank 0's draw is shared).  BatchNorm statistics are per WINDOW on this path (SURVEY finding 3), so the
+    batch composition does not change a window's prediction beyond fp32 summation order; what the order does decide is
+    the order of ``window_pred`` / ``window_index`` (the reference's ``preds`` / ``pred_idx`` lists), the sequence of the
+    ResNet running-statistics updates and which dropout draw a DenseNet window gets.  ``window_abs_index`` keys every
+    result by the absolute window, so the per-patient votes are order-independent."""
+
+    def __init__(self, trainer, store, patient_slot, batch_size=16, shuffle=False, generator=None):
         self.trainer, self.store = trainer, store
         dev = store.tiles.device
         host_slot = torch.as_tensor(patient_slot, dtype=torch.int64)
@@ -590,12 +599,16 @@ class test_epoch_steps(object):
         self.slot = host_slot.to(dev)
         self.votes = torch.zeros((n_pat, 2), dtype=torch.int32, device=dev)
         self.preds, self.losses, self.order, self.absolute = [], [], [], []
-        # the epoch's batches (DataLoader(batch_size) order, unshuffled, + clip_odd_batch_sizes when the model asks for
+        # the epoch's batches (DataLoader(batch_size, shuffle) order + clip_odd_batch_sizes when the model asks for
         # it); their absolute indices are uploaded ONCE, the steps take device slices: no host-to-device copy per step
         n, drop_odd = len(store), trainer_clip_odd_batches(trainer)
+        if shuffle:
+            order = torch.randperm(n, generator=shared_generator(trainer, generator))
+        else:
+            order = torch.arange(n)
         self.rel = []
         for s0 in range(0, n, batch_size):
-            idx = torch.arange(s0, min(n, s0 + batch_size))
+            idx = order[s0:min(n, s0 + batch_size)]
             if drop_odd and batch_size != 1 and len(idx) % 2 == 1:
                 idx = idx[:-1]
             if len(idx):

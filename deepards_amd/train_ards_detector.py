@@ -127,8 +127,12 @@ class BaseTraining(object):
         if _flag(args, 'stop_on_loss'):
             raise NotImplementedError('--stop-on-loss drops into an interactive shell in the reference (:155-157)')
         self.n_kfolds = args.kfolds if args.kfolds else 1
+        self._prev_dtypes = None
         if _flag(args, 'conv_dtype', None):
             from . import functional as F_
+            # the arithmetic / storage switches are process-wide: remember what was set so that restore_dtypes() (called
+            # when train_and_test finishes, and by evaluate.main) leaves a later run in this process what it had before
+            self._prev_dtypes = (F_.conv_dtype(), F_.storage_dtype())
             F_.set_conv_dtype(args.conv_dtype)
             # BASELINE's bf16 configs: bf16 storage too where the network has bf16 kernels throughout (the ResNets)
             if args.conv_dtype == 'bf16' and str(args.base_network).startswith('resnet') and \
@@ -282,13 +286,16 @@ class BaseTraining(object):
     def run_test_epoch(self, epoch_num, model, test_dataset, test_loader, fold_num, optimizer=None, _steps_only=False):
         """:424-465 + record_final_epoch_testing_results (:519-524): no_grad forward with train-mode modules (the
         reference never calls eval()), loss meter, window argmax, per-patient votes -- reduced on the device."""
-        store, batch_size, _ = test_loader
+        store, batch_size, shuffle = test_loader
         trainer = optimizer if optimizer is not None else HotPathTrainer(model, use_graph=_flag(self.args, 'use_graph', True))
         trainer.clip_odd_batches = self.clip_odd_batches
         slot = self.args.test_patient_slot
         if slot is None:
             slot = torch.zeros(store.tiles.shape[0], dtype=torch.int64)
-        steps = test_epoch_steps(trainer, store, slot, batch_size=batch_size)
+        gen = None                                            # the test loader shuffles too unless --unshuffled (:333-338)
+        if shuffle and self.args.seed is not None:
+            gen = torch.Generator().manual_seed(self.args.seed + 1000 * fold_num + epoch_num + 500009)
+        steps = test_epoch_steps(trainer, store, slot, batch_size=batch_size, shuffle=shuffle, generator=gen)
         if _steps_only:                                       # folds in flight: the caller walks the steps and finishes
             return steps
         for _ in steps:
@@ -304,9 +311,25 @@ class BaseTraining(object):
         self.results.patient_results[(fold_num, epoch_num)] = res
         return res
 
+    def restore_dtypes(self):
+        """Put back the process-wide conv arithmetic / activation storage this run replaced (--conv-dtype)."""
+        if self._prev_dtypes is not None:
+            from . import functional as F_
+            conv, storage = self._prev_dtypes
+            F_.set_conv_dtype(conv)
+            if storage != F_.storage_dtype():
+                F_.set_storage_dtype(storage)
+            self._prev_dtypes = None
+
     def train_and_test(self):
         """:340-378 without plotting: fold loop, epoch loop, per-epoch / per-fold whole-module saves under the
         reference's file names (``deepards_amd.checkpoint.model_save_path``)."""
+        try:
+            return self._train_and_test()
+        finally:
+            self.restore_dtypes()
+
+    def _train_and_test(self):
         from .checkpoint import model_save_path
         a = self.args
         saved_models_dir = a.saved_models_dir if getattr(a, 'saved_models_dir', None) else saved_models_default_dir
@@ -332,10 +355,8 @@ class BaseTraining(object):
                     self._save(model, model_save_path(a.save_model, saved_models_dir, self.n_kfolds, fold_num, epoch_num))
             if a.save_model:
                 self._save(model, model_save_path(a.save_model, saved_models_dir, self.n_kfolds, fold_num))
-            prev = getattr(self, 'optimizer', None)
-            if prev is not None and prev is not optimizer and hasattr(prev, 'release_graphs'):
-                prev.release_graphs()                    # the outgoing fold's captured steps go NOW, not in some later gc pass
-            self.model, self.optimizer = model, optimizer
+            optimizer.release_graphs()                   # this fold's captured steps go NOW, not in some later gc pass (the
+            self.model, self.optimizer = model, optimizer    # trainer stays usable: it re-captures on its next step)
         return self.results
 
     def _train_and_test_folds_in_flight(self, n_flight, saved_models_dir):
@@ -426,6 +447,8 @@ class BaseTraining(object):
                 self.model, self.optimizer = model, optimizer
             self.fold_models = getattr(self, 'fold_models', {})
             self.fold_models.update({c[0]: c[2] for c in ctx})
+            for c in ctx:                                # the group's captured steps are released here, explicitly, before
+                c[3].release_graphs()                    # the next group captures its own (ownership rule, train._capture_graph)
         if folds:                                        # like the sequential loop, leave the caller's stores at the last fold
             self._seed_fold_sampler(train_dataset, folds[-1])
             for ds in (train_dataset, test_dataset):

@@ -266,6 +266,38 @@ def test_store_kfold_and_oversampling_index_plumbing_on_the_fixture():
         hold.batch([20])                                   # bounds are checked before anything reaches the gather kernel
 
 
+def test_export_without_patients_refuses_patient_wise_use_and_device_indices_are_tagged(tmp_path):
+    """an older .npz without patient_slot used to get invented patients (arange % 6), so 'patient-wise'
+    folds put one real patient's windows in train AND test; and batch_from_device forwarded any int64 device tensor to
+    the gather kernels, which read tiles[idx] unchecked."""
+    from deepards_amd import ingest
+    ds = ingest.load_npz(os.path.join(GOLD, 'test_dataset_windows.npz'))       # the older export: x, target, mu, std
+    assert ds.patient_slot is None and ds.n_patients == 0
+    store = ds.to_store(device='cpu')                                           # plain training over windows: fine
+    assert store.patient_slot is None and len(store) == 20
+    ds.total_kfolds = 2
+    with pytest.raises(ValueError, match='patient'):
+        ds.to_store(device='cpu')
+    out = ds.save_npz(str(tmp_path / 'again.npz'))
+    assert 'patient_slot' not in np.load(out).files
+    # oversample_all_factor on a fold that lacks one class: the absent class is left out of the request
+    full = ingest.load_npz(os.path.join(GOLD, 'test_dataset.npz'))
+    full.total_kfolds, full.train = 2, True
+    st = full.to_store(device='cpu')
+    st.set_kfold_indexes_for_fold(0)
+    ards_only = [i for i in st.kfold_indexes.tolist() if full.targets[i, 1] == 1]
+    st.set_kfold_indexes(ards_only)
+    st.oversample_all_factor = 2.0
+    st.set_oversampling_indices()
+    assert len(st.kfold_indexes) == 2 * len(ards_only)
+    # batch_from_device accepts slices of what device_indices checked, nothing else (needs a device: shape of the rule
+    # is tested with the storage registry directly)
+    checked = store.device_indices(torch.arange(6))
+    assert checked.untyped_storage().data_ptr() in store._checked_idx
+    with pytest.raises(IndexError):
+        store.device_indices(torch.tensor([0, 20]))
+
+
 # ---- checkpoints ---------------------------------------------------------------------------------------------------------
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'tools'))
 from ref_paths import as_reference_classes as _as_reference_classes      # noqa: E402
@@ -327,6 +359,39 @@ def test_own_and_state_dict_checkpoints_and_reference_file_names(tmp_path):
     assert C.model_save_path('runs/m.pth', 'saved', 5, 3) == os.path.join('saved', 'm-fold3.pth')
     assert C.model_save_path('m.pth', 'saved', 5, 3, epoch_num=2) == os.path.join('saved', 'm-epoch2-fold3.pth')
     assert C.model_save_path('m.pth', 'saved', 1, 0, epoch_num=7) == os.path.join('saved', 'm-epoch7.pth')
+
+
+class _Boom(object):
+    """Pickles as a call of os.system: what a crafted checkpoint would smuggle in."""
+
+    def __init__(self, marker):
+        self.marker = marker
+
+    def __reduce__(self):
+        return (os.system, ('touch %s' % self.marker,))
+
+
+@pytest.mark.parametrize('where', ['attribute', 'buffer_dict'])
+def test_spoofed_own_checkpoint_executes_nothing(tmp_path, where):
+    """A file whose pickle HEAD names a deepards_amd.models class (so checkpoint_kind says 'own') but whose body
+    carries a REDUCE of os.system must be refused before anything runs (the 'own' branch used to be a
+    plain torch.load(weights_only=False))."""
+    import pickle
+    from deepards_amd import checkpoint as C
+    import deepards_amd.models as M
+    marker = str(tmp_path / 'pwned')
+    m = M.CNNLinearNetwork(M.resnet18(), 20, 0)
+    if where == 'attribute':
+        m.payload = _Boom(marker)
+    else:
+        m.breath_block._buffers['payload'] = _Boom(marker)
+    path = str(tmp_path / 'spoof.pth')
+    torch.save(m, path)
+    assert C.checkpoint_kind(path) == 'own'
+    for load in (lambda: C.load_model_weights(path, lambda: None), lambda: C.load_base_network(path, M.base_networks)):
+        with pytest.raises(pickle.UnpicklingError):
+            load()
+    assert not os.path.exists(marker)
 
 
 @pytest.mark.skipif(not os.path.exists('/root/reference/deepards/models/resnet.py'),
