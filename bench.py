@@ -325,18 +325,7 @@ def main():
         if (args.backbone, NB, SL) not in WORK:
             raise SystemExit('no algorithmic-work row for %s NB=%d L=%d (SURVEY 8d has resnet18 40 x 512)' % (args.backbone, NB, SL))
 
-        class BreathBlockLinear(torch.nn.Module):
-            def __init__(self, breath_block, nb, seq_len):
-                super().__init__()
-                self.breath_block, self.nb = breath_block, nb
-                feat = breath_block.n_out_filters * (seq_len // 32 - 6)
-                self.linear_final = torch.nn.Linear(feat * nb, 2)
-
-            def forward(self, x, metadata):
-                b, nb, c, l = x.shape
-                feat = self.breath_block.forward_windows(x.reshape(b * nb, c, l), nb)
-                return F_.Linear2Function.apply(feat.view(b, -1), self.linear_final.weight, self.linear_final.bias)
-        model = BreathBlockLinear(bb, NB, SL).to(dev)
+        model = M.BreathBlockLinear(bb, NB, SL).to(dev)    # deepards_amd/models/torch_cnn_linear_network.py
     else:
         model = M.CNNLinearNetwork(bb, 20, 0).to(dev)
     B = args.batch

@@ -66,6 +66,9 @@ SIGNATURES = {
     'da_stem_conv_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'da_stem_wgrad_workspace': (_Z, [_I, _I]),
     'da_stem_conv_wgrad': (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'da_stem_conv_fwd_g': (_I, [_P, _P, _P] + [_I] * 7 + [_P]),
+    'da_stem_wgrad_workspace_g': (_Z, [_I] * 4),
+    'da_stem_conv_wgrad_g': (_I, [_P, _I, _P, _P, _P] + [_I] * 7 + [_P]),
     'da_bn_chunks': (None, [_I, _I, _I, _IP, _IP]),
     'da_bn_workspace': (_Z, [_I, _I, _I]),
     'da_bn_stats_partial': (_I, [_P, _I, _I, _I, _I, _P, _P]),
@@ -113,6 +116,7 @@ SIGNATURES = {
     'da_clamp_adam': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _F, _F, _P]),
     'da_clamp_adam_dev': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P, _F, _F, _P]),
     'da_gather_normalize': (_I, [_P, _P, ctypes.c_double, ctypes.c_double, _P, _I, _I, _P]),
+    'da_gather_normalize_ch': (_I, [_P, _P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _P, _I, _I, _I, _I, _P]),
     'da_window_median_fwd': (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     'da_window_median_bwd': (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
     'da_lstm_fwd': (_I, [_P] * 11 + [_I, _I, _I, _P]),

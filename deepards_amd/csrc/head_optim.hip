@@ -452,6 +452,24 @@ __global__ __launch_bounds__(256) void gather_normalize_kernel(const double* __r
   for (int i = threadIdx.x; i < tile_elems; i += blockDim.x) dst[i] = (float)((src[i] - mu) / stdv);
 }
 
+// the same for windows with C <= 4 channels (flow + the Re / Im channels of its spectrum, dataset.py:1330-1341): every
+// channel has its own (mu, std) -- the (NB, C, L) broadcast arrays of dataset.py:641,648 -- tile layout [NB][C][L]
+struct ChanFactors {
+  double mu[4];
+  double stdv[4];
+};
+__global__ __launch_bounds__(256) void gather_normalize_ch_kernel(const double* __restrict__ tiles,
+                                                                  const int64_t* __restrict__ idx, ChanFactors f,
+                                                                  float* __restrict__ out, int tile_elems, int C, int L) {
+  const int b = blockIdx.x;
+  const double* src = tiles + (size_t)idx[b] * tile_elems;
+  float* dst = out + (size_t)b * tile_elems;
+  for (int i = threadIdx.x; i < tile_elems; i += blockDim.x) {
+    const int c = (i / L) % C;
+    dst[i] = (float)((src[i] - f.mu[c]) / f.stdv[c]);
+  }
+}
+
 // one-hot targets gathered the same way (float32 [N][2] -> [B][2])
 __global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, float* __restrict__ out,
                                    int B, int width) {
@@ -742,6 +760,23 @@ int da_gather_normalize(const double* tiles, const int64_t* idx, double mu, doub
   if (!tiles || !idx || !out || tile_elems < 1 || stdv == 0.0) return DA_EINVAL;
   if (B == 0) return DA_OK;
   hipLaunchKernelGGL(gather_normalize_kernel, dim3(B), dim3(256), 0, stream, tiles, idx, mu, stdv, out, tile_elems);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// tiles: [N][NB][C][L] float64, C <= 4; mu / stdv: HOST arrays of C per-channel factors.
+int da_gather_normalize_ch(const double* tiles, const int64_t* idx, const double* mu, const double* stdv, float* out, int B,
+                           int NB, int C, int L, hipStream_t stream) {
+  DA_ENTER();
+  if (!tiles || !idx || !out || !mu || !stdv || NB < 1 || C < 1 || C > 4 || L < 1) return DA_EINVAL;
+  ChanFactors f;
+  for (int c = 0; c < 4; ++c) {
+    f.mu[c] = c < C ? mu[c] : 0.0;
+    f.stdv[c] = c < C ? stdv[c] : 1.0;
+    if (f.stdv[c] == 0.0) return DA_EINVAL;
+  }
+  if (B == 0) return DA_OK;
+  hipLaunchKernelGGL(gather_normalize_ch_kernel, dim3(B), dim3(256), 0, stream, tiles, idx, f, out, NB * C * L, C, L);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

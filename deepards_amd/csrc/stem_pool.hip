@@ -9,65 +9,77 @@
 // broadcast), not a GEMM.
 #include "common.h"
 
-// y[row][l][co] = sum_k w[co][k] * x[row][2l + k - 3];  block = one waveform row.
-template <typename AT>
+// y[row][l][co] = sum_ci sum_k w[co][ci][k] * x[row][ci][S*l + k - K/2];  block = one (rows, CIN, Lin) input row.
+// CIN = 1, K = 7, S = 2 is the reference's default stem (resnet.py:86-87, densenet.py:118-119); CIN = 2 / 3 are the
+// DenseNet FFT inputs (densenet.py:109-115: only_fft / with_fft), CIN = 1, K = 3, S = 1 is resnet's conv1_alt
+// (resnet.py:88-89,145).  Sums run ci-outer, k-inner (for CIN = 1 the order the one-channel kernel always had).
+template <typename AT, int CIN, int K, int S>
 __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             AT* __restrict__ y, int Lin, int Lout, int C0, int ldy) {
-  extern __shared__ float xs[];  // Lin + 6
-  const int row = blockIdx.x;
-  for (int i = threadIdx.x; i < Lin + 6; i += blockDim.x) {
-    int s = i - 3;
-    xs[i] = (s >= 0 && s < Lin) ? x[(size_t)row * Lin + s] : 0.f;
+  extern __shared__ float xs[];  // CIN x (Lin + K - 1)
+  constexpr int PAD = K / 2;
+  const int row = blockIdx.x, LP = Lin + K - 1;
+  for (int i = threadIdx.x; i < CIN * LP; i += blockDim.x) {
+    const int ci = i / LP, s = i - ci * LP - PAD;
+    xs[i] = (s >= 0 && s < Lin) ? x[((size_t)row * CIN + ci) * Lin + s] : 0.f;
   }
   __syncthreads();
   const int co = threadIdx.x % C0, slot = threadIdx.x / C0, nslots = blockDim.x / C0;
   if (slot >= nslots) return;
-  float wk[7];
+  float wk[CIN * K];
 #pragma unroll
-  for (int k = 0; k < 7; ++k) wk[k] = w[co * 7 + k];
+  for (int k = 0; k < CIN * K; ++k) wk[k] = w[co * CIN * K + k];
   for (int l = slot; l < Lout; l += nslots) {
     float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) acc = fmaf(wk[k], xs[2 * l + k], acc);
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc = fmaf(wk[ci * K + k], xs[ci * LP + S * l + k], acc);
     Act<AT>::st1(y + ((size_t)row * Lout + l) * ldy + co, acc);
   }
 }
 
-// partial[blk][co][k] = sum over this block's rows, positions of dy[row][l][co] * x[row][2l+k-3]
-template <typename AT>
+// partial[blk][co][ci][k] = sum over this block's rows, positions of dy[row][l][co] * x[row][ci][S*l + k - K/2]
+template <typename AT, int CIN, int K, int S>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const AT* __restrict__ dy, int lddy,
                                                          const float* __restrict__ x, float* __restrict__ partial,
                                                          int rows, int Lin, int Lout, int C0) {
-  extern __shared__ float sm[];  // xs[Lin+6] then red[nslots][C0*7]
+  extern __shared__ float sm[];  // xs[CIN][Lin+K-1] then red[nslots][C0*CIN*K]
+  constexpr int PAD = K / 2, KK = CIN * K;
+  const int LP = Lin + K - 1;
   float* xs = sm;
-  float* red = sm + (Lin + 6);
+  float* red = sm + CIN * LP;
   const int co = threadIdx.x % C0, slot = threadIdx.x / C0, nslots = blockDim.x / C0;
-  float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float acc[KK];
+#pragma unroll
+  for (int k = 0; k < KK; ++k) acc[k] = 0.f;
   for (int row = blockIdx.x; row < rows; row += gridDim.x) {
     __syncthreads();
-    for (int i = threadIdx.x; i < Lin + 6; i += blockDim.x) {
-      int s = i - 3;
-      xs[i] = (s >= 0 && s < Lin) ? x[(size_t)row * Lin + s] : 0.f;
+    for (int i = threadIdx.x; i < CIN * LP; i += blockDim.x) {
+      const int ci = i / LP, s = i - ci * LP - PAD;
+      xs[i] = (s >= 0 && s < Lin) ? x[((size_t)row * CIN + ci) * Lin + s] : 0.f;
     }
     __syncthreads();
     if (slot < nslots) {
       for (int l = slot; l < Lout; l += nslots) {
         float g = Act<AT>::ld1(dy + ((size_t)row * Lout + l) * lddy + co);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) acc[k] = fmaf(g, xs[2 * l + k], acc[k]);
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc[ci * K + k] = fmaf(g, xs[ci * LP + S * l + k], acc[ci * K + k]);
       }
     }
   }
   __syncthreads();
   if (slot < nslots) {
 #pragma unroll
-    for (int k = 0; k < 7; ++k) red[(slot * C0 + co) * 7 + k] = acc[k];
+    for (int k = 0; k < KK; ++k) red[(slot * C0 + co) * KK + k] = acc[k];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C0 * 7; i += blockDim.x) {
+  for (int i = threadIdx.x; i < C0 * KK; i += blockDim.x) {
     float s = 0.f;
-    for (int sl = 0; sl < nslots; ++sl) s += red[sl * C0 * 7 + i];
-    partial[(size_t)blockIdx.x * C0 * 7 + i] = s;
+    for (int sl = 0; sl < nslots; ++sl) s += red[sl * C0 * KK + i];
+    partial[(size_t)blockIdx.x * C0 * KK + i] = s;
   }
 }
 
@@ -301,38 +313,66 @@ static inline int grid1d(size_t total, int bs) { return (int)((total + bs - 1) /
 extern "C" {
 
 // x: [rows][Lin] raw waveform (C_in = 1).  w: [C0][1][7] (torch layout).  y: [rows][Lin/2][ldy].
-int da_stem_conv_fwd(const float* x, const float* w, void* y, int rows, int Lin, int C0, int ldy,
-                     hipStream_t stream) {
+// the stem shapes this library instantiates: (Cin, K, stride) with pad = K / 2
+#define DA_STEM_DISPATCH(CIN_, K_, S_, STMT)                                   \
+  do {                                                                         \
+    if ((CIN_) == 1 && (K_) == 7 && (S_) == 2) { constexpr int CIN = 1, KS = 7, SS = 2; STMT; }        \
+    else if ((CIN_) == 2 && (K_) == 7 && (S_) == 2) { constexpr int CIN = 2, KS = 7, SS = 2; STMT; }   \
+    else if ((CIN_) == 3 && (K_) == 7 && (S_) == 2) { constexpr int CIN = 3, KS = 7, SS = 2; STMT; }   \
+    else if ((CIN_) == 1 && (K_) == 3 && (S_) == 1) { constexpr int CIN = 1, KS = 3, SS = 1; STMT; }   \
+    else return DA_EINVAL;                                                     \
+  } while (0)
+
+int da_stem_conv_fwd_g(const float* x, const float* w, void* y, int rows, int Lin, int Cin, int K, int stride, int C0,
+                       int ldy, hipStream_t stream) {
   DA_ENTER();
-  if (!x || !w || !y || Lin < 2 || Lin % 2 || C0 < 1 || C0 > 256 || 256 % C0) return DA_EINVAL;
+  if (!x || !w || !y || Lin < 2 || Lin % stride || C0 < 1 || C0 > 256 || 256 % C0 || stride < 1) return DA_EINVAL;
   if (rows == 0) return DA_OK;
-  DA_ACT_DISPATCH(hipLaunchKernelGGL(stem_conv_fwd_kernel<AT>, dim3(rows), dim3(256), (Lin + 6) * sizeof(float), stream, x, w,
-                                     (AT*)y, Lin, Lin / 2, C0, ldy));
+  const int Lout = Lin / stride;                               // (Lin + 2 (K/2) - K) / stride + 1 for odd K, stride | Lin
+  const size_t shm = (size_t)Cin * (Lin + K - 1) * sizeof(float);
+  DA_STEM_DISPATCH(Cin, K, stride,
+                   DA_ACT_DISPATCH(hipLaunchKernelGGL((stem_conv_fwd_kernel<AT, CIN, KS, SS>), dim3(rows), dim3(256), shm,
+                                                      stream, x, w, (AT*)y, Lin, Lout, C0, ldy)));
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
 
-size_t da_stem_wgrad_workspace(int rows, int C0) {
-  int nblk = rows < 512 ? rows : 512;
-  return (size_t)nblk * C0 * 7 * sizeof(float);
+int da_stem_conv_fwd(const float* x, const float* w, void* y, int rows, int Lin, int C0, int ldy,
+                     hipStream_t stream) {
+  return da_stem_conv_fwd_g(x, w, y, rows, Lin, 1, 7, 2, C0, ldy, stream);
 }
 
-int da_stem_conv_wgrad(const void* dy, int lddy, const float* x, float* dw, float* workspace, int rows, int Lin,
-                       int C0, int accumulate, hipStream_t stream) {
+size_t da_stem_wgrad_workspace_g(int rows, int C0, int Cin, int K) {
+  int nblk = rows < 512 ? rows : 512;
+  return (size_t)nblk * C0 * Cin * K * sizeof(float);
+}
+
+size_t da_stem_wgrad_workspace(int rows, int C0) { return da_stem_wgrad_workspace_g(rows, C0, 1, 7); }
+
+int da_stem_conv_wgrad_g(const void* dy, int lddy, const float* x, float* dw, float* workspace, int rows, int Lin,
+                         int Cin, int K, int stride, int C0, int accumulate, hipStream_t stream) {
   DA_ENTER();
-  if (!dy || !x || !dw || !workspace || Lin % 2 || C0 < 1 || C0 > 256 || 256 % C0) return DA_EINVAL;
+  if (!dy || !x || !dw || !workspace || stride < 1 || Lin % stride || C0 < 1 || C0 > 256 || 256 % C0) return DA_EINVAL;
   if (rows == 0) return DA_OK;
   int nblk = rows < 512 ? rows : 512;
   int nslots = 256 / C0;
-  size_t shm = ((Lin + 6) + (size_t)nslots * C0 * 7) * sizeof(float);
-  DA_ACT_DISPATCH(hipLaunchKernelGGL(stem_wgrad_kernel<AT>, dim3(nblk), dim3(256), shm, stream, (const AT*)dy, lddy, x,
-                                     workspace, rows, Lin, Lin / 2, C0));
+  const int Lout = Lin / stride;
+  size_t shm = ((size_t)Cin * (Lin + K - 1) + (size_t)nslots * C0 * Cin * K) * sizeof(float);
+  if (shm > 64 * 1024) return DA_EINVAL;
+  DA_STEM_DISPATCH(Cin, K, stride,
+                   DA_ACT_DISPATCH(hipLaunchKernelGGL((stem_wgrad_kernel<AT, CIN, KS, SS>), dim3(nblk), dim3(256), shm, stream,
+                                                      (const AT*)dy, lddy, x, workspace, rows, Lin, Lout, C0)));
   DA_CHECK_LAUNCH();
-  int n = C0 * 7;
+  int n = C0 * Cin * K;
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((n + 7) / 8), dim3(256), 0, stream, workspace, nblk, n, dw,
                      accumulate);
   DA_CHECK_LAUNCH();
   return DA_OK;
+}
+
+int da_stem_conv_wgrad(const void* dy, int lddy, const float* x, float* dw, float* workspace, int rows, int Lin,
+                       int C0, int accumulate, hipStream_t stream) {
+  return da_stem_conv_wgrad_g(dy, lddy, x, dw, workspace, rows, Lin, 1, 7, 2, C0, accumulate, stream);
 }
 
 // Lout = (Lin + 2 - 3)/2 + 1.  R = rows per BN window.  pool_mode 0 max / 1 avg.

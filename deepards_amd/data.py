@@ -14,16 +14,17 @@ from . import hip_ops as H
 
 class DeviceTileStore(object):
     def __init__(self, windows, targets, mu, std, device='cuda'):
-        """windows: (N, NB, 1, L) float64 array-like of RAW (un-normalised) flow windows; targets (N, 2) one-hot;
-        mu, std: this fold's scaling factors (scalars, dataset.py:627-649)."""
+        """windows: (N, NB, C, L) float64 array-like of RAW (un-normalised) windows -- C = 1: flow; C = 2 / 3: with the
+        spectrum channels of ``tiles.perform_fft`` (dataset.py:1330-1341); targets (N, 2) one-hot; mu, std: this
+        fold's scaling factors (dataset.py:627-649): scalars for one channel, one per channel otherwise."""
         w = torch.as_tensor(windows, dtype=torch.float64)
-        if w.dim() != 4 or w.shape[2] != 1:
-            raise ValueError('windows must be (N, NB, 1, L)')
+        if w.dim() != 4 or not 1 <= w.shape[2] <= 4:
+            raise ValueError('windows must be (N, NB, C <= 4, L)')
         self.tiles = w.contiguous().to(device)
         self.targets = torch.as_tensor(targets, dtype=torch.float32).contiguous().to(device)
         if self.targets.shape != (w.shape[0], 2):
             raise ValueError('targets must be (N, 2) one-hot')
-        self.mu, self.std = float(mu), float(std)
+        self.mu, self.std = self._factors(mu, w.shape[2]), self._factors(std, w.shape[2])
         self.kfold_indexes = None                     # absolute indices of the current fold (dataset.py:765-772)
         self.patients = self.total_kfolds = self.kfold_patient_splits = self.scaling_factors = None
         self.kfold_num = None
@@ -36,6 +37,15 @@ class DeviceTileStore(object):
         self.sampling_rng = None                      # np.random.RandomState for the oversampler; None: numpy's global RNG
         self.hours = None                             # (N, NB) seq_hours of the windows when ingested from a pickle
         self.patient_slot = None                      # (N,) patient slot per window when ingested from a pickle
+
+    @staticmethod
+    def _factors(v, chans):
+        """A fold's mu (or std) as the gather kernel takes it: a float for one-channel windows, a tuple per channel."""
+        import numpy as np
+        a = np.ravel(np.asarray(v, dtype=np.float64))
+        if a.size != chans:
+            raise ValueError('%d scaling factors for %d channels' % (a.size, chans))
+        return float(a[0]) if chans == 1 else tuple(float(q) for q in a)
 
     # ---- k-fold plumbing of ARDSRawDataset (dataset.py:651-670, 672-700, 765-830) --------------------------------
     def enable_kfolds(self, patients, total_kfolds, train=True, random_kfold=False, splits=None, scaling_factors=None):
@@ -59,13 +69,14 @@ class DeviceTileStore(object):
         else:
             self.kfold_patient_splits = kfold_patient_splits(self.patients, labels, self.total_kfolds, random_kfold)
         if scaling_factors:
-            self.scaling_factors = {int(k): (float(m), float(s_)) for k, (m, s_) in scaling_factors.items()}
+            c = self.tiles.shape[2]
+            self.scaling_factors = {int(k): (self._factors(m, c), self._factors(s_, c)) for k, (m, s_) in scaling_factors.items()}
         else:
             host = self.tiles.cpu().numpy()
             self.scaling_factors = {}
             for k, sp in self.kfold_patient_splits.items():
                 mu, std = scaling_factors_for_indices(host, patient_map_to_loc(self.patients, sp['train']))
-                self.scaling_factors[k] = (float(mu[0]), float(std[0]))
+                self.scaling_factors[k] = (self._factors(mu, len(mu)), self._factors(std, len(std)))
         return self
 
     def make_test_store_if_kfold(self):
@@ -130,9 +141,7 @@ class DeviceTileStore(object):
         ``derive_scaling_factors`` / ``_get_scaling_factors_for_indices`` do (dataset.py:627-673)."""
         from .tiles import scaling_factors_for_indices
         mu, std = scaling_factors_for_indices(windows, indices)
-        if mu.shape != (1,):
-            raise ValueError('the tile store holds one-channel flow windows')
-        return cls(windows, targets, float(mu[0]), float(std[0]), device=device)
+        return cls(windows, targets, mu, std, device=device)
 
     def __len__(self):
         return self.tiles.shape[0] if self.kfold_indexes is None else len(self.kfold_indexes)

@@ -233,8 +233,8 @@ def _running(x, R, s, st):
 
 
 class StemFunction(Function):
-    """conv k7 s2 p3 (C_in=1) -> BN -> ReLU -> {Max,Avg}Pool1d(3,2,1).
-    reference models/resnet.py:141-153, models/densenet.py:118-124."""
+    """conv k7 s2 p3 (C_in = 1, or 2 / 3 with the DenseNet FFT channels) -> BN -> ReLU -> {Max,Avg}Pool1d(3,2,1).
+    reference models/resnet.py:141-153, models/densenet.py:109-124.  x2d: (rows, L) or (rows, C_in, L)."""
 
     @staticmethod
     def forward(ctx, x2d, w, gamma, beta, R, pool_mode, st):
@@ -257,6 +257,47 @@ class StemFunction(Function):
         dy0, dgamma, dbeta = _bn_bwd(dz, y0, ctx.R, mean, invstd, gamma, beta, 1, tg, tb, dx=dz)
         dw = H.stem_conv_wgrad(dy0, x2d, out=tw, accumulate=tw is not None)
         return None, None if tw is not None else dw, dgamma, dbeta, None, None, None
+
+
+class DoubleStemFunction(Function):
+    """ResNet(double_conv_first=True), resnet.py:144-153: conv1_alt k3 s1 p1 (1 -> C0) -> bn1 -> conv2 k7 s2 p3 (C0 -> C0)
+    -> bn2 -> ReLU -> pool.  No ReLU between bn1 and conv2; the four parameters that are dead in the default stem
+    (conv1_alt, conv2, bn2.weight / bias, SURVEY finding 6) are live here and conv1 is dead instead.  An option path:
+    the k7 conv runs on the fp32 direct GEMM kernels in three tap groups (forward, each half of the data gradient, the
+    weight gradient) rather than on a kernel of its own."""
+
+    @staticmethod
+    def forward(ctx, x2d, wa, g1, b1, w2, g2, b2, R, pool_mode, st1, st2):
+        if H.act_dtype() != 'f32':
+            raise NotImplementedError('double_conv_first runs with fp32 activation storage only')
+        ya = H.stem_conv_fwd(x2d, wa, stride=1)                       # (rows, L, C0)
+        s1 = _Stats()
+        h = _bn_apply(ya, R, s1, st1, g1, b1, False)
+        wf, wd = H.repack_weight(w2, True, True)
+        y2 = H.conv_fwd(h, wf, 2, 3)                                  # (rows, L / 2, C0)
+        m2, i2 = H.bn_stats(y2, R, st2.eps)
+        out = H.bn_relu_pool_fwd(y2, R, m2, i2, g2, b2, pool_mode)
+        s2 = _Stats()
+        s2.mean, s2.invstd = m2, i2
+        _running(y2, R, s2, st2)
+        ctx.save_for_backward(x2d, ya, s1.mean, s1.invstd, g1, b1, h, wd, y2, m2, i2, g2, b2)
+        ctx.R, ctx.pool_mode = R, pool_mode
+        ctx.gt = _tgt(wa, g1, b1, w2, g2, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2d, ya, m1, i1, g1, b1, h, wd, y2, m2, i2, g2, b2 = ctx.saved_tensors
+        twa, tg1, tb1, tw2, tg2, tb2 = ctx.gt
+        R = ctx.R
+        dz = H.pool_bwd(dout.contiguous(), y2, R, m2, i2, g2, b2, ctx.pool_mode)
+        dy2, dg2, db2 = _bn_bwd(dz, y2, R, m2, i2, g2, b2, 1, tg2, tb2, dx=dz)
+        dw2 = H.conv_wgrad(dy2, h, 7, 2, 3, out=tw2, accumulate=tw2 is not None)
+        dh = H.conv_dgrad(dy2, wd, 2, 3, h.shape[1])
+        dya, dg1, db1 = _bn_bwd(dh, ya, R, m1, i1, g1, b1, 0, tg1, tb1, dx=dh)
+        dwa = H.stem_conv_wgrad(dya, x2d, out=twa, accumulate=twa is not None, k=3, stride=1)
+        return (None, None if twa is not None else dwa, dg1, db1, None if tw2 is not None else dw2, dg2, db2,
+                None, None, None, None)
 
 
 def _bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, tg, tb, out=None, dx=None, want_g=False, add=None, mask=None):

@@ -88,11 +88,12 @@ def conv_out_len(l, k, stride, pad):
 
 
 def conv_fwd(x, wf, stride, pad, out=None):
-    """x (rows,L,Ci), wf packed (K,Co,Ci) -> (rows,Lo,Co).  K in {1,3}."""
+    """x (rows,L,Ci), wf packed (K,Co,Ci) -> (rows,Lo,Co).  K in {1,3} is one launch; a longer kernel (the k7 conv2 of
+    ResNet(double_conv_first), resnet.py:92-93) runs as ceil(K/3) launches of <= 3 taps that accumulate into the output."""
     _rlc(x, 'x')
     k, co, ci = wf.shape
     rows, l, c = x.shape
-    if c != ci or k > 3 or ci % 32 or co % 32:
+    if c != ci or ci % 32 or co % 32:
         raise ValueError('conv_fwd: unsupported shape x%s wf%s' % (tuple(x.shape), tuple(wf.shape)))
     lo = conv_out_len(l, k, stride, pad)
     if out is None:
@@ -101,8 +102,9 @@ def conv_fwd(x, wf, stride, pad, out=None):
         raise ValueError('conv_fwd: bad out shape')
     so = [t - pad for t in range(k)]
     wt = list(range(k))
-    _chk(_lib.lib().da_conv_gemm(_p(x), _p(wf), _p(out), rows, lo, l, c, ci, lo, co, co, 1, 0, stride, k,
-                                 _ints(so), _ints(wt), 0, _stream()), 'da_conv_gemm(fwd)')
+    for g in range(0, k, 3):
+        _chk(_lib.lib().da_conv_gemm(_p(x), _p(wf), _p(out), rows, lo, l, c, ci, lo, co, co, 1, 0, stride, len(so[g:g + 3]),
+                                     _ints(so[g:g + 3]), _ints(wt[g:g + 3]), 1 if g else 0, _stream()), 'da_conv_gemm(fwd)')
     return out
 
 
@@ -266,7 +268,7 @@ def conv_dgrad(dy, wd, stride, pad, l_in, out=None, accumulate=False):
     _rlc(dy, 'dy')
     k, ci, co = wd.shape
     rows, lo, c = dy.shape
-    if c != co or k > 3 or ci % 32 or co % 32:
+    if c != co or ci % 32 or co % 32:
         raise ValueError('conv_dgrad: unsupported shape')
     if out is None:
         if accumulate:
@@ -285,8 +287,10 @@ def conv_dgrad(dy, wd, stride, pad, l_in, out=None, accumulate=False):
                 out[:, r::stride, :].zero_()
             continue
         so = [(r + pad - t) // stride for t in taps]
-        _chk(L.da_conv_gemm(_p(dy), _p(wd), _p(out), rows, lm, lo, co, co, l_in, ci, ci, stride, r, 1, len(taps),
-                            _ints(so), _ints(taps), 1 if accumulate else 0, _stream()), 'da_conv_gemm(dgrad)')
+        for g in range(0, len(taps), 3):                 # <= 3 taps per launch; later groups add to the first
+            _chk(L.da_conv_gemm(_p(dy), _p(wd), _p(out), rows, lm, lo, co, co, l_in, ci, ci, stride, r, 1,
+                                len(taps[g:g + 3]), _ints(so[g:g + 3]), _ints(taps[g:g + 3]),
+                                1 if (accumulate or g) else 0, _stream()), 'da_conv_gemm(dgrad)')
     return out
 
 
@@ -354,8 +358,21 @@ def conv_wgrad(dy, x, k, stride, pad, out=None, accumulate=False, defer=False):
     _rlc(x, 'x')
     rows, lo, co = dy.shape
     rows2, l, ci = x.shape
-    if rows != rows2 or lo != conv_out_len(l, k, stride, pad) or k > 3 or ci % 32 or co % 32:
+    if rows != rows2 or lo != conv_out_len(l, k, stride, pad) or ci % 32 or co % 32 or (k > 3 and defer):
         raise ValueError('conv_wgrad: unsupported shape')
+    if k > 3:         # a kernel longer than 3 taps (resnet's k7 conv2, double_conv_first only): tap groups into slices
+        if out is None:
+            if accumulate:
+                raise ValueError('accumulate needs out')
+            out = torch.empty((co, ci, k), device=x.device, dtype=torch.float32)
+        for g in range(0, k, 3):
+            n = min(3, k - g)
+            part = _conv_wgrad_taps(dy, x, [t - pad for t in range(g, g + n)], stride)
+            if accumulate:
+                out[:, :, g:g + n].add_(part)
+            else:
+                out[:, :, g:g + n].copy_(part)
+        return out
     L = _lib.lib()
     nbytes = L.da_conv_wgrad_workspace(rows, lo, co, ci, k)
     ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
@@ -370,6 +387,19 @@ def conv_wgrad(dy, x, k, stride, pad, out=None, accumulate=False, defer=False):
         out = torch.empty((co, ci, k), device=x.device, dtype=torch.float32)
     _chk(L.da_conv_wgrad(_p(dy), _p(x), _p(out), _p(ws), rows, lo, lo, co, co, l, ci, ci, 1, 0, stride, k,
                          _ints(so), 1 if accumulate else 0, _stream()), 'da_conv_wgrad')
+    return out
+
+
+def _conv_wgrad_taps(dy, x, src_off, stride):
+    """(Co, Ci, len(src_off)) weight gradient of the taps that read x at stride * j + src_off[t]."""
+    rows, lo, co = dy.shape
+    l, ci = x.shape[1], x.shape[2]
+    n = len(src_off)
+    L = _lib.lib()
+    ws = torch.empty((L.da_conv_wgrad_workspace(rows, lo, co, ci, n) // 4,), device=x.device, dtype=torch.float32)
+    out = torch.empty((co, ci, n), device=x.device, dtype=torch.float32)
+    _chk(L.da_conv_wgrad(_p(dy), _p(x), _p(out), _p(ws), rows, lo, lo, co, co, l, ci, ci, 1, 0, stride, n,
+                         _ints(src_off), 0, _stream()), 'da_conv_wgrad')
     return out
 
 
@@ -467,29 +497,41 @@ def repack_multi(weights, winograd=None):
     return outs
 
 
-def stem_conv_fwd(x, w):
-    """x (rows, Lin) raw waveform, w (C0,1,7) -> (rows, Lin/2, C0)."""
+STEM_SHAPES = ((1, 7, 2), (2, 7, 2), (3, 7, 2), (1, 3, 1))      # (Cin, K, stride) the library instantiates; pad = K // 2
+
+
+def stem_conv_fwd(x, w, stride=2):
+    """First convolution of a breath block on the raw rows.  x (rows, Lin) [one channel] or (rows, Cin, Lin),
+    w (C0, Cin, K) -> (rows, Lin / stride, C0) RLC; pad = K // 2.  (Cin, K, stride) in STEM_SHAPES."""
     _f32(x, 'x')
     _f32(w, 'w')
-    rows, lin = x.shape
-    c0 = w.shape[0]
-    if tuple(w.shape[1:]) != (1, 7):
-        raise ValueError('stem conv expects (C0,1,7) weights (in_channels=1)')
-    y = torch.empty((rows, lin // 2, c0), device=x.device, dtype=ACT)
-    _chk(_lib.lib().da_stem_conv_fwd(_p(x), _p(w), _p(y), rows, lin, c0, c0, _stream()), 'da_stem_conv_fwd')
+    if x.dim() == 2:
+        x = x.view(x.shape[0], 1, x.shape[1])
+    rows, cin, lin = x.shape
+    c0, cin_w, k = w.shape
+    if cin_w != cin or (cin, k, stride) not in STEM_SHAPES:
+        raise ValueError('stem conv: x %s with w %s stride %d is not one of the (Cin, K, stride) shapes %s' %
+                         (tuple(x.shape), tuple(w.shape), stride, STEM_SHAPES))
+    y = torch.empty((rows, lin // stride, c0), device=x.device, dtype=ACT)
+    _chk(_lib.lib().da_stem_conv_fwd_g(_p(x), _p(w), _p(y), rows, lin, cin, k, stride, c0, c0, _stream()),
+         'da_stem_conv_fwd_g')
     return y
 
 
-def stem_conv_wgrad(dy, x, out=None, accumulate=False):
+def stem_conv_wgrad(dy, x, out=None, accumulate=False, k=7, stride=2):
     _rlc(dy, 'dy')
+    if x.dim() == 2:
+        x = x.view(x.shape[0], 1, x.shape[1])
     rows, lo, c0 = dy.shape
-    lin = x.shape[1]
+    cin, lin = x.shape[1], x.shape[2]
+    if (cin, k, stride) not in STEM_SHAPES or lo * stride != lin:
+        raise ValueError('stem conv weight gradient: unsupported shape')
     if out is None:
-        out = torch.empty((c0, 1, 7), device=x.device, dtype=torch.float32)
+        out = torch.empty((c0, cin, k), device=x.device, dtype=torch.float32)
     L = _lib.lib()
-    ws = torch.empty((L.da_stem_wgrad_workspace(rows, c0) // 4,), device=x.device, dtype=torch.float32)
-    _chk(L.da_stem_conv_wgrad(_p(dy), c0, _p(x), _p(out), _p(ws), rows, lin, c0, 1 if accumulate else 0, _stream()),
-         'da_stem_conv_wgrad')
+    ws = torch.empty((L.da_stem_wgrad_workspace_g(rows, c0, cin, k) // 4,), device=x.device, dtype=torch.float32)
+    _chk(L.da_stem_conv_wgrad_g(_p(dy), c0, _p(x), _p(out), _p(ws), rows, lin, cin, k, stride, c0,
+                                1 if accumulate else 0, _stream()), 'da_stem_conv_wgrad_g')
     return out
 
 
@@ -850,6 +892,15 @@ def gather_normalize(tiles, idx, mu, std, out=None):
     elif not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == shape):
         raise ValueError('gather_normalize: out must be a contiguous float32 CUDA tensor of shape %s, got %s %s' %
                          (shape, tuple(out.shape), out.dtype))
+    if isinstance(mu, (tuple, list)):          # per-channel factors: (N, NB, C, L) windows with FFT channels
+        if tiles.dim() != 4 or len(mu) != tiles.shape[2] or len(std) != tiles.shape[2] or tiles.shape[2] > 4:
+            raise ValueError('gather_normalize: one (mu, std) per channel of (N, NB, C <= 4, L) tiles expected')
+        c = tiles.shape[2]
+        dbl = ctypes.c_double * c
+        _chk(_lib.lib().da_gather_normalize_ch(_p(tiles), _p(idx), dbl(*[float(v) for v in mu]), dbl(*[float(v) for v in std]),
+                                               _p(out), b, tiles.shape[1], c, tiles.shape[3], _stream()),
+             'da_gather_normalize_ch')
+        return out
     _chk(_lib.lib().da_gather_normalize(_p(tiles), _p(idx), float(mu), float(std), _p(out), b, elems, _stream()),
          'da_gather_normalize')
     return out

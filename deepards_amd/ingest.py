@@ -487,16 +487,27 @@ class IngestedDataset(object):
         np.savez_compressed(path, **out)
         return path
 
+    def with_fft(self, add_fft=False, only_fft=False, fft_real_only=False):
+        """What ``ARDSRawDataset.from_pickle`` does with --with-fft / --only-fft / --fft-real-only (dataset.py:743-762):
+        a dataset that does not carry spectrum channels yet gets them (``_perform_fft``) and its scaling factors are
+        dropped so that they are derived again per channel (``derive_scaling_factors``; ``to_store`` does that);
+        one that already has them (C > 1), or no FFT option, is returned unchanged."""
+        if not (add_fft or only_fft) or self.windows.shape[2] != 1:
+            return self
+        from .tiles import perform_fft
+        self.windows = perform_fft(self.windows, add_fft, only_fft, fft_real_only)
+        self.scaling_factors = {}
+        return self
+
     def to_store(self, device='cuda', fold=None, random_kfold=False):
         """DeviceTileStore over these windows with the scaling factors of ``fold`` (None: the holdout factors, or
         derived from all windows when the pickle holds none).  K-fold datasets: ``enable_kfolds`` is applied with the
         pickled patient splits / factors when present (``from_pickle`` keeps them too, dataset.py:740-741)."""
         from .data import DeviceTileStore
-        if self.windows.shape[2] != 1:
-            raise NotImplementedError('the tile store holds one-channel flow windows (C=%d)' % self.windows.shape[2])
+        chans = self.windows.shape[2]
         key = fold if fold in self.scaling_factors else None
         if key in self.scaling_factors:
-            mu, std = (float(np.ravel(v)[0]) for v in self.scaling_factors[key])
+            mu, std = (np.ravel(v)[:chans] for v in self.scaling_factors[key])
             store = DeviceTileStore(self.windows, self.targets, mu, std, device=device)
         else:
             store = DeviceTileStore.with_derived_scaling(self.windows, self.targets, device=device)
@@ -508,7 +519,7 @@ class IngestedDataset(object):
                 raise ValueError('k-fold splits are patient-wise (dataset.py:765-830) and this dataset file carries no '
                                  'patient information (an export without patient_slot): re-export it with '
                                  'python -m deepards_amd.ingest <dataset.pkl> <out.npz>')
-            factors = {k: (float(np.ravel(m)[0]), float(np.ravel(s)[0])) for k, (m, s) in self.scaling_factors.items()
+            factors = {k: (np.ravel(m)[:chans], np.ravel(s)[:chans]) for k, (m, s) in self.scaling_factors.items()
                        if k is not None} or None
             store.enable_kfolds(self.patient_slot, self.total_kfolds, train=self.train, random_kfold=random_kfold,
                                 splits=self.kfold_patient_splits, scaling_factors=factors)

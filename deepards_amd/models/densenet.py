@@ -102,12 +102,13 @@ class _Features(nn.Sequential):
 
     def forward_rlc(self, x, R, relu):
         _require_cuda(x, 'DenseNet')
-        if x.dim() != 3 or x.shape[1] != 1:
-            raise ValueError('expected (rows, 1, L) input, got %s' % (tuple(x.shape),))
+        cin = self.conv0.in_channels                       # 1, or 2 / 3 with the FFT channels (densenet.py:109-115)
+        if x.dim() != 3 or x.shape[1] != cin:
+            raise ValueError('expected (rows, %d, L) input, got %s' % (cin, tuple(x.shape)))
         rows, _, l = x.shape
         if rows % R:
             raise ValueError('rows not a multiple of rows_per_window')
-        x2d = x.contiguous().float().view(rows, l)
+        x2d = x.contiguous().float()                       # (rows, C_in, L): the stem kernel reads the NCL rows directly
         h = F_.StemFunction.apply(x2d, self.conv0.weight, self.norm0.weight, self.norm0.bias, R, F_.POOL_MAX,
                                   F_.BNState(self.norm0))
         use_drop = self.training and self.drop_rate > 0
@@ -135,13 +136,16 @@ class DenseNet(nn.Module):
     def __init__(self, growth_rate=32, block_config=(6, 12, 24, 16), num_init_features=64, bn_size=4,
                  drop_rate=0.2, num_classes=1000, with_fft=False, only_fft=False, fft_real_only=False):
         super(DenseNet, self).__init__()
-        if with_fft or only_fft:
-            raise NotImplementedError('FFT input channels are outside the accelerated hot path (in_channels=1)')
+        # densenet.py:109-115: flow + Re/Im of its spectrum (with_fft: 3 channels), the spectrum alone (only_fft: 2), one
+        # less without the imaginary part (fft_real_only); the channels come from the dataset (dataset.py:1330-1341,
+        # deepards_amd.tiles.perform_fft)
+        fft_real_modifier = -1 if fft_real_only else 0
+        initial_chans = 3 + fft_real_modifier if with_fft else (2 + fft_real_modifier if only_fft else 1)
         if growth_rate % 32 or (bn_size * growth_rate) % 32 or num_init_features % 32 or 256 % num_init_features:
             raise NotImplementedError('channel counts must be multiples of 32')
         self.drop_rate = drop_rate
         self.features = _Features(OrderedDict((
-            ('conv0', conv1d(1, num_init_features, 7, 2)), ('norm0', _bn(num_init_features)),
+            ('conv0', conv1d(initial_chans, num_init_features, 7, 2)), ('norm0', _bn(num_init_features)),
             ('relu0', nn.ReLU(inplace=True)), ('pool0', nn.MaxPool1d(kernel_size=3, stride=2, padding=1)))))
         width, self.n_layers = num_init_features, 0
         for i, n in enumerate(block_config):

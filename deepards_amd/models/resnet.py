@@ -70,8 +70,6 @@ class ResNet(nn.Module):
         super(ResNet, self).__init__()
         if block is not BasicBlock:
             raise NotImplementedError('only BasicBlock (resnet18/34 style) is on the accelerated path')
-        if double_conv_first:
-            raise NotImplementedError('double_conv_first is outside the accelerated hot path')
         if initial_planes not in (64, 128, 256):
             raise NotImplementedError('initial_planes must be 64, 128 or 256 on the accelerated path')
         if first_pool_type not in _POOLS:
@@ -109,8 +107,13 @@ class ResNet(nn.Module):
             raise ValueError('rows not a multiple of rows_per_window')
         x2d = x.contiguous().float().view(rows, l)
         pool = F_.POOL_MAX if self.first_pool_type == 'max' else F_.POOL_AVG
-        h = F_.StemFunction.apply(x2d, self.conv1.weight, self.bn1.weight, self.bn1.bias, rows_per_window, pool,
-                                  F_.BNState(self.bn1))
+        if self.double_conv_first:          # resnet.py:144-149: conv1_alt -> bn1 -> conv2 -> bn2 (conv1 is the dead one then)
+            h = F_.DoubleStemFunction.apply(x2d, self.conv1_alt.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
+                                            self.bn2.weight, self.bn2.bias, rows_per_window, pool, F_.BNState(self.bn1),
+                                            F_.BNState(self.bn2))
+        else:
+            h = F_.StemFunction.apply(x2d, self.conv1.weight, self.bn1.weight, self.bn1.bias, rows_per_window, pool,
+                                      F_.BNState(self.bn1))
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
                 h = blk.forward_rlc(h, rows_per_window)

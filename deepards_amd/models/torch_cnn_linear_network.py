@@ -136,3 +136,28 @@ class CNNLSTMNetwork(_WindowHead):
                                            nb, h0, c0)
         out = F_.Linear2Function.apply(hs.view(b * nb, -1), self.linear_final.weight, self.linear_final.bias)
         return out.view(b, nb, 2), (hx, cx)
+
+
+class BreathBlockLinear(nn.Module):
+    """NOT a class of the reference: the model around BASELINE configs[4]'s tile shape (resnet18, nb 40, seq_len 512),
+    which the reference cannot run -- ``CNNLinearNetwork.forward`` refuses anything but 224 samples
+    (torch_cnn_linear_network.py:106-107) and never concatenates the 9 metadata inputs its head is sized for (SURVEY
+    finding 8).  STATED, not mirrored: the breath block on (B * NB, 1, L) rows with per-window BatchNorm exactly as
+    ``breath_block(x[i])`` would see them, its features (``AvgPool1d(7, 1)`` leaves L / 32 - 6 positions per channel,
+    flattened channel-major like ``view(N, -1)``, resnet.py:159-160) flattened per window like ``view(-1)``
+    (:110-112), one ``Linear(F * NB, 2)`` head, no metadata.  Used by ``bench.py --nb 40 --seq-len 512`` and by the
+    model-level parity tests of that shape."""
+
+    def __init__(self, breath_block, nb, seq_len):
+        nn.Module.__init__(self)
+        if seq_len % 32 or seq_len < 224:
+            raise ValueError('seq_len must be a multiple of 32, at least 224')
+        self.breath_block, self.nb, self.seq_size = breath_block, nb, seq_len
+        self.linear_final = nn.Linear(breath_block.n_out_filters * (seq_len // 32 - 6) * nb, 2)
+
+    def forward(self, x, metadata):
+        b, nb, c, l = x.shape
+        if l != self.seq_size or nb != self.nb:
+            raise Exception('input breaths must have sequence length of %d in windows of %d' % (self.seq_size, self.nb))
+        feat = self.breath_block.forward_windows(x.reshape(b * nb, c, l), nb)
+        return F_.Linear2Function.apply(feat.view(b, -1), self.linear_final.weight, self.linear_final.bias)

@@ -48,6 +48,27 @@ def scaling_factors_for_indices(windows, indices=None):
     return mu, np.sqrt(std_sum / obs_count)
 
 
+def perform_fft(windows, add_fft=False, only_fft=False, fft_real_only=False):
+    """``ARDSRawDataset._perform_fft`` (dataset.py:1330-1341) on (N, NB, C, L) windows: per window
+    ``trans = np.fft.fftshift(np.fft.fft(seq, axis=-1))``, channels ``[trans.real]`` (fft_real_only) or
+    ``[trans.real, trans.imag]`` appended to the flow channel (add_fft) or replacing it (only_fft) along axis 1.
+    Restated call for call -- INCLUDING that ``fftshift`` is given no ``axes`` there, so it rolls every axis of the
+    (NB, C, L) window: the spectrum's rows end up NB // 2 sub-batch rows away from the flow rows they came from (and the
+    single-channel axis is unmoved).  That is what the reference trains on, so it is what this returns.  Same numpy
+    functions as the reference calls; dataset.py itself does not import here, so parity is unpinned beyond that."""
+    w = np.asarray(windows, dtype=np.float64)
+    if not add_fft and not only_fft:
+        return w
+    if w.ndim != 4:
+        raise ValueError('windows must be (N, NB, C, L)')
+    out = []
+    for seq in w:
+        trans = np.fft.fftshift(np.fft.fft(seq, axis=-1))
+        fft_chans = [trans.real] if fft_real_only else [trans.real, trans.imag]
+        out.append(np.concatenate(([seq] if add_fft else []) + fft_chans, axis=1))
+    return np.ascontiguousarray(np.stack(out))
+
+
 def should_drop_frame(seq_vent_bns, n_sub_batches, frac_missing=VENT_BN_FRAC_MISSING):
     """The vent-BN continuity rule of ``_should_we_drop_frame`` (:1308-1321; the optional autocorrelation filter
     ``drop_if_under_r2`` is off by default and not restated)."""

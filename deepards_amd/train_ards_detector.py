@@ -205,7 +205,9 @@ class BaseTraining(object):
             raise ValueError('no dataset: pass --train-from-pickle <dataset.pkl|.npz> (or args.train_store / args.test_store); '
                              'building one from raw ventilator files (--data-path) is outside the accelerated path')
         from .ingest import load_dataset
-        ds = load_dataset(a.train_from_pickle)
+        fft = dict(add_fft=bool(_flag(a, 'with_fft')), only_fft=bool(_flag(a, 'only_fft')),
+                   fft_real_only=bool(_flag(a, 'fft_real_only')))
+        ds = load_dataset(a.train_from_pickle).with_fft(**fft)            # dataset.py:743-762
         if a.kfolds is not None and ds.total_kfolds is None:
             ds.total_kfolds = a.kfolds                            # an unfolded pickle split now (:126-133 reads args.kfolds)
         ds.train = True
@@ -223,7 +225,7 @@ class BaseTraining(object):
         if not a.test_from_pickle and a.kfolds is not None:
             test = train.make_test_store_if_kfold()
         elif a.test_from_pickle:
-            tds = load_dataset(a.test_from_pickle)
+            tds = load_dataset(a.test_from_pickle).with_fft(**fft)
             tds.train = False
             test = tds.to_store(self.device)
             test.mu, test.std = train.mu, train.std               # test_dataset.scaling_factors = train_dataset's (:285)

@@ -146,6 +146,15 @@ int da_stem_conv_fwd(const float* x, const float* w, da_act_t* y, int rows, int 
 size_t da_stem_wgrad_workspace(int rows, int C0);
 int da_stem_conv_wgrad(const da_act_t* dy, int lddy, const float* x, float* dw, float* workspace, int rows, int Lin,
                        int C0, int accumulate, da_stream_t stream);
+/* The same for the other first convolutions the constructors can select: x [rows][Cin][Lin] (the NCL rows the dataset
+ * hands over), w [C0][Cin][K], pad = K / 2, Lin % stride == 0 -> y [rows][Lin / stride][ldy].  Instantiated shapes
+ * (Cin, K, stride): (1, 7, 2) the default; (2, 7, 2) / (3, 7, 2) DenseNet(only_fft / with_fft) conv0, densenet.py:109-119;
+ * (1, 3, 1) ResNet(double_conv_first).conv1_alt, resnet.py:88-89,145.  Any other shape returns -1. */
+int da_stem_conv_fwd_g(const float* x, const float* w, da_act_t* y, int rows, int Lin, int Cin, int K, int stride, int C0,
+                       int ldy, da_stream_t stream);
+size_t da_stem_wgrad_workspace_g(int rows, int C0, int Cin, int K);
+int da_stem_conv_wgrad_g(const da_act_t* dy, int lddy, const float* x, float* dw, float* workspace, int rows, int Lin,
+                         int Cin, int K, int stride, int C0, int accumulate, da_stream_t stream);
 
 /* ---- window-grouped train-mode BatchNorm1d (+ReLU, +residual) ------------------------------
  * resnet.py:27-38,143,152 ; densenet.py:23-29,72-74,146 ; per-window statistics because
@@ -256,6 +265,11 @@ int da_clamp_adam_dev(float* p, const float* g, float* m, float* v, size_t n, fl
  * + the .float() cast of train_ards_detector.py:150-152; replaces DataLoader/collate/H2D per step. */
 int da_gather_normalize(const double* tiles, const int64_t* idx, double mu, double stdv, float* out, int B,
                         int tile_elems, da_stream_t stream);
+/* windows with C <= 4 channels, [N][NB][C][L]: the flow channel plus the real / imaginary channels of its spectrum
+ * (ARDSRawDataset._perform_fft dataset.py:1330-1341, selected by --with-fft / --only-fft / --fft-real-only,
+ * train_ards_detector.py:228-230); every channel has its own factors (dataset.py:627-649).  mu / stdv: HOST arrays [C]. */
+int da_gather_normalize_ch(const double* tiles, const int64_t* idx, const double* mu, const double* stdv, float* out, int B,
+                           int NB, int C, int L, da_stream_t stream);
 /* ---- sibling heads of CNNLinearNetwork (torch_cnn_linear_network.py:7-89) ---------------------- */
 /* CNNLinearComprToRF: lower median over the NB breath rows of each window (torch.median(outputs, dim=1)[0], :47);
    x [B*NB][ld], out [B][F], idx [B][F] = selected row (for the backward); NB <= 64.  The mean of CNNLinearToMean

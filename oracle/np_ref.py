@@ -294,15 +294,34 @@ def _stem(t, x, conv, bn, pool_type='max'):
     return y3, (lambda d: b_conv(b_bn(b_relu(b_pool(d)))))
 
 
+def _stem_double(t, x, prefix, pool_type='max'):
+    """ResNet.forward with double_conv_first (resnet.py:144-153): conv1_alt (k3 s1 p1) -> bn1 -> conv2 (k7 s2 p3) -> bn2
+    -> relu -> first_pool; no ReLU between bn1 and conv2."""
+    ya, b_ca = _conv(t, x, prefix + 'conv1_alt.weight', 1, 1, need_dx=False)
+    h, b_bn1 = _bn(t, ya, prefix + 'bn1', store=True)
+    y2, b_c2 = _conv(t, h, prefix + 'conv2.weight', 2, 3)
+    y3, b_bn2 = _bn(t, y2, prefix + 'bn2')
+    y4, b_relu = _relu(t, y3, prefix + 'bn2.relu', store=False)
+    if pool_type == 'max':
+        y5, b_pool = _maxpool(t, y4, prefix + 'bn2.maxpool')
+    else:
+        y5 = t.rs(avgpool3s2p1_fwd(y4))
+        b_pool = lambda d: t.rs(avgpool3s2p1_bwd(d, y4.shape[2]))
+    return y5, (lambda d: b_ca(b_bn1(b_c2(b_bn2(b_relu(b_pool(d)))))))
+
+
 RESNET_LAYERS = {'resnet18': (2, 2, 2, 2), 'resnet34': (3, 4, 6, 3)}              # resnet.py:166-187
 DENSENET_BLOCKS = {'densenet18': (2, 2, 2, 2), 'densenet121': (6, 12, 24, 16),    # densenet.py:223-275 (growth 32)
                    'densenet169': (6, 12, 32, 32), 'densenet201': (6, 12, 48, 32)}
 
 
-def resnet18_features(t, x, prefix='breath_block.', first_pool_type='max', layers=(2, 2, 2, 2)):
+def resnet18_features(t, x, prefix='breath_block.', first_pool_type='max', layers=(2, 2, 2, 2), double_conv_first=False):
     """ResNet.forward (resnet.py:141-163) with BasicBlock (resnet.py:24-40); layers [2,2,2,2] = resnet18,
     [3,4,6,3] = resnet34."""
-    h, b_stem = _stem(t, x, prefix + 'conv1.weight', prefix + 'bn1', first_pool_type)
+    if double_conv_first:
+        h, b_stem = _stem_double(t, x, prefix, first_pool_type)
+    else:
+        h, b_stem = _stem(t, x, prefix + 'conv1.weight', prefix + 'bn1', first_pool_type)
     backs = [b_stem]
     inpl = 64
     for li, planes in enumerate([64, 128, 256, 512]):
@@ -490,7 +509,7 @@ def lstm_bwd(x, w_ih, w_hh, tape, dh_all):
 
 def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_batches=20,
                                 first_pool_type='max', drop_masks=None, need_grads=True, head='linear',
-                                bf16_convs=False, bf16_storage=False):
+                                bf16_convs=False, bf16_storage=False, double_conv_first=False):
     """CNNLinearNetwork.forward over a batch (torch_cnn_linear_network.py:104-113) + BCE loss
     (train_ards_detector.py:929-930) + backward.  x (B,NB,C,224); target (B,2) one-hot.
     params: dict name -> ndarray with the reference's state_dict keys.
@@ -515,7 +534,8 @@ def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_ba
     t.bf16_storage = bf16_storage            # resnets only (the device has no bf16-storage DenseNet)
     rows = x.reshape(b * nb, c, l)
     if backbone in RESNET_LAYERS:
-        feat, fbwd = resnet18_features(t, rows, first_pool_type=first_pool_type, layers=RESNET_LAYERS[backbone])
+        feat, fbwd = resnet18_features(t, rows, first_pool_type=first_pool_type, layers=RESNET_LAYERS[backbone],
+                                       double_conv_first=double_conv_first)
     elif backbone in DENSENET_BLOCKS:
         feat, fbwd = densenet18_features(t, rows, drop_masks=drop_masks, block_config=DENSENET_BLOCKS[backbone])
     else:

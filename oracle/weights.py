@@ -96,7 +96,8 @@ DEAD_RESNET_PARAMS = ('breath_block.conv1_alt.weight', 'breath_block.conv2.weigh
                       'breath_block.bn2.weight', 'breath_block.bn2.bias')
 
 
-def seeded_params(backbone, seed=0, n_sub_batches=20, dtype=np.float32, bn_bias_shift=0.0, head='linear', lstm_hidden=16):
+def seeded_params(backbone, seed=0, n_sub_batches=20, dtype=np.float32, bn_bias_shift=0.0, head='linear', lstm_hidden=16,
+                  in_ch=1):
     """Deterministic weights: conv ~ N(0, sqrt(2/(k*C_out))) as the reference's init
     (resnet.py:115-118, densenet.py:154-157); BN gamma ~ U(.5,1.5), beta ~ N(0,.1) (NOT the
     reference's 1/0 -- randomised so that parity tests see gamma/beta); linear ~ U(+-1/sqrt(in)).
@@ -104,7 +105,7 @@ def seeded_params(backbone, seed=0, n_sub_batches=20, dtype=np.float32, bn_bias_
     no activation decisions an fp32 rounding could flip, which makes whole-model GRADIENT parity a
     well-posed 1e-4 comparison (see tests/test_model_gpu.py)."""
     params = {}
-    for name, shape, kind in param_spec(backbone, n_sub_batches, head=head, lstm_hidden=lstm_hidden):
+    for name, shape, kind in param_spec(backbone, n_sub_batches, in_ch=in_ch, head=head, lstm_hidden=lstm_hidden):
         rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
         if kind == 'conv':
             std = np.sqrt(2.0 / (shape[2] * shape[0]))

@@ -9,7 +9,8 @@ from oracle import np_ref
 from oracle.weights import seeded_params, digest, DEAD_RESNET_PARAMS
 
 GOLD = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), 'golden', '*net18_*.npz'))
-              if not os.path.basename(p).startswith('head_'))
+              if not os.path.basename(p).startswith(('head_', 'opt_')))
+OPT_GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'opt_*.npz')))
 HEAD_GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'head_*.npz')))
 BB_GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'bb_*.npz')))
 
@@ -67,6 +68,60 @@ def test_np_oracle_sibling_heads_match_reference(path):
         np.testing.assert_allclose(out['hx'], g['hx64'][0], rtol=0, atol=1e-12)
         np.testing.assert_allclose(out['cx'], g['cx64'][0], rtol=0, atol=1e-12)
         assert 'lstm.weight_hh_l0' in out['grads']
+
+
+def opt_reference(g):
+    """The oracle run for a constructor-option golden (oracle/make_golden_options.py)."""
+    backbone = str(g['backbone'])
+    params = {k: v.astype(np.float64) for k, v in seeded_params(backbone, int(g['seed']), bn_bias_shift=float(g['bn_bias_shift']),
+                                                                   in_ch=int(g['in_ch'])).items()}
+    out = np_ref.cnn_linear_forward_backward(params, g['x'].astype(np.float64), g['target'].astype(np.float64),
+                                             backbone=backbone, first_pool_type=str(g['first_pool_type']),
+                                             double_conv_first=bool(g['opt_double_conv_first']) if 'opt_double_conv_first' in g else False)
+    return params, out
+
+
+@pytest.mark.parametrize('path', OPT_GOLD, ids=[os.path.basename(p)[:-4] for p in OPT_GOLD])
+def test_np_oracle_constructor_options_match_reference(path):
+    """densenet18(with_fft / only_fft / fft_real_only) (densenet.py:109-115: conv0 with 3 / 2 / 2 / 1 input channels) and
+    resnet18(double_conv_first=True) (resnet.py:90-96,142-149) in the oracle vs the reference classes: logits, loss, every
+    gradient; with double_conv_first conv1 is the dead parameter and conv1_alt / conv2 / bn2 are live."""
+    g = _load(path)
+    params, out = opt_reference(g)
+    np.testing.assert_allclose(out['logits'], g['logits64'], rtol=0, atol=1e-10)
+    assert abs(out['loss'] - float(g['loss64'])) < 1e-12
+    names = [k[len('grad64/'):] for k in g if k.startswith('grad64/')]
+    for name in names:
+        np.testing.assert_allclose(digest(out['grads'][name]), g['grad64/' + name], rtol=1e-8, atol=1e-9, err_msg=name)
+    assert sorted(names) == sorted(out['grads'])
+    if 'opt_double_conv_first' in g:
+        assert 'breath_block.conv1.weight' not in names and 'breath_block.conv2.weight' in names
+        assert 'breath_block.conv1_alt.weight' in names and 'breath_block.bn2.bias' in names
+    else:
+        assert params['breath_block.features.conv0.weight'].shape[1] == g['x'].shape[2] == int(g['in_ch'])
+
+
+def test_perform_fft_restates_the_reference_call_for_call():
+    """tiles.perform_fft vs the literal expression of ARDSRawDataset._perform_fft (dataset.py:1330-1341) -- including the
+    axes-less fftshift that also rolls the sub-batch rows by NB // 2 -- and the per-channel scaling factors."""
+    from deepards_amd.tiles import perform_fft, scaling_factors_for_indices
+    rng = np.random.RandomState(3)
+    w = rng.randn(5, 20, 1, 224) * 20
+    full = perform_fft(w, add_fft=True)
+    assert full.shape == (5, 20, 3, 224)
+    for i in range(5):
+        trans = np.fft.fftshift(np.fft.fft(w[i], axis=-1))
+        assert np.array_equal(full[i], np.concatenate([w[i], trans.real, trans.imag], axis=1))
+        # the spectrum rows sit 10 rows away from the flow rows they came from (fftshift over every axis)
+        spec = np.fft.fftshift(np.fft.fft(w[i], axis=-1), axes=-1)
+        assert np.allclose(full[i][:, 1], np.roll(spec.real[:, 0], 10, axis=0))
+    assert perform_fft(w, only_fft=True).shape == (5, 20, 2, 224)
+    assert perform_fft(w, add_fft=True, fft_real_only=True).shape == (5, 20, 2, 224)
+    assert perform_fft(w, only_fft=True, fft_real_only=True).shape == (5, 20, 1, 224)
+    assert perform_fft(w) is not None and np.array_equal(perform_fft(w), w)
+    mu, std = scaling_factors_for_indices(full, [0, 2, 3])
+    sel = full[[0, 2, 3]]
+    assert mu.shape == (3,) and np.allclose(mu, sel.mean(axis=(0, 1, 3))) and np.allclose(std, sel.std(axis=(0, 1, 3)))
 
 
 @pytest.mark.parametrize('path', BB_GOLD, ids=[os.path.basename(p)[:-4] for p in BB_GOLD])

@@ -49,3 +49,71 @@ def decision_matched_gradients(ref, ours, log_tag='', tols=(1e-5, 3e-5), log=pri
         if worst < 1e-4:
             break
     return got, chosen, len(cands)
+
+
+def rel_l2(a, b):
+    nb = float(np.linalg.norm(b))
+    return float(np.linalg.norm(a - b) / (nb if nb > 1e-9 else 1.0))      # ~zero references: absolute
+
+
+def assert_gradients_match(ref, ours, tag='', strict=False, max_flips=12, log=print, allow=None):
+    """THE gradient yardstick of this suite (BASELINE north_star: 1e-4): every parameter of ``ours`` (name -> float64
+    array) within 1e-4 (rel-l2, or max abs err <= 1e-4 * max(1, max|ref|)) of the oracle's exact gradients under the
+    activation decisions this run took (``decision_matched_gradients``); at most ``max_flips`` adopted flips, no ReLU
+    flip when ``strict`` (goldens whose every ReLU is active; a DenseNet stem's max-pool keeps its near-ties even there:
+    two neighbouring conv outputs 1e-5 apart are not moved by a BatchNorm shift).  ``allow(name) -> bool`` exempts named parameters (callers document
+    why).  Returns (worst rel-l2, flips)."""
+    matched, flips, ncand = decision_matched_gradients(ref, ours, tag, log=log)
+    if strict:
+        assert not [f for f in flips if not f[0].endswith('.maxpool')], flips
+    assert len(flips) <= max_flips, flips
+    worst, bad = 0.0, []
+    for n in ours:
+        if n not in matched:
+            continue
+        abs_err = float(np.abs(ours[n] - matched[n]).max())
+        rl2 = rel_l2(ours[n], matched[n])
+        worst = max(worst, rl2)
+        scale = max(1.0, float(np.abs(matched[n]).max()))
+        if not (rl2 <= 1e-4 or abs_err <= 1e-4 * scale) and not (allow is not None and allow(n)):
+            bad.append((n, abs_err, rl2, rel_l2(ours[n], ref['grads'][n])))
+    log('   %s worst grad rel-l2 %.3e with %d flips of %d candidates' % (tag, worst, len(flips), ncand))
+    assert not bad, bad
+    return worst, flips
+
+
+def feature_reference(params64, rows_per_window, x64, cotangent, backbone='resnet18', **tape_flags):
+    """The oracle at breath-block level -- features of ``x64`` (rows, 1, L) and the parameter gradients of
+    sum(features * cotangent) -- in the form ``decision_matched_gradients`` wants (grads, tape, rebackward).  Used where
+    CNNLinearNetwork itself refuses the shape (seq_len != 224, torch_cnn_linear_network.py:106-107)."""
+    t = np_ref._Tape(params64, rows_per_window)
+    for k, v in tape_flags.items():
+        setattr(t, k, v)
+    fn = np_ref.resnet18_features if backbone.startswith('resnet') else np_ref.densenet18_features
+    feat, bwd = fn(t, x64)
+    extra = {}
+    if callable(cotangent):                 # a head stated by the caller: feat -> (d loss / d feat, its own gradients, ...)
+        cotangent, extra = cotangent(feat)
+
+    def run():
+        t.g = {}
+        bwd(cotangent)
+        g = dict(t.g)
+        g.update(extra.get('grads', {}))
+        return g
+
+    def rebackward(flips):
+        saved = {}
+        for name, i in flips:
+            d = t.decisions[name]
+            key = 'mask' if d['kind'] == 'relu' else 'idx'
+            saved.setdefault(name, (key, d[key]))
+            np_ref._apply_flip(t, name, i)
+        try:
+            return run()
+        finally:
+            for name, (key, val) in saved.items():
+                t.decisions[name][key] = val
+    out = dict(feat=feat, grads=run(), tape=t, rebackward=rebackward)
+    out.update({k: v for k, v in extra.items() if k != 'grads'})
+    return out
