@@ -56,7 +56,7 @@ def parse():
     ap.add_argument('--storage', default=None, choices=['f32', 'bf16'],
                     help='activation storage under --dtype bf16: bf16 (default: BASELINE configs[2] / [4], bf16 storage with '
                          'fp32 statistics and accumulators) or f32 (round 1: bf16 operands only)')
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f32x3'],
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f32x3', 'f32x3p'],
                     help="arithmetic of the k3 s1 convs' forward / data gradient: f32 (the headline, BASELINE configs[1]) or "
                          "bf16 operands with fp32 sums (BASELINE configs[2])")
     return ap.parse_args()
@@ -67,6 +67,7 @@ class KernelTimer(object):
 
     REPEAT = 8                              # launches per bracket in the repeated measurement
     REPEATED = ('da_conv3_winograd', 'da_conv3_winograd4', 'da_conv3_bf16', 'da_conv3_x3')     # x,u,y,rows,L,ldx,C,ldy,N,accumulate,stream
+    REPEATED_X3P = ('da_conv3_x3p',)                                                            # x,wpk,y,rows,L,C,ldy,N,accumulate,stream
 
     def __init__(self, lib, torch, act_bytes=4.0):
         self.lib, self.torch, self.act_bytes = lib, torch, act_bytes
@@ -80,12 +81,13 @@ class KernelTimer(object):
         off): an event bracket costs several microseconds of its own (marker packets, cache write-back at the
         timestamp), which a single-launch bracket adds to a 20-50 us kernel and a bracket of 8 does not."""
         import ctypes
-        need = int(a[3]) * int(a[4]) * int(a[7])
+        x3p = name in self.REPEATED_X3P
+        need = int(a[3]) * int(a[4]) * int(a[6 if x3p else 7])
         if self.scratch is None or self.scratch.numel() < need:
             self.scratch = self.torch.empty(need, device='cuda', dtype=self.torch.float32)
         b = list(a)
         b[2] = ctypes.c_void_p(self.scratch.data_ptr())
-        b[9] = 0
+        b[8 if x3p else 9] = 0
         e0 = self.torch.cuda.Event(enable_timing=True)
         e1 = self.torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -112,6 +114,9 @@ class KernelTimer(object):
             pts = {'da_conv3_winograd': 4, 'da_conv3_winograd4': 6, 'da_conv3_bf16': 1.5, 'da_conv3_x3': 4.5}[name]
             return (2.0 * a[3] * a[4] * a[6] * a[8] * 3,
                     f * (a[3] * a[4] * a[6] + a[3] * a[4] * a[8] * (2 if a[9] else 1) + pts * a[6] * a[8]))
+        if name == 'da_conv3_x3p':          # x,wpk,y,rows,L,C,ldy,N,accumulate: x3 input (6 B / element), fp32 output, 18 B / weight
+            return (2.0 * a[3] * a[4] * a[5] * a[7] * 3,
+                    6.0 * a[3] * a[4] * a[5] + 4.0 * a[3] * a[4] * a[7] * (2 if a[8] else 1) + 18.0 * a[5] * a[7])
         if name == 'da_conv_wgrad_multi':   # jobs (host array of da_wgrad_job), n
             j = a[0]
             return (sum(2.0 * j[i].rows * j[i].Lm * j[i].N * j[i].C * j[i].ntaps for i in range(a[1])),
@@ -152,7 +157,7 @@ class KernelTimer(object):
                 rc = _fn(*a)
                 e1.record()
                 self.records.setdefault(_n, []).append((e0, e1) + self.work_of(_n, a))
-                if _n in self.REPEATED:
+                if _n in self.REPEATED or _n in self.REPEATED_X3P:
                     self._repeat(_n, _fn, a)
                 return rc
             setattr(self.lib, n, wrapped)
@@ -306,7 +311,7 @@ def main():
 
     from deepards_amd import functional as F_
     F_.set_conv_dtype(args.dtype)
-    fp32like = args.dtype in ('f32', 'f32x3')            # f32x3: fp32-equivalent products on the bf16 pipe (opt-in)
+    fp32like = args.dtype in ('f32', 'f32x3', 'f32x3p')            # f32x3: fp32-equivalent products on the bf16 pipe (opt-in)
     storage = args.storage or ('f32' if fp32like else args.dtype)
     if fp32like and storage != 'f32':
         raise SystemExit('--storage bf16 needs --dtype bf16')
@@ -393,7 +398,7 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': (('%s breath block + Linear(F*NB, 2) head (stated, not mirrored: the reference cannot run this shape), '
                                  'synthetic (B=%d per GPU, %d, 1, %d) train step, %s (tile shape of BASELINE configs[4])' %
-                                 (args.backbone, B, NB, SL, 'fp32' if args.dtype == 'f32' else 'fp32 via three-term bf16 splits (opt-in)' if args.dtype == 'f32x3' else 'bf16 MFMA operands / fp32 sums in the residual-block convs, %s activation storage, fp32 statistics' % storage))
+                                 (args.backbone, B, NB, SL, 'fp32' if args.dtype == 'f32' else 'fp32 via three-term bf16 splits (opt-in)' if args.dtype in ('f32x3', 'f32x3p') else 'bf16 MFMA operands / fp32 sums in the residual-block convs, %s activation storage, fp32 statistics' % storage))
                                 if c5_shape else
                                 ('cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) fp32 train step (BASELINE configs[1])'
                                  if args.dtype == 'f32' else
@@ -401,6 +406,11 @@ def main():
                                  'the residual-block conv products as exact three-term bf16 splits (six bf16 MFMA products per multiply, '
                                  'fp32 sums, fp32 storage) -- not the default path'
                                  if args.dtype == 'f32x3' else
+                                 'cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) fp32 train step (BASELINE configs[1]); arithmetic: fp32 storage '
+                                 'of parameters / statistics / conv outputs / gradients, the k3 s1 conv products (forward, data and weight '
+                                 'gradient) as exact three-term bf16 splits on the bf16 matrix cores (six MFMA products per multiply, fp32 sums; '
+                                 'their operands stored pre-split by the BatchNorm / pool kernels), stride-2 / 1x1 convs on the fp32 matrix cores'
+                                 if args.dtype == 'f32x3p' else
                                  'cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) train step, bf16 MFMA operands / fp32 sums in the '
                                  'residual-block convs (forward, data and weight gradient), ' + storage + ' activation storage, fp32 '
                                  'statistics / optimizer (BASELINE configs[2])') % (args.backbone, B)),
@@ -456,7 +466,8 @@ def main():
         # instrumented EAGER steps: HIP events around every C-ABI launch, on the launch stream
         kt = KernelTimer(lib, torch, act_bytes=2.0 if F_.storage_dtype() == 'bf16' else 4.0)
         names = [n for n in _lib.SIGNATURES if n not in ('da_version', 'da_conv_wgrad_workspace', 'da_stem_wgrad_workspace', 'da_bn_workspace', 'da_debug_set', 'da_bn_chunks', 'da_conv_wgrad_splits', 'da_conv_wgrad_plan', 'da_bn_debug_two_stage', 'da_bn_debug_target_blocks', 'da_abi_sizes', 'da_wino_debug_tail', 'da_wino_debug_pchunk', 'da_wino_weights', 'da_wino4_weights',
-                                                          'da_hip_runtime_symbol')]
+                                                          'da_hip_runtime_symbol', 'da_stem_wgrad_workspace_g', 'da_set_act_dtype', 'da_get_act_dtype',
+                                                          'da_sizeof_wgrad_reduce_desc', 'da_sizeof_bn_running_desc', 'da_sizeof_bn_pgrad_desc', 'da_bn_mask_words')]
         tr_e = HotPathTrainer(model, optimizer='sgd', use_graph=False)
         tr_e.bucket, tr_e.state = tr.bucket, tr.state
         try:
@@ -483,6 +494,8 @@ def main():
             'da_conv3_bf16': 'conv3_bf16_kernel (k3 s1 conv forward + data gradient, v_mfma_f32_32x32x16_bf16)',
             'da_conv3_x3': 'conv3_x3_kernel (k3 s1 conv forward + data gradient, fp32 products as six v_mfma_f32_32x32x16_bf16 of '
                            'three-term splits; peak = the bf16 MFMA peak / 6)',
+            'da_conv3_x3p': 'conv3_x3p_kernel (k3 s1 conv forward + data gradient on pre-split (x3) operands: fp32 products as six '
+                            'v_mfma_f32_32x32x16_bf16 of exact three-term splits, no VALU in the K loop; peak = the bf16 MFMA peak / 6)',
             'da_conv_bf16_multi': 'conv_bf16_gen_kernel<*> (stride-2 / 1x1 convs, bf16 operands)',
             'da_bn_fwd': 'bn_fwd_fused_kernel<*> (per-window BatchNorm (+ReLU)(+residual) forward, single pass)',
             'da_bn_fwd_mask': 'bn_fwd_fused_kernel<*> (block-output BatchNorm + residual + ReLU forward, ReLU bit mask)',
@@ -492,7 +505,7 @@ def main():
             'da_pool_bwd': 'pool_bwd_kernel (stem max/avg pool + ReLU backward)',
         }
         PEAK = {'da_conv3_bf16': PEAK_BF16_MFMA_TFLOPS, 'da_conv_bf16_multi': PEAK_BF16_MFMA_TFLOPS,
-                'da_conv3_x3': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)}
+                'da_conv3_x3': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1), 'da_conv3_x3p': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)}
         cands = [k for k in summ if k in KERNEL_OF and (summ[k]['flops'] or summ[k]['bytes'])]
         dname = max(cands, key=lambda k: summ[k].get('rep_total_ms', summ[k]['total_ms']))   # argmax over all of them
         dom = summ[dname]
@@ -509,7 +522,7 @@ def main():
             traffic, traffic_note = None, 'the PMC passes under profiles/ ran the default workload (B=64, nb20, seq224) only'
         else:
             traffic, traffic_note = pmc_traffic(dname, ('bf16' if F_.storage_dtype() == 'bf16' else 'bf16_f32storage') if args.dtype == 'bf16' else
-                                                ('f32x3' if args.dtype == 'f32x3' else ''))
+                                                (args.dtype if args.dtype in ('f32x3', 'f32x3p') else ''))
         out['roofline'] = {'bound': bound, 'kernel': KERNEL_OF[dname], 'entry': dname,
                            'achieved': round(ach, 2), 'peak': peak, 'unit': unit,
                            'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_note,

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libdeepards_hip.so')
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'deepards_hip.h')
-SOURCES = ['conv_gemm.hip', 'conv_wino.hip', 'conv_bf16.hip', 'conv_x3.hip', 'bn.hip', 'stem_pool.hip', 'head_optim.hip']
+SOURCES = ['conv_gemm.hip', 'conv_wino.hip', 'conv_bf16.hip', 'conv_x3.hip', 'conv_x3p.hip', 'bn.hip', 'stem_pool.hip', 'head_optim.hip']
 
 _P, _I, _F, _Z, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_uint
 _IP = ctypes.POINTER(ctypes.c_int)
@@ -75,6 +75,9 @@ SIGNATURES = {
     'da_bn_stats_merge': (_I, [_P, _I, _I, _I, _F, _P, _P, _P]),
     'da_bn_running_multi': (_I, [ctypes.POINTER(BnRunningDesc), _I, _P]),
     'da_bn_apply': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _F, _P]),
+    'da_bn_fwd_x': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _I, _I, _P]),
+    'da_bn_bwd_x': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P]),
+    'da_bn_relu_pool_fwd_x': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     'da_bn_fwd': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
     'da_bn_debug_two_stage': (_I, [_I]),
     'da_bn_debug_target_blocks': (_I, [_I]),
@@ -92,6 +95,9 @@ SIGNATURES = {
     'da_conv3_bf16': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'da_pack_conv3_bf16': (_I, [_P, _P, _P, _I, _I, _P]),
     'da_conv3_x3': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'da_conv3_x3p': (_I, [_P, _P, _P] + [_I] * 6 + [_P]),
+    'da_x3_split': (_I, [_P, _I, _P, _Z, _I, _P]),
+    'da_x3_merge': (_I, [_P, _P, _I, _Z, _I, _P]),
     'da_pack_conv3_x3': (_I, [_P, _P, _P, _I, _I, _P]),
     'da_conv_bf16_multi': (_I, [ctypes.POINTER(ConvJob), _I, _P]),
     'da_wino_debug_tail': (_I, [_I]),

@@ -375,7 +375,9 @@ __device__ __forceinline__ void quad_block_sum(f32x4 (&v)[NV], float* red) {
 }
 
 // mean / invstd of the window (two-pass from registers), published, and out = act(bn(x) (+res))
-template <typename AT, int NPOS, int QB>
+// RX3 / OX3: the residual is read / the output is stored in the x3 format (common.h: exact three-term bf16 split, 3 C bf16
+// per position; float activations only) -- the producers of the k3 s1 convs' inputs under conv arithmetic 'f32x3'.
+template <typename AT, int NPOS, int QB, int RX3 = 0, int OX3 = 0>
 __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const AT* __restrict__ x, int ldx,
                                                             const AT* __restrict__ res, int ldr,
                                                             AT* __restrict__ out, int ldo, int Wn, int C,
@@ -439,8 +441,10 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const AT* __restrict
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mu[e]) * is[e] * ga[e] + be[e];
-      if (rb) {
-        f32x4 r = Act<AT>::ld4(rb + (uint32_t)(p * ldr + q * 4));
+      if (res) {
+        f32x4 r;
+        if constexpr (RX3) r = X3::ld4(reinterpret_cast<const __bf16*>(res) + (base + p) * (size_t)(3 * C), c0);
+        else r = Act<AT>::ld4(rb + (uint32_t)(p * ldr + q * 4));
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] += r[e];
       }
@@ -451,7 +455,8 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const AT* __restrict
           o[e] = fmaxf(o[e], 0.f);
         }
       }
-      Act<AT>::st4(ob + (uint32_t)(p * ldo + q * 4), o);
+      if constexpr (OX3) X3::st4(reinterpret_cast<__bf16*>(out) + (base + p) * (size_t)(3 * C), c0, o);
+      else Act<AT>::st4(ob + (uint32_t)(p * ldo + q * 4), o);
     }
   }
   // ReLU decisions of this thread's 4 x NPOS elements: the backward kernel (same geometry, same thread -> element map)
@@ -460,7 +465,9 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const AT* __restrict
 }
 
 // same arithmetic as bn_bwd_reduce_kernel + bn_bwd_apply_kernel with the slab held in registers
-template <typename AT, int NPOS, int QB>
+// DX3: dx (the gradient w.r.t. the BatchNorm input = the conv output: the data-gradient and weight-gradient convs' operand)
+// is stored in the x3 format; gout stays float (the convs accumulate the branch gradient into it).
+template <typename AT, int NPOS, int QB, int DX3 = 0>
 __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict__ dout, int ldd,
                                                             const AT* __restrict__ x, int ldx,
                                                             const AT* __restrict__ outp, int ldo,
@@ -539,7 +546,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict
 #pragma unroll
         for (int e = 0; e < 4; ++e) d[e] += av[e];
       }
-      Act<AT>::st4(dxb + (uint32_t)(p * lddx + q * 4), d);
+      if constexpr (DX3) X3::st4(reinterpret_cast<__bf16*>(dx) + (base + p) * (size_t)(3 * C), c0, d);
+      else Act<AT>::st4(dxb + (uint32_t)(p * lddx + q * 4), d);
       if (gb) Act<AT>::st4(gb + (uint32_t)(p * ldg + q * 4), g[k]);
     }
   }
@@ -766,6 +774,75 @@ int da_bn_fwd(const void* x, int ldx, const void* res, int ldr, void* out, int l
               float* mean, float* invstd, const float* gamma, const float* beta, int relu, float eps, float* scratch,
               hipStream_t stream) {
   return bn_fwd_impl(x, ldx, res, ldr, out, ldo, W, Wn, C, mean, invstd, gamma, beta, relu, eps, scratch, nullptr, stream);
+}
+
+// da_bn_fwd / da_bn_fwd_mask with x3 operands (float activations, single-pass geometry only: returns -1 for a shape
+// that would take the two-stage kernels -- ask da_bn_mask_words() > 0 first): res_x3 / out_x3 say which of `res`, `out`
+// are in the x3 format (3 C bf16 per position, pitches ignored for those); mask may be NULL.
+int da_bn_fwd_x(const float* x, int ldx, const void* res, int ldr, void* out, int ldo, int W, int Wn, int C, float* mean,
+                float* invstd, const float* gamma, const float* beta, int relu, float eps, unsigned long long* mask,
+                int res_x3, int out_x3, hipStream_t stream) {
+  DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;
+  if (!x || !out || !mean || !invstd || !gamma || !beta || C % CG || ldx % 4 || Wn < 1) return DA_EINVAL;
+  if ((!out_x3 && ldo % 4) || (res && !res_x3 && ldr % 4) || ((res_x3 || out_x3) && C % 16)) return DA_EINVAL;
+  if (W == 0) return DA_OK;
+  int cgb = 0;
+  const int threads = bn_fused_geometry(W, Wn, C, &cgb);
+  if (!threads) return DA_EINVAL;
+  const int rx = res && res_x3 ? 1 : 0, ox = out_x3 ? 1 : 0;
+#define BN_FWDX_LAUNCH(QB, CH, RX, OX)                                                                                  \
+  hipLaunchKernelGGL((bn_fwd_fused_kernel<float, FUSED_NPOS, QB, RX, OX>), dim3(W, C / CH), dim3(threads), 0, stream, x, ldx,   \
+                     (const float*)res, ldr, (float*)out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd, mask)
+#define BN_FWDX_QB(QB, CH)                                  \
+  do {                                                      \
+    if (rx && ox) BN_FWDX_LAUNCH(QB, CH, 1, 1);             \
+    else if (rx) BN_FWDX_LAUNCH(QB, CH, 1, 0);              \
+    else if (ox) BN_FWDX_LAUNCH(QB, CH, 0, 1);              \
+    else BN_FWDX_LAUNCH(QB, CH, 0, 0);                      \
+  } while (0)
+  if (cgb == 32) BN_FWDX_QB(3, 32);
+  else if (cgb == 16) BN_FWDX_QB(2, 16);
+  else BN_FWDX_QB(1, 8);
+#undef BN_FWDX_QB
+#undef BN_FWDX_LAUNCH
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// da_bn_bwd / da_bn_bwd_mask with dx optionally stored in the x3 format (dx_x3); dout, x, gout float.  mask != NULL: the
+// ReLU decisions of da_bn_fwd_x; else mask_mode 0 (no ReLU) or 1 (ReLU, recomputed from bn(x)).  Single-pass geometry only.
+int da_bn_bwd_x(const float* dout, int ldd, const float* x, int ldx, void* dx, int lddx, float* gout, int ldg, int W, int Wn,
+                int C, const float* mean, const float* invstd, const float* gamma, const float* beta, int mask_mode,
+                float* ds, const unsigned long long* mask, int dx_x3, hipStream_t stream) {
+  DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;
+  if (mask) mask_mode = 3;
+  if (!dout || !x || !dx || !mean || !invstd || !gamma || !beta || !ds) return DA_EINVAL;
+  if (C % CG || ldd % 4 || ldx % 4 || (!dx_x3 && lddx % 4) || (dx_x3 && C % 16) || (gout && ldg % 4)) return DA_EINVAL;
+  if (mask_mode != 0 && mask_mode != 1 && mask_mode != 3) return DA_EINVAL;
+  if (W == 0) return DA_OK;
+  int cgb = 0;
+  const int threads = bn_fused_geometry(W, Wn, C, &cgb);
+  if (!threads) return DA_EINVAL;
+  float* s1 = ds;
+  float* s2 = ds + (size_t)W * C;
+#define BN_BWDX_LAUNCH(QB, CH, DX)                                                                                        \
+  hipLaunchKernelGGL((bn_bwd_fused_kernel<float, FUSED_NPOS, QB, DX>), dim3(W, C / CH), dim3(threads), 0, stream, dout, ldd, x,  \
+                     ldx, (const float*)nullptr, 0, (float*)dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, \
+                     s2, (const float*)nullptr, 0, mask)
+#define BN_BWDX_QB(QB, CH)                       \
+  do {                                           \
+    if (dx_x3) BN_BWDX_LAUNCH(QB, CH, 1);        \
+    else BN_BWDX_LAUNCH(QB, CH, 0);              \
+  } while (0)
+  if (cgb == 32) BN_BWDX_QB(3, 32);
+  else if (cgb == 16) BN_BWDX_QB(2, 16);
+  else BN_BWDX_QB(1, 8);
+#undef BN_BWDX_QB
+#undef BN_BWDX_LAUNCH
+  DA_CHECK_LAUNCH();
+  return DA_OK;
 }
 
 // tests: 1 = always take the two-stage kernels (so both paths are checked against the oracle)

@@ -44,6 +44,44 @@ template <> struct Act<__bf16> {
   static __device__ __forceinline__ float ld1(const __bf16* p) { return (float)*p; }
   static __device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
 };
+// The "x3" activation format (conv arithmetic 'f32x3'): an fp32 value stored as its EXACT three-term bf16 split
+//     x = h + m + l,   h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m)        (round-to-nearest-even, 3 x 8 bits)
+// so that the convolutions that consume it can take fp32-equivalent products on the bf16 matrix cores (conv_x3p.hip)
+// without splitting anything themselves.  Layout per position: C/16 groups of [h 16 ch | m 16 ch | l 16 ch] = 48 bf16;
+// 3 C bf16 = 6 C bytes per position, no channel pitch.  Reading it back (residual adds, tests) is h + m + l: exact,
+// every partial sum is a truncation of x's own 24-bit significand.  Only the BatchNorm / pool kernels in front of an x3
+// consumer store it; statistics, sums and every conv OUTPUT stay plain fp32.
+struct X3 {
+  static __device__ __forceinline__ f32x2v cvt4(const f32x4& v) {      // 4 bf16 (nearest-even) as the bits of 2 floats
+    const f32x2v lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    const bf16x2v a = __builtin_convertvector(lo, bf16x2v), b = __builtin_convertvector(hi, bf16x2v);
+    return f32x2v{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)};
+  }
+  static __device__ __forceinline__ f32x4 widen4(const f32x2v& b) {    // the 4 bf16 back as floats (exact)
+    const uint32_t u0 = __float_as_uint(b[0]), u1 = __float_as_uint(b[1]);
+    return f32x4{__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 << 16),
+                 __uint_as_float(u1 & 0xffff0000u)};
+  }
+  // element offset (bf16) of channel c0's h term inside a position; m at + 16, l at + 32
+  static __device__ __forceinline__ int off(int c0) { return (c0 >> 4) * 48 + (c0 & 15); }
+  static __device__ __forceinline__ void st4(__bf16* pos, int c0, const f32x4& v) {     // channels c0 .. c0 + 3, c0 % 4 == 0
+    const f32x2v h = cvt4(v);
+    const f32x4 r1 = v - widen4(h);
+    const f32x2v m = cvt4(r1);
+    const f32x4 r2 = r1 - widen4(m);
+    __bf16* d = pos + off(c0);
+    *reinterpret_cast<f32x2v*>(d) = h;
+    *reinterpret_cast<f32x2v*>(d + 16) = m;
+    *reinterpret_cast<f32x2v*>(d + 32) = cvt4(r2);
+  }
+  static __device__ __forceinline__ f32x4 ld4(const __bf16* pos, int c0) {
+    const __bf16* d = pos + off(c0);
+    const f32x4 h = widen4(*reinterpret_cast<const f32x2v*>(d)), m = widen4(*reinterpret_cast<const f32x2v*>(d + 16)),
+                l = widen4(*reinterpret_cast<const f32x2v*>(d + 32));
+    return (h + m) + l;
+  }
+};
+
 extern int g_act_bf16;                 // head_optim.hip; set by da_set_act_dtype
 // run STMT once with `AT` = the current activation storage type
 #define DA_ACT_DISPATCH(STMT)  \

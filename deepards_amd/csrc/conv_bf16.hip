@@ -60,6 +60,25 @@ template <> struct Stage<__bf16> {
   static __device__ __forceinline__ f32x2v bits(const reg& v) { return v; }
 };
 
+// activations in the x3 format (common.h): the three bf16 terms of 4 channels are 3 x 8 bytes, 32 bytes apart
+struct X3T {};
+template <> struct Stage<X3T> {
+  struct reg { f32x2v h, m, l; };
+  static __device__ __forceinline__ reg zero() { return reg{f32x2v{0.f, 0.f}, f32x2v{0.f, 0.f}, f32x2v{0.f, 0.f}}; }
+};
+// four channels (c0 .. c0 + 3, c0 % 4 == 0) of position `pos` of a [positions][ld] tensor of storage type AT (ld =
+// channel pitch in elements; x3: the tensor has `ld` channels and 3 ld bf16 per position)
+template <typename AT>
+__device__ __forceinline__ typename Stage<AT>::reg stage_ld(const void* base, size_t pos, int ld, int c0) {
+  if constexpr (__is_same(AT, X3T)) {
+    const __bf16* d = reinterpret_cast<const __bf16*>(base) + pos * (size_t)(3 * ld) + X3::off(c0);
+    return typename Stage<X3T>::reg{*reinterpret_cast<const f32x2v*>(d), *reinterpret_cast<const f32x2v*>(d + 16),
+                                    *reinterpret_cast<const f32x2v*>(d + 32)};
+  } else {
+    return Stage<AT>::ld(reinterpret_cast<const AT*>(base) + pos * (size_t)ld + c0);
+  }
+}
+
 template <typename AT>
 __global__ __launch_bounds__(256) void conv3_bf16_kernel(ConvBf16Args a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[CB_LDS_BYTES];
@@ -414,6 +433,14 @@ template <> struct WBStage<float, 3> {
 };
 
 // acc += A B over the NS x NS split terms that matter (small terms first)
+template <> struct WBStage<X3T, 3> {                       // pre-split operands: three plain 8-byte stores, no arithmetic
+  static __device__ __forceinline__ void put(unsigned char* d, const Stage<X3T>::reg& v) {
+    *reinterpret_cast<f32x2v*>(d) = v.h;
+    *reinterpret_cast<f32x2v*>(d + 128) = v.m;
+    *reinterpret_cast<f32x2v*>(d + 256) = v.l;
+  }
+};
+
 template <int NS>
 __device__ __forceinline__ void wb_mfma(f32x16& acc, const f32x4* a, const f32x4* b) {
 #define WB_M(i, j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc, 0, 0, 0)
@@ -433,8 +460,6 @@ __device__ __forceinline__ f32x2v ds_read_tr16(const unsigned char* p) {
 template <typename AT, int NS>
 __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const int block_id, unsigned char* lds) {
   constexpr int KP = WB<NS>::KP, PITCH = WB<NS>::PITCH, NP = KP / 16;
-  const AT* ady = reinterpret_cast<const AT*>(a.dy);
-  const AT* axx = reinterpret_cast<const AT*>(a.x);
   unsigned char* Ys = lds;                              // [KP][PITCH]      dY at padded positions k0 .. k0+KP-1
   unsigned char* Xs = lds + KP * PITCH;                 // [KP + 2][PITCH]  X at padded positions k0-1 .. k0+KP
 
@@ -456,7 +481,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const in
       const int l = (ok ? Pp : 0) - (int)sq * L1;
       ok = ok && l < a.L;
       typename Stage<AT>::reg v = Stage<AT>::zero();
-      if (ok) v = Stage<AT>::ld(ady + ((size_t)sq * a.L + l) * a.lddy + n_blk + lq * 4);
+      if (ok) v = stage_ld<AT>(a.dy, (size_t)sq * a.L + l, a.lddy, n_blk + lq * 4);
       ry[p] = v;
     }
 #pragma unroll
@@ -468,7 +493,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const in
       const int l = (ok ? Pp : 0) - (int)sq * L1;
       ok = ok && l < a.L;
       typename Stage<AT>::reg v = Stage<AT>::zero();
-      if (ok) v = Stage<AT>::ld(axx + ((size_t)sq * a.L + l) * a.ldx + c_blk + lq * 4);
+      if (ok) v = stage_ld<AT>(a.x, (size_t)sq * a.L + l, a.ldx, c_blk + lq * 4);
       rx[p] = v;
     }
   };
@@ -733,6 +758,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16_multi_kernel(WgradBf16Table t)
   else wgrad_bf16_s2_body<1, AT, NS>(t.d[i], b, lds);
 }
 
+// the k3 s1 p1 jobs on x3 operands (conv arithmetic 'f32x3', job code 49): wgrad_bf16_body with plain copies for staging
+__global__ __launch_bounds__(256) void wgrad_x3p_multi_kernel(WgradBf16Table t) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[WB<3>::LDS_BYTES];
+  int i = 0;
+  while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
+  const int b = xcd_chunked_bf(blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i]);
+  wgrad_bf16_body<X3T, 3>(t.d[i], b, lds);
+}
+
 // jobs the bf16 kernels take: channel counts multiples of 64 and  k3 s1 p1 | k3 s2 p1 | k1 s2 p0 (even input length)
 bool bf16_wgrad_eligible(const da_wgrad_job& j) {
   if (j.N % 64 || j.C % 64 || j.N < 64 || j.C < 64 || j.dy_stride != 1 || j.dy_off != 0 || j.Lm != j.Ldy) return false;
@@ -764,7 +798,8 @@ int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, int code, hipStream_t s) 
     if (!cnt) return DA_OK;
     t.n = cnt;
     t.first_block[cnt] = blocks;
-    if (code == 48) hipLaunchKernelGGL((wgrad_bf16_multi_kernel<float, 3>), dim3(blocks), dim3(256), 0, s, t);
+    if (code == 49) hipLaunchKernelGGL(wgrad_x3p_multi_kernel, dim3(blocks), dim3(256), 0, s, t);
+    else if (code == 48) hipLaunchKernelGGL((wgrad_bf16_multi_kernel<float, 3>), dim3(blocks), dim3(256), 0, s, t);
     else DA_ACT_DISPATCH(hipLaunchKernelGGL((wgrad_bf16_multi_kernel<AT, 1>), dim3(blocks), dim3(256), 0, s, t));
     DA_CHECK_LAUNCH();
     cnt = 0;
@@ -774,7 +809,8 @@ int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, int code, hipStream_t s) 
   for (int i = 0; i < n; ++i) {
     const da_wgrad_job& j = jobs[i];
     if (j.winograd != code) continue;
-    if (code == 48 && g_act_bf16) return DA_EINVAL;      // the split kernels read fp32 activations
+    if ((code == 48 || code == 49) && g_act_bf16) return DA_EINVAL;      // the split kernels belong to float activations
+    if (code == 49 && j.src_stride != 1) return DA_EINVAL;               // x3 operands: the k3 s1 p1 form only
     int splits, pchunk;
     bf16_wgrad_plan(j.rows, j.Lm, &splits, &pchunk);
     WgradBf16Args& a = t.d[cnt];

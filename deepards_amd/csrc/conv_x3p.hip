@@ -1,0 +1,286 @@
+// fp32 convolutions on the bf16 matrix cores with PRE-SPLIT operands ("f32x3", storage form): the k3 s1 p1 Conv1d forward
+// / data gradient of conv_x3.hip (reference models/resnet.py:5-8,27-38) fed by activations their PRODUCERS already wrote
+// as exact three-term bf16 splits (common.h: the "x3" activation format), so this kernel has no VALU work in its K loop
+// at all -- it moves bf16 bytes into LDS and issues MFMAs.
+//
+// Why: on gfx950 the fp32 matrix rate is 1/16 of the bf16 one.  x = h + m + l with h = bf16(x), m = bf16(x - h),
+// l = bf16(x - h - m) is EXACT for finite fp32 (3 x 8 significand bits), each bf16 x bf16 product is exact in the MFMA's
+// fp32 accumulate, and x w = hh' + hm' + mh' + hl' + lh' + mm' + (terms below 2^-23 |x w|, one fp32 rounding): fp32
+// results at 6/16 of the fp32 MFMA cost, in DIRECT form (no Winograd error growth: measured error vs fp64 below the
+// native fp32 direct kernel's).  Round 2 built this with the split done while staging (conv_x3.hip) and found it
+// break-even: the split costs ~6 VALU instructions per staged element on the issue port the MFMAs share, and the tripled
+// panel went through registers -> ds_write.  Here the BatchNorm / pool kernels (latency-bound: the 1.5x bytes are free
+// there) store h | m | l, the weights come pre-split from the batched repack, and both operands reach the MFMAs
+// through LDS with plain 16-byte copies.
+//
+// x3 activation format (common.h): per position C/16 groups of [h 16 ch | m 16 ch | l 16 ch] bf16 = 96 bytes per group,
+// 6 C bytes per position: one K step (16 channels) of one panel row is ONE contiguous 96-byte run.
+//
+// Block = (64 MT) positions x 64 output channels, 4 waves of (32 MT) x 32 (v_mfma_f32_32x32x16_bf16, MT accumulators);
+// MT = 2 for the full tiles, MT = 1 for the tiles of the partly filled last round (see da_conv3_x3p).  K step = 16
+// channels x 3 taps = 18 MT MFMAs per wave.  LDS per K step: the activation panel [64 MT + 2 rows + a zero row][112 B]
+// (96 data + 16 pad: the 16 rows a ds_read_b128 lane group touches fall on 16 different 16-byte slots) and the weight
+// chunk [3 taps][2 n halves][3 terms][64 lanes][16 B] = 18 KB exactly as the repack lays it out in HBM (fragment-major:
+// a wave's B fragment is one conflict-free 1 KB read) -- both double-buffered, ONE barrier per K step; the loads of step
+// k + 2 are in flight while step k multiplies.  Sequence edges: a tap that would cross one reads the zero row.
+#include "common.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define XP_TN 64
+#define XP_PITCH 112
+#define XP_BCHUNK (18 * 1024)                       // bytes of one (64-channel tile, K step) weight chunk
+
+__device__ __forceinline__ int xcd_chunked_xp(int id, int total) {   // consecutive work items share an XCD (conv_gemm.hip)
+  const int q = total >> 3, r = total & 7;
+  const int xcd = id & 7, s = id >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + s;
+}
+
+struct ConvX3pArgs {
+  const __bf16* x;      // [M] positions of x3 format, C channels: 3 C bf16 per position
+  const __bf16* w;      // [N / 64][C / 16] chunks of XP_BCHUNK bytes (da_repack_desc.points = 49)
+  float* y;             // [M][ldy] fp32, first N channels
+  int M, L, C, ldy, N, accumulate;
+  int full_m;           // M-tile rows (of 128 positions) that run as full tiles: full_m * (N / 64) blocks of MT = 2
+  int tail_m;           // the remaining M-tile rows run as 2 * tail_m * (N / 64) half tiles (MT = 1), FIRST in the launch
+  FastDiv divL;
+};
+
+template <int MT>
+__device__ __forceinline__ void conv3_x3p_body(const ConvX3pArgs& a, const int P0, const int n_blk, unsigned char* lds) {
+  constexpr int TM = 64 * MT, XROWS = TM + 2, PROWS = XROWS + 1;     // + the zero row
+  constexpr int XBYTES = PROWS * XP_PITCH;
+  constexpr int NXP = (XROWS * 6 + 255) / 256;                       // 16-byte pieces of the panel per thread
+  unsigned char* Xs = lds;                          // 2 x [PROWS][112]
+  unsigned char* Bs = lds + 2 * XBYTES;             // 2 x 18 KB
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kch = a.C >> 4;
+  const size_t xrow_bytes = (size_t)a.C * 6;
+
+  // panel loader: piece q of the panel = (row q / 6, 16-byte slot q % 6).  Rows outside [0, M) are read from a clamped
+  // (valid) address: no output that is stored ever uses them (a tap that would reads the zero row).
+  const unsigned char* xsrc[NXP];
+  int xdst[NXP];
+  bool xon[NXP];
+#pragma unroll
+  for (int p = 0; p < NXP; ++p) {
+    const int q = tid + 256 * p;
+    xon[p] = q < XROWS * 6;
+    const int r = xon[p] ? q / 6 : 0, s = xon[p] ? q - r * 6 : 0;
+    long P = (long)P0 - 1 + r;
+    P = P < 0 ? 0 : (P >= a.M ? a.M - 1 : P);
+    xsrc[p] = reinterpret_cast<const unsigned char*>(a.x) + (size_t)P * xrow_bytes + s * 16;
+    xdst[p] = r * XP_PITCH + s * 16;
+  }
+  // weight chunk loader: 1152 pieces of 16 bytes, linear
+  const unsigned char* bsrc = reinterpret_cast<const unsigned char*>(a.w) + (size_t)(n_blk >> 6) * kch * XP_BCHUNK + tid * 16;
+
+  f32x4 rx[NXP], rb[5];
+  auto gload = [&](int ks) {
+#pragma unroll
+    for (int p = 0; p < NXP; ++p)
+      if (xon[p]) rx[p] = *reinterpret_cast<const f32x4*>(xsrc[p] + ks * 96);
+    const unsigned char* b = bsrc + (size_t)ks * XP_BCHUNK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b + i * 4096);
+    if (tid < 128) rb[4] = *reinterpret_cast<const f32x4*>(b + 4 * 4096);
+  };
+  auto stage = [&](int buf) {
+    unsigned char* xs = Xs + buf * XBYTES;
+    unsigned char* bs = Bs + buf * XP_BCHUNK + tid * 16;
+#pragma unroll
+    for (int p = 0; p < NXP; ++p)
+      if (xon[p]) *reinterpret_cast<f32x4*>(xs + xdst[p]) = rx[p];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(bs + i * 4096) = rb[i];
+    if (tid < 128) *reinterpret_cast<f32x4*>(bs + 4 * 4096) = rb[4];
+  };
+
+  const int frow = lane & 31, kg = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  // LDS offset of the A fragment of (row tile mt, tap t): the panel row of position + t - 1, or the zero row when that
+  // position lies across a sequence edge
+  int aoff[MT][3];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const long P = (long)P0 + (wm * MT + mt) * 32 + frow;
+    const uint32_t Pc = (uint32_t)(P < a.M ? P : 0);
+    const int l = (int)(Pc - fdiv(Pc, a.divL) * (uint32_t)a.L);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const bool edge = (t == 0 && l == 0) || (t == 2 && l == a.L - 1);
+      aoff[mt][t] = (edge ? XROWS : (wm * MT + mt) * 32 + t + frow) * XP_PITCH + kg * 16;
+    }
+  }
+  const int boff = wn * 3 * 1024 + lane * 16;       // + tap * 6 KB + term * 1 KB
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  if (tid < 14) {                                   // the zero rows of both panel buffers (7 16-byte slots each)
+    const int bsel = tid >= 7, piece = tid - 7 * bsel;
+    *reinterpret_cast<f32x4*>(Xs + bsel * XBYTES + XROWS * XP_PITCH + piece * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  gload(0);
+  stage(0);
+  gload(kch > 1 ? 1 : 0);
+  __syncthreads();
+  for (int ks = 0; ks < kch; ++ks) {
+    const int cur = ks & 1;
+    const unsigned char* xs = Xs + cur * XBYTES;
+    const unsigned char* bs = Bs + cur * XP_BCHUNK + boff;
+    stage(cur ^ 1);                                 // step ks + 1 (already in registers); its buffer was released by the last barrier
+    gload(ks + 2 < kch ? ks + 2 : kch - 1);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      f32x4 bv[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) bv[s] = *reinterpret_cast<const f32x4*>(bs + t * 6144 + s * 1024);
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, bv[0]), bm = __builtin_bit_cast(bf16x8, bv[1]),
+                   bl = __builtin_bit_cast(bf16x8, bv[2]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x4 av[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) av[s] = *reinterpret_cast<const f32x4*>(xs + aoff[mt][t] + s * 32);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, av[0]), am = __builtin_bit_cast(bf16x8, av[1]),
+                     al = __builtin_bit_cast(bf16x8, av[2]);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mt], 0, 0, 0);      // small terms first
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // lane holds output channel n_blk + wn*32 + l%32 of the positions (r & 3) + 8 (r >> 2) + 4 (l / 32) of each 32-row tile
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long P = (long)P0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      if (P < a.M) {
+        float* o = a.y + P * a.ldy + n_blk + wn * 32 + frow;
+        float v = acc[mt][r];
+        if (a.accumulate) v += *o;
+        *o = v;
+      }
+    }
+}
+
+#define XP_LDS_BYTES (2 * (128 + 3) * XP_PITCH + 2 * XP_BCHUNK)
+
+// Work items: `full_tiles` tiles of 128 x 64 and, for the partly filled last round of a launch (full tile slots
+// full_tiles .. full_tiles + tail_tiles - 1), twice as many 64 x 64 tiles -- each half the MFMA time of a full one, so the
+// last round costs about half a round.  The half tiles are the FIRST blocks of the launch.
+__global__ __launch_bounds__(256, 2) void conv3_x3p_kernel(ConvX3pArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // XP_LDS_BYTES (> 64 KB: dynamic)
+  const int ntn = a.N / XP_TN;
+  const int tail_blocks = 2 * a.tail_m * ntn;
+  if ((int)blockIdx.x < tail_blocks) {
+    const int id = xcd_chunked_xp(blockIdx.x, tail_blocks);        // channel tile fastest: the halves of one panel share an L2
+    conv3_x3p_body<1>(a, a.full_m * 128 + (id / ntn) * 64, (id % ntn) * XP_TN, lds);
+  } else {
+    const int tile = xcd_chunked_xp(blockIdx.x - tail_blocks, a.full_m * ntn);
+    conv3_x3p_body<2>(a, (tile / ntn) * 128, (tile % ntn) * XP_TN, lds);
+  }
+}
+
+// fp32 [npos][ld] (first C channels) -> x3 [npos][C/16][3][16] and back (tests, and the boundaries where a producer
+// without an x3 store form meets an x3 consumer)
+__global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__ x, int ld, __bf16* __restrict__ out, size_t npos,
+                                                       int C) {
+  const int nq = C >> 2;
+  const size_t total = npos * nq;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pos = i / nq;
+    const int c0 = (int)(i - pos * nq) * 4;
+    X3::st4(out + pos * 3 * C, c0, *reinterpret_cast<const f32x4*>(x + pos * ld + c0));
+  }
+}
+__global__ __launch_bounds__(256) void x3_merge_kernel(const __bf16* __restrict__ x, float* __restrict__ out, int ld, size_t npos,
+                                                       int C) {
+  const int nq = C >> 2;
+  const size_t total = npos * nq;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pos = i / nq;
+    const int c0 = (int)(i - pos * nq) * 4;
+    *reinterpret_cast<f32x4*>(out + pos * ld + c0) = X3::ld4(x + pos * 3 * C, c0);
+  }
+}
+
+extern "C" {
+
+// y (+)= conv1d(x, k = 3, stride 1, pad 1) per row of L positions; x: x3 format [rows * L][C/16][3][16] bf16, wpk: the
+// chunked split-bf16 pack (da_repack_desc.points = 49 / da_pack_conv3_x3p), y: [rows][L][ldy] fp32 (first N channels).
+// C % 16 == 0, N % 64 == 0.  replaces reference models/resnet.py:5-8 (conv2x2), forward and (wd pack) data gradient
+int da_conv3_x3p(const void* x, const void* wpk, float* y, int rows, int L, int C, int ldy, int N, int accumulate,
+                 hipStream_t stream) {
+  DA_ENTER();
+  if (!x || !wpk || !y || rows < 0 || L < 1 || C % 16 || N % XP_TN || C < 16 || N < XP_TN || ldy < N) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  const long M = (long)rows * L;
+  if (M >= 0x7fffffffl) return DA_EINVAL;
+  ConvX3pArgs a;
+  a.x = reinterpret_cast<const __bf16*>(x); a.w = reinterpret_cast<const __bf16*>(wpk); a.y = y;
+  a.M = (int)M; a.L = L; a.C = C; a.ldy = ldy; a.N = N; a.accumulate = accumulate;
+  a.divL = make_fastdiv((uint32_t)L);
+  const int ntn = N / XP_TN;
+  const long mtiles = (M + 127) / 128;
+  const long tiles = mtiles * ntn;
+  if (tiles > 0x3fffffffl) return DA_EINVAL;
+  // the partly filled last round (512 resident blocks: 2 per CU) runs as half tiles -- whole M-tile rows of them
+  long tail_m = 0;
+  static int g_tail = -1;
+  static bool attr_set = false;
+  if (g_tail < 0) {
+    const char* e = getenv("DA_X3_TAIL");
+    g_tail = e ? atoi(e) : 1;
+  }
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_x3p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            XP_LDS_BYTES) != hipSuccess)
+      return DA_EINVAL;
+    attr_set = true;
+  }
+  if (g_tail) tail_m = tiles < 512 ? mtiles : (tiles % 512) / ntn;
+  a.tail_m = (int)tail_m;
+  a.full_m = (int)(mtiles - tail_m);
+  const long blocks = (long)a.full_m * ntn + 2l * tail_m * ntn;
+  hipLaunchKernelGGL(conv3_x3p_kernel, dim3((unsigned)blocks), dim3(256), XP_LDS_BYTES, stream, a);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+int da_x3_split(const float* x, int ld, void* out, size_t npos, int C, hipStream_t stream) {
+  DA_ENTER();
+  if (!x || !out || C % 16 || ld < C || ld % 4) return DA_EINVAL;
+  if (npos == 0) return DA_OK;
+  size_t g = (npos * (C >> 2) + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)g), dim3(256), 0, stream, x, ld, reinterpret_cast<__bf16*>(out), npos, C);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+int da_x3_merge(const void* x, float* out, int ld, size_t npos, int C, hipStream_t stream) {
+  DA_ENTER();
+  if (!x || !out || C % 16 || ld < C || ld % 4) return DA_EINVAL;
+  if (npos == 0) return DA_OK;
+  size_t g = (npos * (C >> 2) + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(x3_merge_kernel, dim3((unsigned)g), dim3(256), 0, stream, reinterpret_cast<const __bf16*>(x), out, ld, npos, C);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+}  // extern "C"

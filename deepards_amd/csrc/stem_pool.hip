@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
 
 // out[row][j][c] = pool_{l in {2j-1,2j,2j+1}} relu(bn(y[row][l][c]));  pool_mode 0 = max (-inf pad),
 // 1 = avg (count_include_pad, zeros).  One thread per (output position, channel quad).
-template <typename AT>
+template <typename AT, int OX3 = 0>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const AT* __restrict__ y, int ldy,
                                                                AT* __restrict__ out, int ldo, int rows, int R,
                                                                int Lin, int Lout, int C, const float* __restrict__ mean,
@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const AT* __restr
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] *= (1.0f / 3.0f);
   }
-  Act<AT>::st4(out + po * ldo + c0, o);
+  if constexpr (OX3) X3::st4(reinterpret_cast<__bf16*>(out) + po * (size_t)(3 * C), c0, o);   // x3 format (common.h)
+  else Act<AT>::st4(out + po * ldo + c0, o);
 }
 
 // Gradient w.r.t. the ReLU output at stem resolution: dz[row][l][c] = sum over the (<= 2) pooling
@@ -340,6 +341,22 @@ int da_stem_conv_fwd_g(const float* x, const float* w, void* y, int rows, int Li
 int da_stem_conv_fwd(const float* x, const float* w, void* y, int rows, int Lin, int C0, int ldy,
                      hipStream_t stream) {
   return da_stem_conv_fwd_g(x, w, y, rows, Lin, 1, 7, 2, C0, ldy, stream);
+}
+
+// da_bn_relu_pool_fwd with the output stored in the x3 format (float activations; the input of layer1's k3 s1 convs under
+// conv arithmetic 'f32x3'): out = [rows * Lout] positions of 3 C bf16.
+int da_bn_relu_pool_fwd_x(const float* y, int ldy, void* out, int rows, int R, int Lin, int C, const float* mean,
+                          const float* invstd, const float* gamma, const float* beta, int pool_mode, hipStream_t stream) {
+  DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;
+  if (!y || !out || C % 16 || ldy % 4 || R < 1 || rows % R) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  int Lout = (Lin - 1) / 2 + 1;
+  size_t total = (size_t)rows * Lout * (C / 4);
+  hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<float, 1>), dim3(grid1d(total, 256)), dim3(256), 0, stream, y, ldy, (float*)out, 0,
+                     rows, R, Lin, Lout, C, mean, invstd, gamma, beta, pool_mode);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
 }
 
 size_t da_stem_wgrad_workspace_g(int rows, int C0, int Cin, int K) {

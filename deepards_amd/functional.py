@@ -48,8 +48,8 @@ def training_step(model=None):
                   and m.weight.is_cuda]
             ws = [m.weight for m in ms]
             wino = [_is_wino(m.weight, m.stride[0], m.padding[0]) for m in ms]
-            for w, e in zip(ws, H.repack_multi(ws, wino)):
-                _STEP['pack'][w.data_ptr()] = e
+            for w, c, e in zip(ws, wino, H.repack_multi(ws, wino)):
+                _STEP['pack'][(w.data_ptr(), int(c))] = e
         yield
     finally:
         _STEP.update(on=False, pack={}, running=[], pgrad=[], wgrad=[], wslab=[])
@@ -91,18 +91,21 @@ _PAIR_S2 = os.environ.get('DA_PAIR_S2', '1') != '0'      # stride-2 block heads:
 _WINO4_MIN_C = int(os.environ.get('DA_WINO4_MINC', '512'))   # channels from which F(4,3) beats F(2,3) (scripts/bench_wino.py)
 
 
-# Arithmetic of the k3 s1 p1 convs' forward / data gradient: 'f32' (default: Winograd on the fp32 matrix cores, the
-# path every 1e-4 parity claim is about), 'bf16' (BASELINE config C3: operands rounded to bf16, fp32 sums, conv_bf16.hip;
-# also the k3 s1 weight gradients unless DA_WGRAD_BF16=0) or 'f32x3' (fp32-equivalent products from exact three-term
-# bf16 splits on the bf16 matrix cores, conv_x3.hip; the weight gradients too with DA_WGRAD_X3=1).
+# Arithmetic of the k3 s1 p1 convs' forward / data gradient: 'f32' (Winograd on the fp32 matrix cores), 'bf16' (BASELINE
+# config C3: operands rounded to bf16, fp32 sums, conv_bf16.hip; also the k3 s1 weight gradients unless DA_WGRAD_BF16=0),
+# 'f32x3' (fp32-equivalent products from exact three-term bf16 splits on the bf16 matrix cores, split while staging:
+# conv_x3.hip, round 2; the weight gradients too with DA_WGRAD_X3=1) or 'f32x3p' (the same arithmetic with the split done by
+# the PRODUCERS: the BatchNorm / pool kernels in front of a k3 s1 conv store the x3 format, conv_x3p.hip and the x3
+# weight-gradient kernel read it; forward, data gradient and weight gradient).
 _CONV_DTYPE = os.environ.get('DA_CONV_DTYPE', 'f32')
+CONV_DTYPES = ('f32', 'bf16', 'f32x3', 'f32x3p')
 
 
 def set_conv_dtype(name):
-    """'f32', 'bf16' or 'f32x3' (see _CONV_DTYPE); captured steps keep the arithmetic they were captured with."""
+    """One of CONV_DTYPES (see _CONV_DTYPE); captured steps keep the arithmetic they were captured with."""
     global _CONV_DTYPE
-    if name not in ('f32', 'bf16', 'f32x3'):
-        raise ValueError("conv dtype must be 'f32', 'bf16' or 'f32x3'")
+    if name not in CONV_DTYPES:
+        raise ValueError('conv dtype must be one of %s' % (CONV_DTYPES,))
     if name != 'bf16' and H.act_dtype() == 'bf16':
         H.set_act_dtype('f32')                     # fp32 convs read fp32 activations
     _CONV_DTYPE = name
@@ -143,6 +146,13 @@ def _is_wino(w, stride, pad):
         return 0
     if _CONV_DTYPE == 'f32x3' and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
         return 48                                   # split-bf16 products, direct form (conv_x3.hip)
+    if _CONV_DTYPE == 'f32x3p' and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
+        return 49                                   # the same on x3 (pre-split) operands (conv_x3p.hip); float operands: _fp32_code
+    return _fp32_code(w)
+
+
+def _fp32_code(w):
+    """The fp32 kernel of a k3 s1 p1 conv whose operand is a float tensor: Winograd F(2,3) / F(4,3) or direct."""
     if not _WINOGRAD:
         return 0
     return 6 if min(w.shape[0], w.shape[1]) >= _WINO4_MIN_C else 4
@@ -151,14 +161,12 @@ def _is_wino(w, stride, pad):
 def _pack(w, code):
     """(wf, wd, uf, ud) of a conv weight: direct packs (code 0), Winograd taps or bf16 tap packs (in the uf / ud
     places), repacked once per step."""
-    e = _STEP['pack'].get(w.data_ptr()) if _STEP['on'] else None
-    want = w.shape[2] if code in (16, 48) else (code if code else 0)
-    if e is None or (e[2] is None if code else e[0] is None) or \
-            (code and (e[2].shape[0] != want or (e[2].dtype == torch.bfloat16) != (code in (16, 48)) or
-                      (e[2].dim() == 6) != (code == 48))):
+    key = (w.data_ptr(), int(code))                 # a weight may be packed in two forms in one step (x3 and fp32 consumers)
+    e = _STEP['pack'].get(key) if _STEP['on'] else None
+    if e is None:
         e = H.repack_multi([w], [code])[0]
         if _STEP['on']:
-            _STEP['pack'][w.data_ptr()] = e
+            _STEP['pack'][key] = e
     return e
 
 
@@ -170,6 +178,10 @@ def _need_bf16_kernel(code, w, stride, pad):
 
 def _conv_fwd(x, w, stride, pad):
     code = _is_wino(w, stride, pad)
+    if code == 49:
+        if H.is_x3(x):
+            return H.conv3_x3p(x, _pack(w, 49)[2])
+        code = _fp32_code(w)                        # a float operand (a shape without x3 producers): the fp32 kernels
     if code == 16 and stride == 2 and x.shape[1] % 2:
         code = 0                                    # odd length: the fp32 kernel
     _need_bf16_kernel(code, w, stride, pad)
@@ -184,6 +196,10 @@ def _conv_fwd(x, w, stride, pad):
 
 def _conv_dgrad(dy, w, stride, pad, l_in, out=None, accumulate=False):
     code = _is_wino(w, stride, pad)
+    if code == 49:
+        if H.is_x3(dy):
+            return H.conv3_x3p(dy, _pack(w, 49)[3], out=out, accumulate=accumulate)
+        code = _fp32_code(w)
     if code == 16 and stride == 2 and l_in % 2:
         code = 0
     _need_bf16_kernel(code, w, stride, pad)
@@ -203,6 +219,52 @@ def _tgt(*params):
     gradient bucket).  With a destination the backward kernels accumulate straight into it and autograd
     gets None (no AccumulateGrad add kernel); without, gradients are returned the usual way."""
     return tuple(None if p is None else getattr(p, '_da_grad', None) for p in params)
+
+
+# ---- the x3 flow (conv arithmetic 'f32x3p') -------------------------------------------------------------------------------
+# An activation that feeds a k3 s1 conv is stored ONLY in the x3 format (H.is_x3: bf16 (rows, L, C/16, 3, 16)).  autograd
+# checks a gradient's shape against the tensor it belongs to, and the gradients stay float (rows, L, C) -- so the tensor
+# that carries the autograd edge between two blocks is a zero-stride float "handle" of the logical shape (no memory, never
+# read), and the x3 data travels beside it as a second, non-differentiable argument / result of the block Functions.
+_HANDLES = {}
+
+
+def x3_handle(x3):
+    rows, l, g = x3.shape[:3]
+    z = _HANDLES.get(x3.device)
+    if z is None:
+        z = _HANDLES[x3.device] = torch.zeros(1, device=x3.device, dtype=torch.float32)
+    return z.expand(rows, l, g * 16)
+
+
+def x3_block_ok(rows, l, c, R):
+    """Whether a block whose activations are (rows, L, C) in windows of R rows can run its k3 s1 convs on x3 operands:
+    conv arithmetic 'f32x3p', float storage, 64-multiple channels and the single-pass BatchNorm geometry (its store forms)."""
+    return _CONV_DTYPE == 'f32x3p' and H.act_dtype() == 'f32' and c % 64 == 0 and H.bn_x3_ok(rows, l, c, R)
+
+
+def _bn_apply_x(x, R, s, st, gamma, beta, relu, res=None, want_mask=False, out_x3=True):
+    """_bn_apply through the x3 store forms (H.bn_fwd_x): the output in the x3 format and / or an x3 residual."""
+    r = H.bn_fwd_x(x, R, gamma, beta, relu=relu, res=res, eps=st.eps, want_mask=want_mask, out_x3=out_x3)
+    s.mean, s.invstd = r[1], r[2]
+    s.mask = r[3] if want_mask else None
+    _running(x, R, s, st)
+    return r[0]
+
+
+def _bn_bwd_x(dout, x, R, mean, invstd, gamma, beta, mode, tg, tb, want_g=False, mask=None, dx_x3=True):
+    """_bn_bwd through H.bn_bwd_x (dx in the x3 format); -> (dx, dgamma|None, dbeta|None[, g])."""
+    dx, g, ds = H.bn_bwd_x(dout, x, R, mean, invstd, gamma, beta, mode, want_g=want_g, mask=mask, dx_x3=dx_x3)
+    direct = tg is not None and tb is not None
+    dg = db = None
+    if direct and _STEP['on']:
+        _STEP['pgrad'].append((ds, tg, tb))
+    elif direct:
+        H.bn_param_grad_multi([(ds, tg, tb)], accumulate=True)
+    else:
+        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        H.bn_param_grad_multi([(ds, dg, db)], accumulate=False)
+    return (dx, dg, db, g) if want_g else (dx, dg, db)
 
 
 class _Stats(object):
@@ -237,26 +299,29 @@ class StemFunction(Function):
     reference models/resnet.py:141-153, models/densenet.py:109-124.  x2d: (rows, L) or (rows, C_in, L)."""
 
     @staticmethod
-    def forward(ctx, x2d, w, gamma, beta, R, pool_mode, st):
+    def forward(ctx, x2d, w, gamma, beta, R, pool_mode, st, want_out3=False):
         y0 = H.stem_conv_fwd(x2d, w)
         mean, invstd = H.bn_stats(y0, R, st.eps)
-        out = H.bn_relu_pool_fwd(y0, R, mean, invstd, gamma, beta, pool_mode)
+        out = H.bn_relu_pool_fwd(y0, R, mean, invstd, gamma, beta, pool_mode, out_x3=want_out3)
         s_ = _Stats()
         s_.mean, s_.invstd = mean, invstd
         _running(y0, R, s_, st)
         ctx.save_for_backward(x2d, y0, mean, invstd, gamma, beta)
         ctx.R, ctx.pool_mode = R, pool_mode
         ctx.gt = _tgt(w, gamma, beta)
+        if want_out3:                               # (handle, x3 data): see "the x3 flow" above
+            ctx.mark_non_differentiable(out)
+            return x3_handle(out), out
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _d3=None):
         x2d, y0, mean, invstd, gamma, beta = ctx.saved_tensors
         tw, tg, tb = ctx.gt
         dz = H.pool_bwd(dout.contiguous(), y0, ctx.R, mean, invstd, gamma, beta, ctx.pool_mode)
         dy0, dgamma, dbeta = _bn_bwd(dz, y0, ctx.R, mean, invstd, gamma, beta, 1, tg, tb, dx=dz)
         dw = H.stem_conv_wgrad(dy0, x2d, out=tw, accumulate=tw is not None)
-        return None, None if tw is not None else dw, dgamma, dbeta, None, None, None
+        return None, None if tw is not None else dw, dgamma, dbeta, None, None, None, None
 
 
 class DoubleStemFunction(Function):
@@ -267,7 +332,7 @@ class DoubleStemFunction(Function):
     weight gradient) rather than on a kernel of its own."""
 
     @staticmethod
-    def forward(ctx, x2d, wa, g1, b1, w2, g2, b2, R, pool_mode, st1, st2):
+    def forward(ctx, x2d, wa, g1, b1, w2, g2, b2, R, pool_mode, st1, st2, want_out3=False):
         if H.act_dtype() != 'f32':
             raise NotImplementedError('double_conv_first runs with fp32 activation storage only')
         ya = H.stem_conv_fwd(x2d, wa, stride=1)                       # (rows, L, C0)
@@ -276,17 +341,20 @@ class DoubleStemFunction(Function):
         wf, wd = H.repack_weight(w2, True, True)
         y2 = H.conv_fwd(h, wf, 2, 3)                                  # (rows, L / 2, C0)
         m2, i2 = H.bn_stats(y2, R, st2.eps)
-        out = H.bn_relu_pool_fwd(y2, R, m2, i2, g2, b2, pool_mode)
+        out = H.bn_relu_pool_fwd(y2, R, m2, i2, g2, b2, pool_mode, out_x3=want_out3)
         s2 = _Stats()
         s2.mean, s2.invstd = m2, i2
         _running(y2, R, s2, st2)
         ctx.save_for_backward(x2d, ya, s1.mean, s1.invstd, g1, b1, h, wd, y2, m2, i2, g2, b2)
         ctx.R, ctx.pool_mode = R, pool_mode
         ctx.gt = _tgt(wa, g1, b1, w2, g2, b2)
+        if want_out3:
+            ctx.mark_non_differentiable(out)
+            return x3_handle(out), out
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _d3=None):
         x2d, ya, m1, i1, g1, b1, h, wd, y2, m2, i2, g2, b2 = ctx.saved_tensors
         twa, tg1, tb1, tw2, tg2, tb2 = ctx.gt
         R = ctx.R
@@ -297,7 +365,7 @@ class DoubleStemFunction(Function):
         dya, dg1, db1 = _bn_bwd(dh, ya, R, m1, i1, g1, b1, 0, tg1, tb1, dx=dh)
         dwa = H.stem_conv_wgrad(dya, x2d, out=twa, accumulate=twa is not None, k=3, stride=1)
         return (None, None if twa is not None else dwa, dg1, db1, None if tw2 is not None else dw2, dg2, db2,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 def _bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, tg, tb, out=None, dx=None, want_g=False, add=None, mask=None):
@@ -318,9 +386,10 @@ def _wgrad(dy, x, k, stride, pad, tw):
     if tw is not None and _STEP['on']:
         _STEP['wgrad'].append((dy, x, k, stride, pad, tw))     # launched with all the others by flush_backward()
         return None
-    if H.WGRAD_BF16 or H.WGRAD_X3 or H.act_dtype() == 'bf16':   # the bf16-pipe kernels exist in the batched form only
+    if H.WGRAD_BF16 or H.WGRAD_X3 or H.act_dtype() == 'bf16' or H.is_x3(dy):   # the bf16-pipe kernels exist in the batched form only
         (slab,) = H.conv_wgrad_multi([(dy, x, k, stride, pad)])
-        dw = tw if tw is not None else torch.empty((dy.shape[2], x.shape[2], k), device=x.device, dtype=torch.float32)
+        co, ci = (dy.shape[2] * 16, x.shape[2] * 16) if H.is_x3(dy) else (dy.shape[2], x.shape[2])
+        dw = tw if tw is not None else torch.empty((co, ci, k), device=x.device, dtype=torch.float32)
         H.wgrad_reduce_multi([(slab, dw)], accumulate=tw is not None)
         return None if tw is not None else dw
     dw = H.conv_wgrad(dy, x, k, stride, pad, out=tw, accumulate=tw is not None)
@@ -329,14 +398,22 @@ def _wgrad(dy, x, k, stride, pad, tw):
 
 class BasicBlockFunction(Function):
     """conv3(s) -> BN -> ReLU -> conv3 -> BN -> (+ identity | BN(conv1x1(s))) -> ReLU.
-    reference models/resnet.py:24-40 (BasicBlock.forward), :123-131 (downsample)."""
+    reference models/resnet.py:24-40 (BasicBlock.forward), :123-131 (downsample).
+
+    Conv arithmetic 'f32x3p' (the x3 flow above): ``x3`` is the block input in the x3 format when its conv1 is a k3 s1 conv
+    (``x`` is then only the autograd handle), ``want_out3`` asks for the output in the x3 format (the next block's conv1
+    is one); the hidden activation h1 and the gradients in front of the k3 s1 data / weight-gradient convs (dy2, dy1) take
+    the x3 format whenever the shape has the store forms.  Returns ``out`` or ``(handle, out3)``."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, R, st1, st2, std):
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, R, st1, st2, std, x3=None, want_out3=False):
+        in3 = x3 is not None
         bf16_pair = wd is not None and stride == 2 and _PAIR_S2 and x.shape[1] % 2 == 0 and \
             _is_wino(w1, stride, 1) == 16 and _is_wino(wd, stride, 0) == 16
         pair = bf16_pair or (wd is not None and stride == 2 and _PAIR_S2 and not _is_wino(w1, stride, 1))
-        if bf16_pair:     # conv dtype bf16: the same shared launch on the bf16 kernel
+        if in3:           # k3 s1 conv on the pre-split input
+            y1 = _conv_fwd(x3, w1, 1, 1)
+        elif bf16_pair:   # conv dtype bf16: the same shared launch on the bf16 kernel
             y1, yd = H.conv_fwd_bf16_s2(x, _pack(w1, 16)[2], _pack(wd, 16)[2])
         elif pair:    # the stride-2 conv and the 1x1 downsample read the same input: one launch
             y1, yd = H.conv_fwd_multi([(x, _pack(w1, False)[0], stride, 1), (x, _pack(wd, False)[0], stride, 0)])
@@ -345,8 +422,11 @@ class BasicBlockFunction(Function):
         if pair:          # the downsample BatchNorm first: yd is still in L2 / MALL right after the shared launch
             sd = _Stats()   # (forking it beside bn1 / conv2 on another stream was measured slower)
             res = _bn_apply(yd, R, sd, std, gd, bd, False)
+        mid3 = x3_block_ok(y1.shape[0], y1.shape[1], y1.shape[2], R) and _is_wino(w2, 1, 1) == 49
+        if (in3 or want_out3) and not mid3:
+            raise ValueError('x3 input / output asked of a block whose shape has no x3 store forms')
         s1 = _Stats()
-        h1 = _bn_apply(y1, R, s1, st1, g1, b1, True)
+        h1 = _bn_apply_x(y1, R, s1, st1, g1, b1, True) if mid3 else _bn_apply(y1, R, s1, st1, g1, b1, True)
         y2 = _conv_fwd(h1, w2, 1, 1)
         s2 = _Stats()
         if wd is not None:
@@ -357,35 +437,49 @@ class BasicBlockFunction(Function):
             md, idd = sd.mean, sd.invstd
         else:
             yd = md = idd = None
-            res = x
-        out = _bn_apply(y2, R, s2, st2, g2, b2, True, res=res, want_mask=_BN_MASK)
+            res = x3 if in3 else x
+        if mid3:          # x3 residual and / or x3 output: the store forms (always with the ReLU bit mask)
+            out = _bn_apply_x(y2, R, s2, st2, g2, b2, True, res=res, want_mask=True, out_x3=want_out3)
+        else:
+            out = _bn_apply(y2, R, s2, st2, g2, b2, True, res=res, want_mask=_BN_MASK)
         m1, i1, m2, i2 = s1.mean, s1.invstd, s2.mean, s2.invstd
-        ctx.relu_mask = s2.mask if _BN_MASK else None       # 8 bytes per thread instead of re-reading `out` for its sign
-        ctx.has_ds = wd is not None
-        ctx.stride, ctx.R = stride, R
+        use_mask = mid3 or _BN_MASK
+        ctx.relu_mask = s2.mask if use_mask else None       # 8 bytes per thread instead of re-reading `out` for its sign
+        ctx.has_ds, ctx.in3, ctx.mid3 = wd is not None, in3, mid3
+        ctx.stride, ctx.R, ctx.lin = stride, R, x.shape[1]
         ctx.gt = _tgt(w1, g1, b1, w2, g2, b2, wd, gd, bd)
-        saved = [x, w1, g1, b1, w2, g2, b2, y1, m1, i1, h1, y2, m2, i2, out]
+        # (the float block output is only kept when the backward reads it for its sign: no bit mask)
+        saved = [x3 if in3 else x, w1, g1, b1, w2, g2, b2, y1, m1, i1, h1, y2, m2, i2, out if ctx.relu_mask is None else m2]
         if ctx.has_ds:
             saved += [wd, gd, bd, yd, md, idd]
         ctx.save_for_backward(*saved)
+        if want_out3:
+            ctx.mark_non_differentiable(out)
+            return x3_handle(out), out
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _d3=None):
         s = ctx.saved_tensors
         x, w1, g1, b1, w2, g2, b2, y1, m1, i1, h1, y2, m2, i2, out = s[:15]
         tw1, tg1, tb1, tw2, tg2, tb2, twd, tgd, tbd = ctx.gt
-        R, stride = ctx.R, ctx.stride
-        lin = x.shape[1]
+        R, stride, lin = ctx.R, ctx.stride, ctx.lin
+        in3, mid3 = ctx.in3, ctx.mid3
         dout = dout.contiguous()
         # relu + residual add + bn2
-        dy2, dg2, db2, g = _bn_bwd(dout, y2, R, m2, i2, g2, b2, 2, tg2, tb2, out=out, want_g=True, mask=ctx.relu_mask)
+        if mid3:          # dy2 feeds the k3 s1 data-gradient and weight-gradient convs: stored pre-split
+            dy2, dg2, db2, g = _bn_bwd_x(dout, y2, R, m2, i2, g2, b2, 3, tg2, tb2, want_g=True, mask=ctx.relu_mask)
+        else:
+            dy2, dg2, db2, g = _bn_bwd(dout, y2, R, m2, i2, g2, b2, 2, tg2, tb2, out=out, want_g=True, mask=ctx.relu_mask)
         if ctx.has_ds:    # the downsample BatchNorm's backward right away: g is still cache-resident
             wd, gd, bd, yd, md, idd = s[15:]
             dyd, dgd, dbd = _bn_bwd(g, yd, R, md, idd, gd, bd, 0, tgd, tbd, dx=g)
         dw2 = _wgrad(dy2, h1, 3, 1, 1, tw2)
-        dh1 = _conv_dgrad(dy2, w2, 1, 1, h1.shape[1])
-        dy1, dg1, db1 = _bn_bwd(dh1, y1, R, m1, i1, g1, b1, 1, tg1, tb1, dx=dh1)
+        dh1 = _conv_dgrad(dy2, w2, 1, 1, y1.shape[1])
+        if in3:           # conv1 is a k3 s1 conv on x3 operands too
+            dy1, dg1, db1 = _bn_bwd_x(dh1, y1, R, m1, i1, g1, b1, 1, tg1, tb1)
+        else:
+            dy1, dg1, db1 = _bn_bwd(dh1, y1, R, m1, i1, g1, b1, 1, tg1, tb1, dx=dh1)
         dw1 = _wgrad(dy1, x, 3, stride, 1, tw1)
         if ctx.has_ds:
             dwd = _wgrad(dyd, x, 1, stride, 0, twd)
@@ -397,7 +491,7 @@ class BasicBlockFunction(Function):
         else:
             dwd = dgd = dbd = None
             dx = _conv_dgrad(dy1, w1, stride, 1, lin, out=g, accumulate=True)   # identity grad + conv path
-        return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None
+        return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None, None
 
 
 class DenseLayerFunction(Function):

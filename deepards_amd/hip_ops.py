@@ -202,6 +202,58 @@ def conv3_x3(x, wpk, out=None, accumulate=False):
     return out
 
 
+def is_x3(t):
+    """An activation in the x3 format (exact three-term bf16 split, include/deepards_hip.h): (rows, L, C/16, 3, 16) bf16."""
+    return t is not None and t.dtype == torch.bfloat16 and t.dim() == 5 and t.shape[3] == 3 and t.shape[4] == 16
+
+
+def x3_empty(rows, l, c, device):
+    if c % 16:
+        raise ValueError('x3 format needs a channel count that is a multiple of 16')
+    return torch.empty((rows, l, c // 16, 3, 16), device=device, dtype=torch.bfloat16)
+
+
+def x3_split(x):
+    """fp32 (rows, L, C) -> x3 (rows, L, C/16, 3, 16) bf16: h | m | l with h + m + l == x exactly."""
+    _rlc32(x, 'x')
+    rows, l, c = x.shape
+    out = x3_empty(rows, l, c, x.device)
+    _chk(_lib.lib().da_x3_split(_p(x), c, _p(out), rows * l, c, _stream()), 'da_x3_split')
+    return out
+
+
+def x3_merge(x3):
+    """x3 (rows, L, C/16, 3, 16) -> fp32 (rows, L, C) = h + m + l (exact)."""
+    if not (is_x3(x3) and x3.is_cuda and x3.is_contiguous()):
+        raise ValueError('x3_merge: a contiguous x3 CUDA tensor expected')
+    rows, l, g = x3.shape[:3]
+    out = torch.empty((rows, l, g * 16), device=x3.device, dtype=torch.float32)
+    _chk(_lib.lib().da_x3_merge(_p(x3), _p(out), g * 16, rows * l, g * 16, _stream()), 'da_x3_merge')
+    return out
+
+
+def conv3_x3p(x3, wpk, out=None, accumulate=False):
+    """k3 s1 p1 conv of an x3 activation (rows, L, C/16, 3, 16) with the chunked split-bf16 pack wpk (N/64, C/16, 18, 64, 8)
+    (repack_multi code 49): fp32-equivalent products on the bf16 matrix cores, fp32 sums -> (rows, L, N) fp32."""
+    if not (is_x3(x3) and x3.is_cuda and x3.is_contiguous()):
+        raise ValueError('conv3_x3p: a contiguous x3 CUDA tensor expected, got %s %s' % (tuple(x3.shape), x3.dtype))
+    rows, l, g = x3.shape[:3]
+    c = g * 16
+    if wpk.dim() != 5 or wpk.shape[1] != g or tuple(wpk.shape[2:]) != (18, 64, 8) or wpk.dtype != torch.bfloat16 or \
+            not wpk.is_contiguous():
+        raise ValueError('conv3_x3p: unsupported shape x%s w%s' % (tuple(x3.shape), tuple(wpk.shape)))
+    n = wpk.shape[0] * 64
+    if out is None:
+        if accumulate:
+            raise ValueError('accumulate needs out')
+        out = torch.empty((rows, l, n), device=x3.device, dtype=torch.float32)
+    elif tuple(out.shape) != (rows, l, n) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError('conv3_x3p: bad out')
+    _chk(_lib.lib().da_conv3_x3p(_p(x3), _p(wpk), _p(out), rows, l, c, n, n, 1 if accumulate else 0, _stream()),
+         'da_conv3_x3p')
+    return out
+
+
 def _conv_bf16_multi(jobs):
     """jobs: [(x, wpk, out, lm, lsrc, ldst, dst_stride, dst_off, src_stride, src_off, wtap, accumulate)] in one call."""
     arr = (_lib.ConvJob * len(jobs))()
@@ -419,10 +471,17 @@ def conv_wgrad_multi(jobs):
     plan = (ctypes.c_int * 4)()
     outs = []
     for d, (dy, x, k, stride, pad) in zip(arr, jobs):
-        _rlc(dy, 'dy')
-        _rlc(x, 'x')
-        rows, lo, co = dy.shape
-        rows2, l, ci = x.shape
+        both_x3 = is_x3(dy) and is_x3(x)
+        if both_x3:                                   # x3 operands (conv arithmetic 'f32x3'): the k3 s1 p1 split-bf16 kernel
+            if not (dy.is_cuda and dy.is_contiguous() and x.is_contiguous() and k == 3 and stride == 1 and pad == 1):
+                raise ValueError('conv_wgrad_multi: x3 operands belong to k3 s1 p1 jobs')
+            rows, lo, co = dy.shape[0], dy.shape[1], dy.shape[2] * 16
+            rows2, l, ci = x.shape[0], x.shape[1], x.shape[2] * 16
+        else:
+            _rlc(dy, 'dy')
+            _rlc(x, 'x')
+            rows, lo, co = dy.shape
+            rows2, l, ci = x.shape
         if rows != rows2 or lo != conv_out_len(l, k, stride, pad) or k > 3 or ci % 32 or co % 32:
             raise ValueError('conv_wgrad_multi: unsupported shape')
         wino = 1 if (WINOGRAD_WGRAD and k == 3 and stride == 1 and pad == 1 and co % 64 == 0 and ci % 64 == 0) else 0
@@ -434,6 +493,10 @@ def conv_wgrad_multi(jobs):
                 (k == 3 and stride == 1 and pad == 1) or
                 (stride == 2 and l % 2 == 0 and ((k == 3 and pad == 1) or (k == 1 and pad == 0)))):
             wino = 48                                # three-term bf16 splits, six products: fp32-equivalent
+        if both_x3:
+            if co % 64 or ci % 64:
+                raise ValueError('conv_wgrad_multi: x3 operands need channel counts that are multiples of 64')
+            wino = 49
         _chk(L.da_conv_wgrad_plan(rows, lo, co, ci, k, wino, plan), 'da_conv_wgrad_plan')
         ws = torch.empty((plan[2] * k * co * ci,), device=x.device, dtype=torch.float32)
         d.dy, d.x, d.workspace = dy.data_ptr(), x.data_ptr(), ws.data_ptr()
@@ -472,7 +535,7 @@ def repack_multi(weights, winograd=None):
         wino = bool(code)
         if wino and k != 3 and not (code == 16 and k == 1):
             raise ValueError('winograd taps need a 3-tap weight')
-        pts = code if wino and code in (6, 16, 48) else 4
+        pts = code if wino and code in (6, 16, 48, 49) else 4
         mk = lambda *shape: torch.empty(shape, device=w.device, dtype=torch.float32)
         wf, wd = (None, None) if wino else (mk(k, co, ci), mk(k, ci, co))
         if pts == 16:                                # bf16 tap packs (3, Co, Ci) / (3, Ci, Co)
@@ -485,6 +548,11 @@ def repack_multi(weights, winograd=None):
                 raise ValueError('split-bf16 packs need channel counts that are multiples of 32')
             uf = torch.empty((3, co // 32, ci // 16, 3, 64, 8), device=w.device, dtype=torch.bfloat16)
             ud = torch.empty((3, ci // 32, co // 16, 3, 64, 8), device=w.device, dtype=torch.bfloat16)
+        elif pts == 49:                              # chunked split-bf16 packs of conv3_x3p (18 KB per 64 x 16 chunk)
+            if co % 64 or ci % 64:
+                raise ValueError('chunked split-bf16 packs need channel counts that are multiples of 64')
+            uf = torch.empty((co // 64, ci // 16, 18, 64, 8), device=w.device, dtype=torch.bfloat16)
+            ud = torch.empty((ci // 64, co // 16, 18, 64, 8), device=w.device, dtype=torch.bfloat16)
         else:
             uf, ud = (mk(pts, co, ci), mk(pts, ci, co)) if wino else (None, None)
         descs.append((w.data_ptr(), _p(wf), _p(wd), _p(uf), _p(ud), co, ci, k, pts))
@@ -629,6 +697,50 @@ def bn_fwd(x, R, gamma, beta, relu=True, res=None, eps=1e-5, out=None, want_mask
     return (out, mean, invstd, mask) if want_mask else (out, mean, invstd)
 
 
+def bn_x3_ok(rows, l, c, R):
+    """Whether the BatchNorm of a (rows, L, C) tensor in windows of R rows has the single-pass geometry the x3 store forms
+    exist for (a window slab fits one block's registers: R * L <= 1280 at the usual channel counts)."""
+    return c % 16 == 0 and rows % R == 0 and _lib.lib().da_bn_mask_words(rows // R, R * l, c) > 0
+
+
+def bn_fwd_x(x, R, gamma, beta, relu=True, res=None, eps=1e-5, want_mask=False, out_x3=True):
+    """bn_fwd on float activations whose output (out_x3) and / or residual (an x3 tensor) are in the x3 format: the
+    producers of the k3 s1 convs' operands under conv arithmetic 'f32x3'.  -> out, mean, invstd[, mask]."""
+    _rlc32(x, 'x')
+    rows, l, c = x.shape
+    if rows % R:
+        raise ValueError('rows %d not a multiple of rows_per_window %d' % (rows, R))
+    w = rows // R
+    res_x3 = is_x3(res)
+    if res is not None and (tuple(res.shape) != ((rows, l, c // 16, 3, 16) if res_x3 else (rows, l, c)) or not res.is_contiguous()):
+        raise ValueError('residual shape mismatch')
+    out = x3_empty(rows, l, c, x.device) if out_x3 else torch.empty_like(x)
+    mean = torch.empty((w, c), device=x.device, dtype=torch.float32)
+    invstd = torch.empty((w, c), device=x.device, dtype=torch.float32)
+    mask = None
+    if want_mask and relu:
+        mask = torch.empty((_lib.lib().da_bn_mask_words(w, R * l, c),), device=x.device, dtype=torch.int64)
+    _chk(_lib.lib().da_bn_fwd_x(_p(x), c, _p(res), c, _p(out), c, w, R * l, c, _p(mean), _p(invstd), _p(gamma), _p(beta),
+                                1 if relu else 0, eps, _p(mask), 1 if res_x3 else 0, 1 if out_x3 else 0, _stream()),
+         'da_bn_fwd_x')
+    return (out, mean, invstd, mask) if want_mask else (out, mean, invstd)
+
+
+def bn_bwd_x(dout, x, R, mean, invstd, gamma, beta, mask_mode, want_g=False, mask=None, dx_x3=True):
+    """bn_bwd on float activations with dx stored in the x3 format (dx_x3); parameter gradients are always deferred
+    (fold ds with bn_param_grad_multi).  -> dx, g (float, only when want_g), ds."""
+    _rlc32(dout, 'dout')
+    _rlc32(x, 'x')
+    rows, l, c = x.shape
+    w = rows // R
+    dx = x3_empty(rows, l, c, x.device) if dx_x3 else torch.empty_like(x)
+    g = torch.empty_like(x) if want_g else None
+    ds = torch.empty((2, w, c), device=x.device, dtype=torch.float32)
+    _chk(_lib.lib().da_bn_bwd_x(_p(dout), c, _p(x), c, _p(dx), c, _p(g), c, w, R * l, c, _p(mean), _p(invstd), _p(gamma),
+                                _p(beta), mask_mode, _p(ds), _p(mask), 1 if dx_x3 else 0, _stream()), 'da_bn_bwd_x')
+    return dx, g, ds
+
+
 def bn_debug_two_stage(on):
     _chk(_lib.lib().da_bn_debug_two_stage(1 if on else 0), 'da_bn_debug_two_stage')
 
@@ -689,10 +801,16 @@ def bn_param_grad_multi(items, accumulate=True):
 # ------------------------------------------------------------------------------------------------
 # pools
 # ------------------------------------------------------------------------------------------------
-def bn_relu_pool_fwd(y, R, mean, invstd, gamma, beta, pool_mode):
+def bn_relu_pool_fwd(y, R, mean, invstd, gamma, beta, pool_mode, out_x3=False):
     _rlc(y, 'y')
     rows, lin, c = y.shape
     lout = (lin - 1) // 2 + 1
+    if out_x3:                      # the pooled map in the x3 format (layer1's k3 s1 convs under conv arithmetic 'f32x3')
+        _rlc32(y, 'y')
+        out = x3_empty(rows, lout, c, y.device)
+        _chk(_lib.lib().da_bn_relu_pool_fwd_x(_p(y), c, _p(out), rows, R, lin, c, _p(mean), _p(invstd), _p(gamma), _p(beta),
+                                              pool_mode, _stream()), 'da_bn_relu_pool_fwd_x')
+        return out
     out = torch.empty((rows, lout, c), device=y.device, dtype=ACT)
     _chk(_lib.lib().da_bn_relu_pool_fwd(_p(y), c, _p(out), c, rows, R, lin, c, _p(mean), _p(invstd), _p(gamma),
                                         _p(beta), pool_mode, _stream()), 'da_bn_relu_pool_fwd')

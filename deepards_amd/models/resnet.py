@@ -49,13 +49,20 @@ class BasicBlock(nn.Module):
             self.add_module(name, mod)
         self.downsample, self.stride = downsample, stride
 
-    def forward_rlc(self, x, R):
-        """x: (rows, L, C) channels-last; R rows per BatchNorm window."""
+    def forward_rlc(self, x, R, x3=None, want_out3=False):
+        """x: (rows, L, C) channels-last; R rows per BatchNorm window.  Conv arithmetic 'f32x3p': ``x3`` = the input in the
+        x3 format (``x`` is then the autograd handle) and ``want_out3`` asks for ``(handle, out3)`` (functional: the x3 flow)."""
         ds = self.downsample
         dsw = (None, None, None, None) if ds is None else (ds[0].weight, ds[1].weight, ds[1].bias, F_.BNState(ds[1]))
         return F_.BasicBlockFunction.apply(
             x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias,
-            dsw[0], dsw[1], dsw[2], self.stride, R, F_.BNState(self.bn1), F_.BNState(self.bn2), dsw[3])
+            dsw[0], dsw[1], dsw[2], self.stride, R, F_.BNState(self.bn1), F_.BNState(self.bn2), dsw[3], x3, want_out3)
+
+    def takes_x3(self, rows, l_in, R):
+        """Whether this block's conv1 reads the x3 format under the current conv arithmetic: a k3 s1 conv (no downsample)
+        on a shape that has the x3 store forms."""
+        return self.downsample is None and self.stride == 1 and \
+            F_.x3_block_ok(rows, l_in, self.conv1.in_channels, R) and F_._is_wino(self.conv1.weight, 1, 1) == 49
 
 
 _POOLS = {'max': nn.MaxPool1d, 'avg': nn.AvgPool1d}
@@ -107,16 +114,27 @@ class ResNet(nn.Module):
             raise ValueError('rows not a multiple of rows_per_window')
         x2d = x.contiguous().float().view(rows, l)
         pool = F_.POOL_MAX if self.first_pool_type == 'max' else F_.POOL_AVG
+        # which blocks read their input in the x3 format (conv arithmetic 'f32x3p'): decided from the shapes up front, so
+        # that every producer knows what its consumer wants
+        blocks = [blk for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for blk in layer]
+        lens, cur = [], ((l // 2) - 1) // 2 + 1              # stem conv s2, then pool(3, 2, 1)
+        for blk in blocks:
+            lens.append(cur)
+            cur = (cur - 1) // blk.stride + 1 if blk.stride > 1 else cur
+        takes3 = [blk.takes_x3(rows, li, rows_per_window) for blk, li in zip(blocks, lens)] + [False]
         if self.double_conv_first:          # resnet.py:144-149: conv1_alt -> bn1 -> conv2 -> bn2 (conv1 is the dead one then)
             h = F_.DoubleStemFunction.apply(x2d, self.conv1_alt.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
                                             self.bn2.weight, self.bn2.bias, rows_per_window, pool, F_.BNState(self.bn1),
-                                            F_.BNState(self.bn2))
+                                            F_.BNState(self.bn2), takes3[0])
         else:
             h = F_.StemFunction.apply(x2d, self.conv1.weight, self.bn1.weight, self.bn1.bias, rows_per_window, pool,
-                                      F_.BNState(self.bn1))
-        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
-            for blk in layer:
-                h = blk.forward_rlc(h, rows_per_window)
+                                      F_.BNState(self.bn1), takes3[0])
+        for i, blk in enumerate(blocks):
+            if takes3[i]:
+                h, h3 = h
+                h = blk.forward_rlc(h, rows_per_window, h3, takes3[i + 1])
+            else:
+                h = blk.forward_rlc(h, rows_per_window, None, takes3[i + 1])
         if h.shape[1] < 7:
             raise ValueError('AvgPool1d(7, stride=1) needs a final length >= 7 (seq_len >= 224); got %d' % h.shape[1])
         return F_.GlobalAvgPoolFunction.apply(h)

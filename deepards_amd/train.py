@@ -21,6 +21,7 @@ MI355X-first differences (results identical, see tests):
 import contextlib
 import gc
 import math
+import os
 
 import torch
 
@@ -86,6 +87,43 @@ def legal_batch_len(n, batch_size, world_size=1):
     of windows (N=70, batch 16, world 4: the tail of 6 trains on 4 windows instead of raising)."""
     m = batch_multiple(batch_size, world_size)
     return n - n % m
+
+
+def fold_group_layout(world_size, rank, n_groups, n_folds):
+    """BASELINE config C4 ("5-fold data-parallel over 4 GPUs") as fold groups x data-parallel sub-groups: the ranks are
+    dealt to ``n_groups`` contiguous groups of world_size / n_groups ranks; group g trains the folds g, g + n_groups, ...
+    data-parallel over ITS ranks while the other groups train theirs.  n_groups = 1: every fold over all ranks (one after
+    the other); n_groups = world_size: every rank trains its own folds (what the reference's
+    scripts/main/run_non_pretraining_experiments.py:17-25 does with one process per GPU).
+    -> (rank lists of all groups, this rank's group, the folds of that group)."""
+    if n_groups < 1 or world_size % n_groups:
+        raise ValueError('%d fold groups do not divide %d ranks' % (n_groups, world_size))
+    per = world_size // n_groups
+    groups = [list(range(g * per, (g + 1) * per)) for g in range(n_groups)]
+    mine = rank // per
+    return groups, mine, [f for f in range(n_folds) if f % n_groups == mine]
+
+
+def make_fold_groups(n_groups, n_folds):
+    """The process groups of ``fold_group_layout`` (every rank creates every group, in the same order, as
+    ``dist.new_group`` requires) -> (this rank's sub-group, its size, this rank's rank in it, its folds)."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    groups, mine, folds = fold_group_layout(world, rank, n_groups, n_folds)
+    pgs = [dist.new_group(ranks=g) for g in groups]
+    return pgs[mine], len(groups[mine]), rank - groups[mine][0], folds
+
+
+def gather_fold_results(patient_results, is_group_leader):
+    """Every rank ends with every fold's patient results: the leaders of the fold groups contribute theirs (the other
+    ranks of a group hold the same numbers), merged over the WORLD group."""
+    import torch.distributed as dist
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, patient_results if is_group_leader else {})
+    merged = {}
+    for p in parts:
+        merged.update(p)
+    return merged
 
 
 def _logits(out):
@@ -160,7 +198,10 @@ class HotPathTrainer(object):
         self.last_logits = None
         self.allreduce_calls = 0
         self._synced = False
-        self._graph_opt_shared = None      # the captured update (data parallel): independent of the batch shape
+        self._graph_opt_shared = None      # the captured update (data parallel, two-graph form): independent of the batch shape
+        # data parallel: try to capture the all-reduce INSIDE the step graph (DA_DP_CAPTURE_ALLREDUCE=0: always two graphs)
+        self._capture_allreduce = os.environ.get('DA_DP_CAPTURE_ALLREDUCE', '1') != '0'
+        self.allreduce_in_graph = False
 
     # ---- replicas ----------------------------------------------------------------------------
     def sync_replicas(self):
@@ -263,11 +304,28 @@ class HotPathTrainer(object):
             for b, c in zip(self.model.buffers(), saved):
                 b.copy_(c)
         torch.cuda.current_stream().wait_stream(s)
-        graph = torch.cuda.CUDAGraph()
-        with _capture_graph(graph):
-            static_out = self._eager_single_gpu_parts(*static)
-        graph_opt = None
-        if self.world_size > 1:
+        graph, static_out, graph_opt = None, None, None
+        if self.world_size > 1 and self._capture_allreduce:
+            # Data parallel, preferred form: ONE graph holds backward | all-reduce | update.  RCCL collectives are
+            # stream-capturable; inside the graph the exchange needs no host round trip and no extra launches per step
+            # (round 2 replayed backward, called dist.all_reduce eagerly, replayed the update).  If the process group
+            # refuses to be captured the two-graph form below takes over -- decided once per trainer.
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with _capture_graph(graph):
+                    static_out = self._eager_whole_step(*static)
+                self.allreduce_in_graph = True
+            except Exception as e:                       # noqa: BLE001 -- any refusal selects the fallback
+                import warnings
+                warnings.warn('all-reduce could not be captured into the step graph (%s: %s); using the two-graph form '
+                              '(backward | eager all-reduce | update)' % (type(e).__name__, e))
+                self._capture_allreduce, self.allreduce_in_graph, graph = False, False, None
+                torch.cuda.synchronize()
+        if graph is None:
+            graph = torch.cuda.CUDAGraph()
+            with _capture_graph(graph):
+                static_out = self._eager_single_gpu_parts(*static)
+        if self.world_size > 1 and not self.allreduce_in_graph:
             graph_opt = self._graph_opt_shared
             if graph_opt is None:                        # the update does not depend on the batch shape: one graph
                 graph_opt = torch.cuda.CUDAGraph()
@@ -276,6 +334,14 @@ class HotPathTrainer(object):
                 self._graph_opt_shared = graph_opt
         ent = self._graphs[tuple(inputs.shape)] = (graph, static, static_out, graph_opt)
         return ent
+
+    def _eager_whole_step(self, inputs, target):
+        """zero-grad, forward, loss, backward, gradient all-reduce, update: the data-parallel step as one capturable chain."""
+        self.bucket.zero_grad()
+        loss, logits = self._forward_backward(inputs, target)
+        self.bucket.allreduce(self.group)
+        self._optimizer_step()
+        return loss, logits
 
     def _eager_single_gpu_parts(self, inputs, target):
         self.bucket.zero_grad()
@@ -310,8 +376,11 @@ class HotPathTrainer(object):
                 static[1].copy_(target)
             graph.replay()
             if self.world_size > 1:
-                self._allreduce()
-                graph_opt.replay()
+                if graph_opt is None:                    # the all-reduce is a node of the step graph
+                    self.allreduce_calls += 1
+                else:
+                    self._allreduce()
+                    graph_opt.replay()
             loss, logits = static_out
         self.steps += 1
         self.last_loss, self.last_logits = loss, logits

@@ -51,7 +51,7 @@ BUILD_DEFAULTS = dict(
     clip_grad=None, with_fft=None, only_fft=None, fft_real_only=None, random_kfold=None, bootstrap=None,
     kfolds=None, only_fold=None, load_checkpoint=None, load_base_network=None, save_model=None, saved_models_dir=None,
     train_from_pickle=None, train_to_pickle=None, test_from_pickle=None, test_to_pickle=None,
-    experiment_name='deepards_amd', config_override=None, folds_in_flight=None,
+    experiment_name='deepards_amd', config_override=None, folds_in_flight=None, fold_groups=None,
 )
 
 # make_args(): the merged view with every reference default, for callers that build ``args`` in Python
@@ -341,8 +341,17 @@ class BaseTraining(object):
         n_flight = int(n_flight)
         if n_flight > 1 and self.n_kfolds > 1 and a.kfolds is not None:
             return self._train_and_test_folds_in_flight(n_flight, saved_models_dir)
+        my_folds = None
+        n_groups = int(getattr(a, 'fold_groups', None) or 1)
+        if n_groups > 1:
+            # config C4: fold groups x data-parallel sub-groups (deepards_amd.train.fold_group_layout)
+            if self._data_parallel()[0] == 1:
+                raise ValueError('--fold-groups needs torch.distributed (python -m torch.distributed.run ...)')
+            from .train import make_fold_groups
+            group, gworld, grank, my_folds = make_fold_groups(n_groups, self.n_kfolds)
+            self._dp_override = (gworld, grank, group)
         for fold_num, (train_dataset, train_loader, test_dataset, test_loader) in enumerate(self.get_splits()):
-            if a.only_fold and fold_num != a.only_fold:
+            if (a.only_fold and fold_num != a.only_fold) or (my_folds is not None and fold_num not in my_folds):
                 continue
             model = self.get_model()
             optimizer = self.get_optimizer(model, *self._data_parallel())
@@ -359,6 +368,9 @@ class BaseTraining(object):
                 self._save(model, model_save_path(a.save_model, saved_models_dir, self.n_kfolds, fold_num))
             optimizer.release_graphs()                   # this fold's captured steps go NOW, not in some later gc pass (the
             self.model, self.optimizer = model, optimizer    # trainer stays usable: it re-captures on its next step)
+        if my_folds is not None:                         # every rank ends with every fold's patient results
+            from .train import gather_fold_results
+            self.results.patient_results = gather_fold_results(self.results.patient_results, self._data_parallel()[1] == 0)
         return self.results
 
     def _train_and_test_folds_in_flight(self, n_flight, saved_models_dir):
@@ -464,11 +476,15 @@ class BaseTraining(object):
         os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
         torch.save(model, path)
 
-    @staticmethod
-    def _data_parallel():
+    _dp_override = None
+
+    def _data_parallel(self):
         """(world_size, rank, group): one process per GPU under torch.distributed (RCCL) instead of nn.DataParallel (:96);
-        every rank takes its window shard of each batch, gradients meet in one all-reduce (deepards_amd.train)."""
+        every rank takes its window shard of each batch, gradients meet in one all-reduce (deepards_amd.train).  With
+        --fold-groups the triple describes this rank's data-parallel SUB-group."""
         import torch.distributed as dist
+        if self._dp_override is not None:
+            return self._dp_override
         if dist.is_available() and dist.is_initialized():
             return dist.get_world_size(), dist.get_rank(), None
         return 1, 0, None
@@ -633,10 +649,13 @@ def build_parser():
     # this build's own switches
     parser.add_argument('--seed', type=int, help='seed of the initialisation, the shuffles and the oversampler')
     parser.add_argument('--no-graph', dest='use_graph', action='store_false', default=None, help='run the step eagerly')
-    parser.add_argument('--conv-dtype', choices=['f32', 'bf16', 'f32x3'], help='arithmetic of the residual-block convs')
+    parser.add_argument('--conv-dtype', choices=['f32', 'bf16', 'f32x3', 'f32x3p'], help='arithmetic of the residual-block convs')
     parser.add_argument('--folds-in-flight', type=int, help='k-folds trained side by side on this GPU, each on its own stream '
                         '(same per-fold results as one after the other; a B <= 64 step leaves the chip partly idle).  '
                         'Default: min(5, kfolds) on one GPU, 1 under data parallelism; 1 = the sequential loop')
+    parser.add_argument('--fold-groups', type=int, help='under torch.distributed: split the ranks into this many groups; group g '
+                        'trains folds g, g + G, ... data-parallel over its own ranks (BASELINE config C4: 5 folds over 4 GPUs '
+                        'as e.g. 2 groups x 2 ranks).  Default 1: every fold over all ranks')
     parser.add_argument('--act-dtype', choices=['f32', 'bf16'], help='activation storage under --conv-dtype bf16 (default bf16 for ResNets)')
     return parser
 

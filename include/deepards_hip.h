@@ -112,6 +112,18 @@ int da_pack_conv3_bf16(const float* w, void* wf, void* wd, int co, int ci, da_st
 int da_conv3_x3(const float* x, const void* wpk, float* y, int rows, int L, int ldx, int C, int ldy, int N,
                 int accumulate, da_stream_t stream);
 int da_pack_conv3_x3(const float* w, void* wf, void* wd, int co, int ci, da_stream_t stream);
+/* ---- the same arithmetic with PRE-SPLIT operands (conv_x3p.hip; conv arithmetic 'f32x3', the default since round 3) ----
+ * The "x3" activation format: an fp32 activation stored as its exact three-term bf16 split, per position C/16 groups of
+ * [h 16 ch | m 16 ch | l 16 ch] bf16 (3 C bf16 = 6 C bytes per position, no pitch).  The BatchNorm / pool kernels in front
+ * of a k3 s1 p1 conv store it (da_bn_fwd_x / da_bn_bwd_x / da_bn_relu_pool_fwd_x below), da_x3_split / da_x3_merge convert
+ * fp32 <-> x3 for tests and boundaries.  da_conv3_x3p: same nn.Conv1d calls as da_conv3_x3 (resnet.py:5-8,27-38), x in
+ * x3 format, y fp32; wpk: the chunked split-bf16 pack -- (N/64) x (C/16) chunks of 18 KB laid out
+ * [3 taps][2 halves of 32 outputs][3 terms][64 lanes][8 bf16] -- which da_repack_desc.points = 49 emits (Uf forward,
+ * Ud data gradient; Co, Ci multiples of 64).  C % 16 == 0, N % 64 == 0. */
+int da_conv3_x3p(const void* x, const void* wpk, float* y, int rows, int L, int C, int ldy, int N, int accumulate,
+                 da_stream_t stream);
+int da_x3_split(const float* x, int ld, void* out, size_t npos, int C, da_stream_t stream);
+int da_x3_merge(const void* x, float* out, int ld, size_t npos, int C, da_stream_t stream);
 /* da_conv_gemm_multi's contract with bf16 operands for the stride-2 block heads and 1x1 downsamples
  * (resnet.py:5-8,126-128), forward and data gradient: per job Lsrc == src_stride * Lm, source offsets within a span of
  * 2, x2 == NULL, w = bf16 [taps][N][C] (da_repack_desc.points = 16 emits them for K = 1 and K = 3); the jobs of a call
@@ -121,7 +133,9 @@ int da_conv_bf16_multi(const da_conv_job* jobs, int n, da_stream_t stream);   /*
 typedef struct {
   const float* dy; const float* x; float* workspace;
   int rows, Lm, Ldy, lddy, N, Lx, ldx, C, dy_stride, dy_off, src_stride, ntaps; int src_off[3];
-  int winograd;   /* != 0: k3 s1 p1 job (N, C multiples of 64) in Winograd F(2,3) form; plan with winograd = 1 */
+  int winograd;   /* != 0: k3 s1 p1 job (N, C multiples of 64) in Winograd F(2,3) form; plan with winograd = 1;
+                     16: bf16 operands; 48: split-bf16 products of fp32 operands; 49: the same with dy AND x in the x3
+                     format (see da_conv3_x3p; lddy == N, ldx == C), k3 s1 p1 only */
 } da_wgrad_job;
 int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, da_stream_t stream);  /* winograd == 16 jobs: dy / x are da_act_t tensors (the only kind accepted while bf16 is selected) */
 /* deferred slab reduction: da_conv_wgrad with dw == NULL leaves da_conv_wgrad_splits() slabs in the workspace */
@@ -214,12 +228,25 @@ int da_bn_bwd_add(const da_act_t* dout, int ldd, const da_act_t* x, int ldx, con
                   const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma, float* dbeta,
                   int accumulate, const da_act_t* add, int ldadd, da_stream_t stream);
 int da_bn_param_grad_multi(const da_bn_pgrad_desc* descs, int n, int accumulate, da_stream_t stream);
+/* The same BatchNorm forward / backward (resnet.py:27-38) in front of an x3 consumer (conv arithmetic 'f32x3', see
+ * da_conv3_x3p): float in, and res_x3 / out_x3 / dx_x3 say which of `res`, `out`, `dx` are in the x3 format (their pitches are
+ * ignored).  Single-pass geometry only (da_bn_mask_words() > 0; -1 otherwise); mask may be NULL (no ReLU bit mask wanted /
+ * mask_mode 0 or 1 in the backward). */
+int da_bn_fwd_x(const float* x, int ldx, const void* res, int ldr, void* out, int ldo, int W, int Wn, int C, float* mean,
+                float* invstd, const float* gamma, const float* beta, int relu, float eps, unsigned long long* mask,
+                int res_x3, int out_x3, da_stream_t stream);
+int da_bn_bwd_x(const float* dout, int ldd, const float* x, int ldx, void* dx, int lddx, float* gout, int ldg, int W, int Wn,
+                int C, const float* mean, const float* invstd, const float* gamma, const float* beta, int mask_mode,
+                float* ds, const unsigned long long* mask, int dx_x3, da_stream_t stream);
 
 /* ---- pools ------------------------------------------------------------------------------
  * stem BN+ReLU+{Max,Avg}Pool1d(3,2,1): resnet.py:100-104,152-153 ; densenet.py:120-123 */
 int da_bn_relu_pool_fwd(const da_act_t* y, int ldy, da_act_t* out, int ldo, int rows, int R, int Lin, int C,
                         const float* mean, const float* invstd, const float* gamma, const float* beta,
                         int pool_mode, da_stream_t stream);
+/* ... with the pooled output stored in the x3 format (float activations): layer1's input under conv arithmetic 'f32x3' */
+int da_bn_relu_pool_fwd_x(const float* y, int ldy, void* out, int rows, int R, int Lin, int C, const float* mean,
+                          const float* invstd, const float* gamma, const float* beta, int pool_mode, da_stream_t stream);
 int da_pool_bwd(const da_act_t* dout, int ldd, const da_act_t* y, int ldy, da_act_t* dz, int lddz, int rows, int R, int Lin,
                 int C, const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode,
                 da_stream_t stream);

@@ -296,6 +296,68 @@ def test_data_parallel_gloo_world2_matches_full_batch():
     assert np.abs(g0 - ref).max() < 1e-6 * (1 + np.abs(ref).max())
 
 
+def _fold_group_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from deepards_amd.train import FlatBucket, HotPathTrainer, gather_fold_results, make_fold_groups, shared_generator
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    group, gworld, grank, folds = make_fold_groups(2, 5)               # 2 fold groups x 2 ranks, 5 folds (config C4's shape)
+    # the gradient exchange stays inside the sub-group
+    p = torch.nn.Parameter(torch.zeros(70))
+    p.grad = torch.full((70,), float(rank + 1))
+    bucket = FlatBucket([p])
+    bucket.allreduce(group)
+    # replica sync + one shared permutation per sub-group
+    import deepards_amd.models as M
+    torch.manual_seed(100 + rank)
+    model = M.CNNLinearNetwork(M.densenet18(), 20, 0)
+    tr = HotPathTrainer(model, world_size=gworld, rank=grank, process_group=group)
+    tr.sync_replicas()
+    w = model.linear_final.weight.detach().clone()
+    torch.manual_seed(900 + rank)
+    perm = torch.randperm(12, generator=shared_generator(tr, None))
+    res = {(f, 1): {'votes': np.full((3, 2), 10 * f + grank)} for f in folds}
+    merged = gather_fold_results(res, grank == 0)
+    q.put((rank, gworld, grank, folds, float(bucket.g[0]), w.numpy(), perm.numpy(),
+           sorted(merged), {k: int(v['votes'][0, 0]) for k, v in merged.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fold_groups_times_data_parallel_subgroups_gloo_world4():
+    """BASELINE config C4's shape on the host side: 4 ranks as 2 fold groups x 2 data-parallel ranks
+    (train.fold_group_layout / make_fold_groups, --fold-groups): folds dealt round-robin to the groups, the gradient
+    all-reduce, the replica sync and the shared permutation stay inside a sub-group, and every rank ends with every fold's
+    patient results (gather_fold_results takes them from the group leaders)."""
+    import torch.multiprocessing as mp
+    from deepards_amd.train import fold_group_layout
+    assert fold_group_layout(4, 3, 2, 5) == ([[0, 1], [2, 3]], 1, [1, 3])
+    assert fold_group_layout(4, 0, 1, 5)[2] == [0, 1, 2, 3, 4] and fold_group_layout(4, 2, 4, 5) == ([[0], [1], [2], [3]], 2, [2])
+    with pytest.raises(ValueError):
+        fold_group_layout(4, 0, 3, 5)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_fold_group_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [(r[1], r[2]) for r in res] == [(2, 0), (2, 1), (2, 0), (2, 1)]
+    assert [r[3] for r in res] == [[0, 2, 4], [0, 2, 4], [1, 3], [1, 3]]
+    assert [r[4] for r in res] == [3.0, 3.0, 7.0, 7.0]                   # 1 + 2 and 3 + 4: sums within the sub-groups
+    assert np.array_equal(res[0][5], res[1][5]) and np.array_equal(res[2][5], res[3][5])      # each group holds ITS leader's weights
+    assert not np.array_equal(res[0][5], res[2][5])
+    assert np.array_equal(res[0][6], res[1][6]) and np.array_equal(res[2][6], res[3][6])      # one permutation per group
+    for r in res:                                                         # every rank: all five folds, the leaders' numbers
+        assert r[7] == [(f, 1) for f in range(5)]
+        assert r[8] == {(f, 1): 10 * f for f in range(5)}
+
+
 def test_driver_mirror_names_and_no_cpu_path():
     """deepards_amd.train_ards_detector keeps the reference driver's names (train_ards_detector.py:45-69, 73-512,
     925-939, 1410-1436) and refuses to run without a GPU."""

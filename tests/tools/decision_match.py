@@ -4,7 +4,7 @@ import numpy as np
 from oracle import np_ref
 
 
-def decision_matched_gradients(ref, ours, log_tag='', tols=(1e-5, 3e-5), log=print):
+def decision_matched_gradients(ref, ours, log_tag='', tols=(1e-5, 3e-5), log=print, max_eval=128):
     """The exact (fp64 oracle) gradients under the activation decisions THIS run took.
 
     An fp32 forward differs from the fp64 one by ~1e-6 relative, enough to take a ReLU / max-pool decision the other way
@@ -16,7 +16,9 @@ def decision_matched_gradients(ref, ours, log_tag='', tols=(1e-5, 3e-5), log=pri
     Matching pursuit over the candidates in order of decreasing effect: a flip is adopted when the current residual
     (ours - exact - adopted effects) projects onto D_e with coefficient > 1/2.  The adopted set is then applied at once
     in an exact re-run.  Effects are matched on a fixed coordinate subsample (<= 2048 per parameter), the verdict is
-    taken by the caller on the full tensors.  Returns (gradients, flips adopted, number of candidates)."""
+    taken by the caller on the full tensors.  At most ``max_eval`` candidates are evaluated per tolerance, those closest
+    to their decision boundary first (every evaluation is one oracle backward: seconds for the deeper backbones).
+    Returns (gradients, flips adopted, number of candidates)."""
     base = ref['grads']
     names = [n for n in base if n in ours]
     # gradients that are analytically zero (a conv in front of a BatchNorm when every ReLU is active) get a unit
@@ -31,7 +33,7 @@ def decision_matched_gradients(ref, ours, log_tag='', tols=(1e-5, 3e-5), log=pri
                                      (np.sqrt(base[n].size / len(sub[n])) / scale[n]) for n in names])
     got, chosen, cands = base, [], []
     for tol in tols:
-        cands = np_ref.ambiguous_decisions(ref['tape'], tol)
+        cands = sorted(np_ref.ambiguous_decisions(ref['tape'], tol), key=lambda c: c[2])[:max_eval]
         effects = [pack(ref['rebackward']([(name, i)])) for name, i, _ in cands]
         resid = pack(ours)
         chosen = []
