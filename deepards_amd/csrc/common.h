@@ -48,8 +48,8 @@ template <> struct Act<__bf16> {
 //     x = h + m + l,   h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m)        (round-to-nearest-even, 3 x 8 bits)
 // so that the convolutions that consume it can take fp32-equivalent products on the bf16 matrix cores (conv_x3p.hip)
 // without splitting anything themselves.  Layout per position: C/16 groups of [h 16 ch | m 16 ch | l 16 ch] = 48 bf16;
-// 3 C bf16 = 6 C bytes per position, no channel pitch.  Reading it back (residual adds, tests) is h + m + l: exact,
-// every partial sum is a truncation of x's own 24-bit significand.  Only the BatchNorm / pool kernels in front of an x3
+// 3 C bf16 = 6 C bytes per position, no channel pitch.  Reading it back (residual adds, tests) is h + (m + l): exact for
+// |x| >= 2^-109 (below that the third term underflows bf16's denormals: absolute error < 2^-133).  Only the BatchNorm / pool kernels in front of an x3
 // consumer store it; statistics, sums and every conv OUTPUT stay plain fp32.
 struct X3 {
   static __device__ __forceinline__ f32x2v cvt4(const f32x4& v) {      // 4 bf16 (nearest-even) as the bits of 2 floats
@@ -78,7 +78,7 @@ struct X3 {
     const __bf16* d = pos + off(c0);
     const f32x4 h = widen4(*reinterpret_cast<const f32x2v*>(d)), m = widen4(*reinterpret_cast<const f32x2v*>(d + 16)),
                 l = widen4(*reinterpret_cast<const f32x2v*>(d + 32));
-    return (h + m) + l;
+    return h + (m + l);                              // m + l = x - h exactly (<= 17 bits), then h + (x - h) = x
   }
 };
 

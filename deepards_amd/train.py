@@ -305,7 +305,7 @@ class HotPathTrainer(object):
                 b.copy_(c)
         torch.cuda.current_stream().wait_stream(s)
         graph, static_out, graph_opt = None, None, None
-        if self.world_size > 1 and self._capture_allreduce:
+        if self.world_size > 1 and self._capture_allreduce and self._collectives_capturable():
             # Data parallel, preferred form: ONE graph holds backward | all-reduce | update.  RCCL collectives are
             # stream-capturable; inside the graph the exchange needs no host round trip and no extra launches per step
             # (round 2 replayed backward, called dist.all_reduce eagerly, replayed the update).  If the process group
@@ -334,6 +334,15 @@ class HotPathTrainer(object):
                 self._graph_opt_shared = graph_opt
         ent = self._graphs[tuple(inputs.shape)] = (graph, static, static_out, graph_opt)
         return ent
+
+    def _collectives_capturable(self):
+        """Only RCCL ('nccl') collectives are stream operations a hipGraph can hold; a gloo all-reduce synchronises the
+        host, and a capture it invalidates cannot be retried in the same process -- so the backend decides, not a trial."""
+        import torch.distributed as dist
+        try:
+            return dist.is_initialized() and dist.get_backend(self.group) == 'nccl'
+        except Exception:                                # noqa: BLE001
+            return False
 
     def _eager_whole_step(self, inputs, target):
         """zero-grad, forward, loss, backward, gradient all-reduce, update: the data-parallel step as one capturable chain."""

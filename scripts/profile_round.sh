@@ -52,3 +52,11 @@ cd $R
 # 6. the C5 tile shape (BASELINE configs[4]: NB 40, L 512), fp32 and bf16
 timeout -k 10 300 python bench.py --nb 40 --seq-len 512 --no-cpu-baseline > $out/${tag}_bench_c5_f32.json 2> /dev/null
 timeout -k 10 300 python bench.py --nb 40 --seq-len 512 --dtype bf16 --no-cpu-baseline > $out/${tag}_bench_c5_bf16.json 2> /dev/null
+# 7. densenet18, the reference's DEFAULT backbone: bench line, kernel stats and the timeline of one captured step
+timeout -k 10 300 python bench.py --backbone densenet18 --no-extra --no-cpu-baseline > $out/${tag}_bench_densenet18.json 2> $out/${tag}_bench_densenet18.err || { tail -5 $out/${tag}_bench_densenet18.err; exit 1; }
+cd /tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_dn -- python3 $R/bench.py --backbone densenet18 --no-extra --no-cpu-baseline --no-roofline > $out/${tag}_bench_densenet18_under_rocprof.json 2> $out/prof_dn.err || { tail -5 $out/prof_dn.err; exit 1; }
+cp $(find $out/prof_dn -name '*kernel_stats.csv' | head -1) $out/${tag}_densenet_kernel_stats.csv
+rm -rf $out/prof_dn
+cd $R
+bash scripts/trace_round.sh ${tag}_densenet --backbone densenet18 > /dev/null
