@@ -38,21 +38,39 @@ __device__ __forceinline__ int xcd_chunked_xp(int id, int total) {   // consecut
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + s;
 }
 
+// LDS fragment reads the compiler does not track (it would wait for ALL outstanding LDS reads in front of every MFMA group):
+// the K loop issues the reads of the next group, then waits -- by count -- for the current group's only.
+__device__ __forceinline__ f32x4 lds_read16(const unsigned char* p) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)p) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(f32x4 (&a)[3], f32x4 (&b)[3]) {     // at most N LDS operations may still be in flight
+  asm volatile("s_waitcnt lgkmcnt(%6)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2])
+               : "n"(N)
+               : "memory");
+}
+
 struct ConvX3pArgs {
   const __bf16* x;      // [M] positions of x3 format, C channels: 3 C bf16 per position
   const __bf16* w;      // [N / 64][C / 16] chunks of XP_BCHUNK bytes (da_repack_desc.points = 49)
   float* y;             // [M][ldy] fp32, first N channels
   int M, L, C, ldy, N, accumulate;
-  int full_m;           // M-tile rows (of 128 positions) that run as full tiles: full_m * (N / 64) blocks of MT = 2
-  int tail_m;           // the remaining M-tile rows run as 2 * tail_m * (N / 64) half tiles (MT = 1), FIRST in the launch
+  int full_m;           // M-tile rows (of 256 positions) that run as full tiles: full_m * (N / 64) blocks
+  int tail_m;           // the remaining M-tile rows run as 4 * tail_m * (N / 64) tiles of 64 x 64, FIRST in the launch
   FastDiv divL;
 };
 
-template <int MT>
+// One tile of (32 MT WM) positions x 64 output channels by the calling block's NT threads: waves 0 .. 2 WM - 1 compute
+// (wave = (wm, wn): rows wm * 32 MT .., channels wn * 32 ..), every thread of the block stages.
+template <int MT, int WM, int NT>
 __device__ __forceinline__ void conv3_x3p_body(const ConvX3pArgs& a, const int P0, const int n_blk, unsigned char* lds) {
-  constexpr int TM = 64 * MT, XROWS = TM + 2, PROWS = XROWS + 1;     // + the zero row
+  constexpr int TM = 32 * MT * WM, XROWS = TM + 2, PROWS = XROWS + 1;     // + the zero row
   constexpr int XBYTES = PROWS * XP_PITCH;
-  constexpr int NXP = (XROWS * 6 + 255) / 256;                       // 16-byte pieces of the panel per thread
+  constexpr int NXP = (XROWS * 6 + NT - 1) / NT;                     // 16-byte pieces of the panel per thread
+  constexpr int NBP = (1152 + NT - 1) / NT;                          // ... of the 18 KB weight chunk
   unsigned char* Xs = lds;                          // 2 x [PROWS][112]
   unsigned char* Bs = lds + 2 * XBYTES;             // 2 x 18 KB
 
@@ -67,7 +85,7 @@ __device__ __forceinline__ void conv3_x3p_body(const ConvX3pArgs& a, const int P
   bool xon[NXP];
 #pragma unroll
   for (int p = 0; p < NXP; ++p) {
-    const int q = tid + 256 * p;
+    const int q = tid + NT * p;
     xon[p] = q < XROWS * 6;
     const int r = xon[p] ? q / 6 : 0, s = xon[p] ? q - r * 6 : 0;
     long P = (long)P0 - 1 + r;
@@ -77,16 +95,19 @@ __device__ __forceinline__ void conv3_x3p_body(const ConvX3pArgs& a, const int P
   }
   // weight chunk loader: 1152 pieces of 16 bytes, linear
   const unsigned char* bsrc = reinterpret_cast<const unsigned char*>(a.w) + (size_t)(n_blk >> 6) * kch * XP_BCHUNK + tid * 16;
+  bool bon[NBP];
+#pragma unroll
+  for (int i = 0; i < NBP; ++i) bon[i] = tid + NT * i < 1152;
 
-  f32x4 rx[NXP], rb[5];
+  f32x4 rx[NXP], rb[NBP];
   auto gload = [&](int ks) {
 #pragma unroll
     for (int p = 0; p < NXP; ++p)
       if (xon[p]) rx[p] = *reinterpret_cast<const f32x4*>(xsrc[p] + ks * 96);
     const unsigned char* b = bsrc + (size_t)ks * XP_BCHUNK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b + i * 4096);
-    if (tid < 128) rb[4] = *reinterpret_cast<const f32x4*>(b + 4 * 4096);
+    for (int i = 0; i < NBP; ++i)
+      if (bon[i]) rb[i] = *reinterpret_cast<const f32x4*>(b + i * NT * 16);
   };
   auto stage = [&](int buf) {
     unsigned char* xs = Xs + buf * XBYTES;
@@ -95,12 +116,13 @@ __device__ __forceinline__ void conv3_x3p_body(const ConvX3pArgs& a, const int P
     for (int p = 0; p < NXP; ++p)
       if (xon[p]) *reinterpret_cast<f32x4*>(xs + xdst[p]) = rx[p];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(bs + i * 4096) = rb[i];
-    if (tid < 128) *reinterpret_cast<f32x4*>(bs + 4 * 4096) = rb[4];
+    for (int i = 0; i < NBP; ++i)
+      if (bon[i]) *reinterpret_cast<f32x4*>(bs + i * NT * 16) = rb[i];
   };
 
+  const bool computes = wave < 2 * WM;              // (the tail tiles of a 512-thread block: waves 4 .. 7 only stage)
   const int frow = lane & 31, kg = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = computes ? wave >> 1 : 0, wn = wave & 1;
   // LDS offset of the A fragment of (row tile mt, tap t): the panel row of position + t - 1, or the zero row when that
   // position lies across a sequence edge
   int aoff[MT][3];
@@ -135,22 +157,44 @@ __device__ __forceinline__ void conv3_x3p_body(const ConvX3pArgs& a, const int P
     const int cur = ks & 1;
     const unsigned char* xs = Xs + cur * XBYTES;
     const unsigned char* bs = Bs + cur * XP_BCHUNK + boff;
-    stage(cur ^ 1);                                 // step ks + 1 (already in registers); its buffer was released by the last barrier
-    gload(ks + 2 < kch ? ks + 2 : kch - 1);
+    // One K step = 3 taps x MT row tiles = 3 MT groups of 6 MFMAs.  The fragments of group g + 1 are read from LDS BEFORE the
+    // MFMAs of group g issue (register double buffer: an LDS round trip hides behind 192 MFMA cycles instead of stalling
+    // both waves of a SIMD at the same moment), and the staging of step ks + 1 / the loads of step ks + 2 sit between the
+    // first groups instead of in front of them, where the matrix pipe would idle.
+    constexpr int G = 3 * MT;
+    f32x4 av[2][3], bv[2][3];
+    auto ld_frags = [&](int g) {
+      const int t = g / MT, mt = g % MT;
+      if (mt == 0) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      f32x4 bv[3];
+        for (int s_ = 0; s_ < 3; ++s_) bv[t & 1][s_] = lds_read16(bs + t * 6144 + s_ * 1024);
+      }
 #pragma unroll
-      for (int s = 0; s < 3; ++s) bv[s] = *reinterpret_cast<const f32x4*>(bs + t * 6144 + s * 1024);
-      const bf16x8 bh = __builtin_bit_cast(bf16x8, bv[0]), bm = __builtin_bit_cast(bf16x8, bv[1]),
-                   bl = __builtin_bit_cast(bf16x8, bv[2]);
+      for (int s_ = 0; s_ < 3; ++s_) av[g & 1][s_] = lds_read16(xs + aoff[mt][t] + s_ * 32);
+    };
+    // The two waves that share a SIMD (waves w and w + 4) must not do the same thing at the same time, or the matrix pipe
+    // idles while both stage and both queue for it afterwards (measured: MFMA, staging and load time simply ADDED UP):
+    // waves 0-3 stage step ks + 1 and load step ks + 2 BEFORE their MFMAs, waves 4-7 AFTER theirs -- within one barrier
+    // interval one half computes while the other moves bytes.
+    const bool early = wave < 4;
+    if (early) {
+      stage(cur ^ 1);                               // step ks + 1 (already in registers); its buffer was released by the last barrier
+      gload(ks + 2 < kch ? ks + 2 : kch - 1);
+    }
+    if (computes) ld_frags(0);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        f32x4 av[3];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) av[s] = *reinterpret_cast<const f32x4*>(xs + aoff[mt][t] + s * 32);
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, av[0]), am = __builtin_bit_cast(bf16x8, av[1]),
-                     al = __builtin_bit_cast(bf16x8, av[2]);
+    for (int g = 0; g < G; ++g) {
+      if (computes && g + 1 < G) ld_frags(g + 1);
+      if (computes) {
+        const int mt = g % MT, tb = (g / MT) & 1, sl = g & 1;
+        // the reads of group g are older than everything issued since: the next group's 3 (+ 3 with a new tap's weights)
+        if (g + 1 >= G) lds_wait<0>(av[sl], bv[tb]);
+        else if ((g + 1) % MT == 0) lds_wait<6>(av[sl], bv[tb]);
+        else lds_wait<3>(av[sl], bv[tb]);
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bv[tb][0]), bm = __builtin_bit_cast(bf16x8, bv[tb][1]),
+                     bl = __builtin_bit_cast(bf16x8, bv[tb][2]);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, av[sl][0]), am = __builtin_bit_cast(bf16x8, av[sl][1]),
+                     al = __builtin_bit_cast(bf16x8, av[sl][2]);
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mt], 0, 0, 0);      // small terms first
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mt], 0, 0, 0);
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[mt], 0, 0, 0);
@@ -158,40 +202,49 @@ __device__ __forceinline__ void conv3_x3p_body(const ConvX3pArgs& a, const int P
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[mt], 0, 0, 0);
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mt], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!early) {
+      stage(cur ^ 1);
+      gload(ks + 2 < kch ? ks + 2 : kch - 1);
     }
     __syncthreads();
   }
 
   // lane holds output channel n_blk + wn*32 + l%32 of the positions (r & 3) + 8 (r >> 2) + 4 (l / 32) of each 32-row tile
+  if (computes) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long P = (long)P0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-      if (P < a.M) {
-        float* o = a.y + P * a.ldy + n_blk + wn * 32 + frow;
-        float v = acc[mt][r];
-        if (a.accumulate) v += *o;
-        *o = v;
+      for (int r = 0; r < 16; ++r) {
+        const long P = (long)P0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (P < a.M) {
+          float* o = a.y + P * a.ldy + n_blk + wn * 32 + frow;
+          float v = acc[mt][r];
+          if (a.accumulate) v += *o;
+          *o = v;
+        }
       }
-    }
+  }
 }
 
-#define XP_LDS_BYTES (2 * (128 + 3) * XP_PITCH + 2 * XP_BCHUNK)
+#define XP_TM 256                                    // full tile: 8 waves = 4 (rows) x 2 (channels), 2 accumulators each
+#define XP_LDS_BYTES (2 * (XP_TM + 3) * XP_PITCH + 2 * XP_BCHUNK)
 
-// Work items: `full_tiles` tiles of 128 x 64 and, for the partly filled last round of a launch (full tile slots
-// full_tiles .. full_tiles + tail_tiles - 1), twice as many 64 x 64 tiles -- each half the MFMA time of a full one, so the
-// last round costs about half a round.  The half tiles are the FIRST blocks of the launch.
-__global__ __launch_bounds__(256, 2) void conv3_x3p_kernel(ConvX3pArgs a) {
+// Work items: full_m * (N / 64) tiles of 256 x 64 (8 waves; ONE resident block per CU: 95 KB of LDS -- a tile this tall
+// is what brings the operand traffic down to what the L2 -> LDS path sustains: 18.7 bytes per clock and CU against 26.7
+// for 128 x 64 tiles, of ~35 achievable) and, for the partly filled last round of a launch, 64 x 64 tiles (a quarter of
+// the MFMA time on 4 of the block's 8 waves, the others help staging): the FIRST blocks of the launch.
+__global__ __launch_bounds__(512, 1) void conv3_x3p_kernel(ConvX3pArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // XP_LDS_BYTES (> 64 KB: dynamic)
   const int ntn = a.N / XP_TN;
-  const int tail_blocks = 2 * a.tail_m * ntn;
+  const int tail_blocks = 4 * a.tail_m * ntn;
   if ((int)blockIdx.x < tail_blocks) {
-    const int id = xcd_chunked_xp(blockIdx.x, tail_blocks);        // channel tile fastest: the halves of one panel share an L2
-    conv3_x3p_body<1>(a, a.full_m * 128 + (id / ntn) * 64, (id % ntn) * XP_TN, lds);
+    const int id = xcd_chunked_xp(blockIdx.x, tail_blocks);        // channel tile fastest: the tiles of one panel share an L2
+    conv3_x3p_body<1, 2, 512>(a, a.full_m * XP_TM + (id / ntn) * 64, (id % ntn) * XP_TN, lds);
   } else {
     const int tile = xcd_chunked_xp(blockIdx.x - tail_blocks, a.full_m * ntn);
-    conv3_x3p_body<2>(a, (tile / ntn) * 128, (tile % ntn) * XP_TN, lds);
+    conv3_x3p_body<2, 4, 512>(a, (tile / ntn) * XP_TM, (tile % ntn) * XP_TN, lds);
   }
 }
 
@@ -235,10 +288,10 @@ int da_conv3_x3p(const void* x, const void* wpk, float* y, int rows, int L, int 
   a.M = (int)M; a.L = L; a.C = C; a.ldy = ldy; a.N = N; a.accumulate = accumulate;
   a.divL = make_fastdiv((uint32_t)L);
   const int ntn = N / XP_TN;
-  const long mtiles = (M + 127) / 128;
+  const long mtiles = (M + XP_TM - 1) / XP_TM;
   const long tiles = mtiles * ntn;
   if (tiles > 0x3fffffffl) return DA_EINVAL;
-  // the partly filled last round (512 resident blocks: 2 per CU) runs as half tiles -- whole M-tile rows of them
+  // the partly filled last round (256 resident blocks: 1 per CU) runs as 64 x 64 tiles -- whole M-tile rows of them
   long tail_m = 0;
   static int g_tail = -1;
   static bool attr_set = false;
@@ -252,11 +305,11 @@ int da_conv3_x3p(const void* x, const void* wpk, float* y, int rows, int L, int 
       return DA_EINVAL;
     attr_set = true;
   }
-  if (g_tail) tail_m = tiles < 512 ? mtiles : (tiles % 512) / ntn;
+  if (g_tail) tail_m = tiles < 256 ? mtiles : (tiles % 256) / ntn;
   a.tail_m = (int)tail_m;
   a.full_m = (int)(mtiles - tail_m);
-  const long blocks = (long)a.full_m * ntn + 2l * tail_m * ntn;
-  hipLaunchKernelGGL(conv3_x3p_kernel, dim3((unsigned)blocks), dim3(256), XP_LDS_BYTES, stream, a);
+  const long blocks = (long)a.full_m * ntn + 4l * tail_m * ntn;
+  hipLaunchKernelGGL(conv3_x3p_kernel, dim3((unsigned)blocks), dim3(512), XP_LDS_BYTES, stream, a);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

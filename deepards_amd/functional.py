@@ -237,10 +237,13 @@ def x3_handle(x3):
     return z.expand(rows, l, g * 16)
 
 
+_X3_MIN_C = int(os.environ.get('DA_X3_MINC', '64'))      # channel count from which a block takes the x3 flow (A/B measurements)
+
+
 def x3_block_ok(rows, l, c, R):
     """Whether a block whose activations are (rows, L, C) in windows of R rows can run its k3 s1 convs on x3 operands:
     conv arithmetic 'f32x3p', float storage, 64-multiple channels and the single-pass BatchNorm geometry (its store forms)."""
-    return _CONV_DTYPE == 'f32x3p' and H.act_dtype() == 'f32' and c % 64 == 0 and H.bn_x3_ok(rows, l, c, R)
+    return _CONV_DTYPE == 'f32x3p' and H.act_dtype() == 'f32' and c % 64 == 0 and c >= _X3_MIN_C and H.bn_x3_ok(rows, l, c, R)
 
 
 def _bn_apply_x(x, R, s, st, gamma, beta, relu, res=None, want_mask=False, out_x3=True):
