@@ -66,7 +66,7 @@ struct ConvX3pArgs {
 // One tile of (32 MT WM) positions x 64 output channels by the calling block's NT threads: waves 0 .. 2 WM - 1 compute
 // (wave = (wm, wn): rows wm * 32 MT .., channels wn * 32 ..), every thread of the block stages.
 template <int MT, int WM, int NT>
-__device__ __forceinline__ void conv3_x3p_body(const ConvX3pArgs& a, const int P0, const int n_blk, unsigned char* lds) {
+__device__ __forceinline__ void conv3_x3p_body(const ConvX3pArgs& a, const int P0, const int n_blk, unsigned char* lds, const bool early) {
   constexpr int TM = 32 * MT * WM, XROWS = TM + 2, PROWS = XROWS + 1;     // + the zero row
   constexpr int XBYTES = PROWS * XP_PITCH;
   constexpr int NXP = (XROWS * 6 + NT - 1) / NT;                     // 16-byte pieces of the panel per thread
@@ -176,7 +176,6 @@ __device__ __forceinline__ void conv3_x3p_body(const ConvX3pArgs& a, const int P
     // idles while both stage and both queue for it afterwards (measured: MFMA, staging and load time simply ADDED UP):
     // waves 0-3 stage step ks + 1 and load step ks + 2 BEFORE their MFMAs, waves 4-7 AFTER theirs -- within one barrier
     // interval one half computes while the other moves bytes.
-    const bool early = wave < 4;
     if (early) {
       stage(cur ^ 1);                               // step ks + 1 (already in registers); its buffer was released by the last barrier
       gload(ks + 2 < kch ? ks + 2 : kch - 1);
@@ -241,10 +240,28 @@ __global__ __launch_bounds__(512, 1) void conv3_x3p_kernel(ConvX3pArgs a) {
   const int tail_blocks = 4 * a.tail_m * ntn;
   if ((int)blockIdx.x < tail_blocks) {
     const int id = xcd_chunked_xp(blockIdx.x, tail_blocks);        // channel tile fastest: the tiles of one panel share an L2
-    conv3_x3p_body<1, 2, 512>(a, a.full_m * XP_TM + (id / ntn) * 64, (id % ntn) * XP_TN, lds);
+    conv3_x3p_body<1, 2, 512>(a, a.full_m * XP_TM + (id / ntn) * 64, (id % ntn) * XP_TN, lds, threadIdx.x < 256);
   } else {
     const int tile = xcd_chunked_xp(blockIdx.x - tail_blocks, a.full_m * ntn);
-    conv3_x3p_body<2, 4, 512>(a, (tile / ntn) * XP_TM, (tile % ntn) * XP_TN, lds);
+    conv3_x3p_body<2, 4, 512>(a, (tile / ntn) * XP_TM, (tile % ntn) * XP_TN, lds, threadIdx.x < 256);
+  }
+}
+
+// Variant 2 (DA_X3_KERNEL=2, A/B measurements): 128 x 64 tiles on 4 waves, TWO resident blocks per CU (66 KB of LDS each);
+// the SIMD partners are then waves of two different blocks, which cannot share a barrier -- the blocks of the first
+// resident round stage before their MFMAs, those of the second after (blockIdx / 256 decides: speed only).
+#define XP2_LDS_BYTES (2 * (128 + 3) * XP_PITCH + 2 * XP_BCHUNK)
+__global__ __launch_bounds__(256, 2) void conv3_x3p_kernel2(ConvX3pArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int ntn = a.N / XP_TN;
+  const int tail_blocks = 2 * a.tail_m * ntn;
+  const bool early = ((blockIdx.x >> 8) & 1) == 0;
+  if ((int)blockIdx.x < tail_blocks) {
+    const int id = xcd_chunked_xp(blockIdx.x, tail_blocks);
+    conv3_x3p_body<1, 2, 256>(a, a.full_m * 128 + (id / ntn) * 64, (id % ntn) * XP_TN, lds, early);
+  } else {
+    const int tile = xcd_chunked_xp(blockIdx.x - tail_blocks, a.full_m * ntn);
+    conv3_x3p_body<2, 2, 256>(a, (tile / ntn) * 128, (tile % ntn) * XP_TN, lds, early);
   }
 }
 
@@ -288,6 +305,27 @@ int da_conv3_x3p(const void* x, const void* wpk, float* y, int rows, int L, int 
   a.M = (int)M; a.L = L; a.C = C; a.ldy = ldy; a.N = N; a.accumulate = accumulate;
   a.divL = make_fastdiv((uint32_t)L);
   const int ntn = N / XP_TN;
+  static int g_kernel = 0;
+  if (!g_kernel) {
+    const char* e = getenv("DA_X3_KERNEL");
+    g_kernel = e ? atoi(e) : 1;
+  }
+  if (g_kernel == 2) {
+    static bool attr2 = false;
+    if (!attr2) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_x3p_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              XP2_LDS_BYTES) != hipSuccess)
+        return DA_EINVAL;
+      attr2 = true;
+    }
+    const long mt2 = (M + 127) / 128, t2 = mt2 * ntn;
+    const long tm2 = t2 < 512 ? mt2 : (t2 % 512) / ntn;
+    a.tail_m = (int)tm2;
+    a.full_m = (int)(mt2 - tm2);
+    hipLaunchKernelGGL(conv3_x3p_kernel2, dim3((unsigned)((long)a.full_m * ntn + 2l * tm2 * ntn)), dim3(256), XP2_LDS_BYTES, stream, a);
+    DA_CHECK_LAUNCH();
+    return DA_OK;
+  }
   const long mtiles = (M + XP_TM - 1) / XP_TM;
   const long tiles = mtiles * ntn;
   if (tiles > 0x3fffffffl) return DA_EINVAL;

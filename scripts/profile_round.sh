@@ -28,13 +28,14 @@ cd $R
 python scripts/pmc_traffic.py $tag $out/prof16_FETCH_SIZE $out/prof16_WRITE_SIZE _bf16
 rm -rf $out/prof16_FETCH_SIZE $out/prof16_WRITE_SIZE
 cp $out/${tag}_traffic.json $out/${tag}_traffic_bf16.json $R/profiles/
-timeout -k 10 500 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err || { tail -5 $out/${tag}_bench.err; exit 1; }
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_stats -- python3 $R/bench.py --no-extra --no-cpu-baseline > $out/${tag}_bench_under_rocprof.json 2> $out/prof_stats.err || { tail -5 $out/prof_stats.err; exit 1; }
 cp $(find $out/prof_stats -name '*kernel_stats.csv' | head -1) $out/${tag}_bench_kernel_stats.csv
 python $R/scripts/stats_family.py $out/${tag}_bench_kernel_stats.csv $out/${tag}_bench_under_rocprof.json > $out/${tag}_dominant_kernel.json
 cd $R
+cp $out/${tag}_dominant_kernel.json $R/profiles/           # the bench line below quotes its in-graph average (same sources: sha checked)
 rm -rf $out/prof_stats
+timeout -k 10 500 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err || { tail -5 $out/${tag}_bench.err; exit 1; }
 # 4. matrix-pipe utilisation of the GEMM kernels (own PMC pass): SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs)
 #    against SQ_BUSY_CYCLES (summed over the 32 shader engines) -> gpurun_out/<tag>_pmc_mfma_busy.json
 cd /tmp
