@@ -652,6 +652,38 @@ def main():
             'alg_tflops': round(w2['flops'] * B * 20 / d2 / 1e12, 2),
             'alg_gbs': round((w2['act_bytes'] * B * 20 + 32 * w2['params']) / d2 / 1e9, 1),
             'note': 'cnn_linear+densenet18 (reference default backbone), drop_rate 0.2 active'}
+        if rank == 0 and not args.no_roofline:
+            # where the DenseNet step goes: the same instrumented eager pass as for the headline (HIP events around every
+            # C-ABI launch), time share per entry point and each against its own roofline
+            kt2 = KernelTimer(lib, torch)
+            tr2e = HotPathTrainer(m2, optimizer='sgd', use_graph=False)
+            tr2e.bucket, tr2e.state = tr2.bucket, tr2.state
+            try:
+                tr2e._eager_step(x, t)
+                kt2.install([n for n in _lib.SIGNATURES if n.startswith(('da_conv', 'da_bn_fwd', 'da_bn_bwd', 'da_concat', 'da_slice',
+                                                                         'da_avgpool', 'da_pool', 'da_stem_conv', 'da_clamp',
+                                                                         'da_wgrad_reduce', 'da_bn_relu', 'da_bn_stats', 'da_linear',
+                                                                         'da_bce', 'da_repack_multi', 'da_bn_param', 'da_dropout'))
+                             and n not in ('da_conv_wgrad_workspace', 'da_conv_wgrad_splits', 'da_conv_wgrad_plan')])
+                for _ in range(3):
+                    tr2e._eager_step(x, t)
+                s2 = kt2.summary()
+            finally:
+                kt2.remove()
+            tot2 = sum(v['total_ms'] for v in s2.values())
+            dn = out['extra']['densenet18']
+            dn['launches_per_step'] = sum(v['calls'] for v in s2.values()) // 3
+            dn['kernel_time_share'] = {k: round(v['total_ms'] / tot2, 4) for k, v in sorted(s2.items(), key=lambda kv: -kv[1]['total_ms'])[:12]}
+            dn['kernel_roofline'] = {}
+            for k, v in s2.items():
+                if v['flops']:
+                    dn['kernel_roofline'][k] = {'tflops': round(v['flops'] / v['total_ms'] / 1e9, 1),
+                                                'frac_mfma': round(v['flops'] / v['total_ms'] / 1e9 / PEAK_FP32_MFMA_TFLOPS, 3),
+                                                'frac_hbm': round(v['bytes'] / v['total_ms'] / 1e6 / PEAK_HBM_GBS, 3)}
+                elif v['bytes']:
+                    dn['kernel_roofline'][k] = {'gbs': round(v['bytes'] / v['total_ms'] / 1e6, 1),
+                                                'frac_hbm': round(v['bytes'] / v['total_ms'] / 1e6 / PEAK_HBM_GBS, 3)}
+            dn['eager_kernel_ms_per_step'] = round(tot2 / 3, 3)
         say('densenet18 extra done')
 
     if world == 1 and not args.no_extra and args.backbone == 'resnet18' and args.dtype == 'f32' and not c5_shape:
