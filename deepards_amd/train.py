@@ -126,6 +126,32 @@ def gather_fold_results(patient_results, is_group_leader):
     return merged
 
 
+def average_replica_buffers(model, world_size, group=None):
+    """Data parallel: the ResNet running statistics are updated from each rank's OWN window shard, so they drift apart
+    between replicas (parameters do not: identical reduced gradients).  Nothing on this path reads them (the reference never
+    calls eval(), SURVEY finding 4), but a checkpoint should not depend on which rank wrote it: before a save every floating
+    buffer is replaced by its mean over the ranks, integer buffers (num_batches_tracked: equal shard sizes, so
+    equal counts) by rank 0's.  One flat all-reduce per dtype."""
+    if world_size == 1:
+        return
+    import torch.distributed as dist
+    floats = [b for b in model.buffers() if b.is_floating_point()]
+    if floats:
+        flat = torch.cat([b.detach().reshape(-1).float() for b in floats])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat /= world_size
+        off = 0
+        with torch.no_grad():
+            for b in floats:
+                n = b.numel()
+                b.copy_(flat[off:off + n].view(b.shape).to(b.dtype))
+                off += n
+    ints = [b for b in model.buffers() if not b.is_floating_point()]
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    for b in ints:
+        dist.broadcast(b, src=src, group=group)
+
+
 def _logits(out):
     """CNNLSTMNetwork returns (logits, (hx, cx)); every batch starts from a zero state here (the reference's stateful
     per-patient carry, train_ards_detector.py:845-849, is the caller's loop: pass hx_cx to the model yourself)."""

@@ -470,8 +470,13 @@ class BaseTraining(object):
         return self.results
 
     def _save(self, model, path):
-        """``torch.save(model, model_path)`` (:364,374): the whole module; under data parallelism rank 0 writes."""
-        if self._data_parallel()[1] != 0:
+        """``torch.save(model, model_path)`` (:364,374): the whole module; under data parallelism the replicas' BatchNorm
+        running statistics (updated from each rank's own shard) are averaged first, then rank 0 of the group writes."""
+        world, rank, group = self._data_parallel()
+        if world > 1:
+            from .train import average_replica_buffers
+            average_replica_buffers(model, world, group)
+        if rank != 0:
             return
         os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
         torch.save(model, path)

@@ -318,10 +318,17 @@ def _fold_group_worker(rank, world, port, q):
     w = model.linear_final.weight.detach().clone()
     torch.manual_seed(900 + rank)
     perm = torch.randperm(12, generator=shared_generator(tr, None))
+    # checkpoint-time averaging of the replicas' running statistics inside the sub-group
+    from deepards_amd.train import average_replica_buffers
+    bn = torch.nn.BatchNorm1d(4)
+    bn.running_mean.fill_(float(rank))
+    bn.num_batches_tracked.fill_(7 + rank)
+    average_replica_buffers(bn, gworld, group)
+    avg = (float(bn.running_mean[0]), int(bn.num_batches_tracked))
     res = {(f, 1): {'votes': np.full((3, 2), 10 * f + grank)} for f in folds}
     merged = gather_fold_results(res, grank == 0)
     q.put((rank, gworld, grank, folds, float(bucket.g[0]), w.numpy(), perm.numpy(),
-           sorted(merged), {k: int(v['votes'][0, 0]) for k, v in merged.items()}))
+           sorted(merged), {k: int(v['votes'][0, 0]) for k, v in merged.items()}, avg))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -353,6 +360,7 @@ def test_fold_groups_times_data_parallel_subgroups_gloo_world4():
     assert np.array_equal(res[0][5], res[1][5]) and np.array_equal(res[2][5], res[3][5])      # each group holds ITS leader's weights
     assert not np.array_equal(res[0][5], res[2][5])
     assert np.array_equal(res[0][6], res[1][6]) and np.array_equal(res[2][6], res[3][6])      # one permutation per group
+    assert [r[9] for r in res] == [(0.5, 7), (0.5, 7), (2.5, 9), (2.5, 9)]   # running stats: group mean; counters: the leader's
     for r in res:                                                         # every rank: all five folds, the leaders' numbers
         assert r[7] == [(f, 1) for f in range(5)]
         assert r[8] == {(f, 1): 10 * f for f in range(5)}
