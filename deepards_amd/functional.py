@@ -325,6 +325,7 @@ class StemFunction(Function):
         ctx.gt = _tgt(w, gamma, beta)
         if want_out3:                               # (handle, x3 data): see "the x3 flow" above
             ctx.mark_non_differentiable(out)
+            ctx.set_materialize_grads(False)        # (or autograd fills a zero "gradient" of the x3 tensor every backward)
             return x3_handle(out), out
         return out
 
@@ -364,6 +365,7 @@ class DoubleStemFunction(Function):
         ctx.gt = _tgt(wa, g1, b1, w2, g2, b2)
         if want_out3:
             ctx.mark_non_differentiable(out)
+            ctx.set_materialize_grads(False)
             return x3_handle(out), out
         return out
 
@@ -471,6 +473,7 @@ class BasicBlockFunction(Function):
         ctx.save_for_backward(*saved)
         if want_out3:
             ctx.mark_non_differentiable(out)
+            ctx.set_materialize_grads(False)
             return x3_handle(out), out
         return out
 
