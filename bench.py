@@ -464,7 +464,7 @@ def main():
     if not np_isfinite(loss):
         raise SystemExit('bench: the loss went non-finite (%r) -- the step is broken, no number is reported' % loss)
     if world > 1:
-        # the exchange step alone: the eager all-reduce of the flat gradient bucket between the two graph replays
+        # the exchange step alone: 20 eager all-reduces of the flat gradient bucket, back to back
         torch.cuda.synchronize()
         barrier()
         t0 = time.perf_counter()
@@ -476,7 +476,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         out['allreduce_ms'] = round(1e3 * float(tt), 4)
         out['allreduce_bytes'] = int(tr.bucket.numel * 4)
-        out['allreduce_exposed'] = True            # issued between the two captured graphs, not overlapped with backward
+        # round 3: under RCCL the all-reduce is a node of the captured step graph (no host round trip, no extra launches); it still
+        # runs AFTER the backward it reduces (not overlapped).  The two-graph form (eager all-reduce between two replays) is the fallback.
+        out['allreduce_in_graph'] = bool(getattr(tr, 'allreduce_in_graph', False))
+        out['allreduce_exposed'] = True
     if rehearse:
         out['rehearsal'] = 'gloo: %d ranks sharing %d GPU(s); throughput is NOT a measurement' % (world, torch.cuda.device_count())
     step_flops = w['flops'] * B * NB
