@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(_HERE, 'libdeepards_hip.so')
+LIB_PATH = os.environ.get('DA_LIB_PATH') or os.path.join(_HERE, 'libdeepards_hip.so')   # (override: A/B builds, scripts/)
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'deepards_hip.h')
 SOURCES = ['conv_gemm.hip', 'conv_wino.hip', 'conv_bf16.hip', 'conv_x3.hip', 'conv_x3p.hip', 'bn.hip', 'stem_pool.hip', 'head_optim.hip']
 

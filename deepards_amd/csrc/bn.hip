@@ -40,7 +40,7 @@ template <typename AT>
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const AT* __restrict__ x, int ld, int Wn, int C,
                                                                int chunk, float* __restrict__ part) {
   __shared__ float red[(SLOTS + 1) * CG];
-  const int w = blockIdx.x, cg = blockIdx.y, pc = blockIdx.z, P = gridDim.z;
+  const int w = row_xcd_chunk(blockIdx.x, gridDim.x), cg = blockIdx.y, pc = blockIdx.z, P = gridDim.z;
   const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
   const int p_beg = pc * chunk, p_end = min(Wn, p_beg + chunk);
   const AT* base = x + (size_t)w * Wn * ld + cg * CG + q * 4;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const AT* __restrict__ x,
                                                        int relu, int chunk, const float* __restrict__ part, int P,
                                                        int schunk, float eps, float* __restrict__ mean_out,
                                                        float* __restrict__ invstd_out) {
-  const int w = blockIdx.x, cg = blockIdx.y;
+  const int w = row_xcd_chunk(blockIdx.x, gridDim.x), cg = blockIdx.y;
   const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
   const int c0 = cg * CG + q * 4;
   f32x4 mu, is;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const AT* __restrict
                                                             const float* __restrict__ beta, int mask_mode,
                                                             float* __restrict__ part) {
   __shared__ float red[(SLOTS + 1) * CG];
-  const int w = blockIdx.x, cg = blockIdx.y, pc = blockIdx.z, P = gridDim.z;
+  const int w = row_xcd_chunk(blockIdx.x, gridDim.x), cg = blockIdx.y, pc = blockIdx.z, P = gridDim.z;
   const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
   const int c0 = cg * CG + q * 4;
   f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const AT* __restrict_
                                                            const float* __restrict__ part, float* __restrict__ ds1,
                                                            float* __restrict__ ds2, const AT* __restrict__ add,
                                                            int ldadd) {
-  const int w = blockIdx.x, cg = blockIdx.y, pc = blockIdx.z, P = gridDim.z;
+  const int w = row_xcd_chunk(blockIdx.x, gridDim.x), cg = blockIdx.y, pc = blockIdx.z, P = gridDim.z;
   const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
   const int c0 = cg * CG + q * 4;
   f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const AT* __restrict
                                                             unsigned long long* __restrict__ mask) {
   __shared__ float red[16 * CG];
   constexpr int NQ = 1 << QB, CGB = 4 * NQ;            // channel quads / channels per block (32 or 16)
-  const int w = blockIdx.x, cg = blockIdx.y, P = blockDim.x >> QB;
+  const int w = row_xcd_chunk(blockIdx.x, gridDim.x), cg = blockIdx.y, P = blockDim.x >> QB;
   const int q = threadIdx.x & (NQ - 1), slot = threadIdx.x >> QB;
   const int c0 = cg * CGB + q * 4;
   const size_t base = (size_t)w * Wn;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict
                                                             const unsigned long long* __restrict__ mask) {
   __shared__ float red[16 * 2 * CG];
   constexpr int NQ = 1 << QB, CGB = 4 * NQ;            // channel quads / channels per block (32 or 16)
-  const int w = blockIdx.x, cg = blockIdx.y, P = blockDim.x >> QB;
+  const int w = row_xcd_chunk(blockIdx.x, gridDim.x), cg = blockIdx.y, P = blockDim.x >> QB;
   const int q = threadIdx.x & (NQ - 1), slot = threadIdx.x >> QB;
   const int c0 = cg * CGB + q * 4;
   // wave-uniform slab bases + 32-bit lane offsets (one SGPR pair + one VGPR per access instead of a 64-bit VGPR pair)

@@ -19,6 +19,22 @@ typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 #define DA_OK 0
 #define DA_EINVAL (-1)
 
+// Row-partitioned kernels (BatchNorm, pools: one block per window of rows) take their window from the block index the way
+// the convolutions take their tiles (conv_gemm.hip xcd_chunked): the blocks that the hardware places on XCD k (block id
+// mod 8) work on the k-th EIGHTH of the rows, so the activation rows a convolution's XCD left in its 4 MB L2 are read by
+// blocks of the same XCD, and what they write waits in the L2 the next convolution's tiles of those rows run on.
+#ifndef DA_ROW_XCD
+#define DA_ROW_XCD 1
+#endif
+__device__ __forceinline__ int row_xcd_chunk(int id, int total) {
+#if DA_ROW_XCD
+  if (total & 7) return id;
+  return (id & 7) * (total >> 3) + (id >> 3);
+#else
+  return id;
+#endif
+}
+
 // Activation storage type.  Every RLC activation / activation-gradient tensor that crosses a kernel boundary is either
 // float (default) or bf16 (da_set_act_dtype(1): BASELINE's bf16 configs; statistics, sums, parameters and their
 // gradients stay float).  Kernels that touch activations are templated on AT and launched through DA_ACT_DISPATCH;

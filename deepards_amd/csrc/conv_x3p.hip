@@ -16,6 +16,10 @@
 // x3 activation format (common.h): per position C/16 groups of [h 16 ch | m 16 ch | l 16 ch] bf16 = 96 bytes per group,
 // 6 C bytes per position: one K step (16 channels) of one panel row is ONE contiguous 96-byte run.
 //
+// Two forms of the same tiles, same MFMA order, bit-identical results: LDS-DMA staging into a 3-slot ring (the default,
+// conv3_x3p_dma_kernel below) and register staging (conv3_x3p_kernel, DA_X3_KERNEL=1: the form measured in round 3's
+// ablations).
+//
 // Block = (64 MT) positions x 64 output channels, 4 waves of (32 MT) x 32 (v_mfma_f32_32x32x16_bf16, MT accumulators);
 // MT = 2 for the full tiles, MT = 1 for the tiles of the partly filled last round (see da_conv3_x3p).  K step = 16
 // channels x 3 taps = 18 MT MFMAs per wave.  LDS per K step: the activation panel [64 MT + 2 rows + a zero row][112 B]
@@ -28,6 +32,9 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef XP_DEFAULT_KERNEL
+#define XP_DEFAULT_KERNEL 4
+#endif
 #define XP_TN 64
 #define XP_PITCH 112
 #define XP_BCHUNK (18 * 1024)                       // bytes of one (64-channel tile, K step) weight chunk
@@ -247,6 +254,185 @@ __global__ __launch_bounds__(512, 1) void conv3_x3p_kernel(ConvX3pArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA form (variant 4): the same tiles and the same MFMA order, but the operands go global -> LDS by
+// global_load_lds_dwordx4 (no VGPR round trip, no ds_write) into a ring of THREE slots: the pieces of K step k + 2 are
+// issued while step k multiplies and have a whole step to land (a counted vmcnt in front of the barrier leaves the newest
+// ones in flight).  A slot = [activation panel: 258 rows x 7 16-byte granules (6 data + 1 pad), padded to whole 1 KB
+// pieces][512 zero bytes][weight chunk 18 KB]; one wave instruction writes 64 consecutive granules from per-lane sources
+// (the lanes that fall on a pad granule fetch their left neighbour again).  A tap across a sequence edge reads zeros at
+// the address of the zero region that is congruent mod 256 to the lane's own panel address: no lane of its ds_read_b128
+// lane group sits on those banks (one shared zero row cost a conflict cycle on every such group: 28 % of the LDS cycles
+// at L = 7).  No staging phase is left, so the two waves of a SIMD are not staggered.
+// ---------------------------------------------------------------------------------------------------------------------
+#define XD_ZOFF 29696                               // 29 pieces of 1 KB hold the 258 x 112 bytes of the panel
+#define XD_BOFF (XD_ZOFF + 512)
+#define XD_SLOT (XD_BOFF + XP_BCHUNK)               // 48,640 = 190 x 256 bytes
+#define XD_LDS_BYTES (3 * XD_SLOT)                  // 145,920
+
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int MT, int WM>
+__device__ __forceinline__ void conv3_x3p_dma_body(const ConvX3pArgs& a, const int P0, const int n_blk, unsigned char* lds) {
+  constexpr int TM = 32 * MT * WM, XROWS = TM + 2, NGX = XROWS * 7;
+  constexpr int NJX = (NGX + 63) / 64, NJ = NJX + 18, NI = (NJ + 7) / 8;        // 1 KB pieces per K step; per wave
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kch = a.C >> 4;
+  const size_t xrow_bytes = (size_t)a.C * 6;
+
+  // piece j = wave + 8 i of a K step: panel granules 64 j .. 64 j + 63 (j < NJX) or 1 KB of the weight chunk
+  const unsigned char* src[NI];                     // this lane's source at K step 0
+  int dst[NI], inc[NI];                             // LDS offset of the piece in a slot (wave-uniform); bytes per K step
+  bool on[NI];
+  const long Pb = P0 > 0 ? P0 - 1 : 0;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int j = wave + 8 * i;
+    on[i] = j < NJ;
+    if (j < NJX) {
+      const int q = 64 * j + lane;
+      int r = q / 7, sl = q - r * 7;
+      r = r < XROWS ? r : XROWS - 1;
+      sl = sl < 6 ? sl : 5;
+      long P = (long)P0 - 1 + r;
+      P = P < 0 ? 0 : (P >= a.M ? a.M - 1 : P);
+      src[i] = reinterpret_cast<const unsigned char*>(a.x) + (size_t)P * xrow_bytes + sl * 16;
+      dst[i] = j * 1024;
+      inc[i] = 96;
+    } else {
+      const int jb = on[i] ? j - NJX : 0;
+      src[i] = reinterpret_cast<const unsigned char*>(a.w) + (size_t)(n_blk >> 6) * kch * XP_BCHUNK + jb * 1024 + lane * 16;
+      dst[i] = XD_BOFF + jb * 1024;
+      inc[i] = XP_BCHUNK;
+    }
+  }
+  (void)Pb;
+  auto issue = [&](int ks, int slot) {              // the pieces of K step ks -> ring slot
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (on[i])
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned char*)(src[i] + (size_t)ks * inc[i]), (lds_byte*)(lds + slot * XD_SLOT + dst[i]), 16, 0,
+                                         0);
+  };
+
+  const bool computes = wave < 2 * WM;
+  const int frow = lane & 31, kg = lane >> 5;
+  const int wm = computes ? wave >> 1 : 0, wn = wave & 1;
+  int aoff[MT][3];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const long P = (long)P0 + (wm * MT + mt) * 32 + frow;
+    const uint32_t Pc = (uint32_t)(P < a.M ? P : 0);
+    const int l = (int)(Pc - fdiv(Pc, a.divL) * (uint32_t)a.L);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const bool edge = (t == 0 && l == 0) || (t == 2 && l == a.L - 1);
+      const int o = ((wm * MT + mt) * 32 + t + frow) * XP_PITCH + kg * 16;
+      aoff[mt][t] = edge ? XD_ZOFF + (o & 255) : o;
+    }
+  }
+  const int boff = XD_BOFF + wn * 3 * 1024 + lane * 16;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  if (tid < 96) {                                   // the zero regions of the three slots (32 granules each)
+    const int sl = tid >> 5;
+    *reinterpret_cast<f32x4*>(lds + sl * XD_SLOT + XD_ZOFF + (tid & 31) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  issue(0, 0);
+  issue(kch > 1 ? 1 : 0, 1);
+  // a wave whose last piece index falls beyond the step's pieces issues NI - 1 per step: the counted wait is per wave
+  const bool all_on = on[NI - 1];
+  auto land = [&]() {                               // everything but this wave's NEWEST step of pieces has landed
+    if (all_on) vm_wait<NI>();
+    else vm_wait<NI - 1>();
+  };
+  land();                                           // step 0 (this wave's pieces; the barrier covers the others')
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int slot = 0;
+  for (int ks = 0; ks < kch; ++ks) {
+    const unsigned char* xs = lds + slot * XD_SLOT;
+    const unsigned char* bs = xs + boff;
+    {                                               // K step ks + 2 -> the slot step ks - 1 was read from (released by the last barrier)
+      const int nslot = slot == 0 ? 2 : slot - 1;
+      issue(ks + 2 < kch ? ks + 2 : kch - 1, nslot);
+    }
+    constexpr int G = 3 * MT;
+    f32x4 av[2][3], bv[2][3];
+    auto ld_frags = [&](int g) {
+      const int t = g / MT, mt = g % MT;
+      if (mt == 0) {
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) bv[t & 1][s_] = lds_read16(bs + t * 6144 + s_ * 1024);
+      }
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) av[g & 1][s_] = lds_read16(xs + aoff[mt][t] + s_ * 32);
+    };
+    if (computes) ld_frags(0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (computes && g + 1 < G) ld_frags(g + 1);
+      if (computes) {
+        const int mt = g % MT, tb = (g / MT) & 1, sl = g & 1;
+        if (g + 1 >= G) lds_wait<0>(av[sl], bv[tb]);
+        else if ((g + 1) % MT == 0) lds_wait<6>(av[sl], bv[tb]);
+        else lds_wait<3>(av[sl], bv[tb]);
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bv[tb][0]), bm = __builtin_bit_cast(bf16x8, bv[tb][1]),
+                     bl = __builtin_bit_cast(bf16x8, bv[tb][2]);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, av[sl][0]), am = __builtin_bit_cast(bf16x8, av[sl][1]),
+                     al = __builtin_bit_cast(bf16x8, av[sl][2]);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mt], 0, 0, 0);      // small terms first
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    land();                                         // step ks + 1 has landed; step ks + 2 stays in flight across the barrier
+    __builtin_amdgcn_s_barrier();
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  vm_wait<0>();
+
+  if (computes) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long P = (long)P0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+        if (P < a.M) {
+          float* o = a.y + P * a.ldy + n_blk + wn * 32 + frow;
+          float v = acc[mt][r];
+          if (a.accumulate) v += *o;
+          *o = v;
+        }
+      }
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void conv3_x3p_dma_kernel(ConvX3pArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];      // XD_LDS_BYTES
+  const int ntn = a.N / XP_TN;
+  const int tail_blocks = 4 * a.tail_m * ntn;
+  if ((int)blockIdx.x < tail_blocks) {
+    const int id = xcd_chunked_xp(blockIdx.x, tail_blocks);
+    conv3_x3p_dma_body<1, 2>(a, a.full_m * XP_TM + (id / ntn) * 64, (id % ntn) * XP_TN, lds);
+  } else {
+    const int tile = xcd_chunked_xp(blockIdx.x - tail_blocks, a.full_m * ntn);
+    conv3_x3p_dma_body<2, 4>(a, (tile / ntn) * XP_TM, (tile % ntn) * XP_TN, lds);
+  }
+}
+
 // Variant 2 (DA_X3_KERNEL=2, A/B measurements): 128 x 64 tiles on 4 waves, TWO resident blocks per CU (66 KB of LDS each);
 // the SIMD partners are then waves of two different blocks, which cannot share a barrier -- the blocks of the first
 // resident round stage before their MFMAs, those of the second after (blockIdx / 256 decides: speed only).
@@ -308,7 +494,7 @@ int da_conv3_x3p(const void* x, const void* wpk, float* y, int rows, int L, int 
   static int g_kernel = 0;
   if (!g_kernel) {
     const char* e = getenv("DA_X3_KERNEL");
-    g_kernel = e ? atoi(e) : 1;
+    g_kernel = e ? atoi(e) : XP_DEFAULT_KERNEL;
   }
   if (g_kernel == 2) {
     static bool attr2 = false;
@@ -347,6 +533,18 @@ int da_conv3_x3p(const void* x, const void* wpk, float* y, int rows, int L, int 
   a.tail_m = (int)tail_m;
   a.full_m = (int)(mtiles - tail_m);
   const long blocks = (long)a.full_m * ntn + 4l * tail_m * ntn;
+  if (g_kernel == 4) {
+    static bool attr4 = false;
+    if (!attr4) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_x3p_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              XD_LDS_BYTES) != hipSuccess)
+        return DA_EINVAL;
+      attr4 = true;
+    }
+    hipLaunchKernelGGL(conv3_x3p_dma_kernel, dim3((unsigned)blocks), dim3(512), XD_LDS_BYTES, stream, a);
+    DA_CHECK_LAUNCH();
+    return DA_OK;
+  }
   hipLaunchKernelGGL(conv3_x3p_kernel, dim3((unsigned)blocks), dim3(512), XP_LDS_BYTES, stream, a);
   DA_CHECK_LAUNCH();
   return DA_OK;
