@@ -96,6 +96,8 @@ SIGNATURES = {
     'da_pack_conv3_bf16': (_I, [_P, _P, _P, _I, _I, _P]),
     'da_conv3_x3': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'da_conv3_x3p': (_I, [_P, _P, _P] + [_I] * 6 + [_P]),
+    'da_conv_x3p_s2_fwd': (_I, [_P] * 5 + [_I] * 4 + [_P]),
+    'da_conv_x3p_s2_dgrad': (_I, [_P] * 5 + [_I] * 4 + [_P]),
     'da_x3_split': (_I, [_P, _I, _P, _Z, _I, _P]),
     'da_x3_merge': (_I, [_P, _P, _I, _Z, _I, _P]),
     'da_pack_conv3_x3': (_I, [_P, _P, _P, _I, _I, _P]),

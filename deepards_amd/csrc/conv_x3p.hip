@@ -452,6 +452,211 @@ __global__ __launch_bounds__(512, 1) void conv3_x3p_dma_kernel(ConvX3pArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The stride-2 block entry on x3 operands: the k3 s2 p1 conv and the 1x1 s2 downsample conv of a BasicBlock read the same
+// input (reference models/resnet.py:16-19,27-29,123-131), their data gradients add into the same dx -- ONE launch each
+// way, same ring / DMA / pipelining as conv3_x3p_dma_body.  Units u = row * Lout + j (the stride-2 side, Lin = 2 Lout):
+//   forward   y1[u] = W1[0] x[2u-1] + W1[1] x[2u] + W1[2] x[2u+1],   yd[u] = Wd x[2u]           (x[2u-1] = 0 at j = 0)
+//   backward  dx[2u] = W1[1]' dy1[u] + Wd' dyd[u],   dx[2u+1] = W1[2]' dy1[u] + W1[0]' dy1[u+1]   (dy1[u+1] = 0 at j = Lout-1)
+// Both are FOUR 32 x 32 products per wave and K step over THREE operand fragments -- A0 = class-A row i, A1 = class-B row
+// i, A2 = class-A row i + 1 -- where class A / B are what the panel holds: forward the odd / even input positions
+// (de-interleaved by the DMA's source addresses: every tap reads unit-stride LDS rows), backward dy1 / dyd.  Tile =
+// 128 units x 64 output channels (two accumulators per wave); the weights of a K step are the k3 chunk (18 KB,
+// repack code 49) and tap 1 of the chunk that holds the 1x1 weights (6 KB).
+// ---------------------------------------------------------------------------------------------------------------------
+#define S2_WOFF 29696                               // panel: (TU + 1) + TU rows x 112 bytes, padded to 29 KB
+#define S2_SLOT (S2_WOFF + XP_BCHUNK + 6144)        // 54,272 = 212 x 256 bytes
+#define S2_ZOFF (3 * S2_SLOT)                       // ONE zero region behind the ring (a lane that reads it takes no slot base)
+#define S2_LDS_BYTES (S2_ZOFF + 512)                // 163,328 of 163,840
+
+struct ConvX3pS2Args {
+  const __bf16* xa;     // class A operand, x3 format: forward x, backward dy1
+  const __bf16* xb;     // class B operand: forward x, backward dyd
+  const __bf16* w1;     // k3 weights, repack code 49: forward pack / data-gradient pack
+  const __bf16* wd;     // 1x1 weights in tap 1 of a code-49 pack
+  float* y0;            // forward y1 [M][N]; backward dx [2 M][N]
+  float* y1;            // forward yd [M][N]; backward unused
+  int M, Lu, K, N;      // units, units per sequence, contraction channels, output channels of this launch
+  int full_m, tail_m;   // as ConvX3pArgs: tiles of 128 units; the partly filled last round as tiles of 64, first in the launch
+  FastDiv divLu;
+};
+
+template <bool DGRAD, int WM>
+__device__ __forceinline__ void conv_x3p_s2_body(const ConvX3pS2Args& a, const int u0, const int n_blk, unsigned char* lds) {
+  constexpr int TU = 32 * WM, RB = TU + 1, XROWS = 2 * TU + 1, NGX = XROWS * 7;   // class B rows start at RB
+  constexpr int NJX = (NGX + 63) / 64, NJ = NJX + 24, NI = (NJ + 7) / 8;
+  constexpr int G = 4, PER = (NI + G - 2) / (G - 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kch = a.K >> 4;
+  const size_t row_bytes = (size_t)a.K * 6;
+  const long pmax = DGRAD ? (long)a.M - 1 : 2l * a.M - 1;
+
+  const unsigned char* src[NI];
+  int dst[NI], inc[NI];
+  bool on[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int j = wave + 8 * i;
+    on[i] = j < NJ;
+    if (j < NJX) {
+      const int q = 64 * j + lane;
+      int r = q / 7, sl = q - r * 7;
+      r = r < XROWS ? r : XROWS - 1;
+      sl = sl < 6 ? sl : 5;
+      const bool cb = r >= RB;
+      const long u = (long)u0 + (cb ? r - RB : r);
+      long P = DGRAD ? u : (cb ? 2 * u : 2 * u - 1);
+      P = P < 0 ? 0 : (P > pmax ? pmax : P);
+      src[i] = reinterpret_cast<const unsigned char*>(cb ? a.xb : a.xa) + (size_t)P * row_bytes + sl * 16;
+      dst[i] = j * 1024;
+      inc[i] = 96;
+    } else {
+      const int jb = on[i] ? j - NJX : 0;             // 0 .. 17: the k3 chunk; 18 .. 23: tap 1 of the 1x1 chunk
+      const size_t chunk0 = (size_t)(n_blk >> 6) * kch * XP_BCHUNK;
+      src[i] = jb < 18 ? reinterpret_cast<const unsigned char*>(a.w1) + chunk0 + jb * 1024 + lane * 16
+                       : reinterpret_cast<const unsigned char*>(a.wd) + chunk0 + 6144 + (jb - 18) * 1024 + lane * 16;
+      dst[i] = S2_WOFF + jb * 1024;
+      inc[i] = XP_BCHUNK;
+    }
+  }
+  auto issue1 = [&](int i, int ks, int slot) {
+    if (on[i])
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned char*)(src[i] + (size_t)ks * inc[i]),
+                                       (lds_byte*)(lds + slot * S2_SLOT + dst[i]), 16, 0, 0);
+  };
+  const bool all_on = on[NI - 1];
+  auto land = [&]() {
+    if (all_on) vm_wait<NI>();
+    else vm_wait<NI - 1>();
+  };
+
+  const bool computes = WM == 4 || wave < 2 * WM;
+  const int frow = lane & 31, kg = lane >> 5;
+  const int wm = computes ? wave >> 1 : 0, wn = wave & 1;
+  const int iu = wm * 32 + frow;                    // this lane's unit inside the tile
+  // fragment offsets inside a slot; the one fragment that can fall across a sequence edge reads the zero region instead
+  // (absolute address, congruent mod 256 to its own: conflict-free), `zsel` = 0 for such a lane and ~0 otherwise
+  const int aoffs[3] = {iu * XP_PITCH + kg * 16, (RB + iu) * XP_PITCH + kg * 16, (iu + 1) * XP_PITCH + kg * 16};
+  const long um = (long)u0 + iu;
+  const uint32_t uc = (uint32_t)(um < a.M ? um : 0);
+  const int ju = (int)(uc - fdiv(uc, a.divLu) * (uint32_t)a.Lu);
+  const bool edge = DGRAD ? ju == a.Lu - 1 : ju == 0;
+  constexpr int EF = DGRAD ? 2 : 0;                 // the fragment the edge applies to
+  const int eoff = edge ? S2_ZOFF + (aoffs[EF] & 255) : aoffs[EF];
+  const unsigned zsel = edge ? 0u : ~0u;
+  const int boff = S2_WOFF + wn * 3 * 1024 + lane * 16;
+  // groups: (A fragment, weight tap: 0 .. 2 of the k3 chunk, 3 = the 1x1 tap, accumulator)
+  constexpr int GA[2][4] = {{0, 1, 2, 1}, {0, 1, 0, 2}};
+  constexpr int GB[2][4] = {{0, 1, 2, 3}, {1, 3, 0, 2}};
+  constexpr int GC[2][4] = {{0, 0, 0, 1}, {0, 0, 1, 1}};
+  constexpr int GLA[2][4] = {{1, 1, 1, 0}, {1, 1, 0, 1}};     // does the group read a NEW A fragment
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  if (tid < 32) *reinterpret_cast<f32x4*>(lds + S2_ZOFF + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NI; ++i) issue1(i, 0, 0);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) issue1(i, kch > 1 ? 1 : 0, 1);
+  land();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  f32x4 av[3][3], bv[2][3];
+  auto ld_frags = [&](int sbase, int g) {           // sbase: byte offset of the slot
+    constexpr int D = DGRAD ? 1 : 0;
+    const int tb = GB[D][g];
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) bv[g & 1][s_] = lds_read16(lds + sbase + boff + tb * 6144 + s_ * 1024);
+    if (GLA[D][g]) {
+      const int fa = GA[D][g];
+      const int o = fa == EF ? eoff + (int)((unsigned)sbase & zsel) : aoffs[fa] + sbase;
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) av[fa][s_] = lds_read16(lds + o + s_ * 32);
+    }
+  };
+  int slot = 0;
+  if (computes) ld_frags(0, 0);
+  for (int ks = 0; ks < kch; ++ks) {
+    const int sbase = slot * S2_SLOT;
+    const int nslot = slot == 0 ? 2 : slot - 1;
+    const int nks = ks + 2 < kch ? ks + 2 : kch - 1;
+    const int slot1 = slot == 2 ? 0 : slot + 1;
+    constexpr int D = DGRAD ? 1 : 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int i = g * PER; i < (g + 1) * PER && i < NI; ++i) issue1(i, nks, nslot);
+      if (computes && g + 1 < G) ld_frags(sbase, g + 1);
+      const int fa = GA[D][g], sl = g & 1;
+      if (g + 1 < G) {
+        if (computes) {
+          if (GLA[D][g + 1]) lds_wait<6>(av[fa], bv[sl]);       // younger than group g's reads: those of group g + 1
+          else lds_wait<3>(av[fa], bv[sl]);
+        }
+      } else {
+        if (computes) lds_wait<0>(av[fa], bv[sl]);
+        land();
+        __builtin_amdgcn_s_barrier();
+        if (computes) ld_frags(slot1 * S2_SLOT, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (computes) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bv[sl][0]), bm = __builtin_bit_cast(bf16x8, bv[sl][1]),
+                     bl = __builtin_bit_cast(bf16x8, bv[sl][2]);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, av[fa][0]), am = __builtin_bit_cast(bf16x8, av[fa][1]),
+                     al = __builtin_bit_cast(bf16x8, av[fa][2]);
+        f32x16& c = acc[GC[D][g]];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);      // small terms first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    slot = slot1;
+  }
+  if (computes) lds_wait<0>(av[0], bv[0]);
+  vm_wait<0>();
+
+  if (computes) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long u = (long)u0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      if (u < a.M) {
+        const int n = n_blk + wn * 32 + frow;
+        if (DGRAD) {
+          a.y0[(size_t)(2 * u) * a.N + n] = acc[0][r];
+          a.y0[(size_t)(2 * u + 1) * a.N + n] = acc[1][r];
+        } else {
+          a.y0[(size_t)u * a.N + n] = acc[0][r];
+          a.y1[(size_t)u * a.N + n] = acc[1][r];
+        }
+      }
+    }
+  }
+}
+
+template <bool DGRAD>
+__global__ __launch_bounds__(512, 1) void conv_x3p_s2_kernel(ConvX3pS2Args a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];      // S2_LDS_BYTES
+  const int ntn = a.N / XP_TN;
+  const int tail_blocks = 2 * a.tail_m * ntn;
+  if ((int)blockIdx.x < tail_blocks) {
+    const int id = xcd_chunked_xp(blockIdx.x, tail_blocks);
+    conv_x3p_s2_body<DGRAD, 2>(a, a.full_m * 128 + (id / ntn) * 64, (id % ntn) * XP_TN, lds);
+  } else {
+    const int tile = xcd_chunked_xp(blockIdx.x - tail_blocks, a.full_m * ntn);
+    conv_x3p_s2_body<DGRAD, 4>(a, (tile / ntn) * 128, (tile % ntn) * XP_TN, lds);
+  }
+}
+
 // Variant 2 (DA_X3_KERNEL=2, A/B measurements): 128 x 64 tiles on 4 waves, TWO resident blocks per CU (66 KB of LDS each);
 // the SIMD partners are then waves of two different blocks, which cannot share a barrier -- the blocks of the first
 // resident round stage before their MFMAs, those of the second after (blockIdx / 256 decides: speed only).
@@ -498,6 +703,72 @@ extern "C" {
 // y (+)= conv1d(x, k = 3, stride 1, pad 1) per row of L positions; x: x3 format [rows * L][C/16][3][16] bf16, wpk: the
 // chunked split-bf16 pack (da_repack_desc.points = 49 / da_pack_conv3_x3p), y: [rows][L][ldy] fp32 (first N channels).
 // C % 16 == 0, N % 64 == 0.  replaces reference models/resnet.py:5-8 (conv2x2), forward and (wd pack) data gradient
+// The stride-2 block entry, forward: y1 = conv(k3, s2, p1)(x; w1), yd = conv(1x1, s2)(x; wd) from ONE read of x.
+// x3: x3 activation (rows, Lin, C), Lin even; w1pk / wdpk: forward packs of repack code 49 (the 1x1 weights in tap 1);
+// y1, yd: (rows, Lin / 2, N) fp32.
+int da_conv_x3p_s2_fwd(const void* x3, const void* w1pk, const void* wdpk, float* y1, float* yd, int rows, int Lin, int C, int N,
+                       hipStream_t stream) {
+  DA_ENTER();
+  if (!x3 || !w1pk || !wdpk || !y1 || !yd || rows < 0 || Lin < 2 || (Lin & 1) || C % 16 || C < 16 || N % XP_TN || N < XP_TN)
+    return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  const long M = (long)rows * (Lin / 2);
+  if (2 * M >= 0x7fffffffl) return DA_EINVAL;
+  ConvX3pS2Args a;
+  a.xa = a.xb = reinterpret_cast<const __bf16*>(x3);
+  a.w1 = reinterpret_cast<const __bf16*>(w1pk); a.wd = reinterpret_cast<const __bf16*>(wdpk);
+  a.y0 = y1; a.y1 = yd;
+  a.M = (int)M; a.Lu = Lin / 2; a.K = C; a.N = N;
+  a.divLu = make_fastdiv((uint32_t)a.Lu);
+  const int ntn = N / XP_TN;
+  const long mtiles = (M + 127) / 128, tiles = mtiles * ntn;
+  const long tail_m = tiles < 256 ? mtiles : (tiles % 256) / ntn;
+  a.tail_m = (int)tail_m; a.full_m = (int)(mtiles - tail_m);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3p_s2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            S2_LDS_BYTES) != hipSuccess)
+      return DA_EINVAL;
+    attr = true;
+  }
+  hipLaunchKernelGGL(conv_x3p_s2_kernel<false>, dim3((unsigned)((long)a.full_m * ntn + 2l * tail_m * ntn)), dim3(512), S2_LDS_BYTES,
+                     stream, a);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// ... and its data gradient: dx (rows, 2 Lout, C) = dgrad(k3 s2)(dy1; w1) + dgrad(1x1 s2)(dyd; wd), every position written.
+// dy1_3, dyd_3: x3 activations (rows, Lout, N); w1pk / wdpk: DATA-GRADIENT packs of repack code 49.
+int da_conv_x3p_s2_dgrad(const void* dy1_3, const void* w1pk, const void* dyd_3, const void* wdpk, float* dx, int rows, int Lout, int N,
+                         int C, hipStream_t stream) {
+  DA_ENTER();
+  if (!dy1_3 || !w1pk || !dyd_3 || !wdpk || !dx || rows < 0 || Lout < 1 || N % 16 || N < 16 || C % XP_TN || C < XP_TN) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  const long M = (long)rows * Lout;
+  if (2 * M >= 0x7fffffffl) return DA_EINVAL;
+  ConvX3pS2Args a;
+  a.xa = reinterpret_cast<const __bf16*>(dy1_3); a.xb = reinterpret_cast<const __bf16*>(dyd_3);
+  a.w1 = reinterpret_cast<const __bf16*>(w1pk); a.wd = reinterpret_cast<const __bf16*>(wdpk);
+  a.y0 = dx; a.y1 = nullptr;
+  a.M = (int)M; a.Lu = Lout; a.K = N; a.N = C;
+  a.divLu = make_fastdiv((uint32_t)Lout);
+  const int ntn = C / XP_TN;
+  const long mtiles = (M + 127) / 128, tiles = mtiles * ntn;
+  const long tail_m = tiles < 256 ? mtiles : (tiles % 256) / ntn;
+  a.tail_m = (int)tail_m; a.full_m = (int)(mtiles - tail_m);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3p_s2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            S2_LDS_BYTES) != hipSuccess)
+      return DA_EINVAL;
+    attr = true;
+  }
+  hipLaunchKernelGGL(conv_x3p_s2_kernel<true>, dim3((unsigned)((long)a.full_m * ntn + 2l * tail_m * ntn)), dim3(512), S2_LDS_BYTES,
+                     stream, a);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
 int da_conv3_x3p(const void* x, const void* wpk, float* y, int rows, int L, int C, int ldy, int N, int accumulate,
                  hipStream_t stream) {
   DA_ENTER();

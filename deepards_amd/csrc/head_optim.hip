@@ -320,7 +320,8 @@ __global__ __launch_bounds__(256) void repack_tiled_kernel(RepackTable t) {
         } else if (d.points == 48) {                              // split-bf16 fragment packs of conv_x3.hip (K == 3)
           for (int k = 0; k < 3; ++k) x3_pack_put(reinterpret_cast<__bf16*>(d.Uf), k, co0 + a, ci0 + b, d.Co, d.Ci, w[k]);
         } else if (d.points == 49) {                              // chunked split-bf16 packs of conv_x3p.hip (K == 3)
-          for (int k = 0; k < 3; ++k) x3p_pack_put(reinterpret_cast<__bf16*>(d.Uf), k, co0 + a, ci0 + b, d.Co, d.Ci, w[k]);
+          if (K == 1) x3p_pack_put(reinterpret_cast<__bf16*>(d.Uf), 1, co0 + a, ci0 + b, d.Co, d.Ci, w[0]);   // 1x1: tap 1 only (conv_x3p_s2)
+          else for (int k = 0; k < 3; ++k) x3p_pack_put(reinterpret_cast<__bf16*>(d.Uf), k, co0 + a, ci0 + b, d.Co, d.Ci, w[k]);
         } else {
           emit_wino_taps(d.Uf + o, tot, w[0], w[1], w[2], d.points);
         }
@@ -339,7 +340,8 @@ __global__ __launch_bounds__(256) void repack_tiled_kernel(RepackTable t) {
         } else if (d.points == 48) {                              // n = ci, c = co, taps reversed
           for (int k = 0; k < 3; ++k) x3_pack_put(reinterpret_cast<__bf16*>(d.Ud), k, ci0 + a, co0 + b, d.Ci, d.Co, w[2 - k]);
         } else if (d.points == 49) {
-          for (int k = 0; k < 3; ++k) x3p_pack_put(reinterpret_cast<__bf16*>(d.Ud), k, ci0 + a, co0 + b, d.Ci, d.Co, w[2 - k]);
+          if (K == 1) x3p_pack_put(reinterpret_cast<__bf16*>(d.Ud), 1, ci0 + a, co0 + b, d.Ci, d.Co, w[0]);
+          else for (int k = 0; k < 3; ++k) x3p_pack_put(reinterpret_cast<__bf16*>(d.Ud), k, ci0 + a, co0 + b, d.Ci, d.Co, w[2 - k]);
         } else {
           emit_wino_taps(d.Ud + o, tot, w[2], w[1], w[0], d.points);
         }
@@ -895,9 +897,9 @@ int da_repack_multi(const da_repack_desc* descs, int n, hipStream_t stream) {
     int m = n - base < 32 ? n - base : 32;
     for (int i = 0; i < m; ++i) {
       const da_repack_desc& s = descs[base + i];
-      if (!s.W || (!s.Wf && !s.Wd && !s.Uf && !s.Ud) || ((s.Uf || s.Ud) && s.K != 3 && s.points != 16)) return DA_EINVAL;
+      if (!s.W || (!s.Wf && !s.Wd && !s.Uf && !s.Ud) || ((s.Uf || s.Ud) && s.K != 3 && s.points != 16 && s.points != 49)) return DA_EINVAL;
       if ((s.points == 16 || s.points == 48 || s.points == 49) && (s.Co % 32 || s.Ci % 32)) return DA_EINVAL;   // bf16 packs: tiled kernel only
-      if ((s.points == 48 || s.points == 49) && s.K != 3) return DA_EINVAL;
+      if ((s.points == 48 && s.K != 3) || (s.points == 49 && s.K != 3 && s.K != 1)) return DA_EINVAL;
       if (s.points == 49 && (s.Co % 64 || s.Ci % 64)) return DA_EINVAL;
       t.d[i] = {s.W, s.Wf, s.Wd, s.Uf, s.Ud, s.Co, s.Ci, s.K, s.points};
     }

@@ -254,6 +254,45 @@ def conv3_x3p(x3, wpk, out=None, accumulate=False):
     return out
 
 
+def _x3p_pack_ok(pk, nt, kc):
+    return pk.dim() == 5 and tuple(pk.shape) == (nt, kc, 18, 64, 8) and pk.dtype == torch.bfloat16 and pk.is_contiguous()
+
+
+def conv_x3p_s2_fwd(x3, w1pk, wdpk):
+    """The stride-2 block entry on x3 operands: (y1, yd) = (conv k3 s2 p1, conv 1x1 s2) of the x3 activation
+    (rows, Lin, C/16, 3, 16), Lin even, from ONE read of it.  w1pk / wdpk: forward packs of repack_multi code 49
+    (N/64, C/16, 18, 64, 8), the 1x1 weights packed with K = 1 (tap 1 of the chunks)."""
+    if not (is_x3(x3) and x3.is_cuda and x3.is_contiguous()):
+        raise ValueError('conv_x3p_s2_fwd: a contiguous x3 CUDA tensor expected')
+    rows, lin, g = x3.shape[:3]
+    if lin % 2 or not _x3p_pack_ok(w1pk, w1pk.shape[0], g) or not _x3p_pack_ok(wdpk, w1pk.shape[0], g):
+        raise ValueError('conv_x3p_s2_fwd: unsupported shape x%s w1%s wd%s' % (tuple(x3.shape), tuple(w1pk.shape), tuple(wdpk.shape)))
+    n = w1pk.shape[0] * 64
+    y1 = torch.empty((rows, lin // 2, n), device=x3.device, dtype=torch.float32)
+    yd = torch.empty_like(y1)
+    _chk(_lib.lib().da_conv_x3p_s2_fwd(_p(x3), _p(w1pk), _p(wdpk), _p(y1), _p(yd), rows, lin, g * 16, n, _stream()), 'da_conv_x3p_s2_fwd')
+    return y1, yd
+
+
+def conv_x3p_s2_dgrad(dy1_3, w1pk, dyd_3, wdpk, out=None):
+    """dx (rows, 2 Lout, C) fp32 = the data gradients of the two convs of conv_x3p_s2_fwd, summed; dy1_3 / dyd_3 x3
+    activations (rows, Lout, N/16, 3, 16), packs: the DATA-GRADIENT side of repack_multi code 49 (C/64, N/16, 18, 64, 8)."""
+    for t in (dy1_3, dyd_3):
+        if not (is_x3(t) and t.is_cuda and t.is_contiguous()):
+            raise ValueError('conv_x3p_s2_dgrad: contiguous x3 CUDA tensors expected')
+    rows, lout, g = dy1_3.shape[:3]
+    if tuple(dyd_3.shape) != tuple(dy1_3.shape) or not _x3p_pack_ok(w1pk, w1pk.shape[0], g) or not _x3p_pack_ok(wdpk, w1pk.shape[0], g):
+        raise ValueError('conv_x3p_s2_dgrad: unsupported shapes')
+    c = w1pk.shape[0] * 64
+    if out is None:
+        out = torch.empty((rows, 2 * lout, c), device=dy1_3.device, dtype=torch.float32)
+    elif tuple(out.shape) != (rows, 2 * lout, c) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError('conv_x3p_s2_dgrad: bad out')
+    _chk(_lib.lib().da_conv_x3p_s2_dgrad(_p(dy1_3), _p(w1pk), _p(dyd_3), _p(wdpk), _p(out), rows, lout, g * 16, c, _stream()),
+         'da_conv_x3p_s2_dgrad')
+    return out
+
+
 def _conv_bf16_multi(jobs):
     """jobs: [(x, wpk, out, lm, lsrc, ldst, dst_stride, dst_off, src_stride, src_off, wtap, accumulate)] in one call."""
     arr = (_lib.ConvJob * len(jobs))()
@@ -533,7 +572,7 @@ def repack_multi(weights, winograd=None):
         co, ci, k = w.shape
         code = winograd[n] if winograd is not None else 0
         wino = bool(code)
-        if wino and k != 3 and not (code == 16 and k == 1):
+        if wino and k != 3 and not (code in (16, 49) and k == 1):
             raise ValueError('winograd taps need a 3-tap weight')
         pts = code if wino and code in (6, 16, 48, 49) else 4
         mk = lambda *shape: torch.empty(shape, device=w.device, dtype=torch.float32)

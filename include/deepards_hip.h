@@ -120,6 +120,16 @@ int da_pack_conv3_x3(const float* w, void* wf, void* wd, int co, int ci, da_stre
  * x3 format, y fp32; wpk: the chunked split-bf16 pack -- (N/64) x (C/16) chunks of 18 KB laid out
  * [3 taps][2 halves of 32 outputs][3 terms][64 lanes][8 bf16] -- which da_repack_desc.points = 49 emits (Uf forward,
  * Ud data gradient; Co, Ci multiples of 64).  C % 16 == 0, N % 64 == 0. */
+/* The stride-2 block entry on x3 operands (conv arithmetic 'f32x3p'), ONE launch each way:
+ * forward   y1 = Conv1d(C, N, 3, stride 2, pad 1)(x) and yd = Conv1d(C, N, 1, stride 2)(x)   -- reference
+ *           models/resnet.py:16-19 (conv3x3 stride 2), :27-29, :123-131 (downsample) on the same block input;
+ * backward  dx = their two data gradients summed, every position written.
+ * x3 / dy1_3 / dyd_3: x3 activations (da_x3_split); packs: da_repack_multi points 49 (forward / data-gradient side; the
+ * 1x1 weights pack with K = 1 into tap 1 of the chunks).  Lin even; C, N multiples of 64. */
+int da_conv_x3p_s2_fwd(const void* x3, const void* w1pk, const void* wdpk, float* y1, float* yd, int rows, int Lin, int C, int N,
+                       da_stream_t stream);
+int da_conv_x3p_s2_dgrad(const void* dy1_3, const void* w1pk, const void* dyd_3, const void* wdpk, float* dx, int rows, int Lout,
+                         int N, int C, da_stream_t stream);
 int da_conv3_x3p(const void* x, const void* wpk, float* y, int rows, int L, int C, int ldy, int N, int accumulate,
                  da_stream_t stream);
 int da_x3_split(const float* x, int ld, void* out, size_t npos, int C, da_stream_t stream);

@@ -239,3 +239,33 @@ def test_x3_flow_is_what_runs_and_matches_the_float_path_closely():
             o.sum().backward()
             assert torch.isfinite(o).all()
     assert F_.conv_dtype() == 'f32'
+
+
+S2_SHAPES = [(64, 128, 56, 40), (128, 256, 28, 40), (256, 512, 14, 40), (64, 64, 8, 3), (128, 64, 6, 77), (256, 512, 14, 1280)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ci,co,lin,rows', S2_SHAPES)
+def test_conv_x3p_s2_pair_matches_fp64(H, ci, co, lin, rows):
+    """The stride-2 block entry on x3 operands (conv_x3p_s2_kernel): the k3 s2 p1 conv and the 1x1 s2 downsample conv of
+    one launch, and their summed data gradient, against the fp64 convolutions (reference models/resnet.py:16-19,123-131);
+    bound: the fp32 direct kernels' own error scale."""
+    torch.manual_seed(ci + lin)
+    x = torch.randn(rows, lin, ci, device='cuda')
+    w1 = torch.randn(co, ci, 3, device='cuda') * (2.0 / (3 * ci)) ** 0.5
+    wd = torch.randn(co, ci, 1, device='cuda') * (2.0 / ci) ** 0.5
+    (_, _, uf1, ud1), (_, _, ufd, udd) = H.repack_multi([w1, wd], [49, 49])
+    y1, yd = H.conv_x3p_s2_fwd(H.x3_split(x), uf1, ufd)
+    xd = x.double().permute(0, 2, 1)
+    r1 = torch.nn.functional.conv1d(xd, w1.double(), stride=2, padding=1).permute(0, 2, 1)
+    rd = torch.nn.functional.conv1d(xd, wd.double(), stride=2).permute(0, 2, 1)
+    e1 = float((y1.double() - r1).abs().max() / r1.abs().max())
+    ed = float((yd.double() - rd).abs().max() / rd.abs().max())
+    dy1, dyd = torch.randn_like(y1) * 1e-2, torch.randn_like(yd) * 1e-2
+    dx = H.conv_x3p_s2_dgrad(H.x3_split(dy1), ud1, H.x3_split(dyd), udd)
+    rdx = torch.nn.functional.conv_transpose1d(dy1.double().permute(0, 2, 1), w1.double(), stride=2, padding=1, output_padding=1) + \
+        torch.nn.functional.conv_transpose1d(dyd.double().permute(0, 2, 1), wd.double(), stride=2, output_padding=1)
+    rdx = rdx.permute(0, 2, 1)
+    ex = float((dx.double() - rdx).abs().max() / rdx.abs().max())
+    log('x3p s2 pair %s: fwd k3 %.2e, 1x1 %.2e, dgrad %.2e vs fp64' % ((ci, co, lin, rows), e1, ed, ex))
+    assert e1 < 3e-6 and ed < 3e-6 and ex < 3e-6
