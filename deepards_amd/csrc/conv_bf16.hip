@@ -601,8 +601,6 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradBf16Args& a, const in
 template <int NTAPS, typename AT, int NS>
 __device__ __forceinline__ void wgrad_bf16_s2_body(const WgradBf16Args& a, const int block_id, unsigned char* lds) {
   constexpr int KP = WB<NS>::KP, PITCH = WB<NS>::PITCH, XPITCH2 = WB<NS>::XPITCH2, X2ROWS = WB<NS>::X2ROWS, NP = KP / 16;
-  const AT* ady = reinterpret_cast<const AT*>(a.dy);
-  const AT* axx = reinterpret_cast<const AT*>(a.x);
   unsigned char* Ys = lds;                              // [KP][PITCH]
   unsigned char* Xs = lds + KP * PITCH;                 // [2 KP + 3][XPITCH2]: input slots 2 k0 .. 2 k0 + 2 KP + 2
 
@@ -625,7 +623,7 @@ __device__ __forceinline__ void wgrad_bf16_s2_body(const WgradBf16Args& a, const
       const int j = (ok ? Pp : 0) - (int)sq * L1;
       ok = ok && j < a.L;
       typename Stage<AT>::reg v = Stage<AT>::zero();
-      if (ok) v = Stage<AT>::ld(ady + ((size_t)sq * a.L + j) * a.lddy + n_blk + lq * 4);
+      if (ok) v = stage_ld<AT>(a.dy, (size_t)sq * a.L + j, a.lddy, n_blk + lq * 4);
       ry[p] = v;
     }
 #pragma unroll
@@ -637,7 +635,7 @@ __device__ __forceinline__ void wgrad_bf16_s2_body(const WgradBf16Args& a, const
       const int sl = (int)((ok ? Qp : 0) - (long)sq * Lx2);
       ok = ok && sl >= 1 && sl <= Lx;
       typename Stage<AT>::reg v = Stage<AT>::zero();
-      if (ok) v = Stage<AT>::ld(axx + ((size_t)sq * Lx + (sl - 1)) * a.ldx + c_blk + lq * 4);
+      if (ok) v = stage_ld<AT>(a.x, (size_t)sq * Lx + (sl - 1), a.ldx, c_blk + lq * 4);
       rx[p] = v;
     }
   };
@@ -758,13 +756,16 @@ __global__ __launch_bounds__(256) void wgrad_bf16_multi_kernel(WgradBf16Table t)
   else wgrad_bf16_s2_body<1, AT, NS>(t.d[i], b, lds);
 }
 
-// the k3 s1 p1 jobs on x3 operands (conv arithmetic 'f32x3', job code 49): wgrad_bf16_body with plain copies for staging
+// the jobs on x3 operands (conv arithmetic 'f32x3p', job code 49: k3 s1 p1, and the k3 s2 p1 / k1 s2 p0 jobs of the
+// stride-2 block entries): the bodies above with plain copies for staging
 __global__ __launch_bounds__(256) void wgrad_x3p_multi_kernel(WgradBf16Table t) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[WB<3>::LDS_BYTES];
   int i = 0;
   while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
   const int b = xcd_chunked_bf(blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i]);
-  wgrad_bf16_body<X3T, 3>(t.d[i], b, lds);
+  if (t.d[i].mode == 0) wgrad_bf16_body<X3T, 3>(t.d[i], b, lds);
+  else if (t.d[i].mode == 1) wgrad_bf16_s2_body<3, X3T, 3>(t.d[i], b, lds);
+  else wgrad_bf16_s2_body<1, X3T, 3>(t.d[i], b, lds);
 }
 
 // jobs the bf16 kernels take: channel counts multiples of 64 and  k3 s1 p1 | k3 s2 p1 | k1 s2 p0 (even input length)
@@ -810,7 +811,6 @@ int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, int code, hipStream_t s) 
     const da_wgrad_job& j = jobs[i];
     if (j.winograd != code) continue;
     if ((code == 48 || code == 49) && g_act_bf16) return DA_EINVAL;      // the split kernels belong to float activations
-    if (code == 49 && j.src_stride != 1) return DA_EINVAL;               // x3 operands: the k3 s1 p1 form only
     int splits, pchunk;
     bf16_wgrad_plan(j.rows, j.Lm, &splits, &pchunk);
     WgradBf16Args& a = t.d[cnt];

@@ -98,6 +98,7 @@ _WINO4_MIN_C = int(os.environ.get('DA_WINO4_MINC', '512'))   # channels from whi
 # the PRODUCERS: the BatchNorm / pool kernels in front of a k3 s1 conv store the x3 format, conv_x3p.hip and the x3
 # weight-gradient kernel read it; forward, data gradient and weight gradient).
 _CONV_DTYPE = os.environ.get('DA_CONV_DTYPE', 'f32')
+_S2_X3 = os.environ.get('DA_X3_S2', '1') != '0'      # 'f32x3p': the stride-2 block entries on x3 operands too (A/B switch)
 CONV_DTYPES = ('f32', 'bf16', 'f32x3', 'f32x3p')
 
 
@@ -149,6 +150,14 @@ def _is_wino(w, stride, pad):
     if _CONV_DTYPE == 'f32x3p' and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
         return 49                                   # the same on x3 (pre-split) operands (conv_x3p.hip); float operands: _fp32_code
     return _fp32_code(w)
+
+
+def s2_x3_ok(w1, wd, l_in):
+    """Whether a stride-2 block entry (k3 s2 p1 conv + 1x1 s2 downsample) runs on x3 operands (conv arithmetic 'f32x3p':
+    H.conv_x3p_s2_fwd / _dgrad and the x3 weight-gradient jobs): even input length, channel counts multiples of 64."""
+    return _CONV_DTYPE == 'f32x3p' and _S2_X3 and H.act_dtype() == 'f32' and wd is not None and l_in % 2 == 0 and \
+        tuple(w1.shape[2:]) == (3,) and tuple(wd.shape[2:]) == (1,) and tuple(wd.shape[:2]) == tuple(w1.shape[:2]) and \
+        w1.shape[0] % 64 == 0 and w1.shape[1] % 64 == 0
 
 
 def _fp32_code(w):
@@ -427,7 +436,13 @@ class BasicBlockFunction(Function):
         bf16_pair = wd is not None and stride == 2 and _PAIR_S2 and x.shape[1] % 2 == 0 and \
             _is_wino(w1, stride, 1) == 16 and _is_wino(wd, stride, 0) == 16
         pair = bf16_pair or (wd is not None and stride == 2 and _PAIR_S2 and not _is_wino(w1, stride, 1))
-        if in3:           # k3 s1 conv on the pre-split input
+        s2x = in3 and stride == 2
+        if s2x:           # the stride-2 block entry on the pre-split input: conv1 and the downsample conv in one launch
+            if not s2_x3_ok(w1, wd, x3.shape[1]):
+                raise ValueError('x3 input handed to a stride-2 block whose shape has no x3 kernels')
+            y1, yd = H.conv_x3p_s2_fwd(x3, _pack(w1, 49)[2], _pack(wd, 49)[2])
+            pair = True
+        elif in3:         # k3 s1 conv on the pre-split input
             y1 = _conv_fwd(x3, w1, 1, 1)
         elif bf16_pair:   # conv dtype bf16: the same shared launch on the bf16 kernel
             y1, yd = H.conv_fwd_bf16_s2(x, _pack(w1, 16)[2], _pack(wd, 16)[2])
@@ -463,7 +478,7 @@ class BasicBlockFunction(Function):
         m1, i1, m2, i2 = s1.mean, s1.invstd, s2.mean, s2.invstd
         use_mask = mid3 or _BN_MASK
         ctx.relu_mask = s2.mask if use_mask else None       # 8 bytes per thread instead of re-reading `out` for its sign
-        ctx.has_ds, ctx.in3, ctx.mid3 = wd is not None, in3, mid3
+        ctx.has_ds, ctx.in3, ctx.mid3, ctx.s2x = wd is not None, in3, mid3, s2x
         ctx.stride, ctx.R, ctx.lin = stride, R, x.shape[1]
         ctx.gt = _tgt(w1, g1, b1, w2, g2, b2, wd, gd, bd)
         # (the float block output is only kept when the backward reads it for its sign: no bit mask)
@@ -492,7 +507,10 @@ class BasicBlockFunction(Function):
             dy2, dg2, db2, g = _bn_bwd(dout, y2, R, m2, i2, g2, b2, 2, tg2, tb2, out=out, want_g=True, mask=ctx.relu_mask)
         if ctx.has_ds:    # the downsample BatchNorm's backward right away: g is still cache-resident
             wd, gd, bd, yd, md, idd = s[15:]
-            dyd, dgd, dbd = _bn_bwd(g, yd, R, md, idd, gd, bd, 0, tgd, tbd, dx=g)
+            if ctx.s2x:       # x3: it feeds the stride-2 data-gradient and weight-gradient kernels
+                dyd, dgd, dbd = _bn_bwd_x(g, yd, R, md, idd, gd, bd, 0, tgd, tbd)
+            else:
+                dyd, dgd, dbd = _bn_bwd(g, yd, R, md, idd, gd, bd, 0, tgd, tbd, dx=g)
         dw2 = _wgrad(dy2, h1, 3, 1, 1, tw2)
         dh1 = _conv_dgrad(dy2, w2, 1, 1, y1.shape[1])
         if in3:           # conv1 is a k3 s1 conv on x3 operands too
@@ -502,7 +520,9 @@ class BasicBlockFunction(Function):
         dw1 = _wgrad(dy1, x, 3, stride, 1, tw1)
         if ctx.has_ds:
             dwd = _wgrad(dyd, x, 1, stride, 0, twd)
-            if stride == 2 and _PAIR_S2 and not _is_wino(w1, stride, 1):
+            if ctx.s2x:
+                dx = H.conv_x3p_s2_dgrad(dy1, _pack(w1, 49)[3], dyd, _pack(wd, 49)[3])
+            elif stride == 2 and _PAIR_S2 and not _is_wino(w1, stride, 1):
                 dx = H.conv_dgrad_s2_pair(dy1, _pack(w1, False)[1], dyd, _pack(wd, False)[1], lin)
             else:
                 dx = _conv_dgrad(dy1, w1, stride, 1, lin)

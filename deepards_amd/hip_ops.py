@@ -511,9 +511,11 @@ def conv_wgrad_multi(jobs):
     outs = []
     for d, (dy, x, k, stride, pad) in zip(arr, jobs):
         both_x3 = is_x3(dy) and is_x3(x)
-        if both_x3:                                   # x3 operands (conv arithmetic 'f32x3'): the k3 s1 p1 split-bf16 kernel
-            if not (dy.is_cuda and dy.is_contiguous() and x.is_contiguous() and k == 3 and stride == 1 and pad == 1):
-                raise ValueError('conv_wgrad_multi: x3 operands belong to k3 s1 p1 jobs')
+        if both_x3:                                   # x3 operands (conv arithmetic 'f32x3p'): the split-bf16 kernels
+            if not (dy.is_cuda and dy.is_contiguous() and x.is_contiguous() and (
+                    (k == 3 and stride == 1 and pad == 1) or
+                    (stride == 2 and x.shape[1] % 2 == 0 and ((k == 3 and pad == 1) or (k == 1 and pad == 0))))):
+                raise ValueError('conv_wgrad_multi: x3 operands belong to k3 s1 p1 / k3 s2 p1 / k1 s2 p0 (even length) jobs')
             rows, lo, co = dy.shape[0], dy.shape[1], dy.shape[2] * 16
             rows2, l, ci = x.shape[0], x.shape[1], x.shape[2] * 16
         else:

@@ -60,9 +60,12 @@ class BasicBlock(nn.Module):
 
     def takes_x3(self, rows, l_in, R):
         """Whether this block's conv1 reads the x3 format under the current conv arithmetic: a k3 s1 conv (no downsample)
-        on a shape that has the x3 store forms."""
-        return self.downsample is None and self.stride == 1 and \
-            F_.x3_block_ok(rows, l_in, self.conv1.in_channels, R) and F_._is_wino(self.conv1.weight, 1, 1) == 49
+        or a stride-2 block entry, on a shape that has the x3 store forms."""
+        if not F_.x3_block_ok(rows, l_in, self.conv1.in_channels, R):
+            return False
+        if self.downsample is not None:           # the stride-2 block entry: conv1 + the 1x1 downsample conv in one launch
+            return self.stride == 2 and F_.s2_x3_ok(self.conv1.weight, self.downsample[0].weight, l_in)
+        return self.stride == 1 and F_._is_wino(self.conv1.weight, 1, 1) == 49
 
 
 _POOLS = {'max': nn.MaxPool1d, 'avg': nn.AvgPool1d}

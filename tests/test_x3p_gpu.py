@@ -269,3 +269,23 @@ def test_conv_x3p_s2_pair_matches_fp64(H, ci, co, lin, rows):
     ex = float((dx.double() - rdx).abs().max() / rdx.abs().max())
     log('x3p s2 pair %s: fwd k3 %.2e, 1x1 %.2e, dgrad %.2e vs fp64' % ((ci, co, lin, rows), e1, ed, ex))
     assert e1 < 3e-6 and ed < 3e-6 and ex < 3e-6
+
+
+@pytest.mark.parametrize('ci,co,lin,rows', [(64, 128, 56, 40), (128, 256, 28, 33), (256, 512, 14, 64), (64, 64, 6, 5)])
+def test_wgrad_on_x3_operands_stride_2(H, ci, co, lin, rows):
+    """dW of the k3 s2 p1 conv and of the 1x1 s2 downsample conv from x3 operands (job code 49, modes 1 / 2 of
+    wgrad_x3p_multi_kernel), one multi launch: error vs fp64 at the fp32 kernels' scale (reference models/resnet.py:16-19,123-131)."""
+    torch.manual_seed(lin)
+    x = torch.randn(rows, lin, ci, device='cuda')
+    dy1 = torch.randn(rows, lin // 2, co, device='cuda') * 1e-2
+    dyd = torch.randn(rows, lin // 2, co, device='cuda') * 1e-2
+    x3 = H.x3_split(x)
+    s1, sd = H.conv_wgrad_multi([(H.x3_split(dy1), x3, 3, 2, 1), (H.x3_split(dyd), x3, 1, 2, 0)])
+    dw1 = torch.empty(co, ci, 3, device='cuda'); dwd = torch.empty(co, ci, 1, device='cuda')
+    H.wgrad_reduce_multi([(s1, dw1), (sd, dwd)], accumulate=False)
+    xp = torch.nn.functional.pad(x.double(), (0, 0, 1, 1))
+    r1 = torch.stack([torch.einsum('rjn,rjc->nc', dy1.double(), xp[:, t:t + lin:2][:, :lin // 2]) for t in range(3)], 2)
+    rd = torch.einsum('rjn,rjc->nc', dyd.double(), x.double()[:, 0::2])[:, :, None]
+    e1, ed = _err(dw1, r1), _err(dwd, rd)
+    log('wgrad on x3 operands, stride 2 %s: k3 %.2e, 1x1 %.2e vs fp64' % ((ci, co, lin, rows), e1, ed))
+    assert e1 < 3e-6 and ed < 3e-6
