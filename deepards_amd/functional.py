@@ -47,7 +47,7 @@ def training_step(model=None):
                   if isinstance(m, torch.nn.Conv1d) and m.kernel_size[0] <= 3 and m.in_channels % 32 == 0
                   and m.weight.is_cuda]
             ws = [m.weight for m in ms]
-            wino = [_is_wino(m.weight, m.stride[0], m.padding[0]) for m in ms]
+            wino = [_step_pack_code(m) for m in ms]
             for w, c, e in zip(ws, wino, H.repack_multi(ws, wino)):
                 _STEP['pack'][(w.data_ptr(), int(c))] = e
         yield
@@ -158,6 +158,16 @@ def s2_x3_ok(w1, wd, l_in):
     return _CONV_DTYPE == 'f32x3p' and _S2_X3 and H.act_dtype() == 'f32' and wd is not None and l_in % 2 == 0 and \
         tuple(w1.shape[2:]) == (3,) and tuple(wd.shape[2:]) == (1,) and tuple(wd.shape[:2]) == tuple(w1.shape[:2]) and \
         w1.shape[0] % 64 == 0 and w1.shape[1] % 64 == 0
+
+
+def _step_pack_code(m):
+    """The pack form the step's batched repack prepares for a conv module (a consumer that needs another form packs it
+    itself, once: _pack)."""
+    w, stride, pad = m.weight, m.stride[0], m.padding[0]
+    if _CONV_DTYPE == 'f32x3p' and _S2_X3 and H.act_dtype() == 'f32' and stride == 2 and w.shape[0] % 64 == 0 and \
+            w.shape[1] % 64 == 0 and (w.shape[2], pad) in ((3, 1), (1, 0)):
+        return 49                                   # the stride-2 block entries on x3 operands (s2_x3_ok)
+    return _is_wino(w, stride, pad)
 
 
 def _fp32_code(w):
