@@ -117,6 +117,12 @@ class KernelTimer(object):
         if name == 'da_conv3_x3p':          # x,wpk,y,rows,L,C,ldy,N,accumulate: x3 input (6 B / element), fp32 output, 18 B / weight
             return (2.0 * a[3] * a[4] * a[5] * a[7] * 3,
                     6.0 * a[3] * a[4] * a[5] + 4.0 * a[3] * a[4] * a[7] * (2 if a[8] else 1) + 18.0 * a[5] * a[7])
+        if name == 'da_conv_x3p_s2_fwd':    # x3,w1pk,wdpk,y1,yd,rows,Lin,C,N: 4 taps (k3 + 1x1) over rows * Lin / 2 outputs
+            return (2.0 * a[5] * (a[6] // 2) * a[7] * a[8] * 4,
+                    6.0 * a[5] * a[6] * a[7] + 2 * 4.0 * a[5] * (a[6] // 2) * a[8] + 4 * 6.0 * a[7] * a[8])
+        if name == 'da_conv_x3p_s2_dgrad':  # dy1_3,w1pk,dyd_3,wdpk,dx,rows,Lout,N,C
+            return (2.0 * a[5] * a[6] * a[7] * a[8] * 4,
+                    2 * 6.0 * a[5] * a[6] * a[7] + 4.0 * a[5] * 2 * a[6] * a[8] + 4 * 6.0 * a[7] * a[8])
         if name == 'da_conv_wgrad_multi':   # jobs (host array of da_wgrad_job), n; x3 operands (code 49) are 6 bytes / element
             j = a[0]
             return (sum(2.0 * j[i].rows * j[i].Lm * j[i].N * j[i].C * j[i].ntaps for i in range(a[1])),
@@ -536,8 +542,10 @@ def main():
             'da_conv3_bf16': 'conv3_bf16_kernel (k3 s1 conv forward + data gradient, v_mfma_f32_32x32x16_bf16)',
             'da_conv3_x3': 'conv3_x3_kernel (k3 s1 conv forward + data gradient, fp32 products as six v_mfma_f32_32x32x16_bf16 of '
                            'three-term splits; peak = the bf16 MFMA peak / 6)',
-            'da_conv3_x3p': 'conv3_x3p_kernel (k3 s1 conv forward + data gradient on pre-split (x3) operands: fp32 products as six '
-                            'v_mfma_f32_32x32x16_bf16 of exact three-term splits, no VALU in the K loop; peak = the bf16 MFMA peak / 6)',
+            'da_conv3_x3p': 'conv3_x3p_dma_kernel (k3 s1 conv forward + data gradient on pre-split (x3) operands: fp32 products as six '
+                            'v_mfma_f32_32x32x16_bf16 of exact three-term splits, operands by LDS-DMA, no VALU in the K loop; peak = the bf16 MFMA peak / 6)',
+            'da_conv_x3p_s2_fwd': 'conv_x3p_s2_kernel<false> (stride-2 block entry: k3 s2 conv + 1x1 s2 downsample in one launch, x3 operands)',
+            'da_conv_x3p_s2_dgrad': 'conv_x3p_s2_kernel<true> (their summed data gradient, x3 operands)',
             'da_conv_bf16_multi': 'conv_bf16_gen_kernel<*> (stride-2 / 1x1 convs, bf16 operands)',
             'da_bn_fwd': 'bn_fwd_fused_kernel<*> (per-window BatchNorm (+ReLU)(+residual) forward, single pass)',
             'da_bn_fwd_mask': 'bn_fwd_fused_kernel<*> (block-output BatchNorm + residual + ReLU forward, ReLU bit mask)',
@@ -556,6 +564,7 @@ def main():
         }
         PEAK = {'da_conv3_bf16': PEAK_BF16_MFMA_TFLOPS, 'da_conv_bf16_multi': PEAK_BF16_MFMA_TFLOPS,
                 'da_conv3_x3': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1), 'da_conv3_x3p': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1),
+                'da_conv_x3p_s2_fwd': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1), 'da_conv_x3p_s2_dgrad': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1),
                 'da_conv_wgrad_multi[code49]': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1), 'da_conv_wgrad_multi[code48]': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1),
                 'da_conv_wgrad_multi[code16]': PEAK_BF16_MFMA_TFLOPS}
         cands = [k for k in summ if k in KERNEL_OF and (summ[k]['flops'] or summ[k]['bytes'])]

@@ -17,8 +17,8 @@
 // 6 C bytes per position: one K step (16 channels) of one panel row is ONE contiguous 96-byte run.
 //
 // Two forms of the same tiles, same MFMA order, bit-identical results: LDS-DMA staging into a 3-slot ring (the default,
-// conv3_x3p_dma_kernel below) and register staging (conv3_x3p_kernel, DA_X3_KERNEL=1: the form measured in round 3's
-// ablations).
+// conv3_x3p_dma_kernel below) and register staging (conv3_x3p_kernel, DA_X3_KERNEL=1: the form of round 3's first
+// ablations; kept for A/B).
 //
 // Block = (64 MT) positions x 64 output channels, 4 waves of (32 MT) x 32 (v_mfma_f32_32x32x16_bf16, MT accumulators);
 // MT = 2 for the full tiles, MT = 1 for the tiles of the partly filled last round (see da_conv3_x3p).  K step = 16
@@ -657,24 +657,6 @@ __global__ __launch_bounds__(512, 1) void conv_x3p_s2_kernel(ConvX3pS2Args a) {
   }
 }
 
-// Variant 2 (DA_X3_KERNEL=2, A/B measurements): 128 x 64 tiles on 4 waves, TWO resident blocks per CU (66 KB of LDS each);
-// the SIMD partners are then waves of two different blocks, which cannot share a barrier -- the blocks of the first
-// resident round stage before their MFMAs, those of the second after (blockIdx / 256 decides: speed only).
-#define XP2_LDS_BYTES (2 * (128 + 3) * XP_PITCH + 2 * XP_BCHUNK)
-__global__ __launch_bounds__(256, 2) void conv3_x3p_kernel2(ConvX3pArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int ntn = a.N / XP_TN;
-  const int tail_blocks = 2 * a.tail_m * ntn;
-  const bool early = ((blockIdx.x >> 8) & 1) == 0;
-  if ((int)blockIdx.x < tail_blocks) {
-    const int id = xcd_chunked_xp(blockIdx.x, tail_blocks);
-    conv3_x3p_body<1, 2, 256>(a, a.full_m * 128 + (id / ntn) * 64, (id % ntn) * XP_TN, lds, early);
-  } else {
-    const int tile = xcd_chunked_xp(blockIdx.x - tail_blocks, a.full_m * ntn);
-    conv3_x3p_body<2, 2, 256>(a, (tile / ntn) * 128, (tile % ntn) * XP_TN, lds, early);
-  }
-}
-
 // fp32 [npos][ld] (first C channels) -> x3 [npos][C/16][3][16] and back (tests, and the boundaries where a producer
 // without an x3 store form meets an x3 consumer)
 __global__ __launch_bounds__(256) void x3_split_kernel(const float* __restrict__ x, int ld, __bf16* __restrict__ out, size_t npos,
@@ -785,22 +767,6 @@ int da_conv3_x3p(const void* x, const void* wpk, float* y, int rows, int L, int 
   if (!g_kernel) {
     const char* e = getenv("DA_X3_KERNEL");
     g_kernel = e ? atoi(e) : XP_DEFAULT_KERNEL;
-  }
-  if (g_kernel == 2) {
-    static bool attr2 = false;
-    if (!attr2) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_x3p_kernel2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              XP2_LDS_BYTES) != hipSuccess)
-        return DA_EINVAL;
-      attr2 = true;
-    }
-    const long mt2 = (M + 127) / 128, t2 = mt2 * ntn;
-    const long tm2 = t2 < 512 ? mt2 : (t2 % 512) / ntn;
-    a.tail_m = (int)tm2;
-    a.full_m = (int)(mt2 - tm2);
-    hipLaunchKernelGGL(conv3_x3p_kernel2, dim3((unsigned)((long)a.full_m * ntn + 2l * tm2 * ntn)), dim3(256), XP2_LDS_BYTES, stream, a);
-    DA_CHECK_LAUNCH();
-    return DA_OK;
   }
   const long mtiles = (M + XP_TM - 1) / XP_TM;
   const long tiles = mtiles * ntn;

@@ -5,6 +5,7 @@
 #      per-kernel averages are those of the bench line's roofline kernel) -> gpurun_out/<tag>_bench_kernel_stats.csv,
 #      the line it printed, and <tag>_dominant_kernel.json (rocprof average of the dominant kernel next to the bench's HIP-event average)
 #   0. PMC passes FETCH_SIZE / WRITE_SIZE (separate runs)   -> gpurun_out/<tag>_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv, <tag>_traffic.json
+#   8. the opt-in 'f32x3p' arithmetic: bench line, kernel stats, per-layer micro timings -> <tag>_bench_f32x3p*.json, <tag>_f32x3p_kernel_stats.csv, <tag>_x3p_micro.txt
 # Copy what should be judged from gpurun_out/ into profiles/.
 set -o pipefail
 tag=${1:-r02}
@@ -61,3 +62,11 @@ cp $(find $out/prof_dn -name '*kernel_stats.csv' | head -1) $out/${tag}_densenet
 rm -rf $out/prof_dn
 cd $R
 bash scripts/trace_round.sh ${tag}_densenet --backbone densenet18 > /dev/null
+# 8. conv arithmetic 'f32x3p' (opt-in): bench line, kernel stats of the same command, per-layer timings against the fp32 kernels
+timeout -k 10 300 python bench.py --dtype f32x3p --no-extra --no-cpu-baseline > $out/${tag}_bench_f32x3p.json 2> $out/${tag}_bench_f32x3p.err || { tail -5 $out/${tag}_bench_f32x3p.err; exit 1; }
+cd /tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_x3p -- python3 $R/bench.py --dtype f32x3p --no-extra --no-cpu-baseline --no-roofline > $out/${tag}_bench_f32x3p_under_rocprof.json 2> $out/prof_x3p.err || { tail -5 $out/prof_x3p.err; exit 1; }
+cp $(find $out/prof_x3p -name '*kernel_stats.csv' | head -1) $out/${tag}_f32x3p_kernel_stats.csv
+rm -rf $out/prof_x3p
+cd $R
+{ python scripts/bench_x3p.py; python scripts/bench_x3p_s2.py; } 2>&1 | grep -v amdgpu.ids > $out/${tag}_x3p_micro.txt

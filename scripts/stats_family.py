@@ -14,7 +14,7 @@ def csrc_sha16():                       # the same identity bench.py stamps and 
     return h.hexdigest()[:16]
 
 
-ENTRY_KERNEL = {'da_conv3_x3p': ('conv3_x3p_kernel',),
+ENTRY_KERNEL = {'da_conv3_x3p': ('conv3_x3p_dma_kernel', 'conv3_x3p_kernel'),
                 'da_conv3_winograd': ('conv3_wino_kernel', 'conv3_wino_bn_kernel'), 'da_conv3_winograd4': ('conv3_wino4k_kernel',),
                 'da_conv_gemm_multi': ('conv_gemm_multi_kernel',), 'da_conv3_bf16': ('conv3_bf16_kernel',),
                 'da_pool_bwd': ('pool_bwd_kernel',), 'da_bn_fwd': ('void bn_fwd_fused_kernel', 'bn_fwd_fused_kernel'),
