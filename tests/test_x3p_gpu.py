@@ -218,20 +218,37 @@ def test_x3_flow_is_what_runs_and_matches_the_float_path_closely():
     m = M.CNNLinearNetwork(M.resnet18(), 20, 0).cuda().train()
     with torch.no_grad():
         want = m(xt, None)
-    seen = []
-    orig = H_.conv3_x3p
+    seen, s2seen, wjobs = [], [], []
+    orig, orig_f, orig_d, orig_w = H_.conv3_x3p, H_.conv_x3p_s2_fwd, H_.conv_x3p_s2_dgrad, H_.conv_wgrad_multi
 
     def spy(x3, wpk, out=None, accumulate=False):
         seen.append(tuple(x3.shape))
         return orig(x3, wpk, out=out, accumulate=accumulate)
+
+    def spy_f(x3, w1pk, wdpk):
+        s2seen.append(('fwd', tuple(x3.shape)))
+        return orig_f(x3, w1pk, wdpk)
+
+    def spy_d(dy1, w1pk, dyd, wdpk, out=None):
+        s2seen.append(('dgrad', tuple(dy1.shape)))
+        return orig_d(dy1, w1pk, dyd, wdpk, out=out)
+
+    def spy_w(jobs):
+        wjobs.extend((H_.is_x3(j[0]) and H_.is_x3(j[1]), j[2], j[3]) for j in jobs)
+        return orig_w(jobs)
     with arithmetic('f32x3p'):
-        H_.conv3_x3p = spy
+        H_.conv3_x3p, H_.conv_x3p_s2_fwd, H_.conv_x3p_s2_dgrad, H_.conv_wgrad_multi = spy, spy_f, spy_d, spy_w
         try:
             out = m(xt, None)
             out.sum().backward()
         finally:
-            H_.conv3_x3p = orig
+            H_.conv3_x3p, H_.conv_x3p_s2_fwd, H_.conv_x3p_s2_dgrad, H_.conv_wgrad_multi = orig, orig_f, orig_d, orig_w
         assert len(seen) == 26 and all(len(s_) == 5 for s_ in seen)       # 13 k3 s1 convs: forward + data gradient
+        # the three stride-2 block entries: one forward and one data-gradient launch each, all on x3 operands ...
+        assert sorted(k for k, _ in s2seen) == ['dgrad'] * 3 + ['fwd'] * 3
+        # ... and every residual-block weight gradient (13 k3 s1, 3 k3 s2, 3 1x1 s2) as an x3 job
+        assert sorted((k, s_) for x3job, k, s_ in wjobs if x3job) == [(1, 2)] * 3 + [(3, 1)] * 13 + [(3, 2)] * 3
+        assert not any(k <= 3 and not x3job for x3job, k, s_ in wjobs)
         assert float((out.detach() - want).abs().max()) < 2e-5
         for bb in (M.resnet18(first_pool_type='avg'), M.resnet18(double_conv_first=True), M.resnet34()):
             mm = M.CNNLinearNetwork(bb, 20, 0).cuda().train()
