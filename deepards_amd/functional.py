@@ -241,7 +241,7 @@ def _tgt(*params):
 
 
 # ---- the x3 flow (conv arithmetic 'f32x3p') -------------------------------------------------------------------------------
-# An activation that feeds a k3 s1 conv is stored ONLY in the x3 format (H.is_x3: bf16 (rows, L, C/16, 3, 16)).  autograd
+# An activation that feeds a k3 s1 conv or a stride-2 block entry (k3 s2 conv + 1x1 s2 downsample) is stored ONLY in the x3 format (H.is_x3: bf16 (rows, L, C/16, 3, 16)).  autograd
 # checks a gradient's shape against the tensor it belongs to, and the gradients stay float (rows, L, C) -- so the tensor
 # that carries the autograd edge between two blocks is a zero-stride float "handle" of the logical shape (no memory, never
 # read), and the x3 data travels beside it as a second, non-differentiable argument / result of the block Functions.
@@ -436,9 +436,10 @@ class BasicBlockFunction(Function):
     reference models/resnet.py:24-40 (BasicBlock.forward), :123-131 (downsample).
 
     Conv arithmetic 'f32x3p' (the x3 flow above): ``x3`` is the block input in the x3 format when its conv1 is a k3 s1 conv
-    (``x`` is then only the autograd handle), ``want_out3`` asks for the output in the x3 format (the next block's conv1
-    is one); the hidden activation h1 and the gradients in front of the k3 s1 data / weight-gradient convs (dy2, dy1) take
-    the x3 format whenever the shape has the store forms.  Returns ``out`` or ``(handle, out3)``."""
+    or the block is a stride-2 entry whose two input convs run as H.conv_x3p_s2_fwd (``x`` is then only the autograd handle),
+    ``want_out3`` asks for the output in the x3 format (the next block reads one); the hidden activation h1 and the gradients
+    in front of the data / weight-gradient convs (dy2, dy1, the downsample branch's dyd) take the x3 format whenever the
+    shape has the store forms.  Returns ``out`` or ``(handle, out3)``."""
 
     @staticmethod
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, R, st1, st2, std, x3=None, want_out3=False):
