@@ -1,4 +1,5 @@
-"""BatchNorm kernels against plain streaming kernels (torch copy / add) on tensors of the bench shapes, hipGraph timed:\nhow far the per-window kernels are from the byte path.  usage: python scripts/bw_probe.py"""
+"""BatchNorm kernels against plain streaming kernels (torch copy / add) on tensors of the bench shapes, hipGraph timed:
+how far the per-window kernels are from the byte path.  usage: python scripts/bw_probe.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
