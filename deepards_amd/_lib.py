@@ -72,6 +72,10 @@ SIGNATURES = {
     'da_bn_chunks': (None, [_I, _I, _I, _IP, _IP]),
     'da_bn_workspace': (_Z, [_I, _I, _I]),
     'da_bn_stats_partial': (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    'da_stem_stats_partial': (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    'da_stem_bn_relu_pool_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
+    'da_stem_bwd_workspace': (_Z, [_I, _I]),
+    'da_stem_bwd': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P]),
     'da_bn_stats_merge': (_I, [_P, _I, _I, _I, _F, _P, _P, _P]),
     'da_bn_running_multi': (_I, [ctypes.POINTER(BnRunningDesc), _I, _P]),
     'da_bn_apply': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _F, _P]),

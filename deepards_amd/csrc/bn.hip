@@ -74,6 +74,84 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const AT* __restr
   }
 }
 
+// The same chunk records for the DEFAULT STEM's BatchNorm without its input in memory: position p of window w is output
+// (row, l) = ((w Wn + p) / Lc, (w Wn + p) % Lc) of the k7 s2 conv on the raw rows, recomputed (common.h StemW4: bit for bit
+// stem_conv_fwd_kernel's value) from the chunk's rows staged in LDS -- same slots, same folds: the records equal
+// bn_stats_partial_kernel's on the stored map.  XSR = floats per staged row (3 zeros in front, zeros behind).
+__global__ __launch_bounds__(256) void stem_stats_partial_kernel(const float* __restrict__ xrows, const float* __restrict__ wt,
+                                                                 int Lin, int Lc, int Wn, int C, int chunk, int XSR,
+                                                                 float* __restrict__ part) {
+  extern __shared__ float sm[];                       // xs[rows of the chunk][XSR] | red[(SLOTS + 1) * CG]
+  const int w = row_xcd_chunk(blockIdx.x, gridDim.x), cg = blockIdx.y, pc = blockIdx.z, P = gridDim.z;
+  const int q = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  const int p_beg = pc * chunk, p_end = min(Wn, p_beg + chunk);
+  const size_t g0 = (size_t)w * Wn + p_beg;
+  const int row0 = (int)(g0 / Lc), l_first = (int)(g0 - (size_t)row0 * Lc);
+  const int nrows = (l_first + (p_end - p_beg) + Lc - 1) / Lc;
+  float* xs = sm;
+  float* red = sm + nrows * XSR;
+  for (int i = threadIdx.x; i < nrows * XSR; i += blockDim.x) {
+    const int r = i / XSR, sx = i - r * XSR - 3;
+    xs[i] = (sx >= 0 && sx < Lin) ? xrows[(size_t)(row0 + r) * Lin + sx] : 0.f;
+  }
+  StemW4 sw;
+  sw.load(wt, cg * CG + q * 4);
+  __syncthreads();
+  // this thread's positions: p_beg + slot, + SLOTS, ...; (r, l) walks along (Lc >= SLOTS is not assumed)
+  auto y_at = [&](int r, int l) {
+    const float* xr = xs + r * XSR + 2 * l;             // input 2 l - 3 sits at xs[r][2 l]
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) acc = fmaf(sw.w[e][k], xr[k], acc);
+      y[e] = acc;
+    }
+    return y;
+  };
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, m[4];
+  {
+    int l = l_first + slot, r = 0;
+    while (l >= Lc) { l -= Lc; ++r; }
+    for (int p = p_beg + slot; p < p_end; p += SLOTS) {
+      const f32x4 v = y_at(r, l);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += v[e];
+      l += SLOTS;
+      while (l >= Lc) { l -= Lc; ++r; }
+    }
+  }
+  block_fold(s, red, slot, q, m);
+  const float inv_n = 1.0f / (float)(p_end - p_beg);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) m[e] *= inv_n;
+  float s2[4] = {0.f, 0.f, 0.f, 0.f}, m2[4];
+  {
+    int l = l_first + slot, r = 0;
+    while (l >= Lc) { l -= Lc; ++r; }
+    for (int p = p_beg + slot; p < p_end; p += SLOTS) {
+      const f32x4 v = y_at(r, l);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float d = v[e] - m[e];
+        s2[e] += d * d;
+      }
+      l += SLOTS;
+      while (l >= Lc) { l -= Lc; ++r; }
+    }
+  }
+  block_fold(s2, red, slot, q, m2);
+  if (slot == 0) {
+    float* o = part + (((size_t)w * P + pc) * 2) * C + cg * CG + q * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = m[e];
+      o[C + e] = m2[e];
+    }
+  }
+}
+
 // merge the P chunk records of one (window, channel) in chunk order (Chan's update)
 __device__ __forceinline__ void bn_merge_chunks(const float* __restrict__ pp, int P, int C, int Wn, int chunk,
                                                 float eps, float& mean, float& invstd) {
@@ -664,6 +742,25 @@ int da_bn_stats_partial(const void* x, int ld, int W, int Wn, int C, float* part
   bn_chunks(W, Wn, C, &P, &chunk);
   DA_ACT_DISPATCH(hipLaunchKernelGGL(bn_stats_partial_kernel<AT>, dim3(W, C / CG, P), dim3(256), 0, stream, (const AT*)x, ld,
                                      Wn, C, chunk, part));
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// stage 1 for the default stem's BatchNorm, its input recomputed from the raw rows (stem_stats_partial_kernel):
+// xrows (rows, Lin) float, wt (C, 1, 7); window = R rows of Lc = Lin / 2 conv outputs.  Records as da_bn_stats_partial's.
+int da_stem_stats_partial(const float* xrows, const float* wt, int rows, int R, int Lin, int C, float* part, hipStream_t stream) {
+  DA_ENTER();
+  if (!xrows || !wt || !part || C % CG || R < 1 || rows % R || Lin < 2 || (Lin & 1) || g_act_bf16) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  const int W = rows / R, Lc = Lin / 2, Wn = R * Lc;
+  int P, chunk;
+  bn_chunks(W, Wn, C, &P, &chunk);
+  const int XSR = Lin + 12;                           // 3 zeros in front, >= 9 behind (the last output reads inputs up to Lin + 1)
+  const int max_rows = (chunk + Lc - 1) / Lc + 1;
+  const size_t shm = ((size_t)max_rows * XSR + (SLOTS + 1) * CG) * sizeof(float);
+  if (shm > 64 * 1024) return DA_EINVAL;
+  hipLaunchKernelGGL(stem_stats_partial_kernel, dim3(W, C / CG, P), dim3(256), shm, stream, xrows, wt, Lin, Lc, Wn, C, chunk, XSR,
+                     part);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

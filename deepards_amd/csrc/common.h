@@ -98,6 +98,38 @@ struct X3 {
   }
 };
 
+// The default stem (conv k7 s2 p3 on ONE input channel: reference models/resnet.py:86-87, densenet.py:118-119) costs 7 FMAs per
+// output and its output is 36.7 MB at B = 64 -- the "recomputing stem" kernels never store it: they take the raw rows and the
+// 64 x 7 weights and recompute an output wherever one is needed.  This is stem_conv_fwd_kernel's value BIT FOR BIT: the same
+// fmaf chain k = 0 .. 6 from zero, zero padding entering as fmaf(w, 0, acc) = acc.
+struct StemW4 {
+  float w[4][7];                       // taps of channels c0 .. c0 + 3
+  __device__ __forceinline__ void load(const float* __restrict__ wt, int c0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int k = 0; k < 7; ++k) w[e][k] = wt[(c0 + e) * 7 + k];
+  }
+  // y[l][c0 .. c0 + 3] of one row; xr = the row (Lin floats, global or LDS), positions outside [0, Lin) are zero
+  __device__ __forceinline__ f32x4 at(const float* __restrict__ xr, int Lin, int l) const {
+    float xv[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const int s = 2 * l + k - 3;
+      xv[k] = (s >= 0 && s < Lin) ? xr[s] : 0.f;
+    }
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) acc = fmaf(w[e][k], xv[k], acc);
+      y[e] = acc;
+    }
+    return y;
+  }
+};
+
 extern int g_act_bf16;                 // head_optim.hip; set by da_set_act_dtype
 // run STMT once with `AT` = the current activation storage type
 #define DA_ACT_DISPATCH(STMT)  \

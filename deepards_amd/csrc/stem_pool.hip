@@ -147,6 +147,111 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const AT* __restr
   else Act<AT>::st4(out + po * ldo + c0, o);
 }
 
+// The same with the stem conv's output RECOMPUTED from the raw rows instead of read: the default stem never stores its
+// 36.7 MB conv output.  Block = rows (grid-strided), the row staged in LDS behind STEM_XPAD zeros; a thread owns 4 channels
+// (28 taps in registers) and a run of consecutive pool windows j: window j = conv positions 2j-1, 2j, 2j+1, of which 2j-1 is
+// the previous step's last -- two new conv outputs per step from a 16-input register window that advances by ONE
+// ds_read_b128.  Values: stem_conv_fwd_kernel's and bn_relu_pool_fwd_kernel's, bit for bit (same fmaf chain, same
+// expression, max is order-free).  Lc = conv outputs per row, Lp = pooled outputs per row.
+#define STEM_XPAD 8                                  // zeros in front of a staged row: xs[STEM_XPAD + s] = x[s]
+
+__device__ __forceinline__ f32x4 stem_y4(const StemW4& sw, const float (&xw)[16], int o) {   // inputs xw[o .. o + 6]
+  f32x4 y;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc = fmaf(sw.w[e][k], xw[o + k], acc);
+    y[e] = acc;
+  }
+  return y;
+}
+// register window of step j: xw[i] = xs[4 j + i] = x[4 j - 8 + i], i = 0 .. 15; conv output l reads inputs 2 l - 3 .. 2 l + 3:
+// position 2j-1 starts at xw[3], 2j at xw[5], 2j+1 at xw[7]
+__device__ __forceinline__ void stem_xw_fill(float (&xw)[16], const float* xs, int j) {
+#pragma unroll
+  for (int i = 0; i < 16; i += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xs + 4 * j + i);
+    xw[i] = v[0]; xw[i + 1] = v[1]; xw[i + 2] = v[2]; xw[i + 3] = v[3];
+  }
+}
+__device__ __forceinline__ void stem_xw_next(float (&xw)[16], const float* xs, int j) {   // from step j - 1's window
+#pragma unroll
+  for (int i = 0; i < 12; ++i) xw[i] = xw[i + 4];
+  const f32x4 v = *reinterpret_cast<const f32x4*>(xs + 4 * j + 12);
+  xw[12] = v[0]; xw[13] = v[1]; xw[14] = v[2]; xw[15] = v[3];
+}
+__host__ __device__ __forceinline__ int stem_xs_floats(int Lin) { return (STEM_XPAD + Lin + 16 + 3) & ~3; }
+
+struct StemBn4 {
+  f32x4 mu, is, ga, be;
+  __device__ __forceinline__ f32x4 z(const f32x4& y) const {        // bn_relu_pool_fwd_kernel's expression
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = fmaxf((y[e] - mu[e]) * is[e] * ga[e] + be[e], 0.f);
+    return r;
+  }
+};
+
+template <int OX3>
+__global__ __launch_bounds__(256) void stem_bn_relu_pool_fwd_kernel(const float* __restrict__ xrows, const float* __restrict__ wt,
+                                                                    float* __restrict__ out, int ldo, int rows, int R, int Lin,
+                                                                    int Lc, int Lp, int C, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, int pool_mode) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // xs[stem_xs_floats(Lin)]
+  const int nq = C >> 2, nruns = blockDim.x / nq, RJ = (Lp + nruns - 1) / nruns;
+  const int XS = stem_xs_floats(Lin);
+  float* xs = sm;
+  const int q = threadIdx.x % nq, run = threadIdx.x / nq, c0 = q * 4;
+  StemW4 sw;
+  sw.load(wt, c0);
+  StemBn4 bn;
+  bn.ga = *reinterpret_cast<const f32x4*>(gamma + c0);
+  bn.be = *reinterpret_cast<const f32x4*>(beta + c0);
+  const int j0 = run * RJ, j1 = min(Lp, j0 + RJ);
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int w = row / R;
+    __syncthreads();
+    for (int i = threadIdx.x; i < XS; i += blockDim.x) {
+      const int sx = i - STEM_XPAD;
+      xs[i] = (sx >= 0 && sx < Lin) ? xrows[(size_t)row * Lin + sx] : 0.f;
+    }
+    __syncthreads();
+    if (j0 >= j1) continue;
+    bn.mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
+    bn.is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * C + c0);
+    float xw[16];
+    stem_xw_fill(xw, xs, j0);
+    f32x4 zm = {0.f, 0.f, 0.f, 0.f};
+    if (j0 > 0) zm = bn.z(stem_y4(sw, xw, 3));
+    for (int j = j0; j < j1; ++j) {
+      if (j > j0) stem_xw_next(xw, xs, j);
+      const bool vm = j > 0, vp = 2 * j + 1 < Lc;
+      const f32x4 z0 = bn.z(stem_y4(sw, xw, 5)), zp = bn.z(stem_y4(sw, xw, 7));
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (pool_mode == 0) {
+          float m = vm ? fmaxf(-INFINITY, zm[e]) : -INFINITY;             // the order of bn_relu_pool_fwd_kernel: t = 0, 1, 2
+          m = fmaxf(m, z0[e]);
+          o[e] = vp ? fmaxf(m, zp[e]) : m;
+        } else {
+          float a = vm ? 0.f + zm[e] : 0.f;
+          a += z0[e];
+          if (vp) a += zp[e];
+          o[e] = a * (1.0f / 3.0f);
+        }
+      }
+      const size_t po = (size_t)row * Lp + j;
+      if constexpr (OX3) X3::st4(reinterpret_cast<__bf16*>(out) + po * (size_t)(3 * C), c0, o);
+      else Act<float>::st4(out + po * ldo + c0, o);
+      zm = zp;
+    }
+  }
+}
+
 // Gradient w.r.t. the ReLU output at stem resolution: dz[row][l][c] = sum over the (<= 2) pooling
 // windows j that contain l of [argmax_j == l] * dout[row][j][c]  (max; first maximum wins, as ATen)
 // or dout[row][j][c]/3 (avg).  The ReLU mask and BN backward are applied afterwards by da_bn_bwd
@@ -210,6 +315,182 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const AT* __restrict__ do
     }
   }
   Act<AT>::st4(dz + pi * lddz + c0, acc);
+}
+
+// ---- the recomputing stem, backward ------------------------------------------------------------------------------------
+// pool backward + BN backward + the stem conv's weight gradient from dout (rows, Lp, C), the RAW rows and the statistics --
+// the conv output y, the ReLU decisions and the pool's arg-maxima are recomputed (pool_bwd_kernel already recomputed the
+// last two from a stored y), nothing of the 36.7 MB stem resolution is read or written:
+//   stem_bwd_kernel<false>  per row: g = dReLU-out (max: the first maximum of each window takes its dout; avg: dout / 3),
+//                           masked by the ReLU, and the row's sums of g and g xhat per channel -> rowpart[row][2][C]
+//   stem_bwd_kernel<true>   per row: the window totals (its R rows' records, in row order; also stored as the BatchNorm's
+//                           ds for dgamma / dbeta), dy = gamma invstd (g - s1 / n - xhat s2 / n) and the weight-gradient
+//                           partials sum_l dy[l][c] x[2 l + k - 3] -> partial[block][c][k] (stem_wgrad_reduce_kernel folds them)
+// A thread owns 4 channels and a run of consecutive POOL windows j of one row.  Window j covers conv positions 2j-1, 2j, 2j+1:
+// per step two new conv outputs (2j, 2j+1; 2j-1 is the previous step's last) from a register window of 11 inputs that
+// advances by one ds_read_b128; position 2j-1 is finished by the step of window j (it also sat in window j-1, whose choice
+// the step before left in a carry -- a run recomputes the window in front of its first one for it), position 2j by its own.
+template <bool APPLY>
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ dout, int ldd, const float* __restrict__ xrows,
+                                                       const float* __restrict__ wt, int rows, int R, int Lin, int Lc, int Lp,
+                                                       int C, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int pool_mode, int RPB, float* __restrict__ rowpart,
+                                                       float* __restrict__ ds, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // xs[stem_xs_floats(Lin)] | tot[2][C] | red[nruns][APPLY ? 7 C : 2 C]
+  const int nq = C >> 2, nruns = blockDim.x / nq, RJ = (Lp + nruns - 1) / nruns;
+  const int XS = stem_xs_floats(Lin);
+  float* xs = sm;                                     // xs[STEM_XPAD + s] = x[s]
+  float* tot = sm + XS;
+  float* red = tot + 2 * C;
+  const int q = threadIdx.x % nq, run = threadIdx.x / nq, c0 = q * 4;
+  StemW4 sw;
+  sw.load(wt, c0);
+  StemBn4 bn;
+  bn.ga = *reinterpret_cast<const f32x4*>(gamma + c0);
+  bn.be = *reinterpret_cast<const f32x4*>(beta + c0);
+  float wacc[4][7];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) wacc[e][k] = 0.f;
+  const float inv_n = 1.0f / (float)(R * Lc);
+  const int j0 = run * RJ, j1 = min(Lp, j0 + RJ);
+  // a block owns RPB consecutive rows of ONE window (RPB divides R): statistics, totals and taps are fetched once
+  const int row_beg = blockIdx.x * RPB, w = row_beg / R;
+  if (APPLY && (int)threadIdx.x < 2 * C) {            // the window's totals: its R row records in row order
+    const int which = threadIdx.x / C, c = threadIdx.x - which * C;
+    float t = 0.f;
+    for (int r = 0; r < R; ++r) t += rowpart[((size_t)(w * R + r) * 2 + which) * C + c];
+    tot[which * C + c] = t;
+    if (ds && row_beg == w * R) ds[((size_t)which * (rows / R) + w) * C + c] = t;
+  }
+  bn.mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
+  bn.is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * C + c0);
+  f32x4 t1n = {0.f, 0.f, 0.f, 0.f}, t2n = t1n;
+  for (int row = row_beg; row < row_beg + RPB; ++row) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < XS; i += blockDim.x) {
+      const int sx = i - STEM_XPAD;
+      xs[i] = (sx >= 0 && sx < Lin) ? xrows[(size_t)row * Lin + sx] : 0.f;
+    }
+    __syncthreads();
+    if (APPLY && row == row_beg) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        t1n[e] = tot[c0 + e] * inv_n;
+        t2n[e] = tot[C + c0 + e] * inv_n;
+      }
+    }
+    const float* drow = dout + (size_t)row * Lp * ldd + c0;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float xw[16];                                     // stem_xw_fill: position 2j-1 starts at xw[3], 2j at xw[5], 2j+1 at xw[7]
+    // one finished position: its g (the windows' choices), its y, the window index of its first input
+    auto finish = [&](const f32x4& gsum, const f32x4& y, int o) {
+      f32x4 g, xh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[e] = (y[e] - bn.mu[e]) * bn.is[e];
+        g[e] = (xh[e] * bn.ga[e] + bn.be[e] > 0.f) ? gsum[e] : 0.f;      // bn_masked_g, mode 1
+      }
+      if (!APPLY) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s1[e] += g[e];
+          s2[e] += g[e] * xh[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = bn.ga[e] * bn.is[e] * (g[e] - t1n[e] - xh[e] * t2n[e]);
+#pragma unroll
+          for (int k = 0; k < 7; ++k) wacc[e][k] = fmaf(d, xw[o + k], wacc[e][k]);
+        }
+      }
+    };
+    // the choice of window j among its positions (2j-1: zm, 2j: z0, 2j+1: zp; validity flags): -> (gm, g0, gp) shares of dout[j]
+    auto choose = [&](const f32x4& zm, const f32x4& z0, const f32x4& zp, bool vm, bool vp, const f32x4& d, f32x4& gm, f32x4& g0,
+                      f32x4& gp) {
+      if (pool_mode == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = d[e] * (1.0f / 3.0f);
+          gm[e] = vm ? t : 0.f; g0[e] = t; gp[e] = vp ? t : 0.f;
+        }
+        return;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {                   // first maximum wins (strict >, from -inf), as pool_bwd_kernel / ATen
+        float best = -INFINITY;
+        int arg = -1;
+        if (vm && zm[e] > best) { best = zm[e]; arg = 0; }
+        if (z0[e] > best) { best = z0[e]; arg = 1; }
+        if (vp && zp[e] > best) { best = zp[e]; arg = 2; }
+        gm[e] = arg == 0 ? d[e] : 0.f;
+        g0[e] = arg == 1 ? d[e] : 0.f;
+        gp[e] = arg == 2 ? d[e] : 0.f;
+      }
+    };
+    if (j0 < j1) {
+      // the carry into position 2 j0 - 1 from window j0 - 1, and that position's y / z
+      f32x4 carry = {0.f, 0.f, 0.f, 0.f}, ym = carry, zm = carry;
+      if (j0 > 0) {
+        stem_xw_fill(xw, xs, j0 - 1);
+        const f32x4 ya = stem_y4(sw, xw, 3), yb = stem_y4(sw, xw, 5);
+        ym = stem_y4(sw, xw, 7);
+        zm = bn.z(ym);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(drow + (size_t)(j0 - 1) * ldd);
+        f32x4 ga_, gb_;
+        choose(bn.z(ya), bn.z(yb), zm, 2 * (j0 - 1) - 1 >= 0, true, d, ga_, gb_, carry);
+      }
+      for (int j = j0; j < j1; ++j) {
+        if (j > 0 && j == j0) stem_xw_next(xw, xs, j);
+        else if (j == j0) stem_xw_fill(xw, xs, j);
+        else stem_xw_next(xw, xs, j);
+        const bool vm = j > 0, vp = 2 * j + 1 < Lc;
+        const f32x4 y0 = stem_y4(sw, xw, 5), yp = stem_y4(sw, xw, 7);
+        const f32x4 z0 = bn.z(y0), zp = bn.z(yp);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(drow + (size_t)j * ldd);
+        f32x4 gm, g0, gp;
+        choose(zm, z0, zp, vm, vp, d, gm, g0, gp);
+        if (vm) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gm[e] += carry[e];
+          finish(gm, ym, 3);
+        }
+        finish(g0, y0, 5);
+        carry = gp; ym = yp; zm = zp;
+        if (j == Lp - 1 && vp) finish(gp, yp, 7);  // the row's last position sits in no further window
+      }
+    }
+    if (!APPLY) {                                     // the row's record: runs folded in run order
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[(run * 2 + 0) * C + c0 + e] = s1[e];
+        red[(run * 2 + 1) * C + c0 + e] = s2[e];
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < 2 * C) {
+        float t = 0.f;
+        for (int r = 0; r < nruns; ++r) t += red[r * 2 * C + threadIdx.x];
+        rowpart[(size_t)row * 2 * C + threadIdx.x] = t;
+      }
+    }
+  }
+  if (APPLY) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int k = 0; k < 7; ++k) red[(run * C + c0 + e) * 7 + k] = wacc[e][k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 7; i += blockDim.x) {
+      float t = 0.f;
+      for (int r = 0; r < nruns; ++r) t += red[r * C * 7 + i];
+      partial[(size_t)blockIdx.x * C * 7 + i] = t;
+    }
+  }
 }
 
 // generic AvgPool1d(k, stride=k) (k=2 transition) and AvgPool1d(L, 1) on an L-long row (k = L -> 1).
@@ -403,6 +684,68 @@ int da_bn_relu_pool_fwd(const void* y, int ldy, void* out, int ldo, int rows, in
   size_t total = (size_t)rows * Lout * (C / 4);
   DA_ACT_DISPATCH(hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<AT>, dim3(grid1d(total, 256)), dim3(256), 0, stream, (const AT*)y,
                                      ldy, (AT*)out, ldo, rows, R, Lin, Lout, C, mean, invstd, gamma, beta, pool_mode));
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// BN + ReLU + pool(3,2,1) of the default stem from the RAW rows (the conv output recomputed, never stored): xrows (rows, Lin),
+// wt (C, 1, 7) -> out (rows, Lp, C) float, or the x3 format when out_x3.  mean / invstd: da_stem_stats_partial + da_bn_stats_merge.
+int da_stem_bn_relu_pool_fwd(const float* xrows, const float* wt, void* out, int ldo, int rows, int R, int Lin, int C,
+                             const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode,
+                             int out_x3, hipStream_t stream) {
+  DA_ENTER();
+  if (!xrows || !wt || !out || C % 4 || (out_x3 ? C % 16 : ldo % 4) || R < 1 || rows % R || Lin < 2 || (Lin & 1) || g_act_bf16)
+    return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  const int Lc = Lin / 2, Lp = (Lc - 1) / 2 + 1;
+  if (256 % (C / 4)) return DA_EINVAL;
+  const size_t shm = (size_t)stem_xs_floats(Lin) * sizeof(float);
+  const int nblk = rows < 1024 ? rows : 1024;
+  if (out_x3)
+    hipLaunchKernelGGL(stem_bn_relu_pool_fwd_kernel<1>, dim3(nblk), dim3(256), shm, stream, xrows, wt, (float*)out, ldo,
+                       rows, R, Lin, Lc, Lp, C, mean, invstd, gamma, beta, pool_mode);
+  else
+    hipLaunchKernelGGL(stem_bn_relu_pool_fwd_kernel<0>, dim3(nblk), dim3(256), shm, stream, xrows, wt, (float*)out, ldo,
+                       rows, R, Lin, Lc, Lp, C, mean, invstd, gamma, beta, pool_mode);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// floats of scratch da_stem_bwd needs: the row records (rows x 2 C) and the weight-gradient partials (blocks x 7 C)
+size_t da_stem_bwd_workspace(int rows, int C) {     // (one partial per block; a block owns >= 1 row)
+  return ((size_t)rows * 2 * C + (size_t)rows * 7 * C) * sizeof(float);
+}
+
+// Backward of the default stem (conv k7 s2 p3 on one channel -> BN -> ReLU -> pool(3,2,1)) from the RAW rows: dout
+// (rows, Lp, C) float -> dw (C, 1, 7) (+= when accumulate) and ds (2, W, C): the BatchNorm's window sums of g / g xhat
+// (da_bn_param_grad_multi folds them into dgamma / dbeta).  Nothing at the stem's resolution is read or written.
+int da_stem_bwd(const float* dout, int ldd, const float* xrows, const float* wt, int rows, int R, int Lin, int C,
+                const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode, float* ds,
+                float* dw, int accumulate, float* workspace, hipStream_t stream) {
+  DA_ENTER();
+  if (!dout || !xrows || !wt || !mean || !invstd || !gamma || !beta || !ds || !dw || !workspace || C % 4 || C < 4 ||
+      256 % (C / 4) || 2 * C > 256 || ldd % 4 || R < 1 || rows % R || Lin < 2 || (Lin & 1) || g_act_bf16)
+    return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  const int Lc = Lin / 2, Lp = (Lc - 1) / 2 + 1, nruns = 256 / (C / 4);
+  float* rowpart = workspace;
+  float* partial = workspace + (size_t)rows * 2 * C;
+  int RPB = 1;                                        // rows per block: the largest divisor of R up to 5
+  for (int d = 2; d <= 5; ++d)
+    if (R % d == 0) RPB = d;
+  const int nblk = rows / RPB;
+  const size_t xsn = (size_t)stem_xs_floats(Lin);
+  const size_t shm1 = (xsn + 2 * C + (size_t)nruns * 2 * C) * sizeof(float);
+  const size_t shm2 = (xsn + 2 * C + (size_t)nruns * 7 * C) * sizeof(float);
+  if (shm2 > 64 * 1024) return DA_EINVAL;
+  hipLaunchKernelGGL(stem_bwd_kernel<false>, dim3(nblk), dim3(256), shm1, stream, dout, ldd, xrows, wt, rows, R, Lin, Lc, Lp, C, mean,
+                     invstd, gamma, beta, pool_mode, RPB, rowpart, (float*)nullptr, (float*)nullptr);
+  DA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(stem_bwd_kernel<true>, dim3(nblk), dim3(256), shm2, stream, dout, ldd, xrows, wt, rows, R, Lin, Lc, Lp, C, mean,
+                     invstd, gamma, beta, pool_mode, RPB, rowpart, ds, partial);
+  DA_CHECK_LAUNCH();
+  const int n = C * 7;
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((n + 7) / 8), dim3(256), 0, stream, partial, nblk, n, dw, accumulate);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

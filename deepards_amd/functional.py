@@ -98,6 +98,7 @@ _WINO4_MIN_C = int(os.environ.get('DA_WINO4_MINC', '512'))   # channels from whi
 # the PRODUCERS: the BatchNorm / pool kernels in front of a k3 s1 conv store the x3 format, conv_x3p.hip and the x3
 # weight-gradient kernel read it; forward, data gradient and weight gradient).
 _CONV_DTYPE = os.environ.get('DA_CONV_DTYPE', 'f32')
+_STEM_FUSED = os.environ.get('DA_STEM_FUSED', '1') != '0'   # the default stem recomputes its conv output instead of storing it
 _S2_X3 = os.environ.get('DA_X3_S2', '1') != '0'      # 'f32x3p': the stride-2 block entries on x3 operands too (A/B switch)
 CONV_DTYPES = ('f32', 'bf16', 'f32x3', 'f32x3p')
 
@@ -333,12 +334,27 @@ class StemFunction(Function):
 
     @staticmethod
     def forward(ctx, x2d, w, gamma, beta, R, pool_mode, st, want_out3=False):
-        y0 = H.stem_conv_fwd(x2d, w)
-        mean, invstd = H.bn_stats(y0, R, st.eps)
-        out = H.bn_relu_pool_fwd(y0, R, mean, invstd, gamma, beta, pool_mode, out_x3=want_out3)
+        # The default stem (one input channel) never stores its conv output -- 36.7 MB at B = 64 for 7 FMAs an element: the
+        # statistics, the apply + pool pass and the whole backward recompute it from the raw rows (bit for bit the same
+        # forward values; H.stem_fused_fwd / stem_fused_bwd).  The other stems (FFT channels, bf16 storage) keep the stored map.
+        ctx.fused = _STEM_FUSED and H.stem_fused_ok(x2d, w, R)
         s_ = _Stats()
+        if ctx.fused:
+            out, mean, invstd = H.stem_fused_fwd(x2d, w, R, gamma, beta, pool_mode, st.eps, out_x3=want_out3)
+            y0 = w                                      # (nothing of the stem's resolution is kept for the backward)
+            wn = R * (x2d.shape[-1] // 2)
+        else:
+            y0 = H.stem_conv_fwd(x2d, w)
+            mean, invstd = H.bn_stats(y0, R, st.eps)
+            out = H.bn_relu_pool_fwd(y0, R, mean, invstd, gamma, beta, pool_mode, out_x3=want_out3)
+            wn = R * y0.shape[1]
         s_.mean, s_.invstd = mean, invstd
-        _running(y0, R, s_, st)
+        if st.running_mean is not None:
+            item = (mean, invstd, wn, st.running_mean, st.running_var, st.num_batches_tracked, st.momentum, st.eps)
+            if _STEP['on']:
+                _STEP['running'].append(item)
+            else:
+                H.bn_running_multi([item])
         ctx.save_for_backward(x2d, y0, mean, invstd, gamma, beta)
         ctx.R, ctx.pool_mode = R, pool_mode
         ctx.gt = _tgt(w, gamma, beta)
@@ -352,6 +368,19 @@ class StemFunction(Function):
     def backward(ctx, dout, _d3=None):
         x2d, y0, mean, invstd, gamma, beta = ctx.saved_tensors
         tw, tg, tb = ctx.gt
+        if ctx.fused:                                   # y0 holds the conv weight here
+            dw, ds = H.stem_fused_bwd(dout.contiguous(), x2d, y0, ctx.R, mean, invstd, gamma, beta, ctx.pool_mode, dw=tw,
+                                      accumulate=tw is not None)
+            dgamma = dbeta = None
+            if tg is not None and tb is not None:
+                if _STEP['on']:
+                    _STEP['pgrad'].append((ds, tg, tb))
+                else:
+                    H.bn_param_grad_multi([(ds, tg, tb)], accumulate=True)
+            else:
+                dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+                H.bn_param_grad_multi([(ds, dgamma, dbeta)], accumulate=False)
+            return None, None if tw is not None else dw, dgamma, dbeta, None, None, None, None
         dz = H.pool_bwd(dout.contiguous(), y0, ctx.R, mean, invstd, gamma, beta, ctx.pool_mode)
         dy0, dgamma, dbeta = _bn_bwd(dz, y0, ctx.R, mean, invstd, gamma, beta, 1, tg, tb, dx=dz)
         dw = H.stem_conv_wgrad(dy0, x2d, out=tw, accumulate=tw is not None)

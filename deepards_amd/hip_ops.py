@@ -858,6 +858,57 @@ def bn_relu_pool_fwd(y, R, mean, invstd, gamma, beta, pool_mode, out_x3=False):
     return out
 
 
+def stem_fused_ok(x2d, w, R):
+    """Whether the recomputing stem kernels take this stem: the default one (one input channel, k7 s2 p3, float storage,
+    even length, 32 / 64 / 128 channels)."""
+    lin = x2d.shape[-1]
+    return ACT == torch.float32 and (x2d.dim() == 2 or x2d.shape[1] == 1) and tuple(w.shape[1:]) == (1, 7) and \
+        lin % 2 == 0 and w.shape[0] in (32, 64, 128) and x2d.shape[0] % R == 0
+
+
+def stem_fused_fwd(x2d, w, R, gamma, beta, pool_mode, eps=1e-5, out_x3=False):
+    """conv k7 s2 p3 -> BatchNorm (per window of R rows) -> ReLU -> pool(3,2,1) of the raw rows (rows, Lin) WITHOUT storing
+    the conv output (recomputed in the statistics and in the apply pass: bit for bit stem_conv_fwd + bn_stats +
+    bn_relu_pool_fwd).  -> out (rows, Lp, C) float or x3, mean, invstd (W, C)."""
+    _f32(x2d, 'x')
+    _f32(w, 'w')
+    x = x2d.reshape(x2d.shape[0], x2d.shape[-1])
+    rows, lin = x.shape
+    c = w.shape[0]
+    wn = rows // R
+    lc = lin // 2
+    lp = (lc - 1) // 2 + 1
+    L = _lib.lib()
+    part = _bn_ws(wn, R * lc, c, x.device)
+    _chk(L.da_stem_stats_partial(_p(x), _p(w), rows, R, lin, c, _p(part), _stream()), 'da_stem_stats_partial')
+    mean = torch.empty((wn, c), device=x.device, dtype=torch.float32)
+    invstd = torch.empty((wn, c), device=x.device, dtype=torch.float32)
+    _chk(L.da_bn_stats_merge(_p(part), wn, R * lc, c, eps, _p(mean), _p(invstd), _stream()), 'da_bn_stats_merge')
+    out = x3_empty(rows, lp, c, x.device) if out_x3 else torch.empty((rows, lp, c), device=x.device, dtype=torch.float32)
+    _chk(L.da_stem_bn_relu_pool_fwd(_p(x), _p(w), _p(out), c, rows, R, lin, c, _p(mean), _p(invstd), _p(gamma), _p(beta),
+                                    pool_mode, 1 if out_x3 else 0, _stream()), 'da_stem_bn_relu_pool_fwd')
+    return out, mean, invstd
+
+
+def stem_fused_bwd(dout, x2d, w, R, mean, invstd, gamma, beta, pool_mode, dw=None, accumulate=False):
+    """Backward of stem_fused_fwd from dout (rows, Lp, C) float and the raw rows: -> dw (C, 1, 7) (+= into ``dw`` when
+    accumulate), ds (2, W, C) = the BatchNorm's window sums (bn_param_grad_multi folds them into dgamma / dbeta)."""
+    _rlc32(dout, 'dout')
+    x = x2d.reshape(x2d.shape[0], x2d.shape[-1])
+    rows, lin = x.shape
+    c = w.shape[0]
+    if dw is None:
+        if accumulate:
+            raise ValueError('accumulate needs dw')
+        dw = torch.empty((c, 1, 7), device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    ds = torch.empty((2, rows // R, c), device=x.device, dtype=torch.float32)
+    ws = torch.empty((L.da_stem_bwd_workspace(rows, c) // 4,), device=x.device, dtype=torch.float32)
+    _chk(L.da_stem_bwd(_p(dout), c, _p(x), _p(w), rows, R, lin, c, _p(mean), _p(invstd), _p(gamma), _p(beta), pool_mode, _p(ds),
+                       _p(dw), 1 if accumulate else 0, _p(ws), _stream()), 'da_stem_bwd')
+    return dw, ds
+
+
 def pool_bwd(dout, y, R, mean, invstd, gamma, beta, pool_mode):
     _rlc(dout, 'dout')
     _rlc(y, 'y')

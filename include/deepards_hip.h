@@ -255,6 +255,22 @@ int da_bn_relu_pool_fwd(const da_act_t* y, int ldy, da_act_t* out, int ldo, int 
                         const float* mean, const float* invstd, const float* gamma, const float* beta,
                         int pool_mode, da_stream_t stream);
 /* ... with the pooled output stored in the x3 format (float activations): layer1's input under conv arithmetic 'f32x3' */
+/* The recomputing default stem (conv k7 s2 p3 on ONE input channel -> BatchNorm -> ReLU -> pool(3,2,1): reference
+ * models/resnet.py:86-87,100-104,141-153, models/densenet.py:118-124): the conv output is 36.7 MB at B = 64 and costs 7 FMAs
+ * an element, so these entry points take the RAW rows xrows (rows, Lin) and the weights wt (C, 1, 7) and recompute it wherever
+ * it is needed instead of storing and re-reading it.  Forward: da_stem_stats_partial (chunk records as da_bn_stats_partial's
+ * on the stored map, bit for bit) -> da_bn_stats_merge -> da_stem_bn_relu_pool_fwd (the pooled map, float or x3: bit for bit
+ * da_stem_conv_fwd + da_bn_relu_pool_fwd).  Backward: da_stem_bwd = da_pool_bwd + da_bn_bwd + da_stem_conv_wgrad in two passes
+ * over dout: dw (C, 1, 7) and ds (2, W, C) for da_bn_param_grad_multi; workspace da_stem_bwd_workspace() bytes.  Float
+ * activation storage, Lin even, C a multiple of 32 (statistics) with 2 C <= 256. */
+int da_stem_stats_partial(const float* xrows, const float* wt, int rows, int R, int Lin, int C, float* part, da_stream_t stream);
+int da_stem_bn_relu_pool_fwd(const float* xrows, const float* wt, void* out, int ldo, int rows, int R, int Lin, int C,
+                             const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode,
+                             int out_x3, da_stream_t stream);
+size_t da_stem_bwd_workspace(int rows, int C);
+int da_stem_bwd(const float* dout, int ldd, const float* xrows, const float* wt, int rows, int R, int Lin, int C,
+                const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode, float* ds,
+                float* dw, int accumulate, float* workspace, da_stream_t stream);
 int da_bn_relu_pool_fwd_x(const float* y, int ldy, void* out, int rows, int R, int Lin, int C, const float* mean,
                           const float* invstd, const float* gamma, const float* beta, int pool_mode, da_stream_t stream);
 int da_pool_bwd(const da_act_t* dout, int ldd, const da_act_t* y, int ldy, da_act_t* dz, int lddz, int rows, int R, int Lin,
