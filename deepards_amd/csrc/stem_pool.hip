@@ -337,13 +337,15 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int pool_mode, int RPB, float* __restrict__ rowpart,
                                                        float* __restrict__ ds, float* __restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // xs[stem_xs_floats(Lin)] | tot[2][C] | red[nruns][APPLY ? 7 C : 2 C]
-  const int nq = C >> 2, nruns = blockDim.x / nq, RJ = (Lp + nruns - 1) / nruns;
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // xs[RS][stem_xs_floats(Lin)] | tot[2][C] | red[slots][APPLY ? 7 C : 2 C]
+  // the block's thread slots (blockDim / quads) are RS rows side by side x NRUN runs of pool windows each: 8 runs keep the
+  // run-start recompute (the window in front of the run) at 2 of 16 conv outputs
+  const int nq = C >> 2, slots = blockDim.x / nq, NRUN = slots < 8 ? slots : 8, RS = slots / NRUN, RJ = (Lp + NRUN - 1) / NRUN;
   const int XS = stem_xs_floats(Lin);
-  float* xs = sm;                                     // xs[STEM_XPAD + s] = x[s]
-  float* tot = sm + XS;
+  float* tot = sm + RS * XS;
   float* red = tot + 2 * C;
-  const int q = threadIdx.x % nq, run = threadIdx.x / nq, c0 = q * 4;
+  const int q = threadIdx.x % nq, slot = threadIdx.x / nq, rs = slot / NRUN, run = slot - rs * NRUN, c0 = q * 4;
+  float* xs = sm + rs * XS;                            // xs[STEM_XPAD + s] = x[s] of this thread's row
   StemW4 sw;
   sw.load(wt, c0);
   StemBn4 bn;
@@ -368,14 +370,15 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
   bn.mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
   bn.is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * C + c0);
   f32x4 t1n = {0.f, 0.f, 0.f, 0.f}, t2n = t1n;
-  for (int row = row_beg; row < row_beg + RPB; ++row) {
+  for (int rb = row_beg; rb < row_beg + RPB; rb += RS) {       // RS divides RPB
+    const int row = rb + rs;
     __syncthreads();
-    for (int i = threadIdx.x; i < XS; i += blockDim.x) {
-      const int sx = i - STEM_XPAD;
-      xs[i] = (sx >= 0 && sx < Lin) ? xrows[(size_t)row * Lin + sx] : 0.f;
+    for (int i = threadIdx.x; i < RS * XS; i += blockDim.x) {
+      const int r = i / XS, sx = i - r * XS - STEM_XPAD;
+      sm[i] = (sx >= 0 && sx < Lin) ? xrows[(size_t)(rb + r) * Lin + sx] : 0.f;
     }
     __syncthreads();
-    if (APPLY && row == row_beg) {
+    if (APPLY && rb == row_beg) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         t1n[e] = tot[c0 + e] * inv_n;
@@ -432,49 +435,48 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
       }
     };
     if (j0 < j1) {
-      // the carry into position 2 j0 - 1 from window j0 - 1, and that position's y / z
+      // the run starts one window early (when there is one): position 2 j0 - 1 also sits in window j0 - 1, whose choice
+      // reaches it through the carry; that warm-up step finishes nothing
+      const int js = j0 > 0 ? j0 - 1 : 0;
+      stem_xw_fill(xw, xs, js);
       f32x4 carry = {0.f, 0.f, 0.f, 0.f}, ym = carry, zm = carry;
-      if (j0 > 0) {
-        stem_xw_fill(xw, xs, j0 - 1);
-        const f32x4 ya = stem_y4(sw, xw, 3), yb = stem_y4(sw, xw, 5);
-        ym = stem_y4(sw, xw, 7);
+      if (js > 0) {
+        ym = stem_y4(sw, xw, 3);
         zm = bn.z(ym);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(drow + (size_t)(j0 - 1) * ldd);
-        f32x4 ga_, gb_;
-        choose(bn.z(ya), bn.z(yb), zm, 2 * (j0 - 1) - 1 >= 0, true, d, ga_, gb_, carry);
       }
-      for (int j = j0; j < j1; ++j) {
-        if (j > 0 && j == j0) stem_xw_next(xw, xs, j);
-        else if (j == j0) stem_xw_fill(xw, xs, j);
-        else stem_xw_next(xw, xs, j);
+      for (int j = js; j < j1; ++j) {
+        if (j > js) stem_xw_next(xw, xs, j);
         const bool vm = j > 0, vp = 2 * j + 1 < Lc;
         const f32x4 y0 = stem_y4(sw, xw, 5), yp = stem_y4(sw, xw, 7);
         const f32x4 z0 = bn.z(y0), zp = bn.z(yp);
         const f32x4 d = *reinterpret_cast<const f32x4*>(drow + (size_t)j * ldd);
         f32x4 gm, g0, gp;
         choose(zm, z0, zp, vm, vp, d, gm, g0, gp);
-        if (vm) {
+        if (j >= j0) {
+          if (vm) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) gm[e] += carry[e];
-          finish(gm, ym, 3);
+            for (int e = 0; e < 4; ++e) gm[e] += carry[e];
+            finish(gm, ym, 3);
+          }
+          finish(g0, y0, 5);
+          if (j == Lp - 1 && vp) finish(gp, yp, 7);    // the row's last position sits in no further window
         }
-        finish(g0, y0, 5);
         carry = gp; ym = yp; zm = zp;
-        if (j == Lp - 1 && vp) finish(gp, yp, 7);  // the row's last position sits in no further window
       }
     }
-    if (!APPLY) {                                     // the row's record: runs folded in run order
+    if (!APPLY) {                                     // the rows' records: each row's runs folded in run order
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        red[(run * 2 + 0) * C + c0 + e] = s1[e];
-        red[(run * 2 + 1) * C + c0 + e] = s2[e];
+        red[(slot * 2 + 0) * C + c0 + e] = s1[e];
+        red[(slot * 2 + 1) * C + c0 + e] = s2[e];
       }
       __syncthreads();
-      if ((int)threadIdx.x < 2 * C) {
+      for (int i = threadIdx.x; i < RS * 2 * C; i += blockDim.x) {
+        const int r = i / (2 * C), t_ = i - r * 2 * C;
         float t = 0.f;
-        for (int r = 0; r < nruns; ++r) t += red[r * 2 * C + threadIdx.x];
-        rowpart[(size_t)row * 2 * C + threadIdx.x] = t;
+        for (int u = 0; u < NRUN; ++u) t += red[(r * NRUN + u) * 2 * C + t_];
+        rowpart[(size_t)(rb + r) * 2 * C + t_] = t;
       }
     }
   }
@@ -483,11 +485,11 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int k = 0; k < 7; ++k) red[(run * C + c0 + e) * 7 + k] = wacc[e][k];
+      for (int k = 0; k < 7; ++k) red[(slot * C + c0 + e) * 7 + k] = wacc[e][k];
     __syncthreads();
     for (int i = threadIdx.x; i < C * 7; i += blockDim.x) {
       float t = 0.f;
-      for (int r = 0; r < nruns; ++r) t += red[r * C * 7 + i];
+      for (int r = 0; r < slots; ++r) t += red[r * C * 7 + i];
       partial[(size_t)blockIdx.x * C * 7 + i] = t;
     }
   }
@@ -730,11 +732,13 @@ int da_stem_bwd(const float* dout, int ldd, const float* xrows, const float* wt,
   const int Lc = Lin / 2, Lp = (Lc - 1) / 2 + 1, nruns = 256 / (C / 4);
   float* rowpart = workspace;
   float* partial = workspace + (size_t)rows * 2 * C;
-  int RPB = 1;                                        // rows per block: the largest divisor of R up to 5
-  for (int d = 2; d <= 5; ++d)
+  const int NRUN = nruns < 8 ? nruns : 8, RS = nruns / NRUN;       // the kernel's slot split (rows side by side x runs)
+  if (R % RS) return DA_EINVAL;
+  int RPB = RS;                                       // rows per block: a multiple of RS that divides R, up to 5 (or RS)
+  for (int d = RS; d <= 5; d += RS)
     if (R % d == 0) RPB = d;
   const int nblk = rows / RPB;
-  const size_t xsn = (size_t)stem_xs_floats(Lin);
+  const size_t xsn = (size_t)RS * stem_xs_floats(Lin);
   const size_t shm1 = (xsn + 2 * C + (size_t)nruns * 2 * C) * sizeof(float);
   const size_t shm2 = (xsn + 2 * C + (size_t)nruns * 7 * C) * sizeof(float);
   if (shm2 > 64 * 1024) return DA_EINVAL;

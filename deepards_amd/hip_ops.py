@@ -860,10 +860,10 @@ def bn_relu_pool_fwd(y, R, mean, invstd, gamma, beta, pool_mode, out_x3=False):
 
 def stem_fused_ok(x2d, w, R):
     """Whether the recomputing stem kernels take this stem: the default one (one input channel, k7 s2 p3, float storage,
-    even length, 32 / 64 / 128 channels)."""
+    even length, 32 / 64 / 128 channels, a window of R rows that the backward's row pairs / quads divide)."""
     lin = x2d.shape[-1]
     return ACT == torch.float32 and (x2d.dim() == 2 or x2d.shape[1] == 1) and tuple(w.shape[1:]) == (1, 7) and \
-        lin % 2 == 0 and w.shape[0] in (32, 64, 128) and x2d.shape[0] % R == 0
+        lin % 2 == 0 and w.shape[0] in (32, 64, 128) and x2d.shape[0] % R == 0 and R % max(1, 128 // w.shape[0]) == 0
 
 
 def stem_fused_fwd(x2d, w, R, gamma, beta, pool_mode, eps=1e-5, out_x3=False):
