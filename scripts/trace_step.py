@@ -4,7 +4,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-idx = [i for i, n in enumerate(names) if 'stem_conv_fwd' in n]
+idx = [i for i, n in enumerate(names) if 'stem_conv_fwd' in n or 'stem_stats_partial' in n]   # the step's first stem kernel
 last = rows[idx[-1] - 2:]
 t0 = int(last[0]['Start_Timestamp'])
 agg, prev_end = {}, None
