@@ -729,24 +729,27 @@ def main():
         # (--dtype f32x3p / --conv-dtype f32x3p: fp32 results, opt-in): the headline stays on the native fp32 kernels
         F_.set_conv_dtype('f32x3p')
         try:
-            torch.manual_seed(0)
-            m4 = M.CNNLinearNetwork(M.resnet18(), 20, 0).to(dev)
-            tr4 = HotPathTrainer(m4, optimizer='sgd', use_graph=not args.no_graph)
-            for _ in range(10):
-                tr4.train_step(x, t)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(max(args.steps, 50)):
-                l4 = tr4.train_step(x, t)
-            torch.cuda.synchronize()
-            d4 = (time.perf_counter() - t1) / max(args.steps, 50)
-            out.setdefault('extra', {})['resnet18_f32x3p'] = {
-                'value': round(B * 20 / d4, 1), 'ms_per_step': round(1e3 * d4, 4), 'dtype': 'f32 (six bf16 MFMA products of exact three-term splits per fp32 product)',
-                'final_loss': round(float(l4), 6),
-                'note': 'cnn_linear+resnet18, same workload as the headline under conv arithmetic f32x3p: activations stored pre-split '
-                        '[h|m|l] by the BatchNorm / pool kernels, every residual-block conv (k3 s1, the stride-2 block entries, their '
-                        'data and weight gradients) on v_mfma_f32_32x32x16_bf16; opt-in (DESIGN.md 7c: the 2.7 ms bar for making it '
-                        'the default was not met)'}
+          try:
+              torch.manual_seed(0)
+              m4 = M.CNNLinearNetwork(M.resnet18(), 20, 0).to(dev)
+              tr4 = HotPathTrainer(m4, optimizer='sgd', use_graph=not args.no_graph)
+              for _ in range(10):
+                  tr4.train_step(x, t)
+              torch.cuda.synchronize()
+              t1 = time.perf_counter()
+              for _ in range(max(args.steps, 50)):
+                  l4 = tr4.train_step(x, t)
+              torch.cuda.synchronize()
+              d4 = (time.perf_counter() - t1) / max(args.steps, 50)
+              out.setdefault('extra', {})['resnet18_f32x3p'] = {
+                  'value': round(B * 20 / d4, 1), 'ms_per_step': round(1e3 * d4, 4), 'dtype': 'f32 (six bf16 MFMA products of exact three-term splits per fp32 product)',
+                  'final_loss': round(float(l4), 6),
+                  'note': 'cnn_linear+resnet18, same workload as the headline under conv arithmetic f32x3p: activations stored pre-split '
+                          '[h|m|l] by the BatchNorm / pool kernels, every residual-block conv (k3 s1, the stride-2 block entries, their '
+                          'data and weight gradients) on v_mfma_f32_32x32x16_bf16; opt-in (DESIGN.md 7c: the 2.7 ms bar for making it '
+                          'the default was not met)'}
+          except Exception as e:                     # an opt-in extra never takes the headline line down with it
+            out.setdefault('extra', {})['resnet18_f32x3p'] = {'error': '%s: %s' % (type(e).__name__, e)}
         finally:
             F_.set_conv_dtype('f32')
         say('f32x3p extra done')
