@@ -56,7 +56,7 @@ def parse():
     ap.add_argument('--storage', default=None, choices=['f32', 'bf16'],
                     help='activation storage under --dtype bf16: bf16 (default: BASELINE configs[2] / [4], bf16 storage with '
                          'fp32 statistics and accumulators) or f32 (round 1: bf16 operands only)')
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f32x3', 'f32x3p'],
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16', 'f32x3p'],
                     help="arithmetic of the k3 s1 convs' forward / data gradient: f32 (the headline, BASELINE configs[1]) or "
                          "bf16 operands with fp32 sums (BASELINE configs[2])")
     return ap.parse_args()
@@ -66,7 +66,7 @@ class KernelTimer(object):
     """Wraps C-ABI entry points with HIP events recorded on the launch stream (eager mode only)."""
 
     REPEAT = 8                              # launches per bracket in the repeated measurement
-    REPEATED = ('da_conv3_winograd', 'da_conv3_winograd4', 'da_conv3_bf16', 'da_conv3_x3')     # x,u,y,rows,L,ldx,C,ldy,N,accumulate,stream
+    REPEATED = ('da_conv3_winograd', 'da_conv3_winograd4', 'da_conv3_bf16')     # x,u,y,rows,L,ldx,C,ldy,N,accumulate,stream
     REPEATED_X3P = ('da_conv3_x3p',)                                                            # x,wpk,y,rows,L,C,ldy,N,accumulate,stream
 
     def __init__(self, lib, torch, act_bytes=4.0):
@@ -110,8 +110,8 @@ class KernelTimer(object):
         if name == 'da_conv_wgrad':      # dy,x,dw,ws,rows,Lm,Ldy,lddy,N,Lx,ldx,C,...,ntaps at index 15
             return (2.0 * a[4] * a[5] * a[8] * a[11] * a[15],
                     f * (a[4] * a[6] * a[8] + a[4] * a[9] * a[11] + a[15] * a[8] * a[11]))
-        if name in ('da_conv3_winograd', 'da_conv3_winograd4', 'da_conv3_bf16', 'da_conv3_x3'):  # x,u,y,rows,L,ldx,C,ldy,N,accumulate
-            pts = {'da_conv3_winograd': 4, 'da_conv3_winograd4': 6, 'da_conv3_bf16': 1.5, 'da_conv3_x3': 4.5}[name]
+        if name in ('da_conv3_winograd', 'da_conv3_winograd4', 'da_conv3_bf16'):  # x,u,y,rows,L,ldx,C,ldy,N,accumulate
+            pts = {'da_conv3_winograd': 4, 'da_conv3_winograd4': 6, 'da_conv3_bf16': 1.5}[name]
             return (2.0 * a[3] * a[4] * a[6] * a[8] * 3,
                     f * (a[3] * a[4] * a[6] + a[3] * a[4] * a[8] * (2 if a[9] else 1) + pts * a[6] * a[8]))
         if name == 'da_conv3_x3p':          # x,wpk,y,rows,L,C,ldy,N,accumulate: x3 input (6 B / element), fp32 output, 18 B / weight
@@ -356,7 +356,7 @@ def main():
 
     from deepards_amd import functional as F_
     F_.set_conv_dtype(args.dtype)
-    fp32like = args.dtype in ('f32', 'f32x3', 'f32x3p')            # f32x3: fp32-equivalent products on the bf16 pipe (opt-in)
+    fp32like = args.dtype in ('f32', 'f32x3p')            # f32x3p: fp32-equivalent products on the bf16 pipe (opt-in)
     storage = args.storage or ('f32' if fp32like else args.dtype)
     if fp32like and storage != 'f32':
         raise SystemExit('--storage bf16 needs --dtype bf16')
@@ -443,14 +443,10 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': (('%s breath block + Linear(F*NB, 2) head (stated, not mirrored: the reference cannot run this shape), '
                                  'synthetic (B=%d per GPU, %d, 1, %d) train step, %s (tile shape of BASELINE configs[4])' %
-                                 (args.backbone, B, NB, SL, 'fp32' if args.dtype == 'f32' else 'fp32 via three-term bf16 splits (opt-in)' if args.dtype in ('f32x3', 'f32x3p') else 'bf16 MFMA operands / fp32 sums in the residual-block convs, %s activation storage, fp32 statistics' % storage))
+                                 (args.backbone, B, NB, SL, 'fp32' if args.dtype == 'f32' else 'fp32 via three-term bf16 splits (opt-in)' if args.dtype == 'f32x3p' else 'bf16 MFMA operands / fp32 sums in the residual-block convs, %s activation storage, fp32 statistics' % storage))
                                 if c5_shape else
                                 ('cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) fp32 train step (BASELINE configs[1])'
                                  if args.dtype == 'f32' else
-                                 'cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) fp32 train step (BASELINE configs[1]); OPT-IN arithmetic: '
-                                 'the residual-block conv products as exact three-term bf16 splits (six bf16 MFMA products per multiply, '
-                                 'fp32 sums, fp32 storage) -- not the default path'
-                                 if args.dtype == 'f32x3' else
                                  'cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) fp32 train step (BASELINE configs[1]); arithmetic: fp32 storage '
                                  'of parameters / statistics / conv outputs / gradients, the k3 s1 conv products (forward, data and weight '
                                  'gradient) as exact three-term bf16 splits on the bf16 matrix cores (six MFMA products per multiply, fp32 sums; '
@@ -540,8 +536,6 @@ def main():
             'da_conv_gemm': 'conv_gemm_tailed_kernel<*> / conv_gemm_kernel<*> (conv fwd + dgrad implicit GEMM, v_mfma_f32_32x32x2_f32)',
             'da_conv_gemm_multi': 'conv_gemm_multi_kernel (stride-2 block heads + 1x1 downsamples, fwd + dgrad, v_mfma_f32_32x32x2_f32)',
             'da_conv3_bf16': 'conv3_bf16_kernel (k3 s1 conv forward + data gradient, v_mfma_f32_32x32x16_bf16)',
-            'da_conv3_x3': 'conv3_x3_kernel (k3 s1 conv forward + data gradient, fp32 products as six v_mfma_f32_32x32x16_bf16 of '
-                           'three-term splits; peak = the bf16 MFMA peak / 6)',
             'da_conv3_x3p': 'conv3_x3p_dma_kernel (k3 s1 conv forward + data gradient on pre-split (x3) operands: fp32 products as six '
                             'v_mfma_f32_32x32x16_bf16 of exact three-term splits, operands by LDS-DMA, no VALU in the K loop; peak = the bf16 MFMA peak / 6)',
             'da_conv_x3p_s2_fwd': 'conv_x3p_s2_kernel<false> (stride-2 block entry: k3 s2 conv + 1x1 s2 downsample in one launch, x3 operands)',
@@ -556,16 +550,15 @@ def main():
             'da_conv_wgrad_multi[code1]': 'wino_wgrad_multi_kernel (k3 s1 weight gradients, Winograd F(2,3) form on v_mfma_f32_32x32x2_f32)',
             'da_conv_wgrad_multi[code49]': 'wgrad_x3p_multi_kernel (k3 s1 weight gradients on pre-split (x3) operands, six v_mfma_f32_32x32x16_bf16 '
                                            'products per multiply)',
-            'da_conv_wgrad_multi[code48]': 'wgrad_bf16_multi_kernel<float, 3> (weight gradients, operands split while staged)',
             'da_conv_wgrad_multi[code16]': 'wgrad_bf16_multi_kernel<*, 1> (weight gradients, bf16 operands)',
             'da_conv_wgrad_multi[direct]': 'conv_wgrad_multi_kernel<*> (stride-2 / 1x1 / small-channel weight gradients, v_mfma_f32_32x32x2_f32)',
             'da_bn_fwd_x': 'bn_fwd_fused_kernel<float, *, x3> (BatchNorm forward storing / reading the x3 format)',
             'da_bn_bwd_x': 'bn_bwd_fused_kernel<float, *, x3> (BatchNorm backward storing dx in the x3 format)',
         }
         PEAK = {'da_conv3_bf16': PEAK_BF16_MFMA_TFLOPS, 'da_conv_bf16_multi': PEAK_BF16_MFMA_TFLOPS,
-                'da_conv3_x3': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1), 'da_conv3_x3p': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1),
+                'da_conv3_x3p': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1),
                 'da_conv_x3p_s2_fwd': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1), 'da_conv_x3p_s2_dgrad': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1),
-                'da_conv_wgrad_multi[code49]': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1), 'da_conv_wgrad_multi[code48]': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1),
+                'da_conv_wgrad_multi[code49]': round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1),
                 'da_conv_wgrad_multi[code16]': PEAK_BF16_MFMA_TFLOPS}
         cands = [k for k in summ if k in KERNEL_OF and (summ[k]['flops'] or summ[k]['bytes'])]
         dname = max(cands, key=lambda k: summ[k].get('rep_total_ms', summ[k]['total_ms']))   # argmax over all of them
@@ -583,7 +576,7 @@ def main():
             traffic, traffic_note = None, 'the PMC passes under profiles/ ran the default workload (B=64, nb20, seq224) only'
         else:
             traffic, traffic_note = pmc_traffic(dname, ('bf16' if F_.storage_dtype() == 'bf16' else 'bf16_f32storage') if args.dtype == 'bf16' else
-                                                (args.dtype if args.dtype in ('f32x3', 'f32x3p') else ''))
+                                                (args.dtype if args.dtype == 'f32x3p' else ''))
         out['roofline'] = {'bound': bound, 'kernel': KERNEL_OF[dname], 'entry': dname,
                            'achieved': round(ach, 2), 'peak': peak, 'unit': unit,
                            'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_note,

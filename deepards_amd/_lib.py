@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('DA_LIB_PATH') or os.path.join(_HERE, 'libdeepards_hip.so')   # (override: A/B builds, scripts/)
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'deepards_hip.h')
-SOURCES = ['conv_gemm.hip', 'conv_wino.hip', 'conv_bf16.hip', 'conv_x3.hip', 'conv_x3p.hip', 'bn.hip', 'stem_pool.hip', 'head_optim.hip']
+SOURCES = ['conv_gemm.hip', 'conv_wino.hip', 'conv_bf16.hip', 'conv_x3p.hip', 'bn.hip', 'stem_pool.hip', 'head_optim.hip']
 
 _P, _I, _F, _Z, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_uint
 _IP = ctypes.POINTER(ctypes.c_int)
@@ -98,13 +98,11 @@ SIGNATURES = {
     'da_conv3_winograd4': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'da_conv3_bf16': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'da_pack_conv3_bf16': (_I, [_P, _P, _P, _I, _I, _P]),
-    'da_conv3_x3': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'da_conv3_x3p': (_I, [_P, _P, _P] + [_I] * 6 + [_P]),
     'da_conv_x3p_s2_fwd': (_I, [_P] * 5 + [_I] * 4 + [_P]),
     'da_conv_x3p_s2_dgrad': (_I, [_P] * 5 + [_I] * 4 + [_P]),
     'da_x3_split': (_I, [_P, _I, _P, _Z, _I, _P]),
     'da_x3_merge': (_I, [_P, _P, _I, _Z, _I, _P]),
-    'da_pack_conv3_x3': (_I, [_P, _P, _P, _I, _I, _P]),
     'da_conv_bf16_multi': (_I, [ctypes.POINTER(ConvJob), _I, _P]),
     'da_wino_debug_tail': (_I, [_I]),
     'da_wino_debug_pchunk': (_I, [_I]),
@@ -184,15 +182,6 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _check_same_runtime(l)
-        for key, env in ((0, 'DA_CONV_TILE'), (1, 'DA_WGRAD_BLOCKS'), (2, 'DA_HALO'), (3, 'DA_TAIL')):      # tuning knobs (scripts/)
-            if os.environ.get(env):
-                l.da_debug_set(key, int(os.environ[env]))
-        if os.environ.get('DA_WINO_TAIL'):
-            l.da_wino_debug_tail(int(os.environ['DA_WINO_TAIL']))
-        if os.environ.get('DA_WINO_PCHUNK'):
-            l.da_wino_debug_pchunk(int(os.environ['DA_WINO_PCHUNK']))
-        if os.environ.get('DA_BN_BLOCKS'):           # blocks per launch the single-pass BatchNorm geometry aims for
-            l.da_bn_debug_target_blocks(int(os.environ['DA_BN_BLOCKS']))
         _lib = l
     return _lib
 

@@ -266,7 +266,10 @@ def load_own_module(path):
     parameters and plain containers are accepted; any other global in the stream raises ``pickle.UnpicklingError``
     before it is looked up.  The class path at the head of the file is therefore not trusted for anything."""
     with torch.serialization.safe_globals(_own_module_classes()):
-        return torch.load(path, weights_only=True, map_location='cpu')
+        model = torch.load(path, weights_only=True, map_location='cpu')
+    for q in model.parameters():                 # (files written before round 4 carry the saving trainer's gradient views)
+        q.__dict__.pop('_da_grad', None)
+    return model
 
 
 def load_model_weights(path, build_model):

@@ -194,8 +194,8 @@ typedef struct {
   int rows, Lm, Ldy, lddy, N, Lx, ldx, C, dy_stride, dy_off, src_stride, ntaps;
   int src_off[3];
   int winograd;          // k3 s1 p1, N and C multiples of 64 -- 1: Winograd F(2,3) form (fp32), 16: bf16 operands /
-                         // fp32 sums, 48: split-bf16 fp32-equivalent products (both conv_bf16.hip; also the stride-2
-                         // jobs); the matching da_conv_wgrad_plan(winograd = 1 / 16 / 48) sizes the workspace
+                         // fp32 sums, 49: split-bf16 fp32-equivalent products on x3 operands (both conv_bf16.hip; also
+                         // the stride-2 jobs); the matching da_conv_wgrad_plan(winograd = 1 / 16 / 49) sizes the workspace
 } da_wgrad_job;
 
 // conv_wino.hip
@@ -206,7 +206,7 @@ int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream);
 // conv_bf16.hip: jobs with winograd == 16 (the same eligibility; bf16 operands, padded-position K)
 bool bf16_wgrad_eligible(const da_wgrad_job& j);
 void bf16_wgrad_plan(int rows, int L, int* splits, int* pchunk);
-int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, int code, hipStream_t stream);   // code 16 (bf16) or 48 (f32x3)
+int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, int code, hipStream_t stream);   // code 16 (bf16) or 49 (x3 operands)
 void bf16_wgrad_set_pchunk(int pchunk);
 
 // One problem of da_conv_gemm_multi: the arguments of da_conv_gemm (include/deepards_hip.h).

@@ -415,24 +415,6 @@ template <typename AT> struct WBStage<AT, 1> {
     *reinterpret_cast<f32x2v*>(d) = Stage<AT>::bits(v);
   }
 };
-template <> struct WBStage<float, 3> {
-  static __device__ __forceinline__ f32x4 widen(const f32x2v& b) {
-    const uint32_t u0 = __float_as_uint(b[0]), u1 = __float_as_uint(b[1]);
-    return f32x4{__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 << 16),
-                 __uint_as_float(u1 & 0xffff0000u)};
-  }
-  static __device__ __forceinline__ void put(unsigned char* d, const f32x4& v) {
-    const f32x2v h = cvt4_bf16(v);
-    const f32x4 r1 = v - widen(h);
-    const f32x2v m = cvt4_bf16(r1);
-    const f32x4 r2 = r1 - widen(m);
-    *reinterpret_cast<f32x2v*>(d) = h;
-    *reinterpret_cast<f32x2v*>(d + 128) = m;
-    *reinterpret_cast<f32x2v*>(d + 256) = cvt4_bf16(r2);
-  }
-};
-
-// acc += A B over the NS x NS split terms that matter (small terms first)
 template <> struct WBStage<X3T, 3> {                       // pre-split operands: three plain 8-byte stores, no arithmetic
   static __device__ __forceinline__ void put(unsigned char* d, const Stage<X3T>::reg& v) {
     *reinterpret_cast<f32x2v*>(d) = v.h;
@@ -441,6 +423,7 @@ template <> struct WBStage<X3T, 3> {                       // pre-split operands
   }
 };
 
+// acc += A B over the NS x NS split terms that matter (small terms first)
 template <int NS>
 __device__ __forceinline__ void wb_mfma(f32x16& acc, const f32x4* a, const f32x4* b) {
 #define WB_M(i, j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc, 0, 0, 0)
@@ -791,7 +774,7 @@ void bf16_wgrad_plan(int rows, int L, int* splits, int* pchunk) {
   *pchunk = (int)pc;
 }
 
-// jobs flagged `code` (16: bf16 operands; 48: fp32-equivalent split-bf16 products, fp32 activations only)
+// jobs flagged `code` (16: bf16 operands; 49: fp32-equivalent split-bf16 products on x3 operands, fp32 activations only)
 int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, int code, hipStream_t s) {
   WgradBf16Table t;
   int cnt = 0, blocks = 0;
@@ -800,7 +783,6 @@ int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, int code, hipStream_t s) 
     t.n = cnt;
     t.first_block[cnt] = blocks;
     if (code == 49) hipLaunchKernelGGL(wgrad_x3p_multi_kernel, dim3(blocks), dim3(256), 0, s, t);
-    else if (code == 48) hipLaunchKernelGGL((wgrad_bf16_multi_kernel<float, 3>), dim3(blocks), dim3(256), 0, s, t);
     else DA_ACT_DISPATCH(hipLaunchKernelGGL((wgrad_bf16_multi_kernel<AT, 1>), dim3(blocks), dim3(256), 0, s, t));
     DA_CHECK_LAUNCH();
     cnt = 0;
@@ -810,7 +792,7 @@ int bf16_wgrad_launch(const da_wgrad_job* jobs, int n, int code, hipStream_t s) 
   for (int i = 0; i < n; ++i) {
     const da_wgrad_job& j = jobs[i];
     if (j.winograd != code) continue;
-    if ((code == 48 || code == 49) && g_act_bf16) return DA_EINVAL;      // the split kernels belong to float activations
+    if (code == 49 && g_act_bf16) return DA_EINVAL;      // the split kernels belong to float activations
     int splits, pchunk;
     bf16_wgrad_plan(j.rows, j.Lm, &splits, &pchunk);
     WgradBf16Args& a = t.d[cnt];

@@ -987,7 +987,7 @@ int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
       return DA_EINVAL;
     if ((uint64_t)j.rows * j.Lm * (uint64_t)j.Lm >= 0xffffffffull) return DA_EINVAL;
     if (g_act_bf16 && j.winograd != 16) return DA_EINVAL;     // bf16 activations: only the bf16-operand kernels read them
-    if (j.winograd == 16 || j.winograd == 48 || j.winograd == 49
+    if (j.winograd == 16 || j.winograd == 49
             ? !bf16_wgrad_eligible(j)
             : (j.winograd ? !wino_wgrad_eligible(j) : !wgrad_plan(j.rows * j.Lm, j.N, j.C, j.ntaps).tn))
       return DA_EINVAL;
@@ -995,7 +995,6 @@ int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
   int rc;
   if ((rc = wino_wgrad_launch(jobs, n, stream))) return rc;   // the heaviest blocks first
   if ((rc = bf16_wgrad_launch(jobs, n, 49, stream))) return rc;      // x3 operands (dy / x are x3 tensors; ld* = channel counts)
-  if ((rc = bf16_wgrad_launch(jobs, n, 48, stream))) return rc;
   if ((rc = bf16_wgrad_launch(jobs, n, 16, stream))) return rc;
   if ((rc = launch_wgrad_group<2, 2, 2, 2>(jobs, n, 128, 128, stream))) return rc;
   if ((rc = launch_wgrad_group<2, 1, 2, 2>(jobs, n, 128, 64, stream))) return rc;
@@ -1017,9 +1016,9 @@ int da_conv_wgrad_splits(int rows, int Lm, int N, int C, int ntaps) {
 int da_conv_wgrad_plan(int rows, int Lm, int N, int C, int ntaps, int winograd, int* out) {
   if (!out || ntaps < 1 || ntaps > 3 || N % 32 || C % 32) return DA_EINVAL;
   if (winograd) {
-    if ((ntaps != 3 && winograd != 16 && winograd != 48 && winograd != 49) || N % 64 || C % 64) return DA_EINVAL;
+    if ((ntaps != 3 && winograd != 16 && winograd != 49) || N % 64 || C % 64) return DA_EINVAL;
     out[0] = 64; out[1] = 64;
-    if (winograd == 16 || winograd == 48 || winograd == 49) bf16_wgrad_plan(rows, Lm, &out[2], &out[3]);     // kchunk counts padded positions
+    if (winograd == 16 || winograd == 49) bf16_wgrad_plan(rows, Lm, &out[2], &out[3]);     // kchunk counts padded positions
     else wino_wgrad_plan(rows, Lm, &out[2], &out[3]);
     return DA_OK;
   }

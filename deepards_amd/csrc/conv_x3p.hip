@@ -17,7 +17,7 @@
 // 6 C bytes per position: one K step (16 channels) of one panel row is ONE contiguous 96-byte run.
 //
 // Two forms of the same tiles, same MFMA order, bit-identical results: LDS-DMA staging into a 3-slot ring (the default,
-// conv3_x3p_dma_kernel below) and register staging (conv3_x3p_kernel, DA_X3_KERNEL=1: the form of round 3's first
+// conv3_x3p_dma_kernel below) and register staging (conv3_x3p_kernel, build with -DXP_DEFAULT_KERNEL=1: the form of round 3's first
 // ablations; kept for A/B).
 //
 // Block = (64 MT) positions x 64 output channels, 4 waves of (32 MT) x 32 (v_mfma_f32_32x32x16_bf16, MT accumulators);
@@ -350,10 +350,16 @@ __device__ __forceinline__ void conv3_x3p_dma_body(const ConvX3pArgs& a, const i
   }
   issue(0, 0);
   issue(kch > 1 ? 1 : 0, 1);
-  // a wave whose last piece index falls beyond the step's pieces issues NI - 1 per step: the counted wait is per wave
-  const bool all_on = on[NI - 1];
+  // The counted wait is PER WAVE and comes from the same on[] that gates issue1(): a wave issues sum(on[i]) pieces per K
+  // step, and since piece j = wave + 8 i grows with i only its LAST index can fall beyond the step's NJ pieces -- the
+  // count is NI or NI - 1, nothing else (one shared constant let a wave with NI - 1 pieces pass the barrier with its
+  // last piece of the step still in flight: the intermittent wrong result of round 3).
+  static_assert(8 * (NI - 1) < NJ && NJ <= 8 * NI, "every wave issues NI or NI - 1 pieces per K step");
+  int issued = 0;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) issued += on[i] ? 1 : 0;
   auto land = [&]() {                               // everything but this wave's NEWEST step of pieces has landed
-    if (all_on) vm_wait<NI>();
+    if (issued == NI) vm_wait<NI>();
     else vm_wait<NI - 1>();
   };
   land();                                           // step 0 (this wave's pieces; the barrier covers the others')
@@ -524,9 +530,12 @@ __device__ __forceinline__ void conv_x3p_s2_body(const ConvX3pS2Args& a, const i
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned char*)(src[i] + (size_t)ks * inc[i]),
                                        (lds_byte*)(lds + slot * S2_SLOT + dst[i]), 16, 0, 0);
   };
-  const bool all_on = on[NI - 1];
+  static_assert(8 * (NI - 1) < NJ && NJ <= 8 * NI, "every wave issues NI or NI - 1 pieces per K step");
+  int issued = 0;                                   // this wave's pieces per K step, from the on[] that gates issue1()
+#pragma unroll
+  for (int i = 0; i < NI; ++i) issued += on[i] ? 1 : 0;
   auto land = [&]() {
-    if (all_on) vm_wait<NI>();
+    if (issued == NI) vm_wait<NI>();
     else vm_wait<NI - 1>();
   };
 
@@ -763,22 +772,14 @@ int da_conv3_x3p(const void* x, const void* wpk, float* y, int rows, int L, int 
   a.M = (int)M; a.L = L; a.C = C; a.ldy = ldy; a.N = N; a.accumulate = accumulate;
   a.divL = make_fastdiv((uint32_t)L);
   const int ntn = N / XP_TN;
-  static int g_kernel = 0;
-  if (!g_kernel) {
-    const char* e = getenv("DA_X3_KERNEL");
-    g_kernel = e ? atoi(e) : XP_DEFAULT_KERNEL;
-  }
+  const int g_kernel = XP_DEFAULT_KERNEL;
   const long mtiles = (M + XP_TM - 1) / XP_TM;
   const long tiles = mtiles * ntn;
   if (tiles > 0x3fffffffl) return DA_EINVAL;
   // the partly filled last round (256 resident blocks: 1 per CU) runs as 64 x 64 tiles -- whole M-tile rows of them
   long tail_m = 0;
-  static int g_tail = -1;
+  const int g_tail = 1;
   static bool attr_set = false;
-  if (g_tail < 0) {
-    const char* e = getenv("DA_X3_TAIL");
-    g_tail = e ? atoi(e) : 1;
-  }
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_x3p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             XP_LDS_BYTES) != hipSuccess)

@@ -263,18 +263,7 @@ __global__ __launch_bounds__(256) void repack_multi_kernel(RepackTable t) {
   }
 }
 
-// one weight into the fragment-major split-bf16 pack of conv3_x3_kernel (conv_x3.hip): element (tap t, n, c), term s at
-//     ((((t * (N/32) + n/32) * (C/16) + c/16) * 3 + s) * 64 + (c%16 / 8) * 32 + n%32) * 8 + c%8
-__device__ __forceinline__ void x3_pack_put(__bf16* pk, int t, int n, int c, int N, int C, float v) {
-  const __bf16 h = (__bf16)v;
-  const float r1 = v - (float)h;
-  const __bf16 m = (__bf16)r1;
-  const __bf16 l = (__bf16)(r1 - (float)m);
-  __bf16* d = pk + ((((size_t)t * (N >> 5) + (n >> 5)) * (C >> 4) + (c >> 4)) * 3 * 64 + ((c & 15) >> 3) * 32 + (n & 31)) * 8 + (c & 7);
-  d[0] = h; d[512] = m; d[1024] = l;
-}
-
-// ... and into the CHUNKED pack of conv3_x3p_kernel (conv_x3p.hip): the 18 KB a block stages per (64-channel tile, 16-channel
+// one weight into the CHUNKED split-bf16 pack of conv3_x3p_kernel (conv_x3p.hip): the 18 KB a block stages per (64-channel tile, 16-channel
 // K step) are contiguous and already in LDS order -- element (tap t, n, c), term s at
 //     (((n/64) * (C/16) + c/16) * 18 + (t * 2 + (n%64)/32) * 3 + s) * 512 + ((c%16 / 8) * 32 + n%32) * 8 + c%8
 __device__ __forceinline__ void x3p_pack_put(__bf16* pk, int t, int n, int c, int N, int C, float v) {
@@ -317,8 +306,6 @@ __global__ __launch_bounds__(256) void repack_tiled_kernel(RepackTable t) {
         if (d.points == 16) {                                     // bf16 tap packs of conv_bf16.hip: [K][Co][Ci]
           __bf16* u = reinterpret_cast<__bf16*>(d.Uf);
           for (int k = 0; k < K; ++k) u[(size_t)k * tot + o] = (__bf16)w[k];
-        } else if (d.points == 48) {                              // split-bf16 fragment packs of conv_x3.hip (K == 3)
-          for (int k = 0; k < 3; ++k) x3_pack_put(reinterpret_cast<__bf16*>(d.Uf), k, co0 + a, ci0 + b, d.Co, d.Ci, w[k]);
         } else if (d.points == 49) {                              // chunked split-bf16 packs of conv_x3p.hip (K == 3)
           if (K == 1) x3p_pack_put(reinterpret_cast<__bf16*>(d.Uf), 1, co0 + a, ci0 + b, d.Co, d.Ci, w[0]);   // 1x1: tap 1 only (conv_x3p_s2)
           else for (int k = 0; k < 3; ++k) x3p_pack_put(reinterpret_cast<__bf16*>(d.Uf), k, co0 + a, ci0 + b, d.Co, d.Ci, w[k]);
@@ -337,8 +324,6 @@ __global__ __launch_bounds__(256) void repack_tiled_kernel(RepackTable t) {
         if (d.points == 16) {                                     // [K][Ci][Co] bf16, taps reversed
           __bf16* u = reinterpret_cast<__bf16*>(d.Ud);
           for (int k = 0; k < K; ++k) u[(size_t)k * tot + o] = (__bf16)w[K - 1 - k];
-        } else if (d.points == 48) {                              // n = ci, c = co, taps reversed
-          for (int k = 0; k < 3; ++k) x3_pack_put(reinterpret_cast<__bf16*>(d.Ud), k, ci0 + a, co0 + b, d.Ci, d.Co, w[2 - k]);
         } else if (d.points == 49) {
           if (K == 1) x3p_pack_put(reinterpret_cast<__bf16*>(d.Ud), 1, ci0 + a, co0 + b, d.Ci, d.Co, w[0]);
           else for (int k = 0; k < 3; ++k) x3p_pack_put(reinterpret_cast<__bf16*>(d.Ud), k, ci0 + a, co0 + b, d.Ci, d.Co, w[2 - k]);
@@ -898,8 +883,8 @@ int da_repack_multi(const da_repack_desc* descs, int n, hipStream_t stream) {
     for (int i = 0; i < m; ++i) {
       const da_repack_desc& s = descs[base + i];
       if (!s.W || (!s.Wf && !s.Wd && !s.Uf && !s.Ud) || ((s.Uf || s.Ud) && s.K != 3 && s.points != 16 && s.points != 49)) return DA_EINVAL;
-      if ((s.points == 16 || s.points == 48 || s.points == 49) && (s.Co % 32 || s.Ci % 32)) return DA_EINVAL;   // bf16 packs: tiled kernel only
-      if ((s.points == 48 && s.K != 3) || (s.points == 49 && s.K != 3 && s.K != 1)) return DA_EINVAL;
+      if ((s.points == 16 || s.points == 49) && (s.Co % 32 || s.Ci % 32)) return DA_EINVAL;   // bf16 packs: tiled kernel only
+      if (s.points == 49 && s.K != 3 && s.K != 1) return DA_EINVAL;
       if (s.points == 49 && (s.Co % 64 || s.Ci % 64)) return DA_EINVAL;
       t.d[i] = {s.W, s.Wf, s.Wd, s.Uf, s.Ud, s.Co, s.Ci, s.K, s.points};
     }

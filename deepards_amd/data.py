@@ -185,14 +185,15 @@ class DeviceTileStore(object):
         if self.kfold_indexes is not None:
             idx = self.kfold_indexes[idx]
         idx = idx.contiguous()
-        # remember the buffer: batch_from_device only accepts slices of index tensors that were checked here
-        import weakref
+        # remember the buffer: batch_from_device only accepts slices of index tensors that were checked here.  STRONG
+        # references (the last few epochs' lists, a few KB each): callers keep only slices, and under inference_mode a
+        # slice does not keep its base alive -- a weak reference would refuse valid slices there.
         live = getattr(self, '_checked_idx', None)
         if live is None:
             live = self._checked_idx = {}
-        for k in [k for k, r in live.items() if r() is None]:
-            del live[k]
-        live[idx.untyped_storage().data_ptr()] = weakref.ref(idx)
+        while len(live) >= 8:
+            del live[next(iter(live))]
+        live[idx.untyped_storage().data_ptr()] = idx
         return idx
 
     def batch_from_device(self, abs_idx, out=None):
@@ -202,7 +203,7 @@ class DeviceTileStore(object):
         if not (abs_idx.is_cuda and abs_idx.dtype == torch.int64 and abs_idx.dim() == 1 and abs_idx.is_contiguous()):
             raise ValueError('batch_from_device: a contiguous 1-D int64 device tensor from device_indices() expected')
         ref = getattr(self, '_checked_idx', {}).get(abs_idx.untyped_storage().data_ptr()) if abs_idx.numel() else True
-        if ref is None or (ref is not True and ref() is None):
+        if ref is None:
             raise ValueError('batch_from_device: indices must be (a slice of) a tensor returned by device_indices(), which '
                              'checks them against the store; use batch() for anything else')
         ox, ot = out if out is not None else (None, None)

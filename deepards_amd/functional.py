@@ -83,24 +83,18 @@ def _launch_wgrads():
     _STEP['wgrad'] = []
 
 
-_WINOGRAD = os.environ.get('DA_WINOGRAD', '1') != '0'
-_BN_MASK = os.environ.get('DA_BN_MASK', '1') != '0'       # block-output BatchNorm: ReLU decisions as a bit mask
-_PAIR_S2 = os.environ.get('DA_PAIR_S2', '1') != '0'      # stride-2 block heads: conv + downsample GEMMs share launches
-
-
-_WINO4_MIN_C = int(os.environ.get('DA_WINO4_MINC', '512'))   # channels from which F(4,3) beats F(2,3) (scripts/bench_wino.py)
+_WINOGRAD = os.environ.get('DA_WINOGRAD', '1') != '0'   # 0: the direct fp32 kernels (the second fp32 implementation the tests compare)
+_WINO4_MIN_C = 512        # channels from which F(4,3) beats F(2,3) (scripts/bench_wino.py; DESIGN appendix)
 
 
 # Arithmetic of the k3 s1 p1 convs' forward / data gradient: 'f32' (Winograd on the fp32 matrix cores), 'bf16' (BASELINE
-# config C3: operands rounded to bf16, fp32 sums, conv_bf16.hip; also the k3 s1 weight gradients unless DA_WGRAD_BF16=0),
-# 'f32x3' (fp32-equivalent products from exact three-term bf16 splits on the bf16 matrix cores, split while staging:
-# conv_x3.hip, round 2; the weight gradients too with DA_WGRAD_X3=1) or 'f32x3p' (the same arithmetic with the split done by
-# the PRODUCERS: the BatchNorm / pool kernels in front of a k3 s1 conv store the x3 format, conv_x3p.hip and the x3
-# weight-gradient kernel read it; forward, data gradient and weight gradient).
+# config C3: operands rounded to bf16, fp32 sums, conv_bf16.hip; also the k3 s1 weight gradients) or 'f32x3p'
+# (fp32-equivalent products from exact three-term bf16 splits on the bf16 matrix cores, the split done by the PRODUCERS:
+# the BatchNorm / pool kernels in front of a k3 s1 conv store the x3 format, conv_x3p.hip and the x3 weight-gradient
+# kernel read it; forward, data gradient and weight gradient; opt-in, frozen since round 3).
 _CONV_DTYPE = os.environ.get('DA_CONV_DTYPE', 'f32')
 _STEM_FUSED = os.environ.get('DA_STEM_FUSED', '1') != '0'   # the default stem recomputes its conv output instead of storing it
-_S2_X3 = os.environ.get('DA_X3_S2', '1') != '0'      # 'f32x3p': the stride-2 block entries on x3 operands too (A/B switch)
-CONV_DTYPES = ('f32', 'bf16', 'f32x3', 'f32x3p')
+CONV_DTYPES = ('f32', 'bf16', 'f32x3p')
 
 
 def set_conv_dtype(name):
@@ -111,8 +105,7 @@ def set_conv_dtype(name):
     if name != 'bf16' and H.act_dtype() == 'bf16':
         H.set_act_dtype('f32')                     # fp32 convs read fp32 activations
     _CONV_DTYPE = name
-    H.WGRAD_BF16 = name == 'bf16' and os.environ.get('DA_WGRAD_BF16', '1') != '0'
-    H.WGRAD_X3 = name == 'f32x3' and os.environ.get('DA_WGRAD_X3', '0') != '0'
+    H.WGRAD_BF16 = name == 'bf16'
 
 
 def conv_dtype():
@@ -146,8 +139,6 @@ def _is_wino(w, stride, pad):
         return 16                                   # also the stride-2 block heads and 1x1 downsamples (even lengths)
     if not (w.shape[2] == 3 and stride == 1 and pad == 1 and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0):
         return 0
-    if _CONV_DTYPE == 'f32x3' and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
-        return 48                                   # split-bf16 products, direct form (conv_x3.hip)
     if _CONV_DTYPE == 'f32x3p' and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
         return 49                                   # the same on x3 (pre-split) operands (conv_x3p.hip); float operands: _fp32_code
     return _fp32_code(w)
@@ -156,7 +147,7 @@ def _is_wino(w, stride, pad):
 def s2_x3_ok(w1, wd, l_in):
     """Whether a stride-2 block entry (k3 s2 p1 conv + 1x1 s2 downsample) runs on x3 operands (conv arithmetic 'f32x3p':
     H.conv_x3p_s2_fwd / _dgrad and the x3 weight-gradient jobs): even input length, channel counts multiples of 64."""
-    return _CONV_DTYPE == 'f32x3p' and _S2_X3 and H.act_dtype() == 'f32' and wd is not None and l_in % 2 == 0 and \
+    return _CONV_DTYPE == 'f32x3p' and H.act_dtype() == 'f32' and wd is not None and l_in % 2 == 0 and \
         tuple(w1.shape[2:]) == (3,) and tuple(wd.shape[2:]) == (1,) and tuple(wd.shape[:2]) == tuple(w1.shape[:2]) and \
         w1.shape[0] % 64 == 0 and w1.shape[1] % 64 == 0
 
@@ -165,7 +156,7 @@ def _step_pack_code(m):
     """The pack form the step's batched repack prepares for a conv module (a consumer that needs another form packs it
     itself, once: _pack)."""
     w, stride, pad = m.weight, m.stride[0], m.padding[0]
-    if _CONV_DTYPE == 'f32x3p' and _S2_X3 and H.act_dtype() == 'f32' and stride == 2 and w.shape[0] % 64 == 0 and \
+    if _CONV_DTYPE == 'f32x3p' and H.act_dtype() == 'f32' and stride == 2 and w.shape[0] % 64 == 0 and \
             w.shape[1] % 64 == 0 and (w.shape[2], pad) in ((3, 1), (1, 0)):
         return 49                                   # the stride-2 block entries on x3 operands (s2_x3_ok)
     return _is_wino(w, stride, pad)
@@ -207,8 +198,6 @@ def _conv_fwd(x, w, stride, pad):
     _need_bf16_kernel(code, w, stride, pad)
     if code == 16:
         return H.conv3_bf16(x, _pack(w, code)[2]) if stride == 1 else H.conv_fwd_bf16_s2(x, _pack(w, code)[2])
-    if code == 48:
-        return H.conv3_x3(x, _pack(w, code)[2])
     if code:
         return H.conv3_winograd(x, _pack(w, code)[2])
     return H.conv_fwd(x, _pack(w, 0)[0], stride, pad)
@@ -227,8 +216,6 @@ def _conv_dgrad(dy, w, stride, pad, l_in, out=None, accumulate=False):
         if stride == 2:
             return H.conv_dgrad_bf16_s2(dy, _pack(w, code)[3], l_in, out=out, accumulate=accumulate)
         return H.conv3_bf16(dy, _pack(w, code)[3], out=out, accumulate=accumulate)
-    if code == 48:
-        return H.conv3_x3(dy, _pack(w, code)[3], out=out, accumulate=accumulate)
     if code:
         return H.conv3_winograd(dy, _pack(w, code)[3], out=out, accumulate=accumulate)
     return H.conv_dgrad(dy, _pack(w, 0)[1], stride, pad, l_in, out=out, accumulate=accumulate)
@@ -257,13 +244,10 @@ def x3_handle(x3):
     return z.expand(rows, l, g * 16)
 
 
-_X3_MIN_C = int(os.environ.get('DA_X3_MINC', '64'))      # channel count from which a block takes the x3 flow (A/B measurements)
-
-
 def x3_block_ok(rows, l, c, R):
     """Whether a block whose activations are (rows, L, C) in windows of R rows can run its k3 s1 convs on x3 operands:
     conv arithmetic 'f32x3p', float storage, 64-multiple channels and the single-pass BatchNorm geometry (its store forms)."""
-    return _CONV_DTYPE == 'f32x3p' and H.act_dtype() == 'f32' and c % 64 == 0 and c >= _X3_MIN_C and H.bn_x3_ok(rows, l, c, R)
+    return _CONV_DTYPE == 'f32x3p' and H.act_dtype() == 'f32' and c % 64 == 0 and H.bn_x3_ok(rows, l, c, R)
 
 
 def _bn_apply_x(x, R, s, st, gamma, beta, relu, res=None, want_mask=False, out_x3=True):
@@ -450,7 +434,7 @@ def _wgrad(dy, x, k, stride, pad, tw):
     if tw is not None and _STEP['on']:
         _STEP['wgrad'].append((dy, x, k, stride, pad, tw))     # launched with all the others by flush_backward()
         return None
-    if H.WGRAD_BF16 or H.WGRAD_X3 or H.act_dtype() == 'bf16' or H.is_x3(dy):   # the bf16-pipe kernels exist in the batched form only
+    if H.WGRAD_BF16 or H.act_dtype() == 'bf16' or H.is_x3(dy):   # the bf16-pipe kernels exist in the batched form only
         (slab,) = H.conv_wgrad_multi([(dy, x, k, stride, pad)])
         co, ci = (dy.shape[2] * 16, x.shape[2] * 16) if H.is_x3(dy) else (dy.shape[2], x.shape[2])
         dw = tw if tw is not None else torch.empty((co, ci, k), device=x.device, dtype=torch.float32)
@@ -473,9 +457,9 @@ class BasicBlockFunction(Function):
     @staticmethod
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, R, st1, st2, std, x3=None, want_out3=False):
         in3 = x3 is not None
-        bf16_pair = wd is not None and stride == 2 and _PAIR_S2 and x.shape[1] % 2 == 0 and \
+        bf16_pair = wd is not None and stride == 2 and x.shape[1] % 2 == 0 and \
             _is_wino(w1, stride, 1) == 16 and _is_wino(wd, stride, 0) == 16
-        pair = bf16_pair or (wd is not None and stride == 2 and _PAIR_S2 and not _is_wino(w1, stride, 1))
+        pair = bf16_pair or (wd is not None and stride == 2 and not _is_wino(w1, stride, 1))
         s2x = in3 and stride == 2
         if s2x:           # the stride-2 block entry on the pre-split input: conv1 and the downsample conv in one launch
             if not s2_x3_ok(w1, wd, x3.shape[1]):
@@ -513,11 +497,10 @@ class BasicBlockFunction(Function):
         if mid3:          # x3 residual and / or x3 output: the store forms (always with the ReLU bit mask)
             out = _bn_apply_x(y2, R, s2, st2, g2, b2, True, res=res, want_mask=True, out_x3=want_out3)
         else:
-            out = _bn_apply(y2, R, s2, st2, g2, b2, True, res=res, want_mask=_BN_MASK)
+            out = _bn_apply(y2, R, s2, st2, g2, b2, True, res=res, want_mask=True)
         _tap(out)
         m1, i1, m2, i2 = s1.mean, s1.invstd, s2.mean, s2.invstd
-        use_mask = mid3 or _BN_MASK
-        ctx.relu_mask = s2.mask if use_mask else None       # 8 bytes per thread instead of re-reading `out` for its sign
+        ctx.relu_mask = s2.mask     # 8 bytes per thread instead of re-reading `out` for its sign (None: two-stage geometry)
         ctx.has_ds, ctx.in3, ctx.mid3, ctx.s2x = wd is not None, in3, mid3, s2x
         ctx.stride, ctx.R, ctx.lin = stride, R, x.shape[1]
         ctx.gt = _tgt(w1, g1, b1, w2, g2, b2, wd, gd, bd)
@@ -562,7 +545,7 @@ class BasicBlockFunction(Function):
             dwd = _wgrad(dyd, x, 1, stride, 0, twd)
             if ctx.s2x:
                 dx = H.conv_x3p_s2_dgrad(dy1, _pack(w1, 49)[3], dyd, _pack(wd, 49)[3])
-            elif stride == 2 and _PAIR_S2 and not _is_wino(w1, stride, 1):
+            elif stride == 2 and not _is_wino(w1, stride, 1):
                 dx = H.conv_dgrad_s2_pair(dy1, _pack(w1, False)[1], dyd, _pack(wd, False)[1], lin)
             else:
                 dx = _conv_dgrad(dy1, w1, stride, 1, lin)

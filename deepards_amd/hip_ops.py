@@ -169,39 +169,6 @@ def conv3_bf16(x, wpk, out=None, accumulate=False):
     return out
 
 
-def pack_conv3_x3(w):
-    """(Co, Ci, 3) fp32 conv weight -> fragment-major split-bf16 packs (wf, wd) for conv3_x3: flat bf16 buffers of
-    3 * 3 * Co * Ci elements, tagged with their (N, C)."""
-    _f32(w, 'w')
-    co, ci, k = w.shape
-    if k != 3 or co % 32 or ci % 32:
-        raise ValueError('pack_conv3_x3: (Co, Ci, 3) weight with Co, Ci multiples of 32 expected')
-    wf = torch.empty((3, co // 32, ci // 16, 3, 64, 8), device=w.device, dtype=torch.bfloat16)
-    wd = torch.empty((3, ci // 32, co // 16, 3, 64, 8), device=w.device, dtype=torch.bfloat16)
-    _chk(_lib.lib().da_pack_conv3_x3(_p(w), _p(wf), _p(wd), co, ci, _stream()), 'da_pack_conv3_x3')
-    return wf, wd
-
-
-def conv3_x3(x, wpk, out=None, accumulate=False):
-    """k3 s1 p1 conv of x (rows, L, C) fp32 with the split-bf16 packs wpk (3, N/32, C/16, 3, 64, 8) of pack_conv3_x3:
-    fp32-equivalent products on the bf16 matrix cores, fp32 sums -> (rows, L, N)."""
-    _rlc32(x, 'x')
-    rows, l, c = x.shape
-    if wpk.dim() != 6 or wpk.shape[0] != 3 or wpk.shape[2] * 16 != c or tuple(wpk.shape[3:]) != (3, 64, 8) or \
-            wpk.shape[1] % 2 or c % 32 or wpk.dtype != torch.bfloat16 or not wpk.is_contiguous():
-        raise ValueError('conv3_x3: unsupported shape x%s w%s' % (tuple(x.shape), tuple(wpk.shape)))
-    n = wpk.shape[1] * 32
-    if out is None:
-        if accumulate:
-            raise ValueError('accumulate needs out')
-        out = torch.empty((rows, l, n), device=x.device, dtype=torch.float32)
-    elif tuple(out.shape) != (rows, l, n) or out.dtype != torch.float32 or not out.is_contiguous():
-        raise ValueError('conv3_x3: bad out')
-    _chk(_lib.lib().da_conv3_x3(_p(x), _p(wpk), _p(out), rows, l, c, c, n, n, 1 if accumulate else 0, _stream()),
-         'da_conv3_x3')
-    return out
-
-
 def is_x3(t):
     """An activation in the x3 format (exact three-term bf16 split, include/deepards_hip.h): (rows, L, C/16, 3, 16) bf16."""
     return t is not None and t.dtype == torch.bfloat16 and t.dim() == 5 and t.shape[3] == 3 and t.shape[4] == 16
@@ -494,9 +461,8 @@ def _conv_wgrad_taps(dy, x, src_off, stride):
     return out
 
 
-WINOGRAD_WGRAD = os.environ.get('DA_WINOGRAD_WGRAD', '1') != '0'
+WINOGRAD_WGRAD = os.environ.get('DA_WINOGRAD', '1') != '0'     # 0: the direct fp32 kernels (as functional._WINOGRAD)
 WGRAD_BF16 = False        # set by functional.set_conv_dtype('bf16'): k3 s1 weight gradients on the bf16 matrix cores
-WGRAD_X3 = False          # fp32-equivalent split-bf16 products ("f32x3") for the same jobs the bf16 kernels take
 
 
 def conv_wgrad_multi(jobs):
@@ -530,10 +496,6 @@ def conv_wgrad_multi(jobs):
                 (k == 3 and stride == 1 and pad == 1) or
                 (stride == 2 and l % 2 == 0 and ((k == 3 and pad == 1) or (k == 1 and pad == 0)))):
             wino = 16                                # bf16 operands / fp32 sums (conv dtype bf16)
-        elif WGRAD_X3 and ACT == torch.float32 and co % 64 == 0 and ci % 64 == 0 and (
-                (k == 3 and stride == 1 and pad == 1) or
-                (stride == 2 and l % 2 == 0 and ((k == 3 and pad == 1) or (k == 1 and pad == 0)))):
-            wino = 48                                # three-term bf16 splits, six products: fp32-equivalent
         if both_x3:
             if co % 64 or ci % 64:
                 raise ValueError('conv_wgrad_multi: x3 operands need channel counts that are multiples of 64')
@@ -566,8 +528,8 @@ def wgrad_reduce_multi(items, accumulate=True):
 def repack_multi(weights, winograd=None):
     """[(Co,Ci,K) weights] -> [(wf, wd, uf, ud)] with one launch per 32 weights.  winograd[i] (K == 3; True / 4:
     F(2,3), 6: F(4,3)): emit the Winograd taps uf (points,Co,Ci) / ud (points,Ci,Co) INSTEAD of the direct packs
-    wf / wd (None in the tuple); 16: bf16 tap packs of conv3_bf16 in the uf / ud places; 48: the split-bf16 fragment
-    packs of conv3_x3 there."""
+    wf / wd (None in the tuple); 16: bf16 tap packs of conv3_bf16 in the uf / ud places; 49: the chunked split-bf16
+    packs of conv3_x3p there."""
     outs, descs = [], []
     for n, w in enumerate(weights):
         _f32(w, 'w')
@@ -576,7 +538,7 @@ def repack_multi(weights, winograd=None):
         wino = bool(code)
         if wino and k != 3 and not (code in (16, 49) and k == 1):
             raise ValueError('winograd taps need a 3-tap weight')
-        pts = code if wino and code in (6, 16, 48, 49) else 4
+        pts = code if wino and code in (6, 16, 49) else 4
         mk = lambda *shape: torch.empty(shape, device=w.device, dtype=torch.float32)
         wf, wd = (None, None) if wino else (mk(k, co, ci), mk(k, ci, co))
         if pts == 16:                                # bf16 tap packs (3, Co, Ci) / (3, Ci, Co)
@@ -584,11 +546,6 @@ def repack_multi(weights, winograd=None):
                 raise ValueError('bf16 tap packs need channel counts that are multiples of 32')
             uf = torch.empty((k, co, ci), device=w.device, dtype=torch.bfloat16)
             ud = torch.empty((k, ci, co), device=w.device, dtype=torch.bfloat16)
-        elif pts == 48:                              # split-bf16 fragment packs of conv3_x3 (pack_conv3_x3f's layout)
-            if co % 32 or ci % 32:
-                raise ValueError('split-bf16 packs need channel counts that are multiples of 32')
-            uf = torch.empty((3, co // 32, ci // 16, 3, 64, 8), device=w.device, dtype=torch.bfloat16)
-            ud = torch.empty((3, ci // 32, co // 16, 3, 64, 8), device=w.device, dtype=torch.bfloat16)
         elif pts == 49:                              # chunked split-bf16 packs of conv3_x3p (18 KB per 64 x 16 chunk)
             if co % 64 or ci % 64:
                 raise ValueError('chunked split-bf16 packs need channel counts that are multiples of 64')
@@ -862,8 +819,18 @@ def stem_fused_ok(x2d, w, R):
     """Whether the recomputing stem kernels take this stem: the default one (one input channel, k7 s2 p3, float storage,
     even length, 32 / 64 / 128 channels, a window of R rows that the backward's row pairs / quads divide)."""
     lin = x2d.shape[-1]
-    return ACT == torch.float32 and (x2d.dim() == 2 or x2d.shape[1] == 1) and tuple(w.shape[1:]) == (1, 7) and \
+    ok = ACT == torch.float32 and (x2d.dim() == 2 or x2d.shape[1] == 1) and tuple(w.shape[1:]) == (1, 7) and \
         lin % 2 == 0 and w.shape[0] in (32, 64, 128) and x2d.shape[0] % R == 0 and R % max(1, 128 // w.shape[0]) == 0
+    if not ok or x2d.shape[0] == 0:
+        return ok
+    # the statistics kernel stages the raw rows of one chunk in LDS (da_stem_stats_partial: (chunk / Lc + 1) rows of
+    # Lin + 12 floats + its fold area, 64 KB at most): with few chunks per window (many windows, or 128 channels) and long
+    # rows -- nb 40 x L 512 -- a chunk does not fit, and the stored-map stem takes the shape as before
+    p_, chunk = ctypes.c_int(), ctypes.c_int()
+    _lib.lib().da_bn_chunks(x2d.shape[0] // R, R * (lin // 2), w.shape[0], ctypes.byref(p_), ctypes.byref(chunk))
+    lc = lin // 2
+    max_rows = (chunk.value + lc - 1) // lc + 1
+    return (max_rows * (lin + 12) + 33 * 32) * 4 <= 64 * 1024
 
 
 def stem_fused_fwd(x2d, w, R, gamma, beta, pool_mode, eps=1e-5, out_x3=False):

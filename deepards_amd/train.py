@@ -56,6 +56,28 @@ def _capture_graph(graph, _ctx=None):
             gc.enable()
 
 
+def graph_branch_count(graph):
+    """Number of nodes of a captured ``torch.cuda.CUDAGraph`` (``enable_debug_mode()`` before the capture) with more than
+    one successor or predecessor -- 0 for the single chain every captured step of this package is meant to be; None when
+    the runtime's DOT dump cannot be produced or read.  (hipGraphDebugDotPrint: edges are lines ``"a" -> "b"``.)"""
+    import re
+    import tempfile
+    try:
+        with tempfile.NamedTemporaryFile(suffix='.dot', delete=True) as f:
+            graph.debug_dump(f.name)
+            txt = open(f.name).read()
+    except Exception:                                    # noqa: BLE001
+        return None
+    edges = re.findall(r'"?([\w.:]+)"?\s*->\s*"?([\w.:]+)"?', txt)
+    if not edges:
+        return None
+    succ, pred = {}, {}
+    for a, b in set(edges):
+        succ[a] = succ.get(a, 0) + 1
+        pred[b] = pred.get(b, 0) + 1
+    return sum(1 for v in succ.values() if v > 1) + sum(1 for v in pred.values() if v > 1)
+
+
 def clip_odd_batch_sizes(obs_idx, seq, metadata, target):
     """train_ards_detector.py:482-494 -- drop the last item of an odd batch."""
     if seq.shape[0] % 2 == 1:
@@ -225,8 +247,8 @@ class HotPathTrainer(object):
         self.allreduce_calls = 0
         self._synced = False
         self._graph_opt_shared = None      # the captured update (data parallel, two-graph form): independent of the batch shape
-        # data parallel: try to capture the all-reduce INSIDE the step graph (DA_DP_CAPTURE_ALLREDUCE=0: always two graphs)
-        self._capture_allreduce = os.environ.get('DA_DP_CAPTURE_ALLREDUCE', '1') != '0'
+        # data parallel: DA_DP_CAPTURE_ALLREDUCE=1 tries to capture the all-reduce INSIDE the step graph (opt-in, see _capture)
+        self._capture_allreduce = os.environ.get('DA_DP_CAPTURE_ALLREDUCE', '0') == '1'
         self.allreduce_in_graph = False
 
     # ---- replicas ----------------------------------------------------------------------------
@@ -332,21 +354,38 @@ class HotPathTrainer(object):
         torch.cuda.current_stream().wait_stream(s)
         graph, static_out, graph_opt = None, None, None
         if self.world_size > 1 and self._capture_allreduce and self._collectives_capturable():
-            # Data parallel, preferred form: ONE graph holds backward | all-reduce | update.  RCCL collectives are
-            # stream-capturable; inside the graph the exchange needs no host round trip and no extra launches per step
-            # (round 2 replayed backward, called dist.all_reduce eagerly, replayed the update).  If the process group
-            # refuses to be captured the two-graph form below takes over -- decided once per trainer.
+            # Data parallel, OPT-IN form (DA_DP_CAPTURE_ALLREDUCE=1): ONE graph holds backward | all-reduce | update.  RCCL
+            # collectives are stream-capturable; inside the graph the exchange needs no host round trip and no extra
+            # launches per step.  The default stays the two-graph form (backward | eager all-reduce | update) until a
+            # world >= 2 RCCL run of this form exists: so far only a world-1 group has carried it.  Three guards:
+            #   * any refusal of the capture selects the two-graph form;
+            #   * the captured graph must be ONE chain -- a process group that enqueues on its own stream would come
+            #     back as a forked branch, and a hipGraphExec with parallel branches owns streams that die with another
+            #     such exec (the segfault of DESIGN.md section 5); a graph with a branch is dropped, not replayed;
+            #   * the ranks AGREE on the form (MIN over the group of "my capture is good"): one rank replaying the
+            #     single graph while its peer waits in an eager all-reduce would deadlock the exchange.
+            ok, why = True, ''
             try:
                 graph = torch.cuda.CUDAGraph()
+                graph.enable_debug_mode()                # (keeps the hipGraph so that its topology can be dumped)
                 with _capture_graph(graph):
                     static_out = self._eager_whole_step(*static)
-                self.allreduce_in_graph = True
+                branches = graph_branch_count(graph)
+                if branches:
+                    ok, why = False, 'the capture holds %d forked branch(es)' % branches
+                elif branches is None:
+                    import warnings
+                    warnings.warn('could not read the captured step graph\'s topology: single-chain form not verified')
             except Exception as e:                       # noqa: BLE001 -- any refusal selects the fallback
-                import warnings
-                warnings.warn('all-reduce could not be captured into the step graph (%s: %s); using the two-graph form '
-                              '(backward | eager all-reduce | update)' % (type(e).__name__, e))
-                self._capture_allreduce, self.allreduce_in_graph, graph = False, False, None
+                ok, why = False, '%s: %s' % (type(e).__name__, e)
                 torch.cuda.synchronize()
+            agreed = self._all_ranks_agree(ok)
+            if not agreed:
+                import warnings
+                warnings.warn('all-reduce not captured into the step graph (%s); using the two-graph form (backward | eager '
+                              'all-reduce | update)' % (why or 'another rank could not'))
+                self._capture_allreduce, graph, static_out = False, None, None
+            self.allreduce_in_graph = agreed
         if graph is None:
             graph = torch.cuda.CUDAGraph()
             with _capture_graph(graph):
@@ -360,6 +399,13 @@ class HotPathTrainer(object):
                 self._graph_opt_shared = graph_opt
         ent = self._graphs[tuple(inputs.shape)] = (graph, static, static_out, graph_opt)
         return ent
+
+    def _all_ranks_agree(self, ok):
+        """MIN over the trainer's process group of ``ok``: every rank takes the same form of the captured step."""
+        import torch.distributed as dist
+        flag = torch.tensor([1 if ok else 0], device=self.bucket.p.device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
 
     def _collectives_capturable(self):
         """Only RCCL ('nccl') collectives are stream operations a hipGraph can hold; a gloo all-reduce synchronises the

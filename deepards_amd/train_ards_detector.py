@@ -479,7 +479,14 @@ class BaseTraining(object):
         if rank != 0:
             return
         os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
-        torch.save(model, path)
+        # a trainer hangs its gradient destinations on the Parameters (``p._da_grad``: views into its flat bucket); pickled
+        # along they would double the file and, in the loaded model, point functional._tgt at a dead buffer
+        stash = [(q, q.__dict__.pop('_da_grad')) for q in model.parameters() if '_da_grad' in q.__dict__]
+        try:
+            torch.save(model, path)
+        finally:
+            for q, g in stash:
+                q._da_grad = g
 
     _dp_override = None
 
@@ -654,7 +661,7 @@ def build_parser():
     # this build's own switches
     parser.add_argument('--seed', type=int, help='seed of the initialisation, the shuffles and the oversampler')
     parser.add_argument('--no-graph', dest='use_graph', action='store_false', default=None, help='run the step eagerly')
-    parser.add_argument('--conv-dtype', choices=['f32', 'bf16', 'f32x3', 'f32x3p'], help='arithmetic of the residual-block convs')
+    parser.add_argument('--conv-dtype', choices=['f32', 'bf16', 'f32x3p'], help='arithmetic of the residual-block convs')
     parser.add_argument('--folds-in-flight', type=int, help='k-folds trained side by side on this GPU, each on its own stream '
                         '(same per-fold results as one after the other; a B <= 64 step leaves the chip partly idle).  '
                         'Default: min(5, kfolds) on one GPU, 1 under data parallelism; 1 = the sequential loop')

@@ -104,19 +104,12 @@ int da_wino4_weights(const float* w, float* u, int co, int ci, int transpose, da
 int da_conv3_bf16(const da_act_t* x, const void* wpk, da_act_t* y, int rows, int L, int ldx, int C, int ldy, int N,
                   int accumulate, da_stream_t stream);
 int da_pack_conv3_bf16(const float* w, void* wf, void* wd, int co, int ci, da_stream_t stream);
-/* ---- fp32 convolutions on the bf16 matrix cores ("f32x3", conv_x3.hip; opt-in arithmetic) ------
- * same nn.Conv1d calls again (resnet.py:5-8,27-38), fp32 in / out / sums: every operand is split exactly into three
- * bf16 terms and a product taken as six bf16 MFMA products (the dropped ones are below one fp32 rounding); direct
- * 3-tap form.  wpk: fragment-major packs [3][N/32][C/16][3][64][8] bf16 from da_pack_conv3_x3 (wf forward, wd data
- * gradient, either may be NULL; da_repack_desc.points = 48 emits the same).  C % 32 == 0, N % 64 == 0. */
-int da_conv3_x3(const float* x, const void* wpk, float* y, int rows, int L, int ldx, int C, int ldy, int N,
-                int accumulate, da_stream_t stream);
-int da_pack_conv3_x3(const float* w, void* wf, void* wd, int co, int ci, da_stream_t stream);
-/* ---- the same arithmetic with PRE-SPLIT operands (conv_x3p.hip; conv arithmetic 'f32x3', the default since round 3) ----
- * The "x3" activation format: an fp32 activation stored as its exact three-term bf16 split, per position C/16 groups of
+/* ---- fp32 convolutions on the bf16 matrix cores with PRE-SPLIT operands (conv_x3p.hip; conv arithmetic 'f32x3p', opt-in) ----
+ * Every operand is split exactly into three bf16 terms and a product taken as six bf16 MFMA products (the dropped ones
+ * are below one fp32 rounding); fp32 in / out / sums.  The "x3" activation format: an fp32 activation stored as its exact three-term bf16 split, per position C/16 groups of
  * [h 16 ch | m 16 ch | l 16 ch] bf16 (3 C bf16 = 6 C bytes per position, no pitch).  The BatchNorm / pool kernels in front
  * of a k3 s1 p1 conv store it (da_bn_fwd_x / da_bn_bwd_x / da_bn_relu_pool_fwd_x below), da_x3_split / da_x3_merge convert
- * fp32 <-> x3 for tests and boundaries.  da_conv3_x3p: same nn.Conv1d calls as da_conv3_x3 (resnet.py:5-8,27-38), x in
+ * fp32 <-> x3 for tests and boundaries.  da_conv3_x3p: same nn.Conv1d calls as da_conv3_bf16 (resnet.py:5-8,27-38), x in
  * x3 format, y fp32; wpk: the chunked split-bf16 pack -- (N/64) x (C/16) chunks of 18 KB laid out
  * [3 taps][2 halves of 32 outputs][3 terms][64 lanes][8 bf16] -- which da_repack_desc.points = 49 emits (Uf forward,
  * Ud data gradient; Co, Ci multiples of 64).  C % 16 == 0, N % 64 == 0. */
@@ -144,7 +137,7 @@ typedef struct {
   const float* dy; const float* x; float* workspace;
   int rows, Lm, Ldy, lddy, N, Lx, ldx, C, dy_stride, dy_off, src_stride, ntaps; int src_off[3];
   int winograd;   /* != 0: k3 s1 p1 job (N, C multiples of 64) in Winograd F(2,3) form; plan with winograd = 1;
-                     16: bf16 operands; 48: split-bf16 products of fp32 operands; 49: the same with dy AND x in the x3
+                     16: bf16 operands; 49: split-bf16 (fp32-equivalent) products with dy AND x in the x3
                      format (see da_conv3_x3p; lddy == N, ldx == C), k3 s1 p1 only */
 } da_wgrad_job;
 int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, da_stream_t stream);  /* winograd == 16 jobs: dy / x are da_act_t tensors (the only kind accepted while bf16 is selected) */

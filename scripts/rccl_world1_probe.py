@@ -52,6 +52,27 @@ lt, pt, two = run(True, False)
 lg, pg, one = run(True, True)
 assert not two and le == lt and torch.equal(pe, pt), 'two-graph form differs from eager'
 assert le == lg and torch.equal(pe, pg), 'single-graph form differs from eager'
-print('captured all-reduce == eager bit for bit; in-graph capture accepted by RCCL: %s' % one)
+print('captured all-reduce == eager bit for bit; in-graph capture accepted by RCCL as ONE chain: %s' % one)
+
+# the capture's failure path: the all-reduce raises INSIDE the first capture (what a process group that refuses to be
+# captured does) -- the trainer must end in the two-graph form, every rank agreeing, with the eager run's losses
+from deepards_amd.train import FlatBucket
+_orig = FlatBucket.allreduce
+_fired = []
+def _refusing(self, group=None):
+    if torch.cuda.is_current_stream_capturing() and not _fired:
+        _fired.append(1)
+        raise RuntimeError('injected: collective refused inside a capture')
+    return _orig(self, group)
+FlatBucket.allreduce = _refusing
+import warnings
+with warnings.catch_warnings(record=True) as wlist:
+    warnings.simplefilter('always')
+    lf, pf, in_graph = run(True, True)
+FlatBucket.allreduce = _orig
+assert _fired and not in_graph, 'the injected refusal did not select the two-graph form'
+assert any('two-graph form' in str(w.message) for w in wlist), [str(w.message) for w in wlist]
+assert le == lf and torch.equal(pe, pf), 'two-graph form after a refused capture differs from eager'
+print('refused capture -> two-graph form, losses and parameters == eager bit for bit')
 dist.destroy_process_group()
 print('rccl world-1 probe ok')

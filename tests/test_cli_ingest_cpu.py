@@ -417,3 +417,32 @@ def test_checkpoint_pickled_by_the_real_reference_classes(tmp_path, legacy):
     mine = C.load_model_weights(path, lambda: M.CNNLinearNetwork(M.resnet18(), 20, 0))
     assert list(mine.state_dict()) == list(ref.state_dict()) and len(mine.state_dict()) == 129
     assert all(torch.equal(a, b) for a, b in zip(mine.state_dict().values(), ref.state_dict().values()))
+
+
+def test_saved_module_carries_no_trainer_gradient_views(tmp_path):
+    """ADVICE round 3: a trainer hangs ``_da_grad`` (a view into its flat gradient bucket) on every live Parameter;
+    ``BaseTraining._save`` must not pickle them (the file doubled in size and the loaded Parameters pointed
+    functional._tgt at a dead buffer), the saving model keeps them, and ``load_own_module`` strips them from older files."""
+    import os
+    from deepards_amd import checkpoint as C
+    from deepards_amd.train_ards_detector import BaseTraining
+    import deepards_amd.models as M
+    torch.manual_seed(2)
+    m = M.CNNLinearNetwork(M.densenet18(), 20, 0)
+    bucket = torch.zeros(sum(p.numel() for p in m.parameters()))
+    off = 0
+    for p in m.parameters():
+        p._da_grad = bucket[off:off + p.numel()].view(p.shape)
+        off += p.numel()
+    plain = str(tmp_path / 'plain.pth')
+    torch.save(m, plain)                                       # what round 3 wrote: the views ride along
+    saver = BaseTraining.__new__(BaseTraining)
+    saver._dp_override = (1, 0, None)
+    stripped = str(tmp_path / 'stripped.pth')
+    saver._save(m, stripped)
+    assert all(hasattr(p, '_da_grad') for p in m.parameters())                 # the live model keeps its destinations
+    assert os.path.getsize(stripped) < 0.7 * os.path.getsize(plain)
+    for path in (plain, stripped):
+        loaded = C.load_own_module(path)
+        assert not any(hasattr(p, '_da_grad') for p in loaded.parameters())
+        assert all(torch.equal(p, q) for p, q in zip(loaded.state_dict().values(), m.state_dict().values()))

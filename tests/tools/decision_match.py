@@ -68,12 +68,15 @@ def is_stem_decision(name):
     return name.endswith(STEM_DECISIONS)
 
 
-def hip_relu_flips(tape, taps, log=print, tag='', near=1e-3):
+def hip_relu_flips(tape, taps, log=print, tag='', near=3e-5):
     """The ReLU decisions the run under test TOOK, as flips of the oracle's: ``taps`` are the post-ReLU activations the
     block Functions recorded (deepards_amd.functional.DECISION_TAP: float (rows, L, C) or x3 tensors, in forward order),
     one per ReLU of the oracle's tape behind the stem (the stem's ReLU and max-pool are fused into one kernel and export
     nothing: ``decision_matched_gradients(only=is_stem_decision)`` searches those).  Every differing element must be one
-    whose fp64 pre-activation is within ``near`` of zero -- anything else is a wrong value, not a decision."""
+    whose fp64 pre-activation is within ``near`` of zero -- anything else is a wrong value, not a decision.  ``near`` is
+    the oracle's own ambiguity tolerance (``decision_matched_gradients(tols=...)``: 3e-5; the largest exported
+    pre-activation ever measured is 7.5e-6): a looser bound would let a 1e-4-sized VALUE error pass as
+    "a decision"."""
     names = [n for n in tape.order if tape.decisions[n]['kind'] == 'relu' and not is_stem_decision(n)]
     assert len(names) == len(taps), 'decision tap: %d activations for %d ReLUs' % (len(taps), len(names))
     flips = []

@@ -24,7 +24,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     sys.exit(0)
 BF16 = os.environ.get('SWEEP_BF16') == '1'      # bf16-operand convs vs the plain fp32 kernels (looser bounds)
 env_fast = dict(os.environ, DA_CONV_DTYPE='bf16') if BF16 else dict(os.environ)
-env_slow = dict(os.environ, DA_WINOGRAD='0', DA_WINOGRAD_WGRAD='0', DA_TAIL='0', DA_WINO_TAIL='0', DA_PAIR_S2='0')
+env_slow = dict(os.environ, DA_WINOGRAD='0')
 for name, env in (('fast', env_fast), ('slow', env_slow)):
     subprocess.check_call([sys.executable, __file__, 'child', '/tmp/sweep_%s.json' % name], env=env)
 import numpy as np
