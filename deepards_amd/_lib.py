@@ -34,7 +34,8 @@ class WgradReduceDesc(ctypes.Structure):
 class WgradJob(ctypes.Structure):
     _fields_ = [('dy', _P), ('x', _P), ('workspace', _P)] + [(n, _I) for n in
                ('rows', 'Lm', 'Ldy', 'lddy', 'N', 'Lx', 'ldx', 'C', 'dy_stride', 'dy_off', 'src_stride', 'ntaps')] + \
-               [('src_off', _I * 3), ('winograd', _I)]
+               [('src_off', _I * 3), ('winograd', _I), ('xform', _I), ('dy_half', _I), ('Wn', _I), ('ldstat', _I),
+                ('mean', _P), ('invstd', _P), ('gamma', _P), ('beta', _P)]
 
 
 class ConvJob(ctypes.Structure):
@@ -91,6 +92,11 @@ SIGNATURES = {
     'da_bn_bwd_mask': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'da_bn_bwd_add': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P]),
     'da_bn_param_grad_multi': (_I, [ctypes.POINTER(BnPgradDesc), _I, _I, _P]),
+    'da_bn_stats_fused': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _F, _P]),
+    'da_bn_relu_ss': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    'da_bn_bwd_ss': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _I, _P, _U, _F, _I, _P, _P]),
+    'da_conv1x1_bn': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    'da_conv3_winograd_drop': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _U, _F, _P]),
     'da_conv_wgrad_splits': (_I, [_I] * 5),
     'da_conv_wgrad_plan': (_I, [_I] * 6 + [ctypes.POINTER(_I)]),
     'da_conv_gemm_multi': (_I, [ctypes.POINTER(ConvJob), _I, _P]),

@@ -421,6 +421,37 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const AT* __restrict_
 // -------------------------------------------------------------------------------------------------
 #define FUSED_NPOS 10
 
+// BatchNorm + ReLU as ONE fused multiply-add per element: h = max(fmaf(x, sc, sh), 0) with sc = gamma invstd,
+// sh = beta - mean sc.  The dense-block path (models/densenet.py:18-44,68-81) never stores h = relu(norm1(x)): the 1x1
+// convolution applies this while it stages its operand, its weight gradient does the same, and the BatchNorm backward
+// recomputes the ReLU decision from it -- every one of them through THIS function on the same (x, mean, invstd, gamma,
+// beta) floats, so the three agree bit for bit on which elements are active (conv_gemm.hip includes the same lines).
+__device__ __forceinline__ void bn_scale_shift(float mean, float invstd, float gamma, float beta, float& sc, float& sh) {
+  sc = gamma * invstd;
+  sh = fmaf(-mean, sc, beta);
+}
+
+// counter-based dropout keep mask of head_optim.hip (da_dropout): element i of the contiguous [npos][G] tensor
+__device__ __forceinline__ uint32_t bn_mix32(uint32_t a, uint32_t b) {
+  uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u);
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+
+// Options of the dense-block BatchNorm backward (da_bn_bwd_ss): mean / invstd from a pitched table; the ReLU decision in
+// the scale / shift form above; the upstream gradient at HALF resolution (a transition's AvgPool1d(2,2) folded in front of
+// its 1x1 conv: dh[2j] = dh[2j+1] = dpooled[j] / 2); a dropout mask applied to the LAST drop_g channels of dx on store
+// (those channels are the previous layer's new features: this kernel is the last to add to their gradient, and what
+// its data / weight gradient convs want is the gradient in front of F.dropout, densenet.py:37-39).
+struct BnBwdExt {
+  int ldstat, half_dout, drop_c0, drop_g;
+  const long long* seed;
+  uint32_t salt;
+  float p;
+};
+
 template <int NV, int NQ>
 __device__ __forceinline__ void quad_block_sum(f32x4 (&v)[NV], float* red) {
   // lanes NQ*s+q of a wave hold the same channel quad q for 64/NQ slots s
@@ -463,7 +494,9 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const AT* __restrict
                                                             const float* __restrict__ beta, int relu, float eps,
                                                             float* __restrict__ mean_out,
                                                             float* __restrict__ invstd_out,
-                                                            unsigned long long* __restrict__ mask) {
+                                                            unsigned long long* __restrict__ mask, int ldstat) {
+  // ldstat: pitch of mean_out / invstd_out ([W][ldstat], >= C: a dense block keeps ONE table for its whole buffer);
+  // out == nullptr: statistics only (da_bn_stats_fused)
   __shared__ float red[16 * CG];
   constexpr int NQ = 1 << QB, CGB = 4 * NQ;            // channel quads / channels per block (32 or 16)
   const int w = row_xcd_chunk(blockIdx.x, gridDim.x), cg = blockIdx.y, P = blockDim.x >> QB;
@@ -472,7 +505,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const AT* __restrict
   const size_t base = (size_t)w * Wn;
   const AT* xb = x + base * ldx + cg * CGB;      // wave-uniform bases + 32-bit lane offsets
   const AT* rb = res ? res + base * ldr + cg * CGB : nullptr;
-  AT* ob = out + base * ldo + cg * CGB;
+  AT* ob = out ? out + base * ldo + cg * CGB : nullptr;
   f32x4 v[NPOS];
 #pragma unroll
   for (int k = 0; k < NPOS; ++k) {
@@ -506,9 +539,10 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const AT* __restrict
 #pragma unroll
   for (int e = 0; e < 4; ++e) is[e] = 1.0f / sqrtf(acc[0][e] * inv_n + eps);
   if (slot == 0) {
-    *reinterpret_cast<f32x4*>(mean_out + (size_t)w * C + c0) = mu;
-    *reinterpret_cast<f32x4*>(invstd_out + (size_t)w * C + c0) = is;
+    *reinterpret_cast<f32x4*>(mean_out + (size_t)w * ldstat + c0) = mu;
+    *reinterpret_cast<f32x4*>(invstd_out + (size_t)w * ldstat + c0) = is;
   }
+  if (!out) return;                                  // (block-uniform)
   const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
   const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c0);
   unsigned long long bits = 0ull;
@@ -545,7 +579,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const AT* __restrict
 // same arithmetic as bn_bwd_reduce_kernel + bn_bwd_apply_kernel with the slab held in registers
 // DX3: dx (the gradient w.r.t. the BatchNorm input = the conv output: the data-gradient and weight-gradient convs' operand)
 // is stored in the x3 format; gout stays float (the convs accumulate the branch gradient into it).
-template <typename AT, int NPOS, int QB, int DX3 = 0>
+template <typename AT, int NPOS, int QB, int DX3 = 0, int EXT = 0>
 __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict__ dout, int ldd,
                                                             const AT* __restrict__ x, int ldx,
                                                             const AT* __restrict__ outp, int ldo,
@@ -556,7 +590,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict
                                                             const float* __restrict__ beta, int mask_mode,
                                                             float* __restrict__ ds1, float* __restrict__ ds2,
                                                             const AT* __restrict__ add, int ldadd,
-                                                            const unsigned long long* __restrict__ mask) {
+                                                            const unsigned long long* __restrict__ mask, BnBwdExt ext) {
   __shared__ float red[16 * 2 * CG];
   constexpr int NQ = 1 << QB, CGB = 4 * NQ;            // channel quads / channels per block (32 or 16)
   const int w = row_xcd_chunk(blockIdx.x, gridDim.x), cg = blockIdx.y, P = blockDim.x >> QB;
@@ -564,14 +598,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict
   const int c0 = cg * CGB + q * 4;
   // wave-uniform slab bases + 32-bit lane offsets (one SGPR pair + one VGPR per access instead of a 64-bit VGPR pair)
   const size_t base = (size_t)w * Wn;
-  const AT* db = dout + base * ldd + cg * CGB;
+  const AT* db = dout + (EXT && ext.half_dout ? base >> 1 : base) * ldd + cg * CGB;      // (Wn even with half_dout)
   const AT* xb = x + base * ldx + cg * CGB;
   const AT* ob = outp ? outp + base * ldo + cg * CGB : nullptr;
   AT* dxb = dx + base * lddx + cg * CGB;
   AT* gb = gout ? gout + base * ldg + cg * CGB : nullptr;
   const AT* ab = add ? add + base * ldadd + cg * CGB : nullptr;       // dx = bn_bwd(...) + add (pass-through gradient)
-  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * C + c0);
-  const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * C + c0);
+  const int lds_ = EXT ? ext.ldstat : C;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * lds_ + c0);
+  const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * lds_ + c0);
   const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
   const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c0);
   f32x4 g[NPOS], xh[NPOS];
@@ -581,8 +616,24 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict
     g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     xh[k] = mu;
     if (p < Wn) {
-      g[k] = Act<AT>::ld4(db + (uint32_t)(p * ldd + q * 4));
+      if (EXT && ext.half_dout) {
+        g[k] = Act<AT>::ld4(db + (uint32_t)((p >> 1) * ldd + q * 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[k][e] *= 0.5f;
+      } else {
+        g[k] = Act<AT>::ld4(db + (uint32_t)(p * ldd + q * 4));
+      }
       xh[k] = Act<AT>::ld4(xb + (uint32_t)(p * ldx + q * 4));
+    }
+  }
+  f32x4 sc, sh;                                       // mask_mode 4: the ReLU decision of the scale / shift form
+  if (EXT) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a_, b_;
+      bn_scale_shift(mu[e], is[e], ga[e], be[e], a_, b_);
+      sc[e] = a_;
+      sh[e] = b_;
     }
   }
   f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -591,9 +642,14 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict
 #pragma unroll
   for (int k = 0; k < NPOS; ++k) {
     const int p = slot + k * P;
+    if (EXT && mask_mode == 4) {   // before xh overwrites the raw value
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[k][e] = (fmaf(xh[k][e], sc[e], sh[e]) > 0.f) ? g[k][e] : 0.f;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) xh[k][e] = (xh[k][e] - mu[e]) * is[e];
-    if (mask_mode == 3) {          // ReLU decisions recorded by the forward kernel (bn_fwd_fused_kernel, same geometry)
+    if (EXT && mask_mode == 4) {
+    } else if (mask_mode == 3) {          // ReLU decisions recorded by the forward kernel (bn_fwd_fused_kernel, same geometry)
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[k][e] = ((mbits >> (k * 4 + e)) & 1ull) ? g[k][e] : 0.f;
     } else if (p < Wn) {
@@ -623,6 +679,18 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict
         const f32x4 av = Act<AT>::ld4(ab + (uint32_t)(p * ldadd + q * 4));
 #pragma unroll
         for (int e = 0; e < 4; ++e) d[e] += av[e];
+      }
+      if (EXT && ext.p > 0.f && c0 >= ext.drop_c0) {  // (wave-uniform for 16- / 32-channel blocks and 32-channel segments)
+        const long long sd = ext.seed[0];
+        const uint32_t key = bn_mix32((uint32_t)sd ^ (uint32_t)(sd >> 32), ext.salt), thr = (uint32_t)(ext.p * 4294967296.0);
+        const float scale = 1.0f / (1.0f - ext.p);
+        const size_t i0 = (base + p) * (size_t)ext.drop_g + (c0 - ext.drop_c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const size_t i = i0 + e;
+          const uint32_t hsh = bn_mix32(key, (uint32_t)i ^ (uint32_t)(i >> 32) * 0x27d4eb2fu);
+          d[e] = hsh >= thr ? d[e] * scale : 0.f;
+        }
       }
       if constexpr (DX3) X3::st4(reinterpret_cast<__bf16*>(dx) + (base + p) * (size_t)(3 * C), c0, d);
       else Act<AT>::st4(dxb + (uint32_t)(p * lddx + q * 4), d);
@@ -684,6 +752,36 @@ __global__ __launch_bounds__(256) void bn_param_grad_multi_kernel(BnPgradTable t
     }
     d.dbeta[c] = accumulate ? d.dbeta[c] + a : a;
     d.dgamma[c] = accumulate ? d.dgamma[c] + b : b;
+  }
+}
+
+// out = max(fmaf(x, sc, sh), 0) with the statistics of a pitched table: the activation the dense-block path never stores
+// (bn_scale_shift above), materialised for tests (their ReLU-decision taps) and for explainers.
+__global__ __launch_bounds__(256) void bn_relu_ss_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out, int ldo,
+                                                         int Wn, int C, size_t npos, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, int ldstat,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         FastDiv divWn) {
+  const int nq = C >> 2;
+  const size_t total = npos * nq;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % nq);
+    const size_t pos = idx / nq;
+    const int c0 = q * 4;
+    const uint32_t w = fdiv((uint32_t)pos, divWn);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + (size_t)w * ldstat + c0);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + (size_t)w * ldstat + c0);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c0);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + pos * ldx + c0);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float sc, sh;
+      bn_scale_shift(mu[e], is[e], ga[e], be[e], sc, sh);
+      o[e] = fmaxf(fmaf(v[e], sc, sh), 0.f);
+    }
+    *reinterpret_cast<f32x4*>(out + pos * ldo + c0) = o;
   }
 }
 
@@ -853,7 +951,7 @@ static int bn_fwd_impl(const void* x, int ldx, const void* res, int ldr, void* o
 #define BN_FWD_LAUNCH(QB, CH)                                                                                        \
   DA_ACT_DISPATCH(hipLaunchKernelGGL((bn_fwd_fused_kernel<AT, FUSED_NPOS, QB>), dim3(W, C / CH), dim3(threads), 0, stream, \
                                      (const AT*)x, ldx, (const AT*)res, ldr, (AT*)out, ldo, Wn, C, gamma, beta, relu, eps,   \
-                                     mean, invstd, mask))
+                                     mean, invstd, mask, C))
     if (cgb == 32) BN_FWD_LAUNCH(3, 32);
     else if (cgb == 16) BN_FWD_LAUNCH(2, 16);
     else BN_FWD_LAUNCH(1, 8);
@@ -890,7 +988,7 @@ int da_bn_fwd_x(const float* x, int ldx, const void* res, int ldr, void* out, in
   const int rx = res && res_x3 ? 1 : 0, ox = out_x3 ? 1 : 0;
 #define BN_FWDX_LAUNCH(QB, CH, RX, OX)                                                                                  \
   hipLaunchKernelGGL((bn_fwd_fused_kernel<float, FUSED_NPOS, QB, RX, OX>), dim3(W, C / CH), dim3(threads), 0, stream, x, ldx,   \
-                     (const float*)res, ldr, (float*)out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd, mask)
+                     (const float*)res, ldr, (float*)out, ldo, Wn, C, gamma, beta, relu, eps, mean, invstd, mask, C)
 #define BN_FWDX_QB(QB, CH)                                  \
   do {                                                      \
     if (rx && ox) BN_FWDX_LAUNCH(QB, CH, 1, 1);             \
@@ -927,7 +1025,7 @@ int da_bn_bwd_x(const float* dout, int ldd, const float* x, int ldx, void* dx, i
 #define BN_BWDX_LAUNCH(QB, CH, DX)                                                                                        \
   hipLaunchKernelGGL((bn_bwd_fused_kernel<float, FUSED_NPOS, QB, DX>), dim3(W, C / CH), dim3(threads), 0, stream, dout, ldd, x,  \
                      ldx, (const float*)nullptr, 0, (float*)dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, \
-                     s2, (const float*)nullptr, 0, mask)
+                     s2, (const float*)nullptr, 0, mask, BnBwdExt{})
 #define BN_BWDX_QB(QB, CH)                       \
   do {                                           \
     if (dx_x3) BN_BWDX_LAUNCH(QB, CH, 1);        \
@@ -981,7 +1079,7 @@ static int bn_bwd_impl(const void* dout, int ldd, const void* x, int ldx, const 
 #define BN_BWD_LAUNCH(QB, CH)                                                                                         \
   DA_ACT_DISPATCH(hipLaunchKernelGGL((bn_bwd_fused_kernel<AT, FUSED_NPOS, QB>), dim3(W, C / CH), dim3(threads), 0, stream,  \
                                      (const AT*)dout, ldd, (const AT*)x, ldx, (const AT*)out, ldo, (AT*)dx, lddx, (AT*)gout,  \
-                                     ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2, (const AT*)add, ldadd, mask))
+                                     ldg, Wn, C, mean, invstd, gamma, beta, mask_mode, s1, s2, (const AT*)add, ldadd, mask, BnBwdExt{}))
     if (cgb == 32) BN_BWD_LAUNCH(3, 32);
     else if (cgb == 16) BN_BWD_LAUNCH(2, 16);
     else BN_BWD_LAUNCH(1, 8);
@@ -1051,6 +1149,84 @@ int da_bn_bwd_add(const void* dout, int ldd, const void* x, int ldx, const void*
   if (!add) return DA_EINVAL;
   return bn_bwd_impl(dout, ldd, x, ldx, out, ldo, dx, lddx, gout, ldg, W, Wn, C, mean, invstd, gamma, beta, mask_mode,
                      scratch, ds, dgamma, dbeta, accumulate, add, ldadd, nullptr, stream);
+}
+
+// ---- dense-block forms (reference models/densenet.py:18-44,46-66,68-81; float activations, single-pass geometry only) ----
+// statistics only: mean / invstd of x[:, 0:C] (pitch ldx) per window into the pitched tables [W][ldstat]
+int da_bn_stats_fused(const float* x, int ldx, int W, int Wn, int C, float* mean, float* invstd, int ldstat, float eps,
+                      hipStream_t stream) {
+  DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;
+  if (!x || !mean || !invstd || C % CG || ldx % 4 || ldx < C || ldstat % 4 || ldstat < C || Wn < 1) return DA_EINVAL;
+  if (W == 0) return DA_OK;
+  int cgb = 0;
+  const int threads = bn_fused_geometry(W, Wn, C, &cgb);
+  if (!threads) return DA_EINVAL;
+#define BN_STATS_LAUNCH(QB, CH)                                                                                         \
+  hipLaunchKernelGGL((bn_fwd_fused_kernel<float, FUSED_NPOS, QB>), dim3(W, C / CH), dim3(threads), 0, stream, x, ldx,           \
+                     (const float*)nullptr, 0, (float*)nullptr, 0, Wn, C, (const float*)nullptr, (const float*)nullptr, 0, eps, \
+                     mean, invstd, (unsigned long long*)nullptr, ldstat)
+  if (cgb == 32) BN_STATS_LAUNCH(3, 32);
+  else if (cgb == 16) BN_STATS_LAUNCH(2, 16);
+  else BN_STATS_LAUNCH(1, 8);
+#undef BN_STATS_LAUNCH
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// out[:, 0:C] = max(fmaf(x, gamma invstd, beta - mean gamma invstd), 0): the activation relu(norm(x)) in the form the
+// dense-block kernels apply on the fly (tests / explainers only; the hot path never materialises it)
+int da_bn_relu_ss(const float* x, int ldx, float* out, int ldo, int W, int Wn, int C, const float* mean, const float* invstd,
+                  int ldstat, const float* gamma, const float* beta, hipStream_t stream) {
+  DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;
+  if (!x || !out || !mean || !invstd || !gamma || !beta || C % 4 || ldx % 4 || ldo % 4 || ldstat % 4 || Wn < 1) return DA_EINVAL;
+  if (W == 0) return DA_OK;
+  const size_t npos = (size_t)W * Wn;
+  if (npos >= 0xffffffffull) return DA_EINVAL;
+  size_t g = (npos * (C >> 2) + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(bn_relu_ss_kernel, dim3((unsigned)g), dim3(256), 0, stream, x, ldx, out, ldo, Wn, C, npos, mean, invstd,
+                     ldstat, gamma, beta, make_fastdiv((uint32_t)Wn));
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// Backward of h = relu(norm(x)) in the scale / shift form (relu != 0) or of norm(x) alone, x = the first C channels of
+// a dense block's buffer (pitch ldx), statistics from its pitched table:
+//   g = dout (half_dout: dout has Wn / 2 positions per window, g[p] = dout[p / 2] / 2) masked by the ReLU decision;
+//   dx = BatchNorm input gradient (+ add[:, 0:C], pitch ldadd -- dx may alias add: the in-place accumulation into the
+//   block's gradient buffer); then, with drop_p > 0, the dropout mask (seed, salt) of the contiguous [W Wn][drop_g]
+//   tensor on the channels [C - drop_g, C) of dx.  ds [2][W][C]: the window sums for da_bn_param_grad_multi.
+int da_bn_bwd_ss(const float* dout, int ldd, const float* x, int ldx, float* dx, int lddx, const float* add, int ldadd, int W,
+                 int Wn, int C, const float* mean, const float* invstd, int ldstat, const float* gamma, const float* beta,
+                 int relu, int half_dout, const long long* drop_seed, unsigned drop_salt, float drop_p, int drop_g, float* ds,
+                 hipStream_t stream) {
+  DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;
+  if (!dout || !x || !dx || !mean || !invstd || !gamma || !beta || !ds) return DA_EINVAL;
+  if (C % CG || ldd % 4 || ldx % 4 || lddx % 4 || (add && ldadd % 4) || ldstat % 4 || ldstat < C || Wn < 1) return DA_EINVAL;
+  if (half_dout && (Wn & 1)) return DA_EINVAL;
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (!drop_seed || drop_g < 4 || drop_g % 4 || drop_g > C))) return DA_EINVAL;
+  if (W == 0) return DA_OK;
+  int cgb = 0;
+  const int threads = bn_fused_geometry(W, Wn, C, &cgb);
+  if (!threads) return DA_EINVAL;
+  BnBwdExt ext;
+  ext.ldstat = ldstat; ext.half_dout = half_dout ? 1 : 0; ext.drop_c0 = C - drop_g; ext.drop_g = drop_g;
+  ext.seed = drop_seed; ext.salt = drop_salt; ext.p = drop_p;
+  float* s1 = ds;
+  float* s2 = ds + (size_t)W * C;
+#define BN_BWDSS_LAUNCH(QB, CH)                                                                                              \
+  hipLaunchKernelGGL((bn_bwd_fused_kernel<float, FUSED_NPOS, QB, 0, 1>), dim3(W, C / CH), dim3(threads), 0, stream, dout, ldd, x,  \
+                     ldx, (const float*)nullptr, 0, dx, lddx, (float*)nullptr, 0, Wn, C, mean, invstd, gamma, beta,                 \
+                     relu ? 4 : 0, s1, s2, add, ldadd, (const unsigned long long*)nullptr, ext)
+  if (cgb == 32) BN_BWDSS_LAUNCH(3, 32);
+  else if (cgb == 16) BN_BWDSS_LAUNCH(2, 16);
+  else BN_BWDSS_LAUNCH(1, 8);
+#undef BN_BWDSS_LAUNCH
+  DA_CHECK_LAUNCH();
+  return DA_OK;
 }
 
 }  // extern "C"

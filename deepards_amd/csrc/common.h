@@ -196,6 +196,14 @@ typedef struct {
   int winograd;          // k3 s1 p1, N and C multiples of 64 -- 1: Winograd F(2,3) form (fp32), 16: bf16 operands /
                          // fp32 sums, 49: split-bf16 fp32-equivalent products on x3 operands (both conv_bf16.hip; also
                          // the stride-2 jobs); the matching da_conv_wgrad_plan(winograd = 1 / 16 / 49) sizes the workspace
+  // dense-block operand forms of plain 1x1 jobs (winograd == 0, ntaps == 1; conv_gemm.hip WgradArgs): xform = 1: X is
+  // relu(BatchNorm(x)) recomputed while staged from the statistics tables [rows * Lm / Wn][ldstat]; dy_half = 1: dY has
+  // Ldy = Lm / 2 positions per row and position j reads dy[j / 2] / 2 (a transition's pooling in front of its conv)
+  int xform, dy_half, Wn, ldstat;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
 } da_wgrad_job;
 
 // conv_wino.hip

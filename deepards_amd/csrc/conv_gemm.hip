@@ -574,6 +574,130 @@ static int conv_gemm_dispatch(const ConvGemmArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Dense-block 1x1 convolution with BatchNorm + ReLU applied WHILE THE OPERAND IS STAGED (reference models/densenet.py:23-26
+// norm1 -> relu1 -> conv1 of a _DenseLayer, :72-79 norm -> relu -> conv -> pool of a _Transition).  x is the first C
+// channels of the block's buffer (pitch ldx); per-(window, channel) statistics come from the block's pitched table; the
+// activation h = max(fmaf(x, sc, sh), 0) (bn_scale_shift) exists only in LDS -- "do not store what two FMAs recompute".
+// POOL = 1: the transition's AvgPool1d(2,2) is applied IN FRONT of the (linear) conv: output row m contracts
+// (h[2m] + h[2m+1]) / 2 -- half the MFMAs, and the full-resolution conv output is never written.
+// 64 x 64 tiles (4 waves of 32 x 32), K step 32; a tile spans at most two windows (host: Wn >= 64), whose scale / shift
+// vectors sit in LDS behind the operand panels.
+// ---------------------------------------------------------------------------------------------
+struct Conv1x1BnArgs {
+  const float* x;
+  const float* w;     // [N][C]
+  float* y;
+  int M, ldx, C, ldy, N, W, Wn, ldstat;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  FastDiv divWn;
+};
+
+__device__ __forceinline__ void bn_scale_shift(float mean, float invstd, float gamma, float beta, float& sc, float& sh) {
+  sc = gamma * invstd;                 // (bn.hip holds the same two lines: the ReLU decisions must agree bit for bit)
+  sh = fmaf(-mean, sc, beta);
+}
+
+template <int POOL>
+__global__ __launch_bounds__(256) void conv1x1_bn_kernel(Conv1x1BnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];          // As | Bs | sc[2][C] | sh[2][C]
+  constexpr int PITCH = 36;
+  float* As = lds;
+  float* Bs = lds + 64 * PITCH;
+  float* scs = lds + 128 * PITCH;
+  float* shs = scs + 2 * a.C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = a.N >> 6;
+  const int lin = xcd_linear_tile(blockIdx.x, gridDim.x);
+  const int m_blk = (lin / ntn) * 64, n_blk = (lin % ntn) * 64;
+  const int lr = tid >> 3, lq = tid & 7;
+  const int w0 = (int)fdiv((uint32_t)m_blk, a.divWn);
+
+  for (int i = tid; i < 2 * a.C; i += 256) {
+    const int ws = i >= a.C ? 1 : 0, c = i - ws * a.C, w = w0 + ws;
+    float sc = 0.f, sh = 0.f;
+    if (w < a.W) bn_scale_shift(a.mean[(size_t)w * a.ldstat + c], a.invstd[(size_t)w * a.ldstat + c], a.gamma[c], a.beta[c], sc, sh);
+    scs[i] = sc;
+    shs[i] = sh;
+  }
+
+  int a_off[2], a_ws[2];
+  bool a_ok[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int m = m_blk + lr + 32 * p;
+    a_ok[p] = m < a.M;
+    const int mm = a_ok[p] ? m : 0;
+    a_ws[p] = ((int)fdiv((uint32_t)mm, a.divWn) - w0) * a.C + lq * 4;
+    a_off[p] = (POOL ? 2 * mm : mm) * a.ldx + lq * 4;
+  }
+  const float* wb = a.w + (size_t)(n_blk + lr) * a.C + lq * 4;
+
+  const int kc = a.C >> 5;
+  f32x4 ra[2][POOL + 1], rb[2];
+  auto gload = [&](int it) {
+    const int c0 = it << 5;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int h = 0; h <= POOL; ++h) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (a_ok[p]) v = *reinterpret_cast<const f32x4*>(a.x + a_off[p] + h * a.ldx + c0);
+        ra[p][h] = v;
+      }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) rb[p] = *reinterpret_cast<const f32x4*>(wb + (size_t)(32 * p) * a.C + c0);
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  gload(0);
+  const int frow = lane & 31, fh = lane >> 5;
+  for (int it = 0; it < kc; ++it) {
+    __syncthreads();
+    const int c0 = it << 5;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(&scs[a_ws[p] + c0]);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(&shs[a_ws[p] + c0]);
+      f32x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        h[e] = fmaxf(fmaf(ra[p][0][e], sc[e], sh[e]), 0.f);
+        if (POOL) h[e] = 0.5f * (h[e] + fmaxf(fmaf(ra[p][POOL][e], sc[e], sh[e]), 0.f));
+      }
+      if (!a_ok[p]) h = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(&As[(lr + 32 * p) * PITCH + lq * 4]) = h;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<f32x4*>(&Bs[(lr + 32 * p) * PITCH + lq * 4]) = rb[p];
+    __syncthreads();
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8) {
+      if (c8 == GLOAD_AT) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < kc) gload(it + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const f32x4 af = *reinterpret_cast<const f32x4*>(&As[(wm * 32 + frow) * PITCH + c8 * 8 + fh * 4]);
+      const f32x4 bf = *reinterpret_cast<const f32x4*>(&Bs[(wn * 32 + frow) * PITCH + c8 * 8 + fh * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
+    }
+  }
+  const int n = n_blk + wn * 32 + frow;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m_blk + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+    if (m < a.M) a.y[(size_t)m * a.ldy + n] = acc[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -586,11 +710,21 @@ struct WgradArgs {
   int ntaps, so0, so1, so2;
   int kchunk;  // positions per split, multiple of 32
   FastDiv divLm;
+  // dense-block forms: xform = 1: the X operand is max(fmaf(x, sc, sh), 0) of the stored tensor (the activation the 1x1
+  // conv's forward applied while staging, see conv1x1_bn_kernel), statistics per window of Wn positions from the pitched
+  // tables; dy_half = 1: dY sits at half resolution (a transition's pooling folded in front of its conv): position j
+  // reads dy[j / 2] / 2
+  int xform, dy_half, ldstat;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  FastDiv divWn;
 };
 
 // output tile (TM*WGM*32 co) x (TN*WGN*32 ci); K = positions, 32 per step; LDS tiles stored as they
 // sit in HBM ([pos][channel]): lane (i, h) reads T[2*kk + h][i] -- 32 consecutive floats per half.
-template <int TM, int TN, int WGM, int WGN>
+template <int TM, int TN, int WGM, int WGN, int XF = 0>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block_id, const int nblocks, float* lds) {
   constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32;
   static_assert(WGM * WGN == 4, "4 waves");
@@ -628,8 +762,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block_i
       if (m < k_end) {
         uint32_t row = fdiv((uint32_t)m, a.divLm);
         int j = m - (int)row * Lm;
-        v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)row * a.Ldy + (size_t)(j * a.dy_stride + a.dy_off)) * a.lddy +
-                                            n_blk + q * 4);
+        const int jd = (XF && a.dy_half) ? (j >> 1) : j * a.dy_stride + a.dy_off;
+        v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)row * a.Ldy + (size_t)jd) * a.lddy + n_blk + q * 4);
+        if (XF && a.dy_half) v *= 0.5f;
       }
       ry[p] = v;
     }
@@ -659,6 +794,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block_i
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int frow = lane & 31, fh = lane >> 5;
+  // xform: this thread's channel quad is the same in every pass (256 % XQ == 0), so its scale / shift vectors are cached
+  // per WINDOW and reloaded only when a staged row enters another one (once per ~Wn / 32 K steps)
+  static_assert(256 % XQ == 0, "one channel quad per thread");
+  int xf_w = -1;
+  f32x4 xf_sc = {0.f, 0.f, 0.f, 0.f}, xf_sh = {0.f, 0.f, 0.f, 0.f};
   if (k_beg < k_end) gload(k_beg);
   for (int k0 = k_beg; k0 < k_end; k0 += 32) {
     __syncthreads();
@@ -666,6 +806,55 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block_i
     for (int p = 0; p < YP; ++p) {
       int idx = tid + 256 * p;
       *reinterpret_cast<f32x4*>(&Ys[(idx / YQ) * BM + (idx % YQ) * 4]) = ry[p];
+    }
+    if (XF && a.xform) {
+      // windows of this K step's 32 positions: nearly always one (Wn >> 32); a step that crosses into the next window
+      // keeps both sets and selects per row
+      const int m_last = min(k0 + 31, k_end - 1);
+      const int w_lo = (int)fdiv((uint32_t)k0, a.divWn), w_hi = (int)fdiv((uint32_t)m_last, a.divWn);
+      const int cq = c_blk + (tid % XQ) * 4;
+      auto load_ss = [&](int w, f32x4& sc, f32x4& sh) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + (size_t)w * a.ldstat + cq);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(a.invstd + (size_t)w * a.ldstat + cq);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + cq);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(a.beta + cq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float sc_, sh_;
+          bn_scale_shift(mu[e], is[e], ga[e], be[e], sc_, sh_);
+          sc[e] = sc_;
+          sh[e] = sh_;
+        }
+      };
+      if (w_lo != xf_w) {
+        load_ss(w_lo, xf_sc, xf_sh);
+        xf_w = w_lo;
+      }
+      if (w_lo == w_hi) {
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+          if (k0 + (tid + 256 * p) / XQ < k_end) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rx[p][e] = fmaxf(fmaf(rx[p][e], xf_sc[e], xf_sh[e]), 0.f);
+          }
+        }
+      } else {                                           // (w_hi == w_lo + 1: Wn >= 32 is checked by the host)
+        f32x4 sc2, sh2;
+        load_ss(w_hi, sc2, sh2);
+        const int m_edge = w_hi * (int)a.divWn.d;
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+          const int m = k0 + (tid + 256 * p) / XQ;
+          if (m < k_end) {
+            const bool hi = m >= m_edge;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rx[p][e] = fmaxf(fmaf(rx[p][e], hi ? sc2[e] : xf_sc[e], hi ? sh2[e] : xf_sh[e]), 0.f);
+          }
+        }
+        xf_sc = sc2;
+        xf_sh = sh2;
+        xf_w = w_hi;
+      }
     }
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
@@ -721,12 +910,12 @@ struct WgradTable {
   int n;
 };
 
-template <int TM, int TN, int WGM, int WGN>
+template <int TM, int TN, int WGM, int WGN, int XF = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_multi_kernel(WgradTable t) {
   __shared__ float lds[32 * (TM * WGM * 32 + TN * WGN * 32)];
   int i = 0;
   while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
-  wgrad_body<TM, TN, WGM, WGN>(t.d[i], blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i], lds);
+  wgrad_body<TM, TN, WGM, WGN, XF>(t.d[i], blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i], lds);
 }
 
 // dW[co][ci][k] (torch layout) (+)= sum_split slab[split][k][co][ci]
@@ -859,7 +1048,7 @@ static WgradPlan wgrad_plan(int M, int N, int C, int ntaps) {
 // C ABI
 // =============================================================================================
 
-template <int TM, int TN, int WGM, int WGN>
+template <int TM, int TN, int WGM, int WGN, int XF = 0>
 static int launch_wgrad_group(const da_wgrad_job* jobs, int n, int tn, int tc, hipStream_t s) {
   constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32;
   WgradTable t;
@@ -868,7 +1057,7 @@ static int launch_wgrad_group(const da_wgrad_job* jobs, int n, int tn, int tc, h
     if (!cnt) return DA_OK;
     t.n = cnt;
     t.first_block[cnt] = blocks;
-    hipLaunchKernelGGL((conv_wgrad_multi_kernel<TM, TN, WGM, WGN>), dim3(blocks), dim3(256), 0, s, t);
+    hipLaunchKernelGGL((conv_wgrad_multi_kernel<TM, TN, WGM, WGN, XF>), dim3(blocks), dim3(256), 0, s, t);
     DA_CHECK_LAUNCH();
     cnt = 0;
     blocks = 0;
@@ -878,6 +1067,7 @@ static int launch_wgrad_group(const da_wgrad_job* jobs, int n, int tn, int tc, h
   std::vector<std::pair<int, int>> order;
   for (int i = 0; i < n; ++i) {
     if (jobs[i].winograd) continue;                       // conv_wino.hip
+    if ((XF != 0) != (jobs[i].xform != 0 || jobs[i].dy_half != 0)) continue;      // the operand forms have kernels of their own
     WgradPlan pl = wgrad_plan(jobs[i].rows * jobs[i].Lm, jobs[i].N, jobs[i].C, jobs[i].ntaps);
     if (pl.tn == tn && pl.tc == tc) order.push_back({-pl.kchunk, i});
   }
@@ -894,6 +1084,9 @@ static int launch_wgrad_group(const da_wgrad_job* jobs, int n, int tn, int tc, h
     a.so0 = j.src_off[0]; a.so1 = j.ntaps > 1 ? j.src_off[1] : 0; a.so2 = j.ntaps > 2 ? j.src_off[2] : 0;
     a.kchunk = pl.kchunk;
     a.divLm = make_fastdiv((uint32_t)j.Lm);
+    a.xform = j.xform; a.dy_half = j.dy_half; a.ldstat = j.ldstat;
+    a.mean = j.mean; a.invstd = j.invstd; a.gamma = j.gamma; a.beta = j.beta;
+    a.divWn = make_fastdiv((uint32_t)(j.Wn > 0 ? j.Wn : 1));
     t.first_block[cnt] = blocks;
     blocks += (j.N / BM) * (j.C / BN) * j.ntaps * pl.splits;
     if (++cnt == 24) {
@@ -969,6 +1162,37 @@ int da_conv_gemm_multi(const da_conv_job* jobs, int n, hipStream_t stream) {
   return launch_conv_multi(a, n, stream);
 }
 
+// y[m][0:N] (pitch ldy) = sum_c W[n][c] * h(m, c), h = relu(BatchNorm(x)) applied while x is staged (conv1x1_bn_kernel):
+// x [rows * Lin][ldx] first C channels, statistics per window of R rows from the pitched tables [rows / R][ldstat];
+// pool != 0: h(m, .) = (h[2m] + h[2m+1]) / 2, Lin even, the output has Lin / 2 positions per row (a _Transition with its
+// AvgPool1d(2,2) in front of the conv).  w: [N][C] (the torch weight of a k = 1 conv as it lies).  N % 64 == 0, C % 32 == 0,
+// R * Lout >= 64.  replaces norm1 -> relu1 -> conv1 (densenet.py:23-26) and norm -> relu -> conv -> pool (:72-79)
+int da_conv1x1_bn(const float* x, int ldx, const float* w, float* y, int ldy, int rows, int R, int Lin, int C, int N, int pool,
+                  const float* mean, const float* invstd, int ldstat, const float* gamma, const float* beta, hipStream_t stream) {
+  DA_ENTER();
+  if (g_act_bf16) return DA_EINVAL;
+  if (!x || !w || !y || !mean || !invstd || !gamma || !beta || rows < 0 || R < 1 || rows % R || Lin < 1) return DA_EINVAL;
+  if (C % 32 || C < 32 || C > 2048 || N % 64 || N < 64 || ldx % 4 || ldx < C || ldy < N || ldstat % 4 || ldstat < C) return DA_EINVAL;
+  if (pool && (Lin & 1)) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  const int Lout = pool ? Lin / 2 : Lin;
+  const long M = (long)rows * Lout;
+  if ((long)R * Lout < 64) return DA_EINVAL;                     // a tile must not span more than two windows
+  if ((uint64_t)rows * Lin * (uint64_t)(ldx > ldy ? ldx : ldy) >= 0x7fffffffull) return DA_EINVAL;   // 32-bit element offsets
+  if ((uint64_t)M * (uint64_t)(R * Lout) >= 0xffffffffull) return DA_EINVAL;
+  Conv1x1BnArgs a;
+  a.x = x; a.w = w; a.y = y;
+  a.M = (int)M; a.ldx = ldx; a.C = C; a.ldy = ldy; a.N = N; a.W = rows / R; a.Wn = R * Lout; a.ldstat = ldstat;
+  a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta;
+  a.divWn = make_fastdiv((uint32_t)a.Wn);
+  const unsigned blocks = (unsigned)(((M + 63) / 64) * (N / 64));
+  const size_t shm = (size_t)(128 * 36 + 4 * C) * sizeof(float);
+  if (pool) hipLaunchKernelGGL(conv1x1_bn_kernel<1>, dim3(blocks), dim3(256), shm, stream, a);
+  else hipLaunchKernelGGL(conv1x1_bn_kernel<0>, dim3(blocks), dim3(256), shm, stream, a);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
 // Bytes of slab workspace da_conv_wgrad needs for this shape.
 size_t da_conv_wgrad_workspace(int rows, int Lm, int N, int C, int ntaps) {
   WgradPlan p = wgrad_plan(rows * Lm, N, C, ntaps);
@@ -986,6 +1210,12 @@ int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
         (j.winograd == 49 && (j.lddy != j.N || j.ldx != j.C)))
       return DA_EINVAL;
     if ((uint64_t)j.rows * j.Lm * (uint64_t)j.Lm >= 0xffffffffull) return DA_EINVAL;
+    if ((j.xform || j.dy_half) && (j.winograd || j.ntaps != 1 || j.src_stride != 1 || j.dy_stride != 1 || j.dy_off || j.src_off[0]))
+      return DA_EINVAL;                                       // the dense-block operand forms belong to plain 1x1 jobs
+    if (j.xform && (j.xform != 1 || !j.mean || !j.invstd || !j.gamma || !j.beta || j.Wn < 1 || j.ldstat < j.C || j.ldstat % 4 ||
+                    j.Wn < 32 || (uint64_t)j.rows * j.Lm * (uint64_t)j.Wn >= 0xffffffffull))
+      return DA_EINVAL;
+    if (j.dy_half && (j.Lm & 1 || j.Ldy * 2 != j.Lm)) return DA_EINVAL;
     if (g_act_bf16 && j.winograd != 16) return DA_EINVAL;     // bf16 activations: only the bf16-operand kernels read them
     if (j.winograd == 16 || j.winograd == 49
             ? !bf16_wgrad_eligible(j)
@@ -1002,6 +1232,16 @@ int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
   if ((rc = launch_wgrad_group<1, 1, 2, 2>(jobs, n, 64, 64, stream))) return rc;
   if ((rc = launch_wgrad_group<1, 1, 4, 1>(jobs, n, 128, 32, stream))) return rc;
   if ((rc = launch_wgrad_group<1, 1, 1, 4>(jobs, n, 32, 128, stream))) return rc;
+  bool any_xf = false;
+  for (int i = 0; i < n; ++i) any_xf = any_xf || jobs[i].xform || jobs[i].dy_half;
+  if (any_xf) {                                           // dense-block operand forms (conv1x1_bn_kernel's weight gradients)
+    if ((rc = launch_wgrad_group<2, 2, 2, 2, 1>(jobs, n, 128, 128, stream))) return rc;
+    if ((rc = launch_wgrad_group<2, 1, 2, 2, 1>(jobs, n, 128, 64, stream))) return rc;
+    if ((rc = launch_wgrad_group<1, 2, 2, 2, 1>(jobs, n, 64, 128, stream))) return rc;
+    if ((rc = launch_wgrad_group<1, 1, 2, 2, 1>(jobs, n, 64, 64, stream))) return rc;
+    if ((rc = launch_wgrad_group<1, 1, 4, 1, 1>(jobs, n, 128, 32, stream))) return rc;
+    if ((rc = launch_wgrad_group<1, 1, 1, 4, 1>(jobs, n, 32, 128, stream))) return rc;
+  }
   return DA_OK;
 }
 
@@ -1072,6 +1312,9 @@ int da_conv_wgrad(const float* dy, const float* x, float* dw, float* workspace, 
   a.ntaps = ntaps;
   a.so0 = src_off[0]; a.so1 = ntaps > 1 ? src_off[1] : 0; a.so2 = ntaps > 2 ? src_off[2] : 0;
   a.divLm = make_fastdiv((uint32_t)Lm);
+  a.xform = 0; a.dy_half = 0; a.ldstat = 0;
+  a.mean = a.invstd = a.gamma = a.beta = nullptr;
+  a.divWn = make_fastdiv(1u);
   if ((uint64_t)a.M * (uint64_t)Lm >= 0xffffffffull) return DA_EINVAL;
   WgradPlan pl = wgrad_plan(a.M, N, C, ntaps);
   if (!pl.tn) return DA_EINVAL;

@@ -28,7 +28,20 @@ struct WinoArgs {
   float* y;         // [rows][L][ldy]
   int MP, L, PL, ldx, C, ldy, N, accumulate;
   FastDiv divPL;
+  // F.dropout on the conv's output in the epilogue (a _DenseLayer's growth conv writes its new features straight into the
+  // block's buffer, densenet.py:36-40): the keep mask of da_dropout on the contiguous [rows * L][N] tensor; p = 0: off
+  const long long* drop_seed;
+  uint32_t drop_salt;
+  float drop_p;
 };
+
+__device__ __forceinline__ uint32_t wino_mix32(uint32_t a, uint32_t b) {      // head_optim.hip mix32
+  uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u);
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
 
 __device__ __forceinline__ int xcd_chunked(int id, int total) {   // same block order as conv_gemm.hip
   const int q = total >> 3, r = total & 7;
@@ -207,6 +220,15 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int til
   }
 
   // output transform + store: lane holds channel n = nt*16 + wino_row(l%16) of the pairs wino_row(4*(l/16) + r)
+  const bool drop = a.drop_p > 0.f;
+  uint32_t dkey = 0u, dthr = 0u;
+  float dscale = 1.f;
+  if (drop) {
+    const long long sd = a.drop_seed[0];
+    dkey = wino_mix32((uint32_t)sd ^ (uint32_t)(sd >> 32), a.drop_salt);
+    dthr = (uint32_t)(a.drop_p * 4294967296.0);
+    dscale = 1.0f / (1.0f - a.drop_p);
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int P = P0 + wp * 16 + wino_row(g * 4 + r);
@@ -219,6 +241,11 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int til
     for (int nt = 0; nt < 2; ++nt) {
       float y0 = acc[0][nt][r] + acc[1][nt][r] + acc[2][nt][r];
       float y1 = acc[1][nt][r] - acc[2][nt][r] - acc[3][nt][r];
+      if (drop) {                                        // element (position, channel) of the contiguous [rows L][N] tensor
+        const size_t e0 = ((size_t)rr * a.L + 2 * i) * (size_t)a.N + n_blk + prow + nt * 16, e1 = e0 + a.N;
+        y0 = wino_mix32(dkey, (uint32_t)e0 ^ (uint32_t)(e0 >> 32) * 0x27d4eb2fu) >= dthr ? y0 * dscale : 0.f;
+        y1 = wino_mix32(dkey, (uint32_t)e1 ^ (uint32_t)(e1 >> 32) * 0x27d4eb2fu) >= dthr ? y1 * dscale : 0.f;
+      }
       float* q0 = y0p + nt * 16;
       if (a.accumulate) {
         y0 += q0[0];
@@ -883,6 +910,7 @@ int da_conv3_winograd4(const float* x, const float* u, float* y, int rows, int L
   a.x = x; a.u = u; a.y = y;
   a.L = L; a.PL = (L + 3) / 4; a.MP = rows * a.PL;        // PL / MP count quads here
   a.ldx = ldx; a.C = C; a.ldy = ldy; a.N = N; a.accumulate = accumulate;
+  a.drop_seed = nullptr; a.drop_salt = 0u; a.drop_p = 0.f;
   a.divPL = make_fastdiv((uint32_t)a.PL);
   if ((uint64_t)a.MP * (uint64_t)a.PL >= 0xffffffffull) return DA_EINVAL;
   const int tiles = ((a.MP + 63) / 64) * (N / 32);
@@ -913,8 +941,8 @@ int da_wino4_weights(const float* w, float* u, int co, int ci, int transpose, hi
 
 // y (+)= conv1d(x, k = 3, stride 1, pad 1) per row with the transformed taps u (da_wino_weights).
 // x: [rows][L][ldx] first C channels; y: [rows][L][ldy] first N channels.  replaces reference models/resnet.py:5-8
-int da_conv3_winograd(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
-                      int accumulate, hipStream_t stream) {
+static int conv3_winograd_impl(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
+                               int accumulate, const long long* drop_seed, unsigned drop_salt, float drop_p, hipStream_t stream) {
   DA_ENTER();
   if (g_act_bf16) return DA_EINVAL;              // float activations only
   if (!x || !u || !y || rows < 0 || L < 1 || C % 32 || N % 32 || C < 32 || N < 32 || ldx % 4 || ldx < C || ldy < N)
@@ -925,6 +953,7 @@ int da_conv3_winograd(const float* x, const float* u, float* y, int rows, int L,
   a.x = x; a.u = u; a.y = y;
   a.L = L; a.PL = (L + 1) / 2; a.MP = rows * a.PL;
   a.ldx = ldx; a.C = C; a.ldy = ldy; a.N = N; a.accumulate = accumulate;
+  a.drop_seed = drop_seed; a.drop_salt = drop_salt; a.drop_p = drop_p;
   a.divPL = make_fastdiv((uint32_t)a.PL);
   if ((uint64_t)a.MP * (uint64_t)a.PL >= 0xffffffffull) return DA_EINVAL;
   const int tiles = ((a.MP + 63) / 64) * (N / 32);
@@ -938,6 +967,20 @@ int da_conv3_winograd(const float* x, const float* u, float* y, int rows, int L,
   hipLaunchKernelGGL(conv3_wino_kernel, dim3(nmini_pad + full), dim3(256), 0, stream, a, nmini, nmini_pad, full);
   DA_CHECK_LAUNCH();
   return DA_OK;
+}
+
+int da_conv3_winograd(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
+                      int accumulate, hipStream_t stream) {
+  return conv3_winograd_impl(x, u, y, rows, L, ldx, C, ldy, N, accumulate, nullptr, 0u, 0.f, stream);
+}
+
+// da_conv3_winograd followed by F.dropout(p) in the epilogue: y = dropout(conv(x)) with the keep mask of da_dropout
+// (seed, salt) on the contiguous [rows * L][N] tensor, written at pitch ldy (a _DenseLayer's growth conv + dropout storing
+// its new features at their channel offset in the block's buffer, reference models/densenet.py:30-40)
+int da_conv3_winograd_drop(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
+                           const long long* drop_seed, unsigned drop_salt, float drop_p, hipStream_t stream) {
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return DA_EINVAL;
+  return conv3_winograd_impl(x, u, y, rows, L, ldx, C, ldy, N, 0, drop_seed, drop_salt, drop_p, stream);
 }
 
 // tuning / tests: 0 = no half tiles for the last round; pchunk > 0: pairs per weight-gradient split

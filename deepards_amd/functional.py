@@ -78,7 +78,7 @@ def _launch_wgrads():
     jobs = _STEP['wgrad']
     if not jobs:
         return
-    slabs = H.conv_wgrad_multi([j[:5] for j in jobs])
+    slabs = H.conv_wgrad_multi([j[:5] + (j[6],) for j in jobs])
     _STEP['wslab'] += [(sl, j[5]) for sl, j in zip(slabs, jobs)]
     _STEP['wgrad'] = []
 
@@ -317,21 +317,32 @@ class StemFunction(Function):
     reference models/resnet.py:141-153, models/densenet.py:109-124.  x2d: (rows, L) or (rows, C_in, L)."""
 
     @staticmethod
-    def forward(ctx, x2d, w, gamma, beta, R, pool_mode, st, want_out3=False):
+    def forward(ctx, x2d, w, gamma, beta, R, pool_mode, st, want_out3=False, out_cb=0):
+        # out_cb > C0: the output is the first C0 channels of a fresh (rows, Lp, out_cb) buffer -- a dense block's pitched
+        # buffer, which its layers then fill (DenseBlockFunction); the buffer is what is returned
         # The default stem (one input channel) never stores its conv output -- 36.7 MB at B = 64 for 7 FMAs an element: the
         # statistics, the apply + pool pass and the whole backward recompute it from the raw rows (bit for bit the same
         # forward values; H.stem_fused_fwd / stem_fused_bwd).  The other stems (FFT channels, bf16 storage) keep the stored map.
         ctx.fused = _STEM_FUSED and H.stem_fused_ok(x2d, w, R)
         s_ = _Stats()
+        c0 = w.shape[0]
+        buf = view = None
+        if out_cb > c0:
+            lc = (x2d.shape[-1] + 2 * (w.shape[2] // 2) - w.shape[2]) // 2 + 1
+            buf = torch.empty((x2d.shape[0], (lc - 1) // 2 + 1, out_cb), device=x2d.device, dtype=torch.float32)
+            view = buf[:, :, :c0]
+        ctx.c0 = c0 if buf is not None else 0
         if ctx.fused:
-            out, mean, invstd = H.stem_fused_fwd(x2d, w, R, gamma, beta, pool_mode, st.eps, out_x3=want_out3)
+            out, mean, invstd = H.stem_fused_fwd(x2d, w, R, gamma, beta, pool_mode, st.eps, out_x3=want_out3, out=view)
             y0 = w                                      # (nothing of the stem's resolution is kept for the backward)
             wn = R * (x2d.shape[-1] // 2)
         else:
             y0 = H.stem_conv_fwd(x2d, w)
             mean, invstd = H.bn_stats(y0, R, st.eps)
-            out = H.bn_relu_pool_fwd(y0, R, mean, invstd, gamma, beta, pool_mode, out_x3=want_out3)
+            out = H.bn_relu_pool_fwd(y0, R, mean, invstd, gamma, beta, pool_mode, out_x3=want_out3, out=view)
             wn = R * y0.shape[1]
+        if buf is not None:
+            out = buf
         s_.mean, s_.invstd = mean, invstd
         if st.running_mean is not None:
             item = (mean, invstd, wn, st.running_mean, st.running_var, st.num_batches_tracked, st.momentum, st.eps)
@@ -352,8 +363,11 @@ class StemFunction(Function):
     def backward(ctx, dout, _d3=None):
         x2d, y0, mean, invstd, gamma, beta = ctx.saved_tensors
         tw, tg, tb = ctx.gt
+        dout = dout.contiguous()
+        if ctx.c0:                                      # the gradient of a pitched buffer: the stem's channels are its first C0
+            dout = dout[:, :, :ctx.c0]
         if ctx.fused:                                   # y0 holds the conv weight here
-            dw, ds = H.stem_fused_bwd(dout.contiguous(), x2d, y0, ctx.R, mean, invstd, gamma, beta, ctx.pool_mode, dw=tw,
+            dw, ds = H.stem_fused_bwd(dout, x2d, y0, ctx.R, mean, invstd, gamma, beta, ctx.pool_mode, dw=tw,
                                       accumulate=tw is not None)
             dgamma = dbeta = None
             if tg is not None and tb is not None:
@@ -364,11 +378,11 @@ class StemFunction(Function):
             else:
                 dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
                 H.bn_param_grad_multi([(ds, dgamma, dbeta)], accumulate=False)
-            return None, None if tw is not None else dw, dgamma, dbeta, None, None, None, None
-        dz = H.pool_bwd(dout.contiguous(), y0, ctx.R, mean, invstd, gamma, beta, ctx.pool_mode)
+            return None, None if tw is not None else dw, dgamma, dbeta, None, None, None, None, None
+        dz = H.pool_bwd(dout, y0, ctx.R, mean, invstd, gamma, beta, ctx.pool_mode)
         dy0, dgamma, dbeta = _bn_bwd(dz, y0, ctx.R, mean, invstd, gamma, beta, 1, tg, tb, dx=dz)
         dw = H.stem_conv_wgrad(dy0, x2d, out=tw, accumulate=tw is not None)
-        return None, None if tw is not None else dw, dgamma, dbeta, None, None, None, None
+        return None, None if tw is not None else dw, dgamma, dbeta, None, None, None, None, None
 
 
 class DoubleStemFunction(Function):
@@ -430,12 +444,16 @@ def _bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, tg, tb, out=None, dx=No
     return res + (g,) if want_g else res
 
 
-def _wgrad(dy, x, k, stride, pad, tw):
+def _wgrad(dy, x, k, stride, pad, tw, extra=None):
+    """Weight gradient of a conv: queued for the step's batched launch (a trainer's gradient destination ``tw``), or run now.
+    ``extra``: the dense-block operand forms of H.conv_wgrad_multi (x recomputed as relu(norm(x)), dy at half resolution);
+    dy / x may then be channel slices of pitched buffers."""
     if tw is not None and _STEP['on']:
-        _STEP['wgrad'].append((dy, x, k, stride, pad, tw))     # launched with all the others by flush_backward()
+        _STEP['wgrad'].append((dy, x, k, stride, pad, tw, extra))     # launched with all the others by flush_backward()
         return None
-    if H.WGRAD_BF16 or H.act_dtype() == 'bf16' or H.is_x3(dy):   # the bf16-pipe kernels exist in the batched form only
-        (slab,) = H.conv_wgrad_multi([(dy, x, k, stride, pad)])
+    if H.WGRAD_BF16 or H.act_dtype() == 'bf16' or H.is_x3(dy) or extra or not (dy.is_contiguous() and x.is_contiguous()):
+        # (the bf16-pipe kernels, the operand forms and pitched operands exist in the batched form only)
+        (slab,) = H.conv_wgrad_multi([(dy, x, k, stride, pad, extra)])
         co, ci = (dy.shape[2] * 16, x.shape[2] * 16) if H.is_x3(dy) else (dy.shape[2], x.shape[2])
         dw = tw if tw is not None else torch.empty((co, ci, k), device=x.device, dtype=torch.float32)
         H.wgrad_reduce_multi([(slab, dw)], accumulate=tw is not None)
@@ -554,6 +572,153 @@ class BasicBlockFunction(Function):
             dwd = dgd = dbd = None
             dx = _conv_dgrad(dy1, w1, stride, 1, lin, out=g, accumulate=True)   # identity grad + conv path
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None, None
+
+
+_DENSE_BLOCK = os.environ.get('DA_DENSE_BLOCK', '1') != '0'   # 0: the per-layer Functions below (the path shapes without the block kernels take)
+
+
+def dense_block_ok(rows, R, l, c0, growth, n_layers, mid, tail_out, use_drop):
+    """Whether a _DenseBlock of ``n_layers`` layers on (rows, l, c0) inputs, followed by a transition to ``tail_out`` channels
+    (0: by norm5), runs as ONE DenseBlockFunction: float storage, the single-pass BatchNorm geometry for every channel count
+    of the block, an even length in front of a transition (its pooling is folded in front of its conv), channel counts the
+    kernels tile (growth % 32, 1x1 outputs % 64), and -- with dropout on -- the Winograd growth conv (its epilogue drops)."""
+    if not (_DENSE_BLOCK and _CONV_DTYPE != 'bf16' and growth % 32 == 0 and c0 % 32 == 0 and mid % 64 == 0 and n_layers >= 1):
+        return False
+    if tail_out and (l % 2 or tail_out % 64 or R * (l // 2) < 64):
+        return False
+    if use_drop and not _WINOGRAD:
+        return False
+    return H.dense_fused_ok(rows, R, l, sorted(set([c0 + k * growth for k in range(n_layers + 1)] + [mid, growth])))
+
+
+class DenseBlockFunction(Function):
+    """A whole _DenseBlock AND the unit that consumes it -- its _Transition, or norm5 (+ReLU) behind the last block -- on ONE
+    pitched buffer (reference models/densenet.py:18-44 _DenseLayer, :46-66 _DenseBlock, :68-81 _Transition, :146,181-182):
+
+    * ``buf`` (rows, L, Cb): the block's input in its first C0 channels (written there by the stem / the previous
+      transition); every layer's growth conv writes its G new channels at their offset, with F.dropout in its epilogue
+      -- torch.cat and the dropout / slice kernels are gone;
+    * ONE statistics table (2, W, Cb) per block: a channel's per-window mean / invstd are computed once, when the channel
+      is written, and reused by every later norm1 and by the transition norm (statistics depend on the data only; gamma and
+      beta differ);
+    * h = relu(norm1(x)) is never stored: the 1x1 conv applies it while it stages its operand (H.conv1x1_bn), its weight
+      gradient recomputes it (H.conv_wgrad_multi xform), the BatchNorm backward takes the ReLU decision from the same fused
+      multiply-add (H.bn_bwd_ss);
+    * backward: ONE gradient buffer (rows, L, Cb); each norm1 backward accumulates into its first Ck channels in place and
+      applies the previous layer's dropout mask to the G channels it is the last to touch;
+    * a transition's AvgPool1d(2,2) is folded in FRONT of its (linear) 1x1 conv: half the products, no full-resolution conv
+      output, and the next block's first C0' channels land in ITS buffer -- which is what this Function returns.
+
+    params: per layer (norm1.weight, norm1.bias, conv1.weight, norm2.weight, norm2.bias, conv2.weight), then the tail's:
+    (norm.weight, norm.bias, conv.weight) for a transition (``tail_cb`` = the next block's buffer width) or
+    (norm5.weight, norm5.bias) for the final norm (``tail_cb`` = 0; ``tail_relu``: F.relu behind it or the bare map)."""
+
+    @staticmethod
+    def forward(ctx, buf, R, c0, growth, n_layers, drop_p, seed, salt0, eps, tail_cb, tail_relu, *params):
+        rows, l, cb = buf.shape
+        w_ = rows // R
+        G = growth
+        stats = torch.empty((2, w_, cb), device=buf.device, dtype=torch.float32)
+        mean_t, invstd_t = stats[0], stats[1]
+        H.bn_stats_fused(buf[:, :, :c0], R, mean_t[:, :c0], invstd_t[:, :c0], eps)
+        drop = drop_p > 0
+        keep = []
+        for k in range(n_layers):
+            g1, b1, w1, g2, b2, w2 = params[6 * k:6 * k + 6]
+            ck = c0 + k * G
+            xk = buf[:, :, :ck]
+            y1 = torch.empty((rows, l, w1.shape[0]), device=buf.device, dtype=torch.float32)
+            H.conv1x1_bn(xk, w1, R, mean_t[:, :ck], invstd_t[:, :ck], g1, b1, y1)
+            if DECISION_TAP is not None:
+                _tap(H.bn_relu_ss(xk, R, mean_t[:, :ck], invstd_t[:, :ck], g1, b1))
+            h2, m2, i2 = H.bn_fwd(y1, R, g2, b2, relu=True, eps=eps)
+            _tap(h2)
+            new = buf[:, :, ck:ck + G]
+            code = _is_wino(w2, 1, 1)
+            if code in (4, 6):
+                H.conv3_winograd(h2, _pack(w2, code)[2], out=new, drop=(seed, salt0 + k, drop_p) if drop else None)
+            else:
+                H.conv_fwd(h2, _pack(w2, 0)[0], 1, 1, out=new)
+            H.bn_stats_fused(new, R, mean_t[:, ck:ck + G], invstd_t[:, ck:ck + G], eps)
+            keep += [y1, m2, i2, h2]
+        if tail_cb:
+            gt, bt, wt = params[6 * n_layers:6 * n_layers + 3]
+            out = torch.empty((rows, l // 2, tail_cb), device=buf.device, dtype=torch.float32)
+            H.conv1x1_bn(buf, wt, R, mean_t, invstd_t, gt, bt, out[:, :, :wt.shape[0]], pool=True)
+            if DECISION_TAP is not None:
+                _tap(H.bn_relu_ss(buf, R, mean_t, invstd_t, gt, bt))
+            keep += [mean_t, invstd_t]          # (placeholders: the tail's statistics are the table's)
+        else:
+            g5, b5 = params[6 * n_layers:6 * n_layers + 2]
+            out, m5, i5 = H.bn_fwd(buf, R, g5, b5, relu=tail_relu, eps=eps)
+            if tail_relu:
+                _tap(out)
+            keep += [m5, i5]
+        ctx.cfg = (R, c0, G, n_layers, drop_p, salt0, tail_cb, tail_relu)
+        ctx.gt = _tgt(*params)
+        ctx.save_for_backward(buf, stats, seed if drop else stats, *keep, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        R, c0, G, n_layers, drop_p, salt0, tail_cb, tail_relu = ctx.cfg
+        sv = ctx.saved_tensors
+        buf, stats, seed = sv[0], sv[1], sv[2]
+        keep = sv[3:3 + 4 * n_layers + 2]
+        params = sv[3 + 4 * n_layers + 2:]
+        tg = ctx.gt
+        rows, l, cb = buf.shape
+        mean_t, invstd_t = stats[0], stats[1]
+        drop = drop_p > 0
+        dout = dout.contiguous()
+        dbuf = torch.empty_like(buf)
+        grads = [None] * len(params)
+
+        def fold(ds, gamma, beta, ig, ib):                  # dgamma / dbeta from a BatchNorm backward's window sums
+            if tg[ig] is not None and tg[ib] is not None:
+                if _STEP['on']:
+                    _STEP['pgrad'].append((ds, tg[ig], tg[ib]))
+                else:
+                    H.bn_param_grad_multi([(ds, tg[ig], tg[ib])], accumulate=True)
+            else:
+                grads[ig], grads[ib] = torch.empty_like(gamma), torch.empty_like(beta)
+                H.bn_param_grad_multi([(ds, grads[ig], grads[ib])], accumulate=False)
+
+        last_drop = (seed, salt0 + n_layers - 1, drop_p, G) if drop else None     # the last layer's new channels
+        pt = 6 * n_layers
+        if tail_cb:
+            gt_, bt_, wt = params[pt:pt + 3]
+            dy = dout[:, :, :wt.shape[0]]
+            grads[pt + 2] = _wgrad(dy, buf, 1, 1, 0, tg[pt + 2],
+                                   {'xform': (mean_t, invstd_t, gt_, bt_, R), 'dy_half': True})
+            dpool = H.conv_dgrad(dy, _pack(wt, 0)[1], 1, 0, l // 2)
+            ds = H.bn_bwd_ss(dpool, buf, R, mean_t, invstd_t, gt_, bt_, 1, dbuf, half_dout=True, drop=last_drop)
+        else:
+            g5, b5 = params[pt:pt + 2]
+            m5, i5 = keep[4 * n_layers], keep[4 * n_layers + 1]
+            ds = H.bn_bwd_ss(dout, buf, R, m5, i5, g5, b5, 2 if tail_relu else 0, dbuf, drop=last_drop)
+            gt_, bt_ = g5, b5
+        fold(ds, gt_, bt_, pt, pt + 1)
+        for k in range(n_layers - 1, -1, -1):
+            g1, b1, w1, g2, b2, w2 = params[6 * k:6 * k + 6]
+            y1, m2, i2, h2 = keep[4 * k:4 * k + 4]
+            ck = c0 + k * G
+            dnew = dbuf[:, :, ck:ck + G]                    # (its dropout mask was applied by the kernel that wrote it last)
+            grads[6 * k + 5] = _wgrad(dnew, h2, 3, 1, 1, tg[6 * k + 5])
+            code = _is_wino(w2, 1, 1)
+            if code in (4, 6):
+                dh2 = H.conv3_winograd(dnew, _pack(w2, code)[3])
+            else:
+                dh2 = H.conv_dgrad(dnew, _pack(w2, 0)[1], 1, 1, l)
+            dy1, grads[6 * k + 3], grads[6 * k + 4] = _bn_bwd(dh2, y1, R, m2, i2, g2, b2, 1, tg[6 * k + 3], tg[6 * k + 4], dx=dh2)
+            xk, mk, ik = buf[:, :, :ck], mean_t[:, :ck], invstd_t[:, :ck]
+            grads[6 * k + 2] = _wgrad(dy1, xk, 1, 1, 0, tg[6 * k + 2], {'xform': (mk, ik, g1, b1, R)})
+            dh = H.conv_dgrad(dy1, _pack(w1, 0)[1], 1, 0, l)
+            dxk = dbuf[:, :, :ck]
+            ds = H.bn_bwd_ss(dh, xk, R, mk, ik, g1, b1, 1, dxk, add=dxk,
+                             drop=(seed, salt0 + k - 1, drop_p, G) if drop and k > 0 else None)
+            fold(ds, g1, b1, 6 * k, 6 * k + 1)
+        return (dbuf,) + (None,) * 10 + tuple(grads)
 
 
 class DenseLayerFunction(Function):

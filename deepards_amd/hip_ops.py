@@ -60,6 +60,29 @@ def _rlc(t, name='tensor'):
     return t
 
 
+def _pv(t, name='tensor'):
+    """A (rows, L, C) float32 CUDA activation whose C channels are a slice of a contiguous (rows, L, ld) buffer (a dense
+    block's pitched buffer, or a plain contiguous tensor: ld == C).  -> the channel pitch ld."""
+    ok = t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.shape[1] >= 1 and t.shape[2] >= 1
+    if ok:
+        ld = t.stride(1) if t.shape[1] > 1 else max(t.shape[2], t.stride(0) // max(t.shape[1], 1))
+        ok = t.stride(2) == 1 and ld >= t.shape[2] and ld % 4 == 0 and t.data_ptr() % 16 == 0 and \
+            (t.shape[0] == 1 or t.stride(0) == t.shape[1] * ld) and (t.shape[1] == 1 or t.stride(1) == ld)
+    if not ok:
+        raise ValueError('%s must be a float32 CUDA (rows, L, C) channel slice of a contiguous buffer, got %s strides %s %s' %
+                         (name, tuple(t.shape), t.stride() if t.dim() == 3 else None, t.dtype))
+    return ld
+
+
+def _sv(t, w, c, name='statistics'):
+    """A (W, C) float32 CUDA slice of a per-block statistics table (W, ldstat) -> ldstat."""
+    if not (t.is_cuda and t.dtype == torch.float32 and tuple(t.shape) == (w, c) and t.stride(1) == 1 and
+            (w == 1 or (t.stride(0) >= c and t.stride(0) % 4 == 0)) and t.data_ptr() % 16 == 0):
+        raise ValueError('%s must be a (W, C) = (%d, %d) float32 CUDA slice of a (W, ld) table, got %s strides %s' %
+                         (name, w, c, tuple(t.shape), t.stride()))
+    return t.stride(0) if w > 1 else max(c, t.stride(0))
+
+
 def _f32(t, name='tensor'):
     if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
         raise ValueError('%s must be a contiguous float32 CUDA tensor' % name)
@@ -90,7 +113,7 @@ def conv_out_len(l, k, stride, pad):
 def conv_fwd(x, wf, stride, pad, out=None):
     """x (rows,L,Ci), wf packed (K,Co,Ci) -> (rows,Lo,Co).  K in {1,3} is one launch; a longer kernel (the k7 conv2 of
     ResNet(double_conv_first), resnet.py:92-93) runs as ceil(K/3) launches of <= 3 taps that accumulate into the output."""
-    _rlc(x, 'x')
+    ldx = _pv(x, 'x') if ACT == torch.float32 else _rlc(x, 'x').shape[2]
     k, co, ci = wf.shape
     rows, l, c = x.shape
     if c != ci or ci % 32 or co % 32:
@@ -100,10 +123,11 @@ def conv_fwd(x, wf, stride, pad, out=None):
         out = torch.empty((rows, lo, co), device=x.device, dtype=torch.float32)
     elif tuple(out.shape) != (rows, lo, co):
         raise ValueError('conv_fwd: bad out shape')
+    ldy = _pv(out, 'out')
     so = [t - pad for t in range(k)]
     wt = list(range(k))
     for g in range(0, k, 3):
-        _chk(_lib.lib().da_conv_gemm(_p(x), _p(wf), _p(out), rows, lo, l, c, ci, lo, co, co, 1, 0, stride, len(so[g:g + 3]),
+        _chk(_lib.lib().da_conv_gemm(_p(x), _p(wf), _p(out), rows, lo, l, ldx, ci, lo, ldy, co, 1, 0, stride, len(so[g:g + 3]),
                                      _ints(so[g:g + 3]), _ints(wt[g:g + 3]), 1 if g else 0, _stream()), 'da_conv_gemm(fwd)')
     return out
 
@@ -120,10 +144,12 @@ def wino_weights(w, transpose=False, points=4):
     return u
 
 
-def conv3_winograd(x, u, out=None, accumulate=False):
+def conv3_winograd(x, u, out=None, accumulate=False, drop=None):
     """k3 s1 p1 conv of x (rows, L, C) with taps u from wino_weights -> (rows, L, N): (4, N, C) taps run
-    F(2,3), (6, N, C) taps F(4,3)."""
-    _rlc(x, 'x')
+    F(2,3), (6, N, C) taps F(4,3).  x and out may be channel slices of pitched buffers (a dense block's);
+    drop = (seed, salt, p): F.dropout on the result in the epilogue (F(2,3) only; the mask of dropout() on the contiguous
+    (rows, L, N) tensor)."""
+    ldx = _pv(x, 'x') if ACT == torch.float32 else _rlc(x, 'x').shape[2]      # (bf16 storage: the library refuses, as before)
     rows, l, c = x.shape
     four, n, c2 = u.shape
     if four not in (4, 6) or c2 != c or c % 32 or n % 32:
@@ -134,8 +160,16 @@ def conv3_winograd(x, u, out=None, accumulate=False):
         out = torch.empty((rows, l, n), device=x.device, dtype=torch.float32)
     elif tuple(out.shape) != (rows, l, n):
         raise ValueError('conv3_winograd: bad out shape')
+    ldy = _pv(out, 'out') if out.dtype == torch.float32 else n
+    if drop is not None and drop[2] > 0:
+        if four != 4 or accumulate:
+            raise ValueError('conv3_winograd: dropout belongs to the F(2,3) kernel, without accumulate')
+        seed, salt, p = drop
+        _chk(_lib.lib().da_conv3_winograd_drop(_p(x), _p(u), _p(out), rows, l, ldx, c, ldy, n, _p(seed), salt, p, _stream()),
+             'da_conv3_winograd_drop')
+        return out
     fn = _lib.lib().da_conv3_winograd if four == 4 else _lib.lib().da_conv3_winograd4
-    _chk(fn(_p(x), _p(u), _p(out), rows, l, c, c, n, n, 1 if accumulate else 0, _stream()), 'da_conv3_winograd')
+    _chk(fn(_p(x), _p(u), _p(out), rows, l, ldx, c, ldy, n, 1 if accumulate else 0, _stream()), 'da_conv3_winograd')
     return out
 
 
@@ -323,7 +357,7 @@ def conv_dgrad_bf16_s2(dy, wd16, l_in, out=None, accumulate=False):
 def conv_dgrad(dy, wd, stride, pad, l_in, out=None, accumulate=False):
     """dy (rows,Lo,Co), wd packed (K,Ci,Co) -> dx (rows,l_in,Ci).  With accumulate the result is
     added into `out`; positions no tap reaches are left untouched (accumulate) or zeroed."""
-    _rlc(dy, 'dy')
+    lddy = _pv(dy, 'dy') if ACT == torch.float32 else _rlc(dy, 'dy').shape[2]
     k, ci, co = wd.shape
     rows, lo, c = dy.shape
     if c != co or ci % 32 or co % 32:
@@ -334,6 +368,7 @@ def conv_dgrad(dy, wd, stride, pad, l_in, out=None, accumulate=False):
         out = torch.empty((rows, l_in, ci), device=dy.device, dtype=torch.float32)
     elif tuple(out.shape) != (rows, l_in, ci):
         raise ValueError('conv_dgrad: bad out shape')
+    ldo = _pv(out, 'out')
     L = _lib.lib()
     for r in range(stride):
         lm = (l_in - r + stride - 1) // stride           # positions l_in = stride*j + r
@@ -346,7 +381,7 @@ def conv_dgrad(dy, wd, stride, pad, l_in, out=None, accumulate=False):
             continue
         so = [(r + pad - t) // stride for t in taps]
         for g in range(0, len(taps), 3):                 # <= 3 taps per launch; later groups add to the first
-            _chk(L.da_conv_gemm(_p(dy), _p(wd), _p(out), rows, lm, lo, co, co, l_in, ci, ci, stride, r, 1,
+            _chk(L.da_conv_gemm(_p(dy), _p(wd), _p(out), rows, lm, lo, lddy, co, l_in, ldo, ci, stride, r, 1,
                                 len(taps[g:g + 3]), _ints(so[g:g + 3]), _ints(taps[g:g + 3]),
                                 1 if (accumulate or g) else 0, _stream()), 'da_conv_gemm(dgrad)')
     return out
@@ -475,7 +510,9 @@ def conv_wgrad_multi(jobs):
     arr = (_lib.WgradJob * len(jobs))()
     plan = (ctypes.c_int * 4)()
     outs = []
-    for d, (dy, x, k, stride, pad) in zip(arr, jobs):
+    for d, job in zip(arr, jobs):
+        dy, x, k, stride, pad = job[:5]
+        extra = job[5] if len(job) > 5 and job[5] else {}         # dense-block operand forms (da_wgrad_job.xform / dy_half)
         both_x3 = is_x3(dy) and is_x3(x)
         if both_x3:                                   # x3 operands (conv arithmetic 'f32x3p'): the split-bf16 kernels
             if not (dy.is_cuda and dy.is_contiguous() and x.is_contiguous() and (
@@ -484,11 +521,22 @@ def conv_wgrad_multi(jobs):
                 raise ValueError('conv_wgrad_multi: x3 operands belong to k3 s1 p1 / k3 s2 p1 / k1 s2 p0 (even length) jobs')
             rows, lo, co = dy.shape[0], dy.shape[1], dy.shape[2] * 16
             rows2, l, ci = x.shape[0], x.shape[1], x.shape[2] * 16
+            lddy, ldx = co, ci
+        elif ACT == torch.float32:                    # float operands may be channel slices of pitched (dense-block) buffers
+            lddy, ldx = _pv(dy, 'dy'), _pv(x, 'x')
+            rows, lo, co = dy.shape
+            rows2, l, ci = x.shape
         else:
             _rlc(dy, 'dy')
             _rlc(x, 'x')
             rows, lo, co = dy.shape
             rows2, l, ci = x.shape
+            lddy, ldx = co, ci
+        ldy_len = lo
+        if extra.get('dy_half'):                      # dY at half resolution: position j of x reads dy[j / 2] / 2
+            if k != 1 or stride != 1 or pad != 0 or l % 2 or lo * 2 != l:
+                raise ValueError('conv_wgrad_multi: dy_half belongs to a 1x1 job whose dy has half the positions of x')
+            lo = l
         if rows != rows2 or lo != conv_out_len(l, k, stride, pad) or k > 3 or ci % 32 or co % 32:
             raise ValueError('conv_wgrad_multi: unsupported shape')
         wino = 1 if (WINOGRAD_WGRAD and k == 3 and stride == 1 and pad == 1 and co % 64 == 0 and ci % 64 == 0) else 0
@@ -503,9 +551,22 @@ def conv_wgrad_multi(jobs):
         _chk(L.da_conv_wgrad_plan(rows, lo, co, ci, k, wino, plan), 'da_conv_wgrad_plan')
         ws = torch.empty((plan[2] * k * co * ci,), device=x.device, dtype=torch.float32)
         d.dy, d.x, d.workspace = dy.data_ptr(), x.data_ptr(), ws.data_ptr()
-        d.rows, d.Lm, d.Ldy, d.lddy, d.N, d.Lx, d.ldx, d.C = rows, lo, lo, co, co, l, ci, ci
+        d.rows, d.Lm, d.Ldy, d.lddy, d.N, d.Lx, d.ldx, d.C = rows, lo, ldy_len, lddy, co, l, ldx, ci
         d.dy_stride, d.dy_off, d.src_stride, d.ntaps = 1, 0, stride, k
         d.winograd = wino
+        if extra:
+            if wino or k != 1:
+                raise ValueError('conv_wgrad_multi: the dense-block operand forms belong to plain 1x1 jobs')
+            d.dy_half = 1 if extra.get('dy_half') else 0
+            if extra.get('xform') is not None:
+                mean_v, invstd_v, gamma, beta, R = extra['xform']
+                if rows % R:
+                    raise ValueError('conv_wgrad_multi: rows not a multiple of rows_per_window')
+                d.xform, d.Wn = 1, R * l
+                d.ldstat = _sv(mean_v, rows // R, ci, 'mean')
+                if _sv(invstd_v, rows // R, ci, 'invstd') != d.ldstat:
+                    raise ValueError('conv_wgrad_multi: mean / invstd must be slices of tables with one pitch')
+                d.mean, d.invstd, d.gamma, d.beta = mean_v.data_ptr(), invstd_v.data_ptr(), _f32(gamma).data_ptr(), _f32(beta).data_ptr()
         for t in range(3):
             d.src_off[t] = t - pad if t < k else 0
         outs.append((ws, plan[2], k, co, ci))
@@ -797,12 +858,105 @@ def bn_param_grad_multi(items, accumulate=True):
 
 
 # ------------------------------------------------------------------------------------------------
+# the dense block as one design (include/deepards_hip.h "the dense block as one design"): a pitched buffer per block, one
+# pitched statistics table per block, relu(norm1(x)) never stored
+# ------------------------------------------------------------------------------------------------
+def dense_fused_ok(rows, R, l, channels):
+    """Whether BatchNorms over (rows, l, C) for every C in ``channels`` have the single-pass geometry the dense-block
+    kernels need (float storage, a window slab in one block's registers, a conv tile within two windows)."""
+    if ACT != torch.float32 or rows % R or R * l < 64:
+        return False
+    L = _lib.lib()
+    return all(c % 32 == 0 and L.da_bn_mask_words(rows // R, R * l, c) > 0 for c in channels)
+
+
+def bn_stats_fused(xv, R, mean_v, invstd_v, eps=1e-5):
+    """Per-window statistics of the channel slice xv (rows, L, C) of a pitched buffer, written into the (W, C) slices
+    mean_v / invstd_v of the block's statistics tables."""
+    ldx = _pv(xv, 'x')
+    rows, l, c = xv.shape
+    w = rows // R
+    ldstat = _sv(mean_v, w, c, 'mean')
+    if rows % R or _sv(invstd_v, w, c, 'invstd') != ldstat:
+        raise ValueError('bn_stats_fused: bad statistics slices')
+    _chk(_lib.lib().da_bn_stats_fused(_p(xv), ldx, w, R * l, c, _p(mean_v), _p(invstd_v), ldstat, eps, _stream()),
+         'da_bn_stats_fused')
+
+
+def bn_relu_ss(xv, R, mean_v, invstd_v, gamma, beta):
+    """relu(norm(xv)) in the fused-multiply-add form the dense-block kernels apply on the fly -> contiguous (rows, L, C)
+    (tests / explainers: the hot path never stores it)."""
+    ldx = _pv(xv, 'x')
+    rows, l, c = xv.shape
+    w = rows // R
+    ldstat = _sv(mean_v, w, c, 'mean')
+    if rows % R or _sv(invstd_v, w, c, 'invstd') != ldstat:
+        raise ValueError('bn_relu_ss: bad statistics slices')
+    out = torch.empty((rows, l, c), device=xv.device, dtype=torch.float32)
+    _chk(_lib.lib().da_bn_relu_ss(_p(xv), ldx, _p(out), c, w, R * l, c, _p(mean_v), _p(invstd_v), ldstat, _p(_f32(gamma)),
+                                  _p(_f32(beta)), _stream()), 'da_bn_relu_ss')
+    return out
+
+
+def bn_bwd_ss(dout, xv, R, mean_v, invstd_v, gamma, beta, relu, dx, add=None, half_dout=False, drop=None):
+    """Backward of relu(norm(xv)) (relu: decision from the fused-multiply-add form) or norm(xv): dout (rows, L, C) -- or
+    (rows, L / 2, C) with half_dout (a transition's pooling in front of its conv) --, dx a (rows, L, C) channel slice that
+    receives the input gradient (+ ``add``, which may be dx itself: in-place accumulation into the block's gradient
+    buffer); drop = (seed, salt, p, g): the dropout mask on the last g channels of dx.  -> ds (2, W, C) window sums."""
+    ldd, ldx, lddx = _pv(dout, 'dout'), _pv(xv, 'x'), _pv(dx, 'dx')
+    rows, l, c = xv.shape
+    w = rows // R
+    if rows % R or tuple(dx.shape) != (rows, l, c) or tuple(dout.shape) != (rows, l // 2 if half_dout else l, c) or \
+            (half_dout and l % 2):
+        raise ValueError('bn_bwd_ss: shape mismatch x%s dout%s dx%s' % (tuple(xv.shape), tuple(dout.shape), tuple(dx.shape)))
+    ldstat = _sv(mean_v, w, c, 'mean')
+    if _sv(invstd_v, w, c, 'invstd') != ldstat:
+        raise ValueError('bn_bwd_ss: bad statistics slices')
+    ldadd = 0
+    if add is not None:
+        if tuple(add.shape) != (rows, l, c):
+            raise ValueError('bn_bwd_ss: bad add operand')
+        ldadd = _pv(add, 'add')
+    seed, salt, p, g = drop if drop is not None else (None, 0, 0.0, 0)
+    ds = torch.empty((2, w, c), device=xv.device, dtype=torch.float32)
+    _chk(_lib.lib().da_bn_bwd_ss(_p(dout), ldd, _p(xv), ldx, _p(dx), lddx, _p(add), ldadd, w, R * l, c, _p(mean_v), _p(invstd_v),
+                                 ldstat, _p(_f32(gamma)), _p(_f32(beta)), 1 if relu else 0, 1 if half_dout else 0,
+                                 _p(seed) if p > 0 else None, salt, p, g, _p(ds), _stream()), 'da_bn_bwd_ss')
+    return ds
+
+
+def conv1x1_bn(xv, w, R, mean_v, invstd_v, gamma, beta, out, pool=False):
+    """out = conv1x1(relu(norm(xv))) with the activation applied while the operand is staged; pool: the transition form
+    (AvgPool1d(2,2) folded in front of the conv: out has L / 2 positions).  w: the (N, C, 1) torch weight; out: a
+    (rows, Lout, N) channel slice (of the next block's buffer, or a plain tensor)."""
+    ldx = _pv(xv, 'x')
+    rows, l, c = xv.shape
+    n = w.shape[0]
+    lo = l // 2 if pool else l
+    if tuple(w.shape) != (n, c, 1) or not w.is_contiguous() or tuple(out.shape) != (rows, lo, n) or rows % R or (pool and l % 2):
+        raise ValueError('conv1x1_bn: unsupported shapes x%s w%s out%s' % (tuple(xv.shape), tuple(w.shape), tuple(out.shape)))
+    ldy = _pv(out, 'out')
+    ldstat = _sv(mean_v, rows // R, c, 'mean')
+    if _sv(invstd_v, rows // R, c, 'invstd') != ldstat:
+        raise ValueError('conv1x1_bn: bad statistics slices')
+    _chk(_lib.lib().da_conv1x1_bn(_p(xv), ldx, _p(_f32(w)), _p(out), ldy, rows, R, l, c, n, 1 if pool else 0, _p(mean_v),
+                                  _p(invstd_v), ldstat, _p(_f32(gamma)), _p(_f32(beta)), _stream()), 'da_conv1x1_bn')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # pools
 # ------------------------------------------------------------------------------------------------
-def bn_relu_pool_fwd(y, R, mean, invstd, gamma, beta, pool_mode, out_x3=False):
+def bn_relu_pool_fwd(y, R, mean, invstd, gamma, beta, pool_mode, out_x3=False, out=None):
     _rlc(y, 'y')
     rows, lin, c = y.shape
     lout = (lin - 1) // 2 + 1
+    if out is not None:                                 # a channel slice of a dense block's pitched buffer (float storage)
+        if out_x3 or tuple(out.shape) != (rows, lout, c) or ACT != torch.float32:
+            raise ValueError('bn_relu_pool_fwd: bad out')
+        _chk(_lib.lib().da_bn_relu_pool_fwd(_p(y), c, _p(out), _pv(out, 'out'), rows, R, lin, c, _p(mean), _p(invstd), _p(gamma),
+                                            _p(beta), pool_mode, _stream()), 'da_bn_relu_pool_fwd')
+        return out
     if out_x3:                      # the pooled map in the x3 format (layer1's k3 s1 convs under conv arithmetic 'f32x3')
         _rlc32(y, 'y')
         out = x3_empty(rows, lout, c, y.device)
@@ -833,7 +987,7 @@ def stem_fused_ok(x2d, w, R):
     return (max_rows * (lin + 12) + 33 * 32) * 4 <= 64 * 1024
 
 
-def stem_fused_fwd(x2d, w, R, gamma, beta, pool_mode, eps=1e-5, out_x3=False):
+def stem_fused_fwd(x2d, w, R, gamma, beta, pool_mode, eps=1e-5, out_x3=False, out=None):
     """conv k7 s2 p3 -> BatchNorm (per window of R rows) -> ReLU -> pool(3,2,1) of the raw rows (rows, Lin) WITHOUT storing
     the conv output (recomputed in the statistics and in the apply pass: bit for bit stem_conv_fwd + bn_stats +
     bn_relu_pool_fwd).  -> out (rows, Lp, C) float or x3, mean, invstd (W, C)."""
@@ -851,8 +1005,14 @@ def stem_fused_fwd(x2d, w, R, gamma, beta, pool_mode, eps=1e-5, out_x3=False):
     mean = torch.empty((wn, c), device=x.device, dtype=torch.float32)
     invstd = torch.empty((wn, c), device=x.device, dtype=torch.float32)
     _chk(L.da_bn_stats_merge(_p(part), wn, R * lc, c, eps, _p(mean), _p(invstd), _stream()), 'da_bn_stats_merge')
-    out = x3_empty(rows, lp, c, x.device) if out_x3 else torch.empty((rows, lp, c), device=x.device, dtype=torch.float32)
-    _chk(L.da_stem_bn_relu_pool_fwd(_p(x), _p(w), _p(out), c, rows, R, lin, c, _p(mean), _p(invstd), _p(gamma), _p(beta),
+    ldo = c
+    if out is not None:                                # a channel slice of a dense block's pitched buffer
+        if out_x3 or tuple(out.shape) != (rows, lp, c):
+            raise ValueError('stem_fused_fwd: bad out')
+        ldo = _pv(out, 'out')
+    else:
+        out = x3_empty(rows, lp, c, x.device) if out_x3 else torch.empty((rows, lp, c), device=x.device, dtype=torch.float32)
+    _chk(L.da_stem_bn_relu_pool_fwd(_p(x), _p(w), _p(out), ldo, rows, R, lin, c, _p(mean), _p(invstd), _p(gamma), _p(beta),
                                     pool_mode, 1 if out_x3 else 0, _stream()), 'da_stem_bn_relu_pool_fwd')
     return out, mean, invstd
 
@@ -860,10 +1020,12 @@ def stem_fused_fwd(x2d, w, R, gamma, beta, pool_mode, eps=1e-5, out_x3=False):
 def stem_fused_bwd(dout, x2d, w, R, mean, invstd, gamma, beta, pool_mode, dw=None, accumulate=False):
     """Backward of stem_fused_fwd from dout (rows, Lp, C) float and the raw rows: -> dw (C, 1, 7) (+= into ``dw`` when
     accumulate), ds (2, W, C) = the BatchNorm's window sums (bn_param_grad_multi folds them into dgamma / dbeta)."""
-    _rlc32(dout, 'dout')
+    ldd = _pv(dout, 'dout')
     x = x2d.reshape(x2d.shape[0], x2d.shape[-1])
     rows, lin = x.shape
     c = w.shape[0]
+    if dout.shape[2] != c:
+        raise ValueError('stem_fused_bwd: dout must have the stem\'s %d channels' % c)
     if dw is None:
         if accumulate:
             raise ValueError('accumulate needs dw')
@@ -871,17 +1033,17 @@ def stem_fused_bwd(dout, x2d, w, R, mean, invstd, gamma, beta, pool_mode, dw=Non
     L = _lib.lib()
     ds = torch.empty((2, rows // R, c), device=x.device, dtype=torch.float32)
     ws = torch.empty((L.da_stem_bwd_workspace(rows, c) // 4,), device=x.device, dtype=torch.float32)
-    _chk(L.da_stem_bwd(_p(dout), c, _p(x), _p(w), rows, R, lin, c, _p(mean), _p(invstd), _p(gamma), _p(beta), pool_mode, _p(ds),
+    _chk(L.da_stem_bwd(_p(dout), ldd, _p(x), _p(w), rows, R, lin, c, _p(mean), _p(invstd), _p(gamma), _p(beta), pool_mode, _p(ds),
                        _p(dw), 1 if accumulate else 0, _p(ws), _stream()), 'da_stem_bwd')
     return dw, ds
 
 
 def pool_bwd(dout, y, R, mean, invstd, gamma, beta, pool_mode):
-    _rlc(dout, 'dout')
+    ldd = _pv(dout, 'dout') if ACT == torch.float32 else _rlc(dout, 'dout').shape[2]
     _rlc(y, 'y')
     rows, lin, c = y.shape
     dz = torch.empty_like(y)
-    _chk(_lib.lib().da_pool_bwd(_p(dout), c, _p(y), c, _p(dz), c, rows, R, lin, c, _p(mean), _p(invstd), _p(gamma),
+    _chk(_lib.lib().da_pool_bwd(_p(dout), ldd, _p(y), c, _p(dz), c, rows, R, lin, c, _p(mean), _p(invstd), _p(gamma),
                                 _p(beta), pool_mode, _stream()), 'da_pool_bwd')
     return dz
 

@@ -109,9 +109,12 @@ class _Features(nn.Sequential):
         if rows % R:
             raise ValueError('rows not a multiple of rows_per_window')
         x2d = x.contiguous().float()                       # (rows, C_in, L): the stem kernel reads the NCL rows directly
+        use_drop = self.training and self.drop_rate > 0
+        plan = self._block_plan(rows, R, l, use_drop)
+        if plan is not None:
+            return self._forward_blocks(x2d, R, relu, use_drop, plan)
         h = F_.StemFunction.apply(x2d, self.conv0.weight, self.norm0.weight, self.norm0.bias, R, F_.POOL_MAX,
                                   F_.BNState(self.norm0))
-        use_drop = self.training and self.drop_rate > 0
         if use_drop:
             self._drop_seed.add_(0x9E3779B97F4A7C15 >> 1)
         salt = 0
@@ -123,6 +126,54 @@ class _Features(nn.Sequential):
             elif isinstance(mod, _Transition):
                 h = mod.forward_rlc(h, R)
         return F_.NormReluFunction.apply(h, self.norm5.weight, self.norm5.bias, R, F_.BNState(self.norm5), relu)
+
+    def _block_plan(self, rows, R, l, use_drop):
+        """[(block, its transition or None, length, C0, Cb)] when EVERY dense block of the network can run as one
+        F_.DenseBlockFunction (one pitched buffer + one statistics table per block, see there), else None: the per-layer
+        Functions below then take the whole network (other shapes, bf16 convs, DA_DENSE_BLOCK=0)."""
+        mods = list(self.children())
+        lb = ((l + 2 * 3 - 7) // 2 + 1 - 1) // 2 + 1            # conv0 k7 s2 p3, pool0 (3, 2, 1)
+        c0 = self.conv0.out_channels
+        plan = []
+        for i, mod in enumerate(mods):
+            if not isinstance(mod, _DenseBlock):
+                continue
+            layers = list(mod.children())
+            growth, mid = layers[0].conv2.out_channels, layers[0].conv1.out_channels
+            tail = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], _Transition) else None
+            cb = c0 + len(layers) * growth
+            if any(ly.conv2.out_channels != growth or ly.conv1.out_channels != mid for ly in layers) or \
+                    not F_.dense_block_ok(rows, R, lb, c0, growth, len(layers), mid, tail.conv.out_channels if tail else 0,
+                                          use_drop):
+                return None
+            plan.append((mod, tail, lb, c0, cb))
+            if tail is not None:
+                c0, lb = tail.conv.out_channels, lb // 2
+        return plan or None
+
+    def _forward_blocks(self, x2d, R, relu, use_drop, plan):
+        """The network as one Function per dense block (+ its transition / norm5), F_.DenseBlockFunction."""
+        h = F_.StemFunction.apply(x2d, self.conv0.weight, self.norm0.weight, self.norm0.bias, R, F_.POOL_MAX,
+                                  F_.BNState(self.norm0), False, plan[0][4])
+        if use_drop:
+            self._drop_seed.add_(0x9E3779B97F4A7C15 >> 1)
+        salt = 1
+        p = self.drop_rate if use_drop else 0.0
+        for n, (blk, tail, lb, c0, cb) in enumerate(plan):
+            layers = list(blk.children())
+            params = []
+            for ly in layers:
+                params += [ly.norm1.weight, ly.norm1.bias, ly.conv1.weight, ly.norm2.weight, ly.norm2.bias, ly.conv2.weight]
+            if tail is not None:
+                params += [tail.norm.weight, tail.norm.bias, tail.conv.weight]
+                tail_cb, eps = plan[n + 1][4], tail.norm.eps
+            else:
+                params += [self.norm5.weight, self.norm5.bias]
+                tail_cb, eps = 0, self.norm5.eps
+            h = F_.DenseBlockFunction.apply(h, R, c0, layers[0].conv2.out_channels, len(layers), p,
+                                            self._drop_seed if use_drop else None, salt, eps, tail_cb, relu, *params)
+            salt += len(layers)
+        return h
 
     def forward(self, x):
         return self.forward_rlc(x, x.shape[0], False).permute(0, 2, 1)

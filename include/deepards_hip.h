@@ -139,6 +139,10 @@ typedef struct {
   int winograd;   /* != 0: k3 s1 p1 job (N, C multiples of 64) in Winograd F(2,3) form; plan with winograd = 1;
                      16: bf16 operands; 49: split-bf16 (fp32-equivalent) products with dy AND x in the x3
                      format (see da_conv3_x3p; lddy == N, ldx == C), k3 s1 p1 only */
+  /* dense-block operand forms of plain 1x1 jobs (winograd == 0, ntaps == 1; see da_conv1x1_bn): xform = 1: X is
+     relu(BatchNorm(x)) recomputed while staged from the statistics tables [rows * Lm / Wn][ldstat] (Wn >= 32);
+     dy_half = 1: dY has Ldy = Lm / 2 positions per row, position j reads dy[j / 2] / 2 */
+  int xform, dy_half, Wn, ldstat; const float* mean; const float* invstd; const float* gamma; const float* beta;
 } da_wgrad_job;
 int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, da_stream_t stream);  /* winograd == 16 jobs: dy / x are da_act_t tensors (the only kind accepted while bf16 is selected) */
 /* deferred slab reduction: da_conv_wgrad with dw == NULL leaves da_conv_wgrad_splits() slabs in the workspace */
@@ -230,6 +234,38 @@ int da_bn_bwd_add(const da_act_t* dout, int ldd, const da_act_t* x, int ldx, con
                   da_act_t* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd, const float* gamma,
                   const float* beta, int mask_mode, float* scratch, float* ds, float* dgamma, float* dbeta,
                   int accumulate, const da_act_t* add, int ldadd, da_stream_t stream);
+/* ---- the dense block as one design (reference models/densenet.py:18-44 _DenseLayer, :46-66 _DenseBlock, :68-81 _Transition)
+ * One pitched buffer [rows][L][Cb] per block: the growth conv writes its 32 new channels at their offset (with F.dropout in
+ * its epilogue), per-(window, channel) statistics live in ONE pitched table per block ([W][ldstat] mean / invstd) and are
+ * reused by every later norm1 and the transition norm, and h = relu(norm1(x)) is never stored: the 1x1 conv applies it while
+ * staging (da_conv1x1_bn), its weight gradient recomputes it (da_wgrad_job.xform), the BatchNorm backward takes the ReLU
+ * decision from the same fused multiply-add (da_bn_bwd_ss).  fp32 activations, single-pass BatchNorm geometry
+ * (da_bn_mask_words() > 0) only; callers keep the per-op entry points above for every other shape. */
+/* statistics only: mean / invstd of x[:, 0:C] per window, written into the pitched tables */
+int da_bn_stats_fused(const float* x, int ldx, int W, int Wn, int C, float* mean, float* invstd, int ldstat, float eps,
+                      da_stream_t stream);
+/* out[:, 0:C] = max(fmaf(x, gamma invstd, beta - mean gamma invstd), 0): the un-stored activation, for tests / explainers */
+int da_bn_relu_ss(const float* x, int ldx, float* out, int ldo, int W, int Wn, int C, const float* mean, const float* invstd,
+                  int ldstat, const float* gamma, const float* beta, da_stream_t stream);
+/* backward of relu(norm(x)) (relu != 0: ReLU decision from the fused multiply-add form) or norm(x): statistics from the
+ * pitched tables; half_dout: dout has Wn / 2 positions per window, g[p] = dout[p / 2] / 2 (a transition's AvgPool1d(2,2) in
+ * front of its conv); dx = input gradient (+ add[:, 0:C]; dx may alias add), then with drop_p > 0 the dropout mask
+ * (da_dropout's, seed / salt, contiguous [W Wn][drop_g]) on dx's channels [C - drop_g, C); ds [2][W][C] window sums */
+int da_bn_bwd_ss(const float* dout, int ldd, const float* x, int ldx, float* dx, int lddx, const float* add, int ldadd, int W,
+                 int Wn, int C, const float* mean, const float* invstd, int ldstat, const float* gamma, const float* beta,
+                 int relu, int half_dout, const long long* drop_seed, unsigned drop_salt, float drop_p, int drop_g, float* ds,
+                 da_stream_t stream);
+/* y[m][0:N] (pitch ldy) = sum_c w[n][c] relu(norm(x))[m][c], the activation applied while x (first C channels, pitch ldx) is
+ * staged; pool != 0: the transition form, (h[2m] + h[2m+1]) / 2 in front of the conv (Lin even, Lin / 2 outputs per row).
+ * w [N][C] = the torch weight of the k = 1 conv as it lies.  N % 64 == 0, C % 32 == 0, R * Lout >= 64.
+ * replaces norm1 -> relu1 -> conv1 (densenet.py:23-26) and norm -> relu -> conv -> pool (:72-79) */
+int da_conv1x1_bn(const float* x, int ldx, const float* w, float* y, int ldy, int rows, int R, int Lin, int C, int N, int pool,
+                  const float* mean, const float* invstd, int ldstat, const float* gamma, const float* beta, da_stream_t stream);
+/* da_conv3_winograd + F.dropout(p) in the epilogue (mask of da_dropout on the contiguous [rows L][N] tensor), y at pitch ldy:
+ * a _DenseLayer's growth conv storing its new features at their channel offset (densenet.py:30-40) */
+int da_conv3_winograd_drop(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
+                           const long long* drop_seed, unsigned drop_salt, float drop_p, da_stream_t stream);
+
 int da_bn_param_grad_multi(const da_bn_pgrad_desc* descs, int n, int accumulate, da_stream_t stream);
 /* The same BatchNorm forward / backward (resnet.py:27-38) in front of an x3 consumer (conv arithmetic 'f32x3', see
  * da_conv3_x3p): float in, and res_x3 / out_x3 / dx_x3 say which of `res`, `out`, `dx` are in the x3 format (their pitches are
