@@ -94,9 +94,10 @@ SIGNATURES = {
     'da_bn_param_grad_multi': (_I, [ctypes.POINTER(BnPgradDesc), _I, _I, _P]),
     'da_bn_stats_fused': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _F, _P]),
     'da_bn_relu_ss': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
-    'da_bn_bwd_ss': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _I, _P, _U, _F, _I, _P, _P]),
-    'da_conv1x1_bn': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
-    'da_conv3_winograd_drop': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _U, _F, _P]),
+    'da_bn_bwd_ss': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _I, _P, _U, _F, _I, _P, _P]),
+    'da_conv1x1_bn': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, ctypes.c_long, _I, _F, _P, _P]),
+    'da_conv3_winograd_drop': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _U, _F, _P, _I, _P]),
+    'da_stat_records_floats': (_Z, [ctypes.c_long, _I]),
     'da_conv_wgrad_splits': (_I, [_I] * 5),
     'da_conv_wgrad_plan': (_I, [_I] * 6 + [ctypes.POINTER(_I)]),
     'da_conv_gemm_multi': (_I, [ctypes.POINTER(ConvJob), _I, _P]),

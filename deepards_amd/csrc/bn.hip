@@ -626,7 +626,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict
       xh[k] = Act<AT>::ld4(xb + (uint32_t)(p * ldx + q * 4));
     }
   }
-  f32x4 sc, sh;                                       // mask_mode 4: the ReLU decision of the scale / shift form
+  // EXT: gamma / beta live on only as sc = gamma invstd (the factor of dx as well) and sh -- the ReLU decision of the scale /
+  // shift form (mask_mode 4); the slab already fills the 128 registers a 1024-thread block may hold
+  f32x4 sc, sh;
   if (EXT) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -648,7 +650,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) xh[k][e] = (xh[k][e] - mu[e]) * is[e];
-    if (EXT && mask_mode == 4) {
+    if (EXT) {                            // modes 0, 2 (sign of the stored output) and 4 only
+      if (mask_mode == 2 && p < Wn) {
+        const f32x4 o = Act<AT>::ld4(ob + (uint32_t)(p * ldo + q * 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[k][e] = (o[e] > 0.f) ? g[k][e] : 0.f;
+      }
     } else if (mask_mode == 3) {          // ReLU decisions recorded by the forward kernel (bn_fwd_fused_kernel, same geometry)
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[k][e] = ((mbits >> (k * 4 + e)) & 1ull) ? g[k][e] : 0.f;
@@ -674,7 +681,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict
       f32x4 d;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        d[e] = ga[e] * is[e] * (g[k][e] - acc[0][e] * inv_n - xh[k][e] * acc[1][e] * inv_n);
+        d[e] = (EXT ? sc[e] : ga[e] * is[e]) * (g[k][e] - acc[0][e] * inv_n - xh[k][e] * acc[1][e] * inv_n);
       if (ab) {
         const f32x4 av = Act<AT>::ld4(ab + (uint32_t)(p * ldadd + q * 4));
 #pragma unroll
@@ -1192,21 +1199,23 @@ int da_bn_relu_ss(const float* x, int ldx, float* out, int ldo, int W, int Wn, i
   return DA_OK;
 }
 
-// Backward of h = relu(norm(x)) in the scale / shift form (relu != 0) or of norm(x) alone, x = the first C channels of
-// a dense block's buffer (pitch ldx), statistics from its pitched table:
+// Backward of h = relu(norm(x)) -- relu = 1: the ReLU decision of the scale / shift form (a forward through da_conv1x1_bn);
+// relu = 2: the sign of the stored output `out` (a forward through da_bn_fwd) -- or of norm(x) alone (relu = 0), x = the
+// first C channels of a dense block's buffer (pitch ldx), statistics from its pitched table:
 //   g = dout (half_dout: dout has Wn / 2 positions per window, g[p] = dout[p / 2] / 2) masked by the ReLU decision;
 //   dx = BatchNorm input gradient (+ add[:, 0:C], pitch ldadd -- dx may alias add: the in-place accumulation into the
 //   block's gradient buffer); then, with drop_p > 0, the dropout mask (seed, salt) of the contiguous [W Wn][drop_g]
 //   tensor on the channels [C - drop_g, C) of dx.  ds [2][W][C]: the window sums for da_bn_param_grad_multi.
-int da_bn_bwd_ss(const float* dout, int ldd, const float* x, int ldx, float* dx, int lddx, const float* add, int ldadd, int W,
-                 int Wn, int C, const float* mean, const float* invstd, int ldstat, const float* gamma, const float* beta,
-                 int relu, int half_dout, const long long* drop_seed, unsigned drop_salt, float drop_p, int drop_g, float* ds,
+int da_bn_bwd_ss(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
+                 const float* add, int ldadd, int W, int Wn, int C, const float* mean, const float* invstd, int ldstat,
+                 const float* gamma, const float* beta, int relu, int half_dout, const long long* drop_seed, unsigned drop_salt, float drop_p, int drop_g, float* ds,
                  hipStream_t stream) {
   DA_ENTER();
   if (g_act_bf16) return DA_EINVAL;
   if (!dout || !x || !dx || !mean || !invstd || !gamma || !beta || !ds) return DA_EINVAL;
   if (C % CG || ldd % 4 || ldx % 4 || lddx % 4 || (add && ldadd % 4) || ldstat % 4 || ldstat < C || Wn < 1) return DA_EINVAL;
   if (half_dout && (Wn & 1)) return DA_EINVAL;
+  if (relu < 0 || relu > 2 || (relu == 2 && (!out || ldo % 4))) return DA_EINVAL;
   if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (!drop_seed || drop_g < 4 || drop_g % 4 || drop_g > C))) return DA_EINVAL;
   if (W == 0) return DA_OK;
   int cgb = 0;
@@ -1219,8 +1228,8 @@ int da_bn_bwd_ss(const float* dout, int ldd, const float* x, int ldx, float* dx,
   float* s2 = ds + (size_t)W * C;
 #define BN_BWDSS_LAUNCH(QB, CH)                                                                                              \
   hipLaunchKernelGGL((bn_bwd_fused_kernel<float, FUSED_NPOS, QB, 0, 1>), dim3(W, C / CH), dim3(threads), 0, stream, dout, ldd, x,  \
-                     ldx, (const float*)nullptr, 0, dx, lddx, (float*)nullptr, 0, Wn, C, mean, invstd, gamma, beta,                 \
-                     relu ? 4 : 0, s1, s2, add, ldadd, (const unsigned long long*)nullptr, ext)
+                     ldx, out, ldo, dx, lddx, (float*)nullptr, 0, Wn, C, mean, invstd, gamma, beta,                                 \
+                     relu == 1 ? 4 : (relu == 2 ? 2 : 0), s1, s2, add, ldadd, (const unsigned long long*)nullptr, ext)
   if (cgb == 32) BN_BWDSS_LAUNCH(3, 32);
   else if (cgb == 16) BN_BWDSS_LAUNCH(2, 16);
   else BN_BWDSS_LAUNCH(1, 8);

@@ -588,11 +588,18 @@ struct Conv1x1BnArgs {
   const float* w;     // [N][C]
   float* y;
   int M, ldx, C, ldy, N, W, Wn, ldstat;
-  const float* mean;
-  const float* invstd;
+  float* mean;        // the block's statistics tables [W][ldstat]: read for the channels below pend_c0, WRITTEN for the rest
+  float* invstd;
   const float* gamma;
   const float* beta;
   FastDiv divWn;
+  // channels [pend_c0, C) have no table entry yet: their statistics arrive as the records their producer's epilogue wrote
+  // (conv_wino.hip conv3_wino_stats_kernel / this kernel's OSTATS form) -- merged here, per block for its own two windows,
+  // and published to the tables by the block that holds the window's first row (n tile 0): later consumers read the tables
+  const float* pend;  // [tiles][2 slots][{mean, M2}][pend_nc] | counts [tiles][2]
+  int pend_c0, pend_nc, pend_Wu, pend_tiles;
+  float eps;
+  float* out_part;    // OSTATS: records of THIS conv's output (N channels, 64-position tiles, windows of Wn positions)
 };
 
 __device__ __forceinline__ void bn_scale_shift(float mean, float invstd, float gamma, float beta, float& sc, float& sh) {
@@ -600,7 +607,46 @@ __device__ __forceinline__ void bn_scale_shift(float mean, float invstd, float g
   sh = fmaf(-mean, sc, beta);
 }
 
-template <int POOL>
+// (mean, invstd) of window w, channel c (of the record's pend_nc) from the tiles' records: Chan's update in tile order.
+// Every block of the consuming conv runs this for its own windows, so it must cost ONE memory latency, not one per record:
+// the records are loaded MERGE_B at a time, the update runs on registers (a serial loop of dependent loads cost 10 us per
+// launch at L = 56: ten records per window).
+#define MERGE_B 4
+__device__ __forceinline__ void merge_stat_records(const float* __restrict__ part, int tiles, int nc, int Wu, int w, int c,
+                                                   float eps, float& mean, float& invstd) {
+  const int u0 = w * Wu;
+  const int r0 = u0 >> 6, r1 = min((u0 + Wu - 1) >> 6, tiles - 1);
+  const float* cnt = part + (size_t)tiles * 4 * nc;
+  float n = 0.f, mu = 0.f, m2 = 0.f;
+  // a tile whose first unit lies in front of the window started in the previous one: the window is its SECOND slot
+#pragma unroll 1
+  for (int rb = r0; rb <= r1; rb += MERGE_B) {           // MERGE_B records in flight at a time (12 registers, not 36)
+    float cn[MERGE_B], mb[MERGE_B], qb[MERGE_B];
+#pragma unroll
+    for (int j = 0; j < MERGE_B; ++j) {
+      const int r = min(rb + j, r1);
+      const int sl = (r << 6) >= u0 ? 0 : 1;
+      const float* rec = part + ((size_t)(r * 2 + sl) * 2) * nc + c;
+      cn[j] = cnt[r * 2 + sl];
+      mb[j] = rec[0];
+      qb[j] = rec[nc];
+    }
+#pragma unroll
+    for (int j = 0; j < MERGE_B; ++j) {
+      const float nb = rb + j <= r1 ? cn[j] : 0.f;
+      if (nb > 0.f) {
+        const float d = mb[j] - mu, nt = n + nb;
+        mu += d * (nb / nt);
+        m2 += qb[j] + d * d * (n * nb / nt);
+        n = nt;
+      }
+    }
+  }
+  mean = mu;
+  invstd = 1.0f / sqrtf(m2 / fmaxf(n, 1.f) + eps);
+}
+
+template <int POOL, int OSTATS = 0>
 __global__ __launch_bounds__(256) void conv1x1_bn_kernel(Conv1x1BnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];          // As | Bs | sc[2][C] | sh[2][C]
   constexpr int PITCH = 36;
@@ -619,7 +665,21 @@ __global__ __launch_bounds__(256) void conv1x1_bn_kernel(Conv1x1BnArgs a) {
   for (int i = tid; i < 2 * a.C; i += 256) {
     const int ws = i >= a.C ? 1 : 0, c = i - ws * a.C, w = w0 + ws;
     float sc = 0.f, sh = 0.f;
-    if (w < a.W) bn_scale_shift(a.mean[(size_t)w * a.ldstat + c], a.invstd[(size_t)w * a.ldstat + c], a.gamma[c], a.beta[c], sc, sh);
+    if (w < a.W) {
+      float mu, is;
+      if (c >= a.pend_c0) {
+        merge_stat_records(a.pend, a.pend_tiles, a.pend_nc, a.pend_Wu, w, c - a.pend_c0, a.eps, mu, is);
+        const int mw = w * a.Wn;                          // the window's first output row: its tile publishes
+        if (n_blk == 0 && mw >= m_blk && mw < m_blk + 64) {
+          a.mean[(size_t)w * a.ldstat + c] = mu;
+          a.invstd[(size_t)w * a.ldstat + c] = is;
+        }
+      } else {
+        mu = a.mean[(size_t)w * a.ldstat + c];
+        is = a.invstd[(size_t)w * a.ldstat + c];
+      }
+      bn_scale_shift(mu, is, a.gamma[c], a.beta[c], sc, sh);
+    }
     scs[i] = sc;
     shs[i] = sh;
   }
@@ -694,6 +754,74 @@ __global__ __launch_bounds__(256) void conv1x1_bn_kernel(Conv1x1BnArgs a) {
   for (int r = 0; r < 16; ++r) {
     const int m = m_blk + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
     if (m < a.M) a.y[(size_t)m * a.ldy + n] = acc[r];
+  }
+  if (OSTATS) {
+    // records of the output (the next block's input channels): count, mean, centred M2 per (window slot, channel) of this
+    // 64-row tile, two passes over the accumulators; lanes l and l + 32 hold a channel's two row halves, waves (wm = 0, 1)
+    // its two 32-row halves -- fixed fold order
+    const int m_edge = (w0 + 1) * a.Wn;                   // rows from here on: the tile's second window
+    float* red = lds;                                     // [2 wm][2 slots][64 ch] | cnt [2 wm][2] | mean [2][64] | tot [2]
+    float* rcnt = red + 256;
+    float* rmean = rcnt + 4;
+    float* rtot = rmean + 128;
+    float ssum[2] = {0.f, 0.f}, scnt[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m_blk + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (m < a.M) {
+        const int sl = m >= m_edge ? 1 : 0;
+        ssum[sl] += acc[r];
+        scnt[sl] += 1.f;
+      }
+    }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      ssum[sl] += __shfl_xor(ssum[sl], 32, 64);
+      scnt[sl] += __shfl_xor(scnt[sl], 32, 64);
+    }
+    __syncthreads();                                      // the operand panels are dead in every wave
+    if (fh == 0) {
+      red[(wm * 2 + 0) * 64 + wn * 32 + frow] = ssum[0];
+      red[(wm * 2 + 1) * 64 + wn * 32 + frow] = ssum[1];
+    }
+    if (lane == 0 && wn == 0) {
+      rcnt[wm * 2] = scnt[0];
+      rcnt[wm * 2 + 1] = scnt[1];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int sl = tid >> 6, ch = tid & 63;
+      const float cn = rcnt[sl] + rcnt[2 + sl];
+      rmean[sl * 64 + ch] = cn > 0.f ? (red[(0 * 2 + sl) * 64 + ch] + red[(1 * 2 + sl) * 64 + ch]) / cn : 0.f;
+      if (ch == 0) rtot[sl] = cn;
+    }
+    __syncthreads();
+    float sq[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m_blk + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (m < a.M) {
+        const int sl = m >= m_edge ? 1 : 0;
+        const float d = acc[r] - rmean[sl * 64 + wn * 32 + frow];
+        sq[sl] += d * d;
+      }
+    }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) sq[sl] += __shfl_xor(sq[sl], 32, 64);
+    __syncthreads();
+    if (fh == 0) {
+      red[(wm * 2 + 0) * 64 + wn * 32 + frow] = sq[0];
+      red[(wm * 2 + 1) * 64 + wn * 32 + frow] = sq[1];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int sl = tid >> 6, ch = tid & 63;
+      const int mt = m_blk >> 6, nmt = (a.M + 63) >> 6;
+      float* rec = a.out_part + ((size_t)(mt * 2 + sl) * 2) * a.N + n_blk + ch;
+      rec[0] = rmean[sl * 64 + ch];
+      rec[a.N] = red[(0 * 2 + sl) * 64 + ch] + red[(1 * 2 + sl) * 64 + ch];
+      if (ch == 0 && n_blk == 0) a.out_part[(size_t)nmt * 4 * a.N + mt * 2 + sl] = rtot[sl];
+    }
   }
 }
 
@@ -809,7 +937,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block_i
     }
     if (XF && a.xform) {
       // windows of this K step's 32 positions: nearly always one (Wn >> 32); a step that crosses into the next window
-      // keeps both sets and selects per row
+      // runs a second pass over its rows with that window's vectors (one cached set: registers are what this kernel lacks)
       const int m_last = min(k0 + 31, k_end - 1);
       const int w_lo = (int)fdiv((uint32_t)k0, a.divWn), w_hi = (int)fdiv((uint32_t)m_last, a.divWn);
       const int cq = c_blk + (tid % XQ) * 4;
@@ -826,34 +954,24 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block_i
           sh[e] = sh_;
         }
       };
-      if (w_lo != xf_w) {
-        load_ss(w_lo, xf_sc, xf_sh);
-        xf_w = w_lo;
-      }
-      if (w_lo == w_hi) {
+      const int m_edge = (w_lo + 1) * (int)a.divWn.d;      // rows from here on belong to w_hi = w_lo + 1 (Wn >= 32: host)
+      const int npass = w_hi != w_lo ? 2 : 1;              // (block-uniform)
+#pragma unroll 1
+      for (int pass = 0; pass < npass; ++pass) {           // ONE code site: a second copy of this costs ~30 registers
+        const int w = w_lo + pass;
+        if (w != xf_w) {
+          load_ss(w, xf_sc, xf_sh);
+          xf_w = w;
+        }
+        const int m_from = pass ? m_edge : 0, m_to = pass ? k_end : min(k_end, m_edge);
 #pragma unroll
         for (int p = 0; p < XP; ++p) {
-          if (k0 + (tid + 256 * p) / XQ < k_end) {
+          const int m = k0 + (tid + 256 * p) / XQ;
+          if (m >= m_from && m < m_to) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) rx[p][e] = fmaxf(fmaf(rx[p][e], xf_sc[e], xf_sh[e]), 0.f);
           }
         }
-      } else {                                           // (w_hi == w_lo + 1: Wn >= 32 is checked by the host)
-        f32x4 sc2, sh2;
-        load_ss(w_hi, sc2, sh2);
-        const int m_edge = w_hi * (int)a.divWn.d;
-#pragma unroll
-        for (int p = 0; p < XP; ++p) {
-          const int m = k0 + (tid + 256 * p) / XQ;
-          if (m < k_end) {
-            const bool hi = m >= m_edge;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rx[p][e] = fmaxf(fmaf(rx[p][e], hi ? sc2[e] : xf_sc[e], hi ? sh2[e] : xf_sh[e]), 0.f);
-          }
-        }
-        xf_sc = sc2;
-        xf_sh = sh2;
-        xf_w = w_hi;
       }
     }
 #pragma unroll
@@ -1167,8 +1285,12 @@ int da_conv_gemm_multi(const da_conv_job* jobs, int n, hipStream_t stream) {
 // pool != 0: h(m, .) = (h[2m] + h[2m+1]) / 2, Lin even, the output has Lin / 2 positions per row (a _Transition with its
 // AvgPool1d(2,2) in front of the conv).  w: [N][C] (the torch weight of a k = 1 conv as it lies).  N % 64 == 0, C % 32 == 0,
 // R * Lout >= 64.  replaces norm1 -> relu1 -> conv1 (densenet.py:23-26) and norm -> relu -> conv -> pool (:72-79)
+// pend != NULL: the channels [pend_c0, C) take their statistics from the records `pend` their producer wrote (pend_units units
+// in all, pend_Wu per window: 64-unit tiles, da_stat_records_floats) and this call PUBLISHES them to the tables;
+// out_part != NULL: this call writes the records of its own output (windows of R * Lout positions, N channels).
 int da_conv1x1_bn(const float* x, int ldx, const float* w, float* y, int ldy, int rows, int R, int Lin, int C, int N, int pool,
-                  const float* mean, const float* invstd, int ldstat, const float* gamma, const float* beta, hipStream_t stream) {
+                  float* mean, float* invstd, int ldstat, const float* gamma, const float* beta, const float* pend, int pend_c0,
+                  long pend_units, int pend_Wu, float eps, float* out_part, hipStream_t stream) {
   DA_ENTER();
   if (g_act_bf16) return DA_EINVAL;
   if (!x || !w || !y || !mean || !invstd || !gamma || !beta || rows < 0 || R < 1 || rows % R || Lin < 1) return DA_EINVAL;
@@ -1185,10 +1307,19 @@ int da_conv1x1_bn(const float* x, int ldx, const float* w, float* y, int ldy, in
   a.M = (int)M; a.ldx = ldx; a.C = C; a.ldy = ldy; a.N = N; a.W = rows / R; a.Wn = R * Lout; a.ldstat = ldstat;
   a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta;
   a.divWn = make_fastdiv((uint32_t)a.Wn);
+  a.pend = pend; a.pend_c0 = C; a.pend_nc = 0; a.pend_Wu = 1; a.pend_tiles = 0; a.eps = eps; a.out_part = out_part;
+  if (pend) {
+    if (pend_c0 < 0 || pend_c0 >= C || pend_units < 1 || pend_Wu < 64 || pend_units % pend_Wu || pend_units / pend_Wu != rows / R)
+      return DA_EINVAL;
+    a.pend_c0 = pend_c0; a.pend_nc = C - pend_c0; a.pend_Wu = pend_Wu; a.pend_tiles = (int)((pend_units + 63) / 64);
+  }
   const unsigned blocks = (unsigned)(((M + 63) / 64) * (N / 64));
   const size_t shm = (size_t)(128 * 36 + 4 * C) * sizeof(float);
-  if (pool) hipLaunchKernelGGL(conv1x1_bn_kernel<1>, dim3(blocks), dim3(256), shm, stream, a);
-  else hipLaunchKernelGGL(conv1x1_bn_kernel<0>, dim3(blocks), dim3(256), shm, stream, a);
+  if (out_part) {
+    if (pool) hipLaunchKernelGGL((conv1x1_bn_kernel<1, 1>), dim3(blocks), dim3(256), shm, stream, a);
+    else hipLaunchKernelGGL((conv1x1_bn_kernel<0, 1>), dim3(blocks), dim3(256), shm, stream, a);
+  } else if (pool) hipLaunchKernelGGL((conv1x1_bn_kernel<1, 0>), dim3(blocks), dim3(256), shm, stream, a);
+  else hipLaunchKernelGGL((conv1x1_bn_kernel<0, 0>), dim3(blocks), dim3(256), shm, stream, a);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

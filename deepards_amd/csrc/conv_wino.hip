@@ -33,6 +33,11 @@ struct WinoArgs {
   const long long* drop_seed;
   uint32_t drop_salt;
   float drop_p;
+  // per-(tile, window) statistics records of the OUTPUT (after the dropout), for the BatchNorms that will normalise these
+  // channels (common.h StatRecords): stat_part != NULL -> every 64-pair tile writes (count, mean, centred M2) per channel
+  // for the <= 2 windows (stat_Wu pairs each, >= 64) it touches; F(2,3) full tiles only (the host launches no half tiles)
+  float* stat_part;
+  int stat_Wu;
 };
 
 __device__ __forceinline__ uint32_t wino_mix32(uint32_t a, uint32_t b) {      // head_optim.hip mix32
@@ -65,7 +70,7 @@ __device__ __forceinline__ int wino_row(int i) {
 // MINI = true : half such a tile (32 pairs), wave = (16 pairs, one 16-channel half of every K step); the two partial
 //               accumulator sets meet in LDS (fixed order).  Used for the partly filled last round of tiles, see
 //               conv_gemm.hip "Tail tiles": a half tile holds its CU for a quarter of a full tile's time.
-template <bool MINI>
+template <bool MINI, bool STATS = false>
 __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int tile, const int sub, float* lds) {
   constexpr int PITCH = WINO_PITCH, PAIRS = MINI ? 32 : 64, AR = PAIRS + 2;
   float* Es = lds;                      // [AR][PITCH] even positions of pairs P0-1 .. P0+PAIRS
@@ -229,12 +234,17 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int til
     dthr = (uint32_t)(a.drop_p * 4294967296.0);
     dscale = 1.0f / (1.0f - a.drop_p);
   }
+  constexpr bool stats = STATS && !MINI;                // (a kernel of its own: the records cost registers)
+  const int edgeP = stats ? (P0 / a.stat_Wu + 1) * a.stat_Wu : 0x7fffffff;      // pairs from here on: the tile's 2nd window
+  // records in ONE pass: sums of (y - pivot) and (y - pivot)^2 per (window slot, channel half), the pivot being this wave's
+  // own first output of the channel -- a value of the distribution, so the variance below loses no digits to cancellation
+  float piv[2] = {0.f, 0.f}, s1[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, s2[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, scnt[2] = {0.f, 0.f};
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int P = P0 + wp * 16 + wino_row(g * 4 + r);
-    if (P >= a.MP) continue;
-    const uint32_t rr = fdiv((uint32_t)P, a.divPL);
-    const int i = P - (int)rr * PL;
+    const bool live = P < a.MP;
+    const uint32_t rr = fdiv((uint32_t)(live ? P : 0), a.divPL);
+    const int i = (live ? P : 0) - (int)rr * PL;
     const bool has1 = 2 * i + 1 < a.L;
     float* y0p = a.y + ((size_t)rr * a.L + 2 * i) * a.ldy + n_blk + prow;
 #pragma unroll
@@ -247,12 +257,79 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int til
         y1 = wino_mix32(dkey, (uint32_t)e1 ^ (uint32_t)(e1 >> 32) * 0x27d4eb2fu) >= dthr ? y1 * dscale : 0.f;
       }
       float* q0 = y0p + nt * 16;
-      if (a.accumulate) {
-        y0 += q0[0];
-        if (has1) y1 += q0[a.ldy];
+      if (live) {
+        if (a.accumulate) {
+          y0 += q0[0];
+          if (has1) y1 += q0[a.ldy];
+        }
+        q0[0] = y0;
+        if (has1) q0[a.ldy] = y1;
       }
-      q0[0] = y0;
-      if (has1) q0[a.ldy] = y1;
+      if (stats) {
+        if (r == 0) piv[nt] = __shfl(live ? y0 : 0.f, (lane & 15) + 16, 64);      // pair row 0 of the wave's tile: g = 1, r = 0
+        if (live) {
+          const int sl = P >= edgeP ? 1 : 0;
+          const float d0 = y0 - piv[nt], d1 = has1 ? y1 - piv[nt] : 0.f;
+          s1[sl][nt] += d0 + d1;
+          s2[sl][nt] += d0 * d0 + d1 * d1;
+          if (nt == 0) scnt[sl] += has1 ? 2.f : 1.f;
+        }
+      }
+    }
+  }
+  if (!stats) return;
+  {
+    // fold over the 4 lanes that share a channel, turn the wave's sums into (count, mean, centred M2), fold the 4 waves
+    // with Chan's update in wave order through LDS (a region of its own behind the operand panels: no barrier to free it)
+    float* wrec = lds + WINO_LDS_FLOATS;                 // [4 waves][2 slots][{mean, M2}][32 ch] | cnt [4][2]
+    float* wcnt = wrec + 4 * 2 * 2 * 32;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        s1[sl][nt] += __shfl_xor(s1[sl][nt], 16, 64);
+        s1[sl][nt] += __shfl_xor(s1[sl][nt], 32, 64);
+        s2[sl][nt] += __shfl_xor(s2[sl][nt], 16, 64);
+        s2[sl][nt] += __shfl_xor(s2[sl][nt], 32, 64);
+      }
+      scnt[sl] += __shfl_xor(scnt[sl], 16, 64);
+      scnt[sl] += __shfl_xor(scnt[sl], 32, 64);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const float cn = scnt[sl], inv = cn > 0.f ? 1.f / cn : 0.f;
+          float* o = wrec + ((wave * 2 + sl) * 2) * 32 + nt * 16 + prow;
+          o[0] = piv[nt] + s1[sl][nt] * inv;
+          o[32] = fmaxf(s2[sl][nt] - s1[sl][nt] * s1[sl][nt] * inv, 0.f);
+        }
+    }
+    if (lane == 0) {
+      wcnt[wave * 2] = scnt[0];
+      wcnt[wave * 2 + 1] = scnt[1];
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int sl = tid >> 5, ch = tid & 31;
+      float n = 0.f, mu = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) {
+        const float nb = wcnt[wv * 2 + sl];
+        if (nb > 0.f) {
+          const float* o = wrec + ((wv * 2 + sl) * 2) * 32 + ch;
+          const float d = o[0] - mu, nt_ = n + nb;
+          mu += d * (nb / nt_);
+          m2 += o[32] + d * d * (n * nb / nt_);
+          n = nt_;
+        }
+      }
+      const int mt = P0 >> 6, nmt = (a.MP + 63) >> 6;
+      float* rec = a.stat_part + ((size_t)(mt * 2 + sl) * 2) * a.N + n_blk + ch;      // [m tile][slot][{mean, M2}][N]
+      rec[0] = mu;
+      rec[a.N] = m2;
+      if (ch == 0 && n_blk == 0) a.stat_part[(size_t)nmt * 4 * a.N + mt * 2 + sl] = n;
     }
   }
 }
@@ -266,6 +343,12 @@ __global__ __launch_bounds__(256) void conv3_wino_kernel(WinoArgs a, int nmini, 
     return;
   }
   conv3_wino_body<false>(a, xcd_chunked(blockIdx.x - nmini_pad, full), 0, lds);
+}
+
+// the same tiles (whole ones only) with the statistics records of the output written from the epilogue (WinoArgs.stat_part)
+__global__ __launch_bounds__(256, 4) void conv3_wino_stats_kernel(WinoArgs a, int full) {
+  __shared__ float lds[WINO_LDS_FLOATS + 4 * 2 * 2 * 32 + 8];
+  conv3_wino_body<false, true>(a, xcd_chunked(blockIdx.x, full), 0, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -911,6 +994,7 @@ int da_conv3_winograd4(const float* x, const float* u, float* y, int rows, int L
   a.L = L; a.PL = (L + 3) / 4; a.MP = rows * a.PL;        // PL / MP count quads here
   a.ldx = ldx; a.C = C; a.ldy = ldy; a.N = N; a.accumulate = accumulate;
   a.drop_seed = nullptr; a.drop_salt = 0u; a.drop_p = 0.f;
+  a.stat_part = nullptr; a.stat_Wu = 1;
   a.divPL = make_fastdiv((uint32_t)a.PL);
   if ((uint64_t)a.MP * (uint64_t)a.PL >= 0xffffffffull) return DA_EINVAL;
   const int tiles = ((a.MP + 63) / 64) * (N / 32);
@@ -942,7 +1026,8 @@ int da_wino4_weights(const float* w, float* u, int co, int ci, int transpose, hi
 // y (+)= conv1d(x, k = 3, stride 1, pad 1) per row with the transformed taps u (da_wino_weights).
 // x: [rows][L][ldx] first C channels; y: [rows][L][ldy] first N channels.  replaces reference models/resnet.py:5-8
 static int conv3_winograd_impl(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
-                               int accumulate, const long long* drop_seed, unsigned drop_salt, float drop_p, hipStream_t stream) {
+                               int accumulate, const long long* drop_seed, unsigned drop_salt, float drop_p, float* stat_part,
+                               int stat_R, hipStream_t stream) {
   DA_ENTER();
   if (g_act_bf16) return DA_EINVAL;              // float activations only
   if (!x || !u || !y || rows < 0 || L < 1 || C % 32 || N % 32 || C < 32 || N < 32 || ldx % 4 || ldx < C || ldy < N)
@@ -954,33 +1039,46 @@ static int conv3_winograd_impl(const float* x, const float* u, float* y, int row
   a.L = L; a.PL = (L + 1) / 2; a.MP = rows * a.PL;
   a.ldx = ldx; a.C = C; a.ldy = ldy; a.N = N; a.accumulate = accumulate;
   a.drop_seed = drop_seed; a.drop_salt = drop_salt; a.drop_p = drop_p;
+  a.stat_part = stat_part; a.stat_Wu = stat_part ? stat_R * a.PL : 1;
+  if (stat_part && (stat_R < 1 || rows % stat_R || a.stat_Wu < 64 || accumulate)) return DA_EINVAL;
   a.divPL = make_fastdiv((uint32_t)a.PL);
   if ((uint64_t)a.MP * (uint64_t)a.PL >= 0xffffffffull) return DA_EINVAL;
   const int tiles = ((a.MP + 63) / 64) * (N / 32);
   const int R = tiles % 256;
   int nmini = 0, full = tiles;
-  if (g_wino_tail && tiles > 256 && R >= 1 && R <= 128) {
+  if (g_wino_tail && !stat_part && tiles > 256 && R >= 1 && R <= 128) {
     nmini = 2 * R;
     full = tiles - R;
   }
   const int nmini_pad = (nmini + 7) / 8 * 8;
-  hipLaunchKernelGGL(conv3_wino_kernel, dim3(nmini_pad + full), dim3(256), 0, stream, a, nmini, nmini_pad, full);
+  if (stat_part) hipLaunchKernelGGL(conv3_wino_stats_kernel, dim3(full), dim3(256), 0, stream, a, full);
+  else hipLaunchKernelGGL(conv3_wino_kernel, dim3(nmini_pad + full), dim3(256), 0, stream, a, nmini, nmini_pad, full);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
 
 int da_conv3_winograd(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
                       int accumulate, hipStream_t stream) {
-  return conv3_winograd_impl(x, u, y, rows, L, ldx, C, ldy, N, accumulate, nullptr, 0u, 0.f, stream);
+  return conv3_winograd_impl(x, u, y, rows, L, ldx, C, ldy, N, accumulate, nullptr, 0u, 0.f, nullptr, 0, stream);
 }
 
 // da_conv3_winograd followed by F.dropout(p) in the epilogue: y = dropout(conv(x)) with the keep mask of da_dropout
 // (seed, salt) on the contiguous [rows * L][N] tensor, written at pitch ldy (a _DenseLayer's growth conv + dropout storing
 // its new features at their channel offset in the block's buffer, reference models/densenet.py:30-40)
+// stat_part != NULL: also the statistics records of the output for windows of R rows (da_stat_records_floats(rows * ceil(L / 2),
+// N) floats; R * ceil(L / 2) >= 64): what the consuming da_conv1x1_bn merges instead of a statistics pass over the new channels
 int da_conv3_winograd_drop(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
-                           const long long* drop_seed, unsigned drop_salt, float drop_p, hipStream_t stream) {
+                           const long long* drop_seed, unsigned drop_salt, float drop_p, float* stat_part, int R,
+                           hipStream_t stream) {
   if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return DA_EINVAL;
-  return conv3_winograd_impl(x, u, y, rows, L, ldx, C, ldy, N, 0, drop_seed, drop_salt, drop_p, stream);
+  return conv3_winograd_impl(x, u, y, rows, L, ldx, C, ldy, N, 0, drop_seed, drop_salt, drop_p, stat_part, R, stream);
+}
+
+// floats of a statistics-record buffer for `units` record units (64 per tile) of N channels:
+// [tiles][2 window slots][{mean, M2}][N] followed by the counts [tiles][2]
+size_t da_stat_records_floats(long units, int N) {
+  const size_t tiles = (size_t)((units + 63) / 64);
+  return tiles * 4 * (size_t)N + tiles * 2;
 }
 
 // tuning / tests: 0 = no half tiles for the last round; pchunk > 0: pairs per weight-gradient split

@@ -614,13 +614,24 @@ class DenseBlockFunction(Function):
     (norm5.weight, norm5.bias) for the final norm (``tail_cb`` = 0; ``tail_relu``: F.relu behind it or the bare map)."""
 
     @staticmethod
-    def forward(ctx, buf, R, c0, growth, n_layers, drop_p, seed, salt0, eps, tail_cb, tail_relu, *params):
+    def forward(ctx, buf, c0_rec, R, c0, growth, n_layers, drop_p, seed, salt0, eps, tail_cb, tail_relu, *params):
+        # Who computes a channel's statistics: the kernel that WRITES the channel, from its epilogue, as per-(tile, window)
+        # records (H.stat_records) that the next 1x1 conv merges in its prologue and publishes to the block's table -- the
+        # growth conv for its G new channels, the previous transition's conv for this block's first C0 (``c0_rec``).  Only
+        # where no such producer exists (the stem's output, a growth conv off the Winograd kernel, windows shorter than a
+        # record tile) a statistics-only pass runs (H.bn_stats_fused).
         rows, l, cb = buf.shape
         w_ = rows // R
         G = growth
         stats = torch.empty((2, w_, cb), device=buf.device, dtype=torch.float32)
         mean_t, invstd_t = stats[0], stats[1]
-        H.bn_stats_fused(buf[:, :, :c0], R, mean_t[:, :c0], invstd_t[:, :c0], eps)
+        pend = None                                     # (records, first channel, units, units per window) not yet in the table
+        if c0_rec is not None:
+            pend = (c0_rec, 0, rows * l, R * l)
+        else:
+            H.bn_stats_fused(buf[:, :, :c0], R, mean_t[:, :c0], invstd_t[:, :c0], eps)
+        pl = (l + 1) // 2
+        rec_ok = R * pl >= 64
         drop = drop_p > 0
         keep = []
         for k in range(n_layers):
@@ -628,23 +639,34 @@ class DenseBlockFunction(Function):
             ck = c0 + k * G
             xk = buf[:, :, :ck]
             y1 = torch.empty((rows, l, w1.shape[0]), device=buf.device, dtype=torch.float32)
-            H.conv1x1_bn(xk, w1, R, mean_t[:, :ck], invstd_t[:, :ck], g1, b1, y1)
+            H.conv1x1_bn(xk, w1, R, mean_t[:, :ck], invstd_t[:, :ck], g1, b1, y1, pend=pend, eps=eps)
+            pend = None
             if DECISION_TAP is not None:
                 _tap(H.bn_relu_ss(xk, R, mean_t[:, :ck], invstd_t[:, :ck], g1, b1))
             h2, m2, i2 = H.bn_fwd(y1, R, g2, b2, relu=True, eps=eps)
             _tap(h2)
             new = buf[:, :, ck:ck + G]
             code = _is_wino(w2, 1, 1)
-            if code in (4, 6):
-                H.conv3_winograd(h2, _pack(w2, code)[2], out=new, drop=(seed, salt0 + k, drop_p) if drop else None)
+            consumed = k + 1 < n_layers or tail_cb            # (norm5 takes its own statistics of the whole buffer)
+            if code == 4:
+                r_ = H.conv3_winograd(h2, _pack(w2, code)[2], out=new, drop=(seed, salt0 + k, drop_p) if drop else None,
+                                      stats_R=R if consumed and rec_ok else 0)
+                if consumed and rec_ok:
+                    pend = (r_[1], ck, rows * pl, R * pl)
+            elif code == 6:
+                H.conv3_winograd(h2, _pack(w2, code)[2], out=new)
             else:
                 H.conv_fwd(h2, _pack(w2, 0)[0], 1, 1, out=new)
-            H.bn_stats_fused(new, R, mean_t[:, ck:ck + G], invstd_t[:, ck:ck + G], eps)
+            if consumed and pend is None:
+                H.bn_stats_fused(new, R, mean_t[:, ck:ck + G], invstd_t[:, ck:ck + G], eps)
             keep += [y1, m2, i2, h2]
+        out_rec = None
         if tail_cb:
             gt, bt, wt = params[6 * n_layers:6 * n_layers + 3]
             out = torch.empty((rows, l // 2, tail_cb), device=buf.device, dtype=torch.float32)
-            H.conv1x1_bn(buf, wt, R, mean_t, invstd_t, gt, bt, out[:, :, :wt.shape[0]], pool=True)
+            r_ = H.conv1x1_bn(buf, wt, R, mean_t, invstd_t, gt, bt, out[:, :, :wt.shape[0]], pool=True, pend=pend, eps=eps,
+                              want_records=True)
+            out_rec = r_[1]                             # the next block's first channels: their statistics, from this epilogue
             if DECISION_TAP is not None:
                 _tap(H.bn_relu_ss(buf, R, mean_t, invstd_t, gt, bt))
             keep += [mean_t, invstd_t]          # (placeholders: the tail's statistics are the table's)
@@ -654,13 +676,18 @@ class DenseBlockFunction(Function):
             if tail_relu:
                 _tap(out)
             keep += [m5, i5]
+            ctx.tail_out = out if tail_relu else None      # (its sign is the backward's ReLU decision)
         ctx.cfg = (R, c0, G, n_layers, drop_p, salt0, tail_cb, tail_relu)
         ctx.gt = _tgt(*params)
         ctx.save_for_backward(buf, stats, seed if drop else stats, *keep, *params)
+        if tail_cb:                                     # (next buffer, the records of its first channels)
+            ctx.mark_non_differentiable(out_rec)
+            ctx.set_materialize_grads(False)
+            return out, out_rec
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _drec=None):
         R, c0, G, n_layers, drop_p, salt0, tail_cb, tail_relu = ctx.cfg
         sv = ctx.saved_tensors
         buf, stats, seed = sv[0], sv[1], sv[2]
@@ -696,7 +723,7 @@ class DenseBlockFunction(Function):
         else:
             g5, b5 = params[pt:pt + 2]
             m5, i5 = keep[4 * n_layers], keep[4 * n_layers + 1]
-            ds = H.bn_bwd_ss(dout, buf, R, m5, i5, g5, b5, 2 if tail_relu else 0, dbuf, drop=last_drop)
+            ds = H.bn_bwd_ss(dout, buf, R, m5, i5, g5, b5, 2 if tail_relu else 0, dbuf, drop=last_drop, out=ctx.tail_out)
             gt_, bt_ = g5, b5
         fold(ds, gt_, bt_, pt, pt + 1)
         for k in range(n_layers - 1, -1, -1):
@@ -718,7 +745,7 @@ class DenseBlockFunction(Function):
             ds = H.bn_bwd_ss(dh, xk, R, mk, ik, g1, b1, 1, dxk, add=dxk,
                              drop=(seed, salt0 + k - 1, drop_p, G) if drop and k > 0 else None)
             fold(ds, g1, b1, 6 * k, 6 * k + 1)
-        return (dbuf,) + (None,) * 10 + tuple(grads)
+        return (dbuf,) + (None,) * 11 + tuple(grads)
 
 
 class DenseLayerFunction(Function):

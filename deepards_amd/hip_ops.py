@@ -144,11 +144,18 @@ def wino_weights(w, transpose=False, points=4):
     return u
 
 
-def conv3_winograd(x, u, out=None, accumulate=False, drop=None):
+def stat_records(units, n, device):
+    """An empty statistics-record buffer for ``units`` record units of ``n`` channels (include/deepards_hip.h,
+    "Statistics records")."""
+    return torch.empty((_lib.lib().da_stat_records_floats(units, n),), device=device, dtype=torch.float32)
+
+
+def conv3_winograd(x, u, out=None, accumulate=False, drop=None, stats_R=0):
     """k3 s1 p1 conv of x (rows, L, C) with taps u from wino_weights -> (rows, L, N): (4, N, C) taps run
     F(2,3), (6, N, C) taps F(4,3).  x and out may be channel slices of pitched buffers (a dense block's);
     drop = (seed, salt, p): F.dropout on the result in the epilogue (F(2,3) only; the mask of dropout() on the contiguous
-    (rows, L, N) tensor)."""
+    (rows, L, N) tensor); stats_R > 0 (F(2,3) only): -> (out, records) with the statistics records of the output for
+    windows of stats_R rows, written by the epilogue (units: output pairs)."""
     ldx = _pv(x, 'x') if ACT == torch.float32 else _rlc(x, 'x').shape[2]      # (bf16 storage: the library refuses, as before)
     rows, l, c = x.shape
     four, n, c2 = u.shape
@@ -161,13 +168,14 @@ def conv3_winograd(x, u, out=None, accumulate=False, drop=None):
     elif tuple(out.shape) != (rows, l, n):
         raise ValueError('conv3_winograd: bad out shape')
     ldy = _pv(out, 'out') if out.dtype == torch.float32 else n
-    if drop is not None and drop[2] > 0:
+    if (drop is not None and drop[2] > 0) or stats_R:
         if four != 4 or accumulate:
-            raise ValueError('conv3_winograd: dropout belongs to the F(2,3) kernel, without accumulate')
-        seed, salt, p = drop
-        _chk(_lib.lib().da_conv3_winograd_drop(_p(x), _p(u), _p(out), rows, l, ldx, c, ldy, n, _p(seed), salt, p, _stream()),
-             'da_conv3_winograd_drop')
-        return out
+            raise ValueError('conv3_winograd: dropout / statistics records belong to the F(2,3) kernel, without accumulate')
+        seed, salt, p = drop if drop is not None and drop[2] > 0 else (None, 0, 0.0)
+        part = stat_records(rows * ((l + 1) // 2), n, x.device) if stats_R else None
+        _chk(_lib.lib().da_conv3_winograd_drop(_p(x), _p(u), _p(out), rows, l, ldx, c, ldy, n, _p(seed), salt, p, _p(part),
+                                               stats_R, _stream()), 'da_conv3_winograd_drop')
+        return (out, part) if stats_R else out
     fn = _lib.lib().da_conv3_winograd if four == 4 else _lib.lib().da_conv3_winograd4
     _chk(fn(_p(x), _p(u), _p(out), rows, l, ldx, c, ldy, n, 1 if accumulate else 0, _stream()), 'da_conv3_winograd')
     return out
@@ -898,9 +906,10 @@ def bn_relu_ss(xv, R, mean_v, invstd_v, gamma, beta):
     return out
 
 
-def bn_bwd_ss(dout, xv, R, mean_v, invstd_v, gamma, beta, relu, dx, add=None, half_dout=False, drop=None):
+def bn_bwd_ss(dout, xv, R, mean_v, invstd_v, gamma, beta, relu, dx, add=None, half_dout=False, drop=None, out=None):
     """Backward of relu(norm(xv)) (relu: decision from the fused-multiply-add form) or norm(xv): dout (rows, L, C) -- or
-    (rows, L / 2, C) with half_dout (a transition's pooling in front of its conv) --, dx a (rows, L, C) channel slice that
+    (rows, L / 2, C) with half_dout (a transition's pooling in front of its conv) --; relu = 1: decision of the fused
+    multiply-add form, 2: the sign of ``out`` (the stored output of a bn_fwd forward), 0: none; dx a (rows, L, C) channel slice that
     receives the input gradient (+ ``add``, which may be dx itself: in-place accumulation into the block's gradient
     buffer); drop = (seed, salt, p, g): the dropout mask on the last g channels of dx.  -> ds (2, W, C) window sums."""
     ldd, ldx, lddx = _pv(dout, 'dout'), _pv(xv, 'x'), _pv(dx, 'dx')
@@ -918,17 +927,25 @@ def bn_bwd_ss(dout, xv, R, mean_v, invstd_v, gamma, beta, relu, dx, add=None, ha
             raise ValueError('bn_bwd_ss: bad add operand')
         ldadd = _pv(add, 'add')
     seed, salt, p, g = drop if drop is not None else (None, 0, 0.0, 0)
+    ldo = 0
+    if relu == 2:
+        if out is None or tuple(out.shape) != (rows, l, c):
+            raise ValueError('bn_bwd_ss: relu = 2 takes its decisions from the stored output')
+        ldo = _pv(out, 'out')
     ds = torch.empty((2, w, c), device=xv.device, dtype=torch.float32)
-    _chk(_lib.lib().da_bn_bwd_ss(_p(dout), ldd, _p(xv), ldx, _p(dx), lddx, _p(add), ldadd, w, R * l, c, _p(mean_v), _p(invstd_v),
-                                 ldstat, _p(_f32(gamma)), _p(_f32(beta)), 1 if relu else 0, 1 if half_dout else 0,
+    _chk(_lib.lib().da_bn_bwd_ss(_p(dout), ldd, _p(xv), ldx, _p(out) if relu == 2 else None, ldo, _p(dx), lddx, _p(add), ldadd, w,
+                                 R * l, c, _p(mean_v), _p(invstd_v), ldstat, _p(_f32(gamma)), _p(_f32(beta)), int(relu), 1 if half_dout else 0,
                                  _p(seed) if p > 0 else None, salt, p, g, _p(ds), _stream()), 'da_bn_bwd_ss')
     return ds
 
 
-def conv1x1_bn(xv, w, R, mean_v, invstd_v, gamma, beta, out, pool=False):
+def conv1x1_bn(xv, w, R, mean_v, invstd_v, gamma, beta, out, pool=False, pend=None, eps=1e-5, want_records=False):
     """out = conv1x1(relu(norm(xv))) with the activation applied while the operand is staged; pool: the transition form
     (AvgPool1d(2,2) folded in front of the conv: out has L / 2 positions).  w: the (N, C, 1) torch weight; out: a
-    (rows, Lout, N) channel slice (of the next block's buffer, or a plain tensor)."""
+    (rows, Lout, N) channel slice (of the next block's buffer, or a plain tensor).  pend = (records, c_first, units,
+    units_per_window): the channels [c_first, C) have no table entry yet -- their statistics are merged from the records
+    their producer's epilogue wrote, and PUBLISHED to mean_v / invstd_v by this call; want_records: -> (out, records of
+    the output) for windows of R rows (units: output positions)."""
     ldx = _pv(xv, 'x')
     rows, l, c = xv.shape
     n = w.shape[0]
@@ -939,9 +956,14 @@ def conv1x1_bn(xv, w, R, mean_v, invstd_v, gamma, beta, out, pool=False):
     ldstat = _sv(mean_v, rows // R, c, 'mean')
     if _sv(invstd_v, rows // R, c, 'invstd') != ldstat:
         raise ValueError('conv1x1_bn: bad statistics slices')
+    rec, c_first, units, wu = pend if pend is not None else (None, 0, 0, 0)
+    if rec is not None and rec.numel() != _lib.lib().da_stat_records_floats(units, c - c_first):
+        raise ValueError('conv1x1_bn: the pending records do not have %d units of %d channels' % (units, c - c_first))
+    part = stat_records(rows * lo, n, xv.device) if want_records else None
     _chk(_lib.lib().da_conv1x1_bn(_p(xv), ldx, _p(_f32(w)), _p(out), ldy, rows, R, l, c, n, 1 if pool else 0, _p(mean_v),
-                                  _p(invstd_v), ldstat, _p(_f32(gamma)), _p(_f32(beta)), _stream()), 'da_conv1x1_bn')
-    return out
+                                  _p(invstd_v), ldstat, _p(_f32(gamma)), _p(_f32(beta)), _p(rec), c_first, units, wu, eps,
+                                  _p(part), _stream()), 'da_conv1x1_bn')
+    return (out, part) if want_records else out
 
 
 # ------------------------------------------------------------------------------------------------

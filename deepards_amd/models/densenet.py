@@ -159,6 +159,7 @@ class _Features(nn.Sequential):
             self._drop_seed.add_(0x9E3779B97F4A7C15 >> 1)
         salt = 1
         p = self.drop_rate if use_drop else 0.0
+        rec = None                                     # statistics records of the buffer's first channels (from a transition)
         for n, (blk, tail, lb, c0, cb) in enumerate(plan):
             layers = list(blk.children())
             params = []
@@ -170,8 +171,10 @@ class _Features(nn.Sequential):
             else:
                 params += [self.norm5.weight, self.norm5.bias]
                 tail_cb, eps = 0, self.norm5.eps
-            h = F_.DenseBlockFunction.apply(h, R, c0, layers[0].conv2.out_channels, len(layers), p,
+            h = F_.DenseBlockFunction.apply(h, rec, R, c0, layers[0].conv2.out_channels, len(layers), p,
                                             self._drop_seed if use_drop else None, salt, eps, tail_cb, relu, *params)
+            if tail is not None:
+                h, rec = h
             salt += len(layers)
         return h
 

@@ -247,24 +247,35 @@ int da_bn_stats_fused(const float* x, int ldx, int W, int Wn, int C, float* mean
 /* out[:, 0:C] = max(fmaf(x, gamma invstd, beta - mean gamma invstd), 0): the un-stored activation, for tests / explainers */
 int da_bn_relu_ss(const float* x, int ldx, float* out, int ldo, int W, int Wn, int C, const float* mean, const float* invstd,
                   int ldstat, const float* gamma, const float* beta, da_stream_t stream);
-/* backward of relu(norm(x)) (relu != 0: ReLU decision from the fused multiply-add form) or norm(x): statistics from the
+/* backward of relu(norm(x)) (relu = 1: ReLU decision from the fused multiply-add form, the forward of da_conv1x1_bn;
+ * relu = 2: from the sign of the stored output `out`, the forward of da_bn_fwd) or norm(x) (relu = 0): statistics from the
  * pitched tables; half_dout: dout has Wn / 2 positions per window, g[p] = dout[p / 2] / 2 (a transition's AvgPool1d(2,2) in
  * front of its conv); dx = input gradient (+ add[:, 0:C]; dx may alias add), then with drop_p > 0 the dropout mask
  * (da_dropout's, seed / salt, contiguous [W Wn][drop_g]) on dx's channels [C - drop_g, C); ds [2][W][C] window sums */
-int da_bn_bwd_ss(const float* dout, int ldd, const float* x, int ldx, float* dx, int lddx, const float* add, int ldadd, int W,
-                 int Wn, int C, const float* mean, const float* invstd, int ldstat, const float* gamma, const float* beta,
-                 int relu, int half_dout, const long long* drop_seed, unsigned drop_salt, float drop_p, int drop_g, float* ds,
+int da_bn_bwd_ss(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
+                 const float* add, int ldadd, int W, int Wn, int C, const float* mean, const float* invstd, int ldstat,
+                 const float* gamma, const float* beta, int relu, int half_dout, const long long* drop_seed, unsigned drop_salt, float drop_p, int drop_g, float* ds,
                  da_stream_t stream);
 /* y[m][0:N] (pitch ldy) = sum_c w[n][c] relu(norm(x))[m][c], the activation applied while x (first C channels, pitch ldx) is
  * staged; pool != 0: the transition form, (h[2m] + h[2m+1]) / 2 in front of the conv (Lin even, Lin / 2 outputs per row).
  * w [N][C] = the torch weight of the k = 1 conv as it lies.  N % 64 == 0, C % 32 == 0, R * Lout >= 64.
  * replaces norm1 -> relu1 -> conv1 (densenet.py:23-26) and norm -> relu -> conv -> pool (:72-79) */
 int da_conv1x1_bn(const float* x, int ldx, const float* w, float* y, int ldy, int rows, int R, int Lin, int C, int N, int pool,
-                  const float* mean, const float* invstd, int ldstat, const float* gamma, const float* beta, da_stream_t stream);
+                  float* mean, float* invstd, int ldstat, const float* gamma, const float* beta, const float* pend, int pend_c0,
+                  long pend_units, int pend_Wu, float eps, float* out_part, da_stream_t stream);
+/* Statistics records: a kernel that WRITES activation channels can hand their per-window BatchNorm statistics over from its
+ * epilogue -- per 64-unit tile and window slot (a tile touches <= 2 windows) the count, mean and centred second moment of
+ * each channel: floats [tiles][2][{mean, M2}][N] then counts [tiles][2] (da_stat_records_floats).  The consuming
+ * da_conv1x1_bn (pend != NULL: channels [pend_c0, C) of its input, pend_units units in windows of pend_Wu >= 64) merges
+ * them per window in tile order (Chan's update, as da_bn_stats_merge) and publishes mean / invstd to the tables, which
+ * every later kernel reads.  Producers: da_conv3_winograd_drop (units = output PAIRS, rows * ceil(L / 2)) and
+ * da_conv1x1_bn(out_part != NULL) (units = its output positions). */
+size_t da_stat_records_floats(long units, int N);
 /* da_conv3_winograd + F.dropout(p) in the epilogue (mask of da_dropout on the contiguous [rows L][N] tensor), y at pitch ldy:
  * a _DenseLayer's growth conv storing its new features at their channel offset (densenet.py:30-40) */
 int da_conv3_winograd_drop(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
-                           const long long* drop_seed, unsigned drop_salt, float drop_p, da_stream_t stream);
+                           const long long* drop_seed, unsigned drop_salt, float drop_p, float* stat_part, int R,
+                           da_stream_t stream);     /* stat_part != NULL: + the records of y for windows of R rows */
 
 int da_bn_param_grad_multi(const da_bn_pgrad_desc* descs, int n, int accumulate, da_stream_t stream);
 /* The same BatchNorm forward / backward (resnet.py:27-38) in front of an x3 consumer (conv arithmetic 'f32x3', see

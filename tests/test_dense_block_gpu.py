@@ -106,8 +106,9 @@ def test_bn_bwd_ss_against_the_oracle(H, rows, R, L, C, half, relu, with_add, dr
     buf, xv = pitched(x, cb)
     mean_t, invstd_t = stat_tables(rows // R, cb)
     H.bn_stats_fused(xv, R, mean_t[:, :C], invstd_t[:, :C])
-    if relu == 2:                      # statistics as da_bn_fwd leaves them (contiguous (W, C)), decision in its form
-        _, m_, i_ = H.bn_fwd(xv.contiguous(), R, cu(gamma), cu(beta), relu=True)
+    out_fwd = None
+    if relu == 2:                      # a forward through da_bn_fwd: its statistics ((W, C) contiguous), the sign of its output
+        out_fwd, m_, i_ = H.bn_fwd(xv.contiguous(), R, cu(gamma), cu(beta), relu=True)
         mean_v, invstd_v = m_, i_
     else:
         mean_v, invstd_v = mean_t[:, :C], invstd_t[:, :C]
@@ -131,7 +132,7 @@ def test_bn_bwd_ss_against_the_oracle(H, rows, R, L, C, half, relu, with_add, dr
         keep = H.dropout(torch.ones(rows, L, G, device='cuda'), seed, 5, 0.2)       # the mask of the contiguous (rows, L, G) tensor
         dx_ref[:, C - G:, :] *= ncl(keep)
     ds = H.bn_bwd_ss(rlc(dout), xv, R, mean_v, invstd_v, cu(gamma), cu(beta), relu, dxv, add=dxv if with_add else None,
-                     half_dout=half, drop=(seed, 5, 0.2, G) if drop else None)
+                     half_dout=half, drop=(seed, 5, 0.2, G) if drop else None, out=out_fwd)
     got = ncl(dxv)
     scale = 1.0 + np.abs(dx_ref).max()
     # an edge element flips its own gradient and shifts its window's sums by one term of ~Wn: compare away from such windows
@@ -248,3 +249,64 @@ def test_block_function_matches_the_per_layer_functions(H, drop):
     # (a ReLU element whose pre-activation sits within fp32 noise of zero may go either way in the two forms: the bound is
     # what ONE such element moves a late layer's gradient by; the golden tests compare under matched decisions)
     assert worst < 3e-2, worst
+
+
+@pytest.mark.parametrize('rows,R,L,drop', [(40, 20, 56, 0.2), (60, 20, 28, 0.0), (40, 20, 14, 0.2), (40, 20, 7, 0.0),
+                                            (1280, 20, 14, 0.2), (1280, 20, 7, 0.2)])
+def test_statistics_records_from_the_growth_conv_epilogue(H, rows, R, L, drop):
+    """The growth conv hands the per-window statistics of its new channels over as records (count, mean, centred M2 per
+    64-pair tile and window slot); the next 1x1 conv merges them in its prologue, publishes them to the block's table and
+    normalises with them: table == numpy statistics of what the conv wrote, conv output == oracle."""
+    rng = np.random.RandomState(rows + L + 3)
+    cb, C0, G, N = 128, 64, 32, 128
+    x0 = rng.randn(rows, C0, L) + rng.randn(1, C0, 1)
+    h2 = np.abs(rng.randn(rows, 128, L))
+    w2 = rng.randn(G, 128, 3) * 0.05
+    buf, x0v = pitched(x0, cb)
+    mean_t, invstd_t = stat_tables(rows // R, cb)
+    H.bn_stats_fused(x0v, R, mean_t[:, :C0], invstd_t[:, :C0])
+    seed = torch.tensor([4242], dtype=torch.int64, device='cuda')
+    new, rec = H.conv3_winograd(rlc(h2), H.wino_weights(cu(w2)), out=buf[:, :, C0:C0 + G],
+                                drop=(seed, 2, drop) if drop else None, stats_R=R)
+    xall = ncl(buf[:, :, :C0 + G])                                  # what the kernels wrote, as float64
+    assert np.isfinite(xall).all()
+    C = C0 + G
+    w1 = rng.randn(N, C, 1) / np.sqrt(C)
+    gamma, beta = rng.rand(C) + 0.5, rng.randn(C) * 0.3
+    y = torch.empty(rows, L, N, device='cuda')
+    pl = (L + 1) // 2
+    H.conv1x1_bn(buf[:, :, :C], cu(w1), R, mean_t[:, :C], invstd_t[:, :C], cu(gamma), cu(beta), y,
+                 pend=(rec, C0, rows * pl, R * pl))
+    h_ref, st = np_ref.bn_window_fwd(xall, gamma, beta, R)
+    close(mean_t[:, C0:C].cpu().numpy(), st[0][:, C0:], tol=2e-6, name='published mean')
+    assert np.abs(invstd_t[:, C0:C].cpu().numpy() / st[1][:, C0:] - 1).max() < 2e-5
+    close(ncl(y), np_ref.conv1d_fwd(np_ref.relu(h_ref), w1, 1, 0), tol=5e-6, name='conv1x1 on merged statistics')
+    assert torch.isnan(mean_t[:, C:]).all()
+
+
+@pytest.mark.parametrize('rows,R,L', [(40, 20, 56), (60, 20, 28), (1280, 20, 14)])
+def test_statistics_records_from_the_transition_conv_epilogue(H, rows, R, L):
+    """The pooled transition conv writes the next block's first channels AND their statistics records; the next block's
+    first 1x1 conv (every input channel pending) merges and publishes them."""
+    rng = np.random.RandomState(rows + L + 5)
+    C, N, cb2 = 128, 64, 128
+    x = rng.randn(rows, C, L) + rng.randn(1, C, 1)
+    wt = rng.randn(N, C, 1) / np.sqrt(C)
+    gamma, beta = rng.rand(C) + 0.5, rng.randn(C) * 0.3
+    _, xv = pitched(x, C)
+    mean_t, invstd_t = stat_tables(rows // R, C)
+    H.bn_stats_fused(xv, R, mean_t, invstd_t)
+    nxt = torch.full((rows, L // 2, cb2), float('nan'), device='cuda')
+    _, rec = H.conv1x1_bn(xv, cu(wt), R, mean_t, invstd_t, cu(gamma), cu(beta), nxt[:, :, :N], pool=True, want_records=True)
+    x2 = ncl(nxt[:, :, :N])
+    h_ref, _ = np_ref.bn_window_fwd(x, gamma, beta, R)
+    close(x2, np_ref.avgpool_fwd(np_ref.conv1d_fwd(np_ref.relu(h_ref), wt, 1, 0), 2, 2), tol=5e-6, name='transition')
+    m2_t, i2_t = stat_tables(rows // R, cb2)
+    w1 = rng.randn(128, N, 1) / np.sqrt(N)
+    g2, b2 = rng.rand(N) + 0.5, rng.randn(N) * 0.3
+    y = torch.empty(rows, L // 2, 128, device='cuda')
+    H.conv1x1_bn(nxt[:, :, :N], cu(w1), R, m2_t[:, :N], i2_t[:, :N], cu(g2), cu(b2), y, pend=(rec, 0, rows * (L // 2), R * (L // 2)))
+    h2_ref, st2 = np_ref.bn_window_fwd(x2, g2, b2, R)
+    close(m2_t[:, :N].cpu().numpy(), st2[0], tol=2e-6, name='published mean')
+    assert np.abs(i2_t[:, :N].cpu().numpy() / st2[1] - 1).max() < 2e-5
+    close(ncl(y), np_ref.conv1d_fwd(np_ref.relu(h2_ref), w1, 1, 0), tol=5e-6, name='first conv of the next block')
