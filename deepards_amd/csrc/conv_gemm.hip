@@ -662,28 +662,6 @@ __global__ __launch_bounds__(256) void conv1x1_bn_kernel(Conv1x1BnArgs a) {
   const int lr = tid >> 3, lq = tid & 7;
   const int w0 = (int)fdiv((uint32_t)m_blk, a.divWn);
 
-  for (int i = tid; i < 2 * a.C; i += 256) {
-    const int ws = i >= a.C ? 1 : 0, c = i - ws * a.C, w = w0 + ws;
-    float sc = 0.f, sh = 0.f;
-    if (w < a.W) {
-      float mu, is;
-      if (c >= a.pend_c0) {
-        merge_stat_records(a.pend, a.pend_tiles, a.pend_nc, a.pend_Wu, w, c - a.pend_c0, a.eps, mu, is);
-        const int mw = w * a.Wn;                          // the window's first output row: its tile publishes
-        if (n_blk == 0 && mw >= m_blk && mw < m_blk + 64) {
-          a.mean[(size_t)w * a.ldstat + c] = mu;
-          a.invstd[(size_t)w * a.ldstat + c] = is;
-        }
-      } else {
-        mu = a.mean[(size_t)w * a.ldstat + c];
-        is = a.invstd[(size_t)w * a.ldstat + c];
-      }
-      bn_scale_shift(mu, is, a.gamma[c], a.beta[c], sc, sh);
-    }
-    scs[i] = sc;
-    shs[i] = sh;
-  }
-
   int a_off[2], a_ws[2];
   bool a_ok[2];
 #pragma unroll
@@ -716,6 +694,29 @@ __global__ __launch_bounds__(256) void conv1x1_bn_kernel(Conv1x1BnArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   gload(0);
+  // the scale / shift vectors of this tile's two windows (its first operand loads are in flight meanwhile)
+  for (int i = tid; i < 2 * a.C; i += 256) {
+    const int ws = i >= a.C ? 1 : 0, c = i - ws * a.C, w = w0 + ws;
+    float sc = 0.f, sh = 0.f;
+    if (w < a.W) {
+      float mu, is;
+      if (c >= a.pend_c0) {
+        merge_stat_records(a.pend, a.pend_tiles, a.pend_nc, a.pend_Wu, w, c - a.pend_c0, a.eps, mu, is);
+        const int mw = w * a.Wn;                          // the window's first output row: its tile publishes
+        if (n_blk == 0 && mw >= m_blk && mw < m_blk + 64) {
+          a.mean[(size_t)w * a.ldstat + c] = mu;
+          a.invstd[(size_t)w * a.ldstat + c] = is;
+        }
+      } else {
+        mu = a.mean[(size_t)w * a.ldstat + c];
+        is = a.invstd[(size_t)w * a.ldstat + c];
+      }
+      bn_scale_shift(mu, is, a.gamma[c], a.beta[c], sc, sh);
+    }
+    scs[i] = sc;
+    shs[i] = sh;
+  }
+
   const int frow = lane & 31, fh = lane >> 5;
   for (int it = 0; it < kc; ++it) {
     __syncthreads();
@@ -892,7 +893,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block_i
         int j = m - (int)row * Lm;
         const int jd = (XF && a.dy_half) ? (j >> 1) : j * a.dy_stride + a.dy_off;
         v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)row * a.Ldy + (size_t)jd) * a.lddy + n_blk + q * 4);
-        if (XF && a.dy_half) v *= 0.5f;
+        // (the factor 1/2 of dy_half goes onto the accumulators in the epilogue: a multiply HERE makes the compiler wait
+        // for every load right behind its issue, and the prefetch of the next K step is gone -- +60 % measured)
       }
       ry[p] = v;
     }
@@ -921,13 +923,33 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block_i
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int frow = lane & 31, fh = lane >> 5;
-  // xform: this thread's channel quad is the same in every pass (256 % XQ == 0), so its scale / shift vectors are cached
-  // per WINDOW and reloaded only when a staged row enters another one (once per ~Wn / 32 K steps)
+  // xform: X is transformed when its FRAGMENT is read -- max(fmaf(x, sc, sh), 0) with the scalars of THIS LANE's channels:
+  // two VALU ops under the MFMAs, nothing between the barriers.  A lane keeps two sets: the window `wa` of the current K
+  // step and wa + 1 (rows of a step that cross into it); they are loaded from the statistics tables right behind the first
+  // operand loads, and when the chunk moves on a window the new "next" set is fetched a whole window ahead of its first use.
+  // (A scale / shift table in LDS, or a transform of the staged tile, put a dependent memory round trip in front of the
+  // first barrier of blocks that run only 5-10 K steps: +60 % at L = 56.)
   static_assert(256 % XQ == 0, "one channel quad per thread");
-  int xf_w = -1;
-  f32x4 xf_sc = {0.f, 0.f, 0.f, 0.f}, xf_sh = {0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 31, fh = lane >> 5;
+  float xsc[TN][2], xsh[TN][2];
+  int wa = 0;
+  const int w_total = XF ? (int)fdiv((uint32_t)(a.M - 1), a.divWn) + 1 : 1;
+  auto load_set = [&](int s_, int w) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int c = c_blk + (wn * TN + j) * 32 + frow;
+      float sc_, sh_;
+      bn_scale_shift(a.mean[(size_t)w * a.ldstat + c], a.invstd[(size_t)w * a.ldstat + c], a.gamma[c], a.beta[c], sc_, sh_);
+      xsc[j][s_] = sc_;
+      xsh[j][s_] = sh_;
+    }
+  };
   if (k_beg < k_end) gload(k_beg);
+  if (XF && k_beg < k_end) {
+    wa = (int)fdiv((uint32_t)k_beg, a.divWn);
+    load_set(0, wa);
+    load_set(1, min(wa + 1, w_total - 1));
+  }
   for (int k0 = k_beg; k0 < k_end; k0 += 32) {
     __syncthreads();
 #pragma unroll
@@ -935,50 +957,30 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block_i
       int idx = tid + 256 * p;
       *reinterpret_cast<f32x4*>(&Ys[(idx / YQ) * BM + (idx % YQ) * 4]) = ry[p];
     }
-    if (XF && a.xform) {
-      // windows of this K step's 32 positions: nearly always one (Wn >> 32); a step that crosses into the next window
-      // runs a second pass over its rows with that window's vectors (one cached set: registers are what this kernel lacks)
-      const int m_last = min(k0 + 31, k_end - 1);
-      const int w_lo = (int)fdiv((uint32_t)k0, a.divWn), w_hi = (int)fdiv((uint32_t)m_last, a.divWn);
-      const int cq = c_blk + (tid % XQ) * 4;
-      auto load_ss = [&](int w, f32x4& sc, f32x4& sh) {
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + (size_t)w * a.ldstat + cq);
-        const f32x4 is = *reinterpret_cast<const f32x4*>(a.invstd + (size_t)w * a.ldstat + cq);
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(a.gamma + cq);
-        const f32x4 be = *reinterpret_cast<const f32x4*>(a.beta + cq);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float sc_, sh_;
-          bn_scale_shift(mu[e], is[e], ga[e], be[e], sc_, sh_);
-          sc[e] = sc_;
-          sh[e] = sh_;
-        }
-      };
-      const int m_edge = (w_lo + 1) * (int)a.divWn.d;      // rows from here on belong to w_hi = w_lo + 1 (Wn >= 32: host)
-      const int npass = w_hi != w_lo ? 2 : 1;              // (block-uniform)
-#pragma unroll 1
-      for (int pass = 0; pass < npass; ++pass) {           // ONE code site: a second copy of this costs ~30 registers
-        const int w = w_lo + pass;
-        if (w != xf_w) {
-          load_ss(w, xf_sc, xf_sh);
-          xf_w = w;
-        }
-        const int m_from = pass ? m_edge : 0, m_to = pass ? k_end : min(k_end, m_edge);
-#pragma unroll
-        for (int p = 0; p < XP; ++p) {
-          const int m = k0 + (tid + 256 * p) / XQ;
-          if (m >= m_from && m < m_to) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rx[p][e] = fmaxf(fmaf(rx[p][e], xf_sc[e], xf_sh[e]), 0.f);
-          }
-        }
-      }
-    }
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
       int idx = tid + 256 * p;
       *reinterpret_cast<f32x4*>(&Xs[(idx / XQ) * BN + (idx % XQ) * 4]) = rx[p];
     }
+    int e_row = 64;                                       // rows of this step from e_row on belong to window wa + 1
+    if (XF) {
+      const int ws = (int)fdiv((uint32_t)k0, a.divWn);
+      if (ws != wa) {                                     // (block-uniform; once per window)
+        if (ws == wa + 1) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            xsc[j][0] = xsc[j][1];
+            xsh[j][0] = xsh[j][1];
+          }
+        } else {
+          load_set(0, ws);
+        }
+        wa = ws;
+        load_set(1, min(ws + 1, w_total - 1));
+      }
+      e_row = (ws + 1) * (int)a.divWn.d - k0;
+    }
+    const bool mixed = e_row < 32;                        // (block-uniform) this step crosses into the next window
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
@@ -992,6 +994,16 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block_i
       for (int i = 0; i < TM; ++i) af[i] = Ys[(2 * kk + fh) * BM + (wm * TM + i) * 32 + frow];
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[j] = Xs[(2 * kk + fh) * BN + (wn * TN + j) * 32 + frow];
+      if (XF) {                                           // (every job of an XF launch has xform: host)
+        if (mixed) {
+          const int hi = 2 * kk + fh >= e_row ? 1 : 0;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[j] = fmaxf(fmaf(bf[j], xsc[j][hi], xsh[j][hi]), 0.f);
+        } else {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[j] = fmaxf(fmaf(bf[j], xsc[j][0], xsh[j][0]), 0.f);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1001,6 +1013,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block_i
   }
 
   float* out = a.slab + ((size_t)split * a.ntaps + t) * a.N * a.C;
+  const float oscale = (XF && a.dy_half) ? 0.5f : 1.0f;  // exact: a power of two
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1009,7 +1022,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block_i
       for (int r = 0; r < 16; ++r) {
         int n = n_blk + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
         int c = c_blk + (wn * TN + j) * 32 + frow;
-        out[(size_t)n * a.C + c] = acc[i][j][r];
+        out[(size_t)n * a.C + c] = acc[i][j][r] * oscale;
       }
 }
 
@@ -1343,6 +1356,7 @@ int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
     if ((uint64_t)j.rows * j.Lm * (uint64_t)j.Lm >= 0xffffffffull) return DA_EINVAL;
     if ((j.xform || j.dy_half) && (j.winograd || j.ntaps != 1 || j.src_stride != 1 || j.dy_stride != 1 || j.dy_off || j.src_off[0]))
       return DA_EINVAL;                                       // the dense-block operand forms belong to plain 1x1 jobs
+    if (j.dy_half && !j.xform) return DA_EINVAL;              // (the half-resolution dY only comes with the recomputed X)
     if (j.xform && (j.xform != 1 || !j.mean || !j.invstd || !j.gamma || !j.beta || j.Wn < 1 || j.ldstat < j.C || j.ldstat % 4 ||
                     j.Wn < 32 || (uint64_t)j.rows * j.Lm * (uint64_t)j.Wn >= 0xffffffffull))
       return DA_EINVAL;
