@@ -98,6 +98,7 @@ SIGNATURES = {
     'da_conv1x1_bn': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, ctypes.c_long, _I, _F, _P, _P]),
     'da_conv3_winograd_drop': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _U, _F, _P, _I, _P]),
     'da_stat_records_floats': (_Z, [ctypes.c_long, _I]),
+    'da_conv3_winograd_bn': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _U, _F, _P, _P]),
     'da_conv_wgrad_splits': (_I, [_I] * 5),
     'da_conv_wgrad_plan': (_I, [_I] * 6 + [ctypes.POINTER(_I)]),
     'da_conv_gemm_multi': (_I, [ctypes.POINTER(ConvJob), _I, _P]),

@@ -421,16 +421,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const AT* __restrict_
 // -------------------------------------------------------------------------------------------------
 #define FUSED_NPOS 10
 
-// BatchNorm + ReLU as ONE fused multiply-add per element: h = max(fmaf(x, sc, sh), 0) with sc = gamma invstd,
-// sh = beta - mean sc.  The dense-block path (models/densenet.py:18-44,68-81) never stores h = relu(norm1(x)): the 1x1
-// convolution applies this while it stages its operand, its weight gradient does the same, and the BatchNorm backward
-// recomputes the ReLU decision from it -- every one of them through THIS function on the same (x, mean, invstd, gamma,
-// beta) floats, so the three agree bit for bit on which elements are active (conv_gemm.hip includes the same lines).
-__device__ __forceinline__ void bn_scale_shift(float mean, float invstd, float gamma, float beta, float& sc, float& sh) {
-  sc = gamma * invstd;
-  sh = fmaf(-mean, sc, beta);
-}
-
 // counter-based dropout keep mask of head_optim.hip (da_dropout): element i of the contiguous [npos][G] tensor
 __device__ __forceinline__ uint32_t bn_mix32(uint32_t a, uint32_t b) {
   uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u);

@@ -174,6 +174,56 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// BatchNorm + ReLU as ONE fused multiply-add per element: h = max(fmaf(x, sc, sh), 0) with sc = gamma invstd,
+// sh = beta - mean sc.  The dense-block path (models/densenet.py:18-44,68-81) never stores relu(norm(x)): the convolutions
+// apply this while they stage their operand, the weight gradients do the same, and the BatchNorm backward recomputes the
+// ReLU decision from it -- every one of them through THIS function on the same (x, mean, invstd, gamma, beta) floats, so
+// they agree bit for bit on which elements are active.
+__device__ __forceinline__ void bn_scale_shift(float mean, float invstd, float gamma, float beta, float& sc, float& sh) {
+  sc = gamma * invstd;
+  sh = fmaf(-mean, sc, beta);
+}
+
+// Statistics records (include/deepards_hip.h): (mean, invstd) of window w, channel c (of the record's nc) from the 64-unit
+// tiles' records [tiles][2 slots][{mean, M2}][nc] | counts [tiles][2]: Chan's update in tile order.  Every block of a
+// consuming conv runs this for its own windows: the records are loaded MERGE_B at a time, the update runs on registers.
+// A tile whose first unit lies in front of the window started in the previous one: the window is its SECOND slot.
+// (Measured alternatives, whole densenet18 step at B = 64 / B = 16: this form 1.287 / 0.791 ms; a two-pass weighted mean
+// without divisions 1.311 / 0.813; the records staged through LDS by the whole block in one sweep 1.308 / 0.813.)
+#define MERGE_B 4
+__device__ __forceinline__ void merge_stat_records(const float* __restrict__ part, int tiles, int nc, int Wu, int w, int c,
+                                                   float eps, float& mean, float& invstd) {
+  const int u0 = w * Wu;
+  const int r0 = u0 >> 6, r1 = min((u0 + Wu - 1) >> 6, tiles - 1);
+  const float* cnt = part + (size_t)tiles * 4 * nc;
+  float n = 0.f, mu = 0.f, m2 = 0.f;
+#pragma unroll 1
+  for (int rb = r0; rb <= r1; rb += MERGE_B) {
+    float cn[MERGE_B], mb[MERGE_B], qb[MERGE_B];
+#pragma unroll
+    for (int j = 0; j < MERGE_B; ++j) {
+      const int r = min(rb + j, r1);
+      const int sl = (r << 6) >= u0 ? 0 : 1;
+      const float* rec = part + ((size_t)(r * 2 + sl) * 2) * nc + c;
+      cn[j] = cnt[r * 2 + sl];
+      mb[j] = rec[0];
+      qb[j] = rec[nc];
+    }
+#pragma unroll
+    for (int j = 0; j < MERGE_B; ++j) {
+      const float nb = rb + j <= r1 ? cn[j] : 0.f;
+      if (nb > 0.f) {
+        const float d = mb[j] - mu, nt = n + nb;
+        mu += d * (nb / nt);
+        m2 += qb[j] + d * d * (n * nb / nt);
+        n = nt;
+      }
+    }
+  }
+  mean = mu;
+  invstd = 1.0f / sqrtf(m2 / fmaxf(n, 1.f) + eps);
+}
+
 // Winograd F(4,3) taps G g of one (output, input) channel pair, written at u[j * stride] (conv_wino.hip)
 __device__ __forceinline__ void wino4_taps(float g0, float g1, float g2, float* u, size_t stride) {
   const float s = g0 + g2;
@@ -196,7 +246,7 @@ typedef struct {
   int winograd;          // k3 s1 p1, N and C multiples of 64 -- 1: Winograd F(2,3) form (fp32), 16: bf16 operands /
                          // fp32 sums, 49: split-bf16 fp32-equivalent products on x3 operands (both conv_bf16.hip; also
                          // the stride-2 jobs); the matching da_conv_wgrad_plan(winograd = 1 / 16 / 49) sizes the workspace
-  // dense-block operand forms of plain 1x1 jobs (winograd == 0, ntaps == 1; conv_gemm.hip WgradArgs): xform = 1: X is
+  // dense-block operand forms of stride-1 jobs on the direct kernels (winograd == 0; conv_gemm.hip WgradArgs): xform = 1: X is
   // relu(BatchNorm(x)) recomputed while staged from the statistics tables [rows * Lm / Wn][ldstat]; dy_half = 1: dY has
   // Ldy = Lm / 2 positions per row and position j reads dy[j / 2] / 2 (a transition's pooling in front of its conv)
   int xform, dy_half, Wn, ldstat;

@@ -602,50 +602,6 @@ struct Conv1x1BnArgs {
   float* out_part;    // OSTATS: records of THIS conv's output (N channels, 64-position tiles, windows of Wn positions)
 };
 
-__device__ __forceinline__ void bn_scale_shift(float mean, float invstd, float gamma, float beta, float& sc, float& sh) {
-  sc = gamma * invstd;                 // (bn.hip holds the same two lines: the ReLU decisions must agree bit for bit)
-  sh = fmaf(-mean, sc, beta);
-}
-
-// (mean, invstd) of window w, channel c (of the record's pend_nc) from the tiles' records: Chan's update in tile order.
-// Every block of the consuming conv runs this for its own windows, so it must cost ONE memory latency, not one per record:
-// the records are loaded MERGE_B at a time, the update runs on registers (a serial loop of dependent loads cost 10 us per
-// launch at L = 56: ten records per window).
-#define MERGE_B 4
-__device__ __forceinline__ void merge_stat_records(const float* __restrict__ part, int tiles, int nc, int Wu, int w, int c,
-                                                   float eps, float& mean, float& invstd) {
-  const int u0 = w * Wu;
-  const int r0 = u0 >> 6, r1 = min((u0 + Wu - 1) >> 6, tiles - 1);
-  const float* cnt = part + (size_t)tiles * 4 * nc;
-  float n = 0.f, mu = 0.f, m2 = 0.f;
-  // a tile whose first unit lies in front of the window started in the previous one: the window is its SECOND slot
-#pragma unroll 1
-  for (int rb = r0; rb <= r1; rb += MERGE_B) {           // MERGE_B records in flight at a time (12 registers, not 36)
-    float cn[MERGE_B], mb[MERGE_B], qb[MERGE_B];
-#pragma unroll
-    for (int j = 0; j < MERGE_B; ++j) {
-      const int r = min(rb + j, r1);
-      const int sl = (r << 6) >= u0 ? 0 : 1;
-      const float* rec = part + ((size_t)(r * 2 + sl) * 2) * nc + c;
-      cn[j] = cnt[r * 2 + sl];
-      mb[j] = rec[0];
-      qb[j] = rec[nc];
-    }
-#pragma unroll
-    for (int j = 0; j < MERGE_B; ++j) {
-      const float nb = rb + j <= r1 ? cn[j] : 0.f;
-      if (nb > 0.f) {
-        const float d = mb[j] - mu, nt = n + nb;
-        mu += d * (nb / nt);
-        m2 += qb[j] + d * d * (n * nb / nt);
-        n = nt;
-      }
-    }
-  }
-  mean = mu;
-  invstd = 1.0f / sqrtf(m2 / fmaxf(n, 1.f) + eps);
-}
-
 template <int POOL, int OSTATS = 0>
 __global__ __launch_bounds__(256) void conv1x1_bn_kernel(Conv1x1BnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];          // As | Bs | sc[2][C] | sh[2][C]
@@ -716,7 +672,6 @@ __global__ __launch_bounds__(256) void conv1x1_bn_kernel(Conv1x1BnArgs a) {
     scs[i] = sc;
     shs[i] = sh;
   }
-
   const int frow = lane & 31, fh = lane >> 5;
   for (int it = 0; it < kc; ++it) {
     __syncthreads();
@@ -891,8 +846,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block_i
       if (m < k_end) {
         uint32_t row = fdiv((uint32_t)m, a.divLm);
         int j = m - (int)row * Lm;
+        // XF: a tap that falls outside the sequence must contribute nothing, but the recomputed X there is relu(sh), not the
+        // zero padding of the stored activation -- so the dY row is zeroed instead (this block works on ONE tap)
+        const bool tap_in = !XF || (j * a.src_stride + so >= 0 && j * a.src_stride + so < a.Lx);
         const int jd = (XF && a.dy_half) ? (j >> 1) : j * a.dy_stride + a.dy_off;
-        v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)row * a.Ldy + (size_t)jd) * a.lddy + n_blk + q * 4);
+        if (tap_in) v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)row * a.Ldy + (size_t)jd) * a.lddy + n_blk + q * 4);
         // (the factor 1/2 of dy_half goes onto the accumulators in the epilogue: a multiply HERE makes the compiler wait
         // for every load right behind its issue, and the prefetch of the next K step is gone -- +60 % measured)
       }
@@ -1354,8 +1312,9 @@ int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
         (j.winograd == 49 && (j.lddy != j.N || j.ldx != j.C)))
       return DA_EINVAL;
     if ((uint64_t)j.rows * j.Lm * (uint64_t)j.Lm >= 0xffffffffull) return DA_EINVAL;
-    if ((j.xform || j.dy_half) && (j.winograd || j.ntaps != 1 || j.src_stride != 1 || j.dy_stride != 1 || j.dy_off || j.src_off[0]))
-      return DA_EINVAL;                                       // the dense-block operand forms belong to plain 1x1 jobs
+    if ((j.xform || j.dy_half) && (j.winograd || j.src_stride != 1 || j.dy_stride != 1 || j.dy_off || j.Lm != j.Lx ||
+                                   (j.dy_half && j.ntaps != 1)))
+      return DA_EINVAL;                                       // the dense-block operand forms: stride-1 jobs on the direct kernels
     if (j.dy_half && !j.xform) return DA_EINVAL;              // (the half-resolution dY only comes with the recomputed X)
     if (j.xform && (j.xform != 1 || !j.mean || !j.invstd || !j.gamma || !j.beta || j.Wn < 1 || j.ldstat < j.C || j.ldstat % 4 ||
                     j.Wn < 32 || (uint64_t)j.rows * j.Lm * (uint64_t)j.Wn >= 0xffffffffull))

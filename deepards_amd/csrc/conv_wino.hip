@@ -38,6 +38,18 @@ struct WinoArgs {
   // for the <= 2 windows (stat_Wu pairs each, >= 64) it touches; F(2,3) full tiles only (the host launches no half tiles)
   float* stat_part;
   int stat_Wu;
+  // XFW (conv3_wino_bn_kernel): x is the OUTPUT of the 1x1 conv in front (densenet.py:27-31 norm2 -> relu2 -> conv2) and
+  // h = max(fmaf(x, sc, sh), 0) is applied while x is staged -- relu(norm2(.)) is never stored.  The statistics of x arrive
+  // as the records the 1x1 conv's epilogue wrote (in_pend: in_tiles tiles of 64 POSITIONS, in_Wu positions per window);
+  // every block merges them for its two windows, the block that holds a window's first pair publishes mean / invstd to
+  // in_mean / in_invstd ([W][C]) for the backward kernels.  C <= 128.
+  const float* in_pend;
+  float* in_mean;
+  float* in_invstd;
+  const float* in_gamma;
+  const float* in_beta;
+  int in_tiles, in_Wu;
+  float in_eps;
 };
 
 __device__ __forceinline__ uint32_t wino_mix32(uint32_t a, uint32_t b) {      // head_optim.hip mix32
@@ -70,7 +82,9 @@ __device__ __forceinline__ int wino_row(int i) {
 // MINI = true : half such a tile (32 pairs), wave = (16 pairs, one 16-channel half of every K step); the two partial
 //               accumulator sets meet in LDS (fixed order).  Used for the partly filled last round of tiles, see
 //               conv_gemm.hip "Tail tiles": a half tile holds its CU for a quarter of a full tile's time.
-template <bool MINI, bool STATS = false>
+#define WINO_STAT_FLOATS (4 * 2 * 2 * 32 + 8)           // the records' fold area behind the operand panels
+#define WINO_XF_FLOATS (2 * 2 * 128)                  // [2 window slots][{sc, sh}][C <= 128] behind that
+template <bool MINI, bool STATS = false, bool XFW = false>
 __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int tile, const int sub, float* lds) {
   constexpr int PITCH = WINO_PITCH, PAIRS = MINI ? 32 : 64, AR = PAIRS + 2;
   float* Es = lds;                      // [AR][PITCH] even positions of pairs P0-1 .. P0+PAIRS
@@ -85,7 +99,7 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int til
 
   // loader: panel rows lr (+32) of both panels, the two rows past PAIRS by the first 32 threads (last slot)
   constexpr int NA = MINI ? 3 : 5;
-  int aoff[NA];
+  int aoff[NA], aslot[NA];
   bool aok[NA];
 #pragma unroll
   for (int p = 0; p < NA; ++p) {
@@ -93,6 +107,7 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int til
     const int e = extra ? PAIRS + (tid >> 4) : (MINI ? lr : lr + 32 * (p & 1));
     const int odd = extra ? ((tid >> 3) & 1) : (MINI ? p : (p >> 1));
     const int P = P0 - 1 + e;
+    aslot[p] = 0;
     bool ok = P >= 0 && P < a.MP && (!extra || tid < 32);
     const uint32_t r = fdiv((uint32_t)(ok ? P : 0), a.divPL);
     const int i = (ok ? P : 0) - (int)r * PL;
@@ -100,9 +115,14 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int til
     ok = ok && pos < a.L;
     aoff[p] = ((int)r * a.L + (ok ? pos : 0)) * a.ldx + lq * 4;
     aok[p] = ok;
+    if (XFW) {   // window slot of the row's pair (a halo pair of another window is masked at the sequence edge anyway)
+      const int sl = (P >= 0 ? P : 0) / a.stat_Wu - P0 / a.stat_Wu;
+      aslot[p] = (sl < 0 ? 0 : (sl > 1 ? 1 : sl)) * 2 * a.C + lq * 4;
+    }
   }
   const float* ub = a.u + (size_t)(n_blk + lr) * a.C + lq * 4;
   const size_t ustride = (size_t)a.N * a.C;
+  float* xtab = lds + WINO_LDS_FLOATS + WINO_STAT_FLOATS;        // XFW: [2 slots][{sc, sh}][C]
 
   f32x4 ra[NA], rb[4];
   auto gload_a = [&](int ks) {
@@ -146,16 +166,44 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int til
 
   const int kc = a.C >> 5;
   gload(0);
+  if (XFW) {   // the scale / shift vectors of this tile's two windows, from the records (first operand loads in flight)
+    const int w0 = P0 / a.stat_Wu, nwin = a.MP / a.stat_Wu;
+    for (int i = tid; i < 2 * a.C; i += 256) {
+      const int ws = i >= a.C ? 1 : 0, c = i - ws * a.C, w = w0 + ws;
+      float sc = 0.f, sh = 0.f;
+      if (w < nwin) {
+        float mu, is;
+        merge_stat_records(a.in_pend, a.in_tiles, a.C, a.in_Wu, w, c, a.in_eps, mu, is);
+        const int wP = w * a.stat_Wu;                     // the window's first pair: its tile publishes
+        if (n_blk == 0 && wP >= P0 && wP < P0 + 64) {
+          a.in_mean[(size_t)w * a.C + c] = mu;
+          a.in_invstd[(size_t)w * a.C + c] = is;
+        }
+        bn_scale_shift(mu, is, a.in_gamma[c], a.in_beta[c], sc, sh);
+      }
+      xtab[(ws * 2) * a.C + c] = sc;
+      xtab[(ws * 2 + 1) * a.C + c] = sh;
+    }
+  }
+  auto xf = [&](int p, int ks) -> f32x4 {                 // the staged value of loader slot p
+    if (!XFW) return ra[p];
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(&xtab[aslot[p] + (ks << 5)]);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(&xtab[aslot[p] + a.C + (ks << 5)]);
+    f32x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = fmaxf(fmaf(ra[p][e], sc[e], sh[e]), 0.f);
+    return aok[p] ? h : f32x4{0.f, 0.f, 0.f, 0.f};        // padding and positions past the sequence stay zeros
+  };
   for (int ks = 0; ks < kc; ++ks) {
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < NA - 1; ++p) {
       const int e = MINI ? lr : lr + 32 * (p & 1);
       const int odd = MINI ? p : (p >> 1);
-      *reinterpret_cast<f32x4*>(&(odd ? Os : Es)[e * PITCH + lq * 4]) = ra[p];
+      *reinterpret_cast<f32x4*>(&(odd ? Os : Es)[e * PITCH + lq * 4]) = xf(p, ks);
     }
     if (tid < 32)
-      *reinterpret_cast<f32x4*>(&(((tid >> 3) & 1) ? Os : Es)[(PAIRS + (tid >> 4)) * PITCH + lq * 4]) = ra[NA - 1];
+      *reinterpret_cast<f32x4*>(&(((tid >> 3) & 1) ? Os : Es)[(PAIRS + (tid >> 4)) * PITCH + lq * 4]) = xf(NA - 1, ks);
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&Us[(j * 32 + lr) * PITCH + lq * 4]) = rb[j];
     __syncthreads();
@@ -334,6 +382,14 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int til
   }
 }
 
+// ... and with relu(norm(x)) applied while x is staged (WinoArgs.in_pend): the growth conv of a _DenseLayer reading the 1x1
+// conv's output directly
+template <bool STATS>
+__global__ __launch_bounds__(256, 3) void conv3_wino_bn_kernel(WinoArgs a, int full) {
+  __shared__ float lds[WINO_LDS_FLOATS + WINO_STAT_FLOATS + WINO_XF_FLOATS];
+  conv3_wino_body<false, STATS, true>(a, xcd_chunked(blockIdx.x, full), 0, lds);
+}
+
 // tiles [0, full) as whole tiles; with nmini > 0 the tiles [full, full + nmini / 2) as half tiles in the first
 // blocks of the launch (padded to a multiple of 8: block id % 8 stays the XCD of the full tiles)
 __global__ __launch_bounds__(256) void conv3_wino_kernel(WinoArgs a, int nmini, int nmini_pad, int full) {
@@ -347,7 +403,7 @@ __global__ __launch_bounds__(256) void conv3_wino_kernel(WinoArgs a, int nmini, 
 
 // the same tiles (whole ones only) with the statistics records of the output written from the epilogue (WinoArgs.stat_part)
 __global__ __launch_bounds__(256, 4) void conv3_wino_stats_kernel(WinoArgs a, int full) {
-  __shared__ float lds[WINO_LDS_FLOATS + 4 * 2 * 2 * 32 + 8];
+  __shared__ float lds[WINO_LDS_FLOATS + WINO_STAT_FLOATS];
   conv3_wino_body<false, true>(a, xcd_chunked(blockIdx.x, full), 0, lds);
 }
 
@@ -1025,9 +1081,13 @@ int da_wino4_weights(const float* w, float* u, int co, int ci, int transpose, hi
 
 // y (+)= conv1d(x, k = 3, stride 1, pad 1) per row with the transformed taps u (da_wino_weights).
 // x: [rows][L][ldx] first C channels; y: [rows][L][ldy] first N channels.  replaces reference models/resnet.py:5-8
+struct WinoBnIn {       // the XFW operands of conv3_winograd_impl (in_pend == NULL: a plain input)
+  const float* pend; float* mean; float* invstd; const float* gamma; const float* beta; float eps;
+};
+
 static int conv3_winograd_impl(const float* x, const float* u, float* y, int rows, int L, int ldx, int C, int ldy, int N,
                                int accumulate, const long long* drop_seed, unsigned drop_salt, float drop_p, float* stat_part,
-                               int stat_R, hipStream_t stream) {
+                               int stat_R, hipStream_t stream, const WinoBnIn* bn = nullptr) {
   DA_ENTER();
   if (g_act_bf16) return DA_EINVAL;              // float activations only
   if (!x || !u || !y || rows < 0 || L < 1 || C % 32 || N % 32 || C < 32 || N < 32 || ldx % 4 || ldx < C || ldy < N)
@@ -1039,19 +1099,28 @@ static int conv3_winograd_impl(const float* x, const float* u, float* y, int row
   a.L = L; a.PL = (L + 1) / 2; a.MP = rows * a.PL;
   a.ldx = ldx; a.C = C; a.ldy = ldy; a.N = N; a.accumulate = accumulate;
   a.drop_seed = drop_seed; a.drop_salt = drop_salt; a.drop_p = drop_p;
-  a.stat_part = stat_part; a.stat_Wu = stat_part ? stat_R * a.PL : 1;
-  if (stat_part && (stat_R < 1 || rows % stat_R || a.stat_Wu < 64 || accumulate)) return DA_EINVAL;
+  a.stat_part = stat_part; a.stat_Wu = (stat_part || bn) ? stat_R * a.PL : 1;
+  if ((stat_part || bn) && (stat_R < 1 || rows % stat_R || a.stat_Wu < 64 || accumulate)) return DA_EINVAL;
+  a.in_pend = nullptr; a.in_mean = a.in_invstd = nullptr; a.in_gamma = a.in_beta = nullptr; a.in_tiles = 0; a.in_Wu = 1; a.in_eps = 0.f;
+  if (bn) {
+    if (!bn->pend || !bn->mean || !bn->invstd || !bn->gamma || !bn->beta || C > 128 || ldx != C) return DA_EINVAL;
+    a.in_pend = bn->pend; a.in_mean = bn->mean; a.in_invstd = bn->invstd; a.in_gamma = bn->gamma; a.in_beta = bn->beta;
+    a.in_eps = bn->eps; a.in_Wu = stat_R * L; a.in_tiles = (int)(((long)rows * L + 63) / 64);
+    if (a.in_Wu < 64) return DA_EINVAL;
+  }
   a.divPL = make_fastdiv((uint32_t)a.PL);
   if ((uint64_t)a.MP * (uint64_t)a.PL >= 0xffffffffull) return DA_EINVAL;
   const int tiles = ((a.MP + 63) / 64) * (N / 32);
   const int R = tiles % 256;
   int nmini = 0, full = tiles;
-  if (g_wino_tail && !stat_part && tiles > 256 && R >= 1 && R <= 128) {
+  if (g_wino_tail && !stat_part && !bn && tiles > 256 && R >= 1 && R <= 128) {
     nmini = 2 * R;
     full = tiles - R;
   }
   const int nmini_pad = (nmini + 7) / 8 * 8;
-  if (stat_part) hipLaunchKernelGGL(conv3_wino_stats_kernel, dim3(full), dim3(256), 0, stream, a, full);
+  if (bn && stat_part) hipLaunchKernelGGL(conv3_wino_bn_kernel<true>, dim3(full), dim3(256), 0, stream, a, full);
+  else if (bn) hipLaunchKernelGGL(conv3_wino_bn_kernel<false>, dim3(full), dim3(256), 0, stream, a, full);
+  else if (stat_part) hipLaunchKernelGGL(conv3_wino_stats_kernel, dim3(full), dim3(256), 0, stream, a, full);
   else hipLaunchKernelGGL(conv3_wino_kernel, dim3(nmini_pad + full), dim3(256), 0, stream, a, nmini, nmini_pad, full);
   DA_CHECK_LAUNCH();
   return DA_OK;
@@ -1072,6 +1141,19 @@ int da_conv3_winograd_drop(const float* x, const float* u, float* y, int rows, i
                            hipStream_t stream) {
   if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return DA_EINVAL;
   return conv3_winograd_impl(x, u, y, rows, L, ldx, C, ldy, N, 0, drop_seed, drop_salt, drop_p, stat_part, R, stream);
+}
+
+// da_conv3_winograd_drop on the OUTPUT x of the 1x1 conv in front, with relu(norm2(x)) applied while x is staged
+// (densenet.py:27-32 norm2 -> relu2 -> conv2; the activation is never stored): x [rows][L][C] contiguous, C <= 128; the
+// statistics of x come as the records `in_pend` that conv's epilogue wrote (da_conv1x1_bn out_part: rows * L positions in
+// windows of R * L) and are PUBLISHED to in_mean / in_invstd [rows / R][C] for the backward kernels.
+int da_conv3_winograd_bn(const float* x, const float* u, float* y, int rows, int L, int C, int ldy, int N, int R,
+                         const float* in_pend, float* in_mean, float* in_invstd, const float* gamma, const float* beta,
+                         float eps, const long long* drop_seed, unsigned drop_salt, float drop_p, float* stat_part,
+                         hipStream_t stream) {
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_seed)) return DA_EINVAL;
+  WinoBnIn bn = {in_pend, in_mean, in_invstd, gamma, beta, eps};
+  return conv3_winograd_impl(x, u, y, rows, L, C, C, ldy, N, 0, drop_seed, drop_salt, drop_p, stat_part, R, stream, &bn);
 }
 
 // floats of a statistics-record buffer for `units` record units (64 per tile) of N channels:

@@ -633,33 +633,49 @@ class DenseBlockFunction(Function):
         pl = (l + 1) // 2
         rec_ok = R * pl >= 64
         drop = drop_p > 0
-        keep = []
+        keep, fused2 = [], []
         for k in range(n_layers):
             g1, b1, w1, g2, b2, w2 = params[6 * k:6 * k + 6]
             ck = c0 + k * G
             xk = buf[:, :, :ck]
-            y1 = torch.empty((rows, l, w1.shape[0]), device=buf.device, dtype=torch.float32)
-            H.conv1x1_bn(xk, w1, R, mean_t[:, :ck], invstd_t[:, :ck], g1, b1, y1, pend=pend, eps=eps)
+            mid = w1.shape[0]
+            y1 = torch.empty((rows, l, mid), device=buf.device, dtype=torch.float32)
+            code = _is_wino(w2, 1, 1)
+            # norm2 -> relu2 -> conv2 as ONE kernel (the Winograd growth conv normalises while it stages, from the records
+            # the 1x1 conv's epilogue hands over): h2 = relu(norm2(y1)) is then never stored either -- ``fuse2``
+            fuse2 = code == 4 and rec_ok and mid <= 128 and R * l >= 64
+            r1 = H.conv1x1_bn(xk, w1, R, mean_t[:, :ck], invstd_t[:, :ck], g1, b1, y1, pend=pend, eps=eps, want_records=fuse2)
             pend = None
             if DECISION_TAP is not None:
                 _tap(H.bn_relu_ss(xk, R, mean_t[:, :ck], invstd_t[:, :ck], g1, b1))
-            h2, m2, i2 = H.bn_fwd(y1, R, g2, b2, relu=True, eps=eps)
-            _tap(h2)
             new = buf[:, :, ck:ck + G]
-            code = _is_wino(w2, 1, 1)
             consumed = k + 1 < n_layers or tail_cb            # (norm5 takes its own statistics of the whole buffer)
-            if code == 4:
-                r_ = H.conv3_winograd(h2, _pack(w2, code)[2], out=new, drop=(seed, salt0 + k, drop_p) if drop else None,
-                                      stats_R=R if consumed and rec_ok else 0)
-                if consumed and rec_ok:
+            dr = (seed, salt0 + k, drop_p) if drop else None
+            if fuse2:
+                m2 = torch.empty((w_, mid), device=buf.device, dtype=torch.float32)
+                i2 = torch.empty_like(m2)
+                r_ = H.conv3_winograd_bn(y1, _pack(w2, code)[2], R, r1[1], m2, i2, g2, b2, new, eps=eps, drop=dr,
+                                         want_records=bool(consumed))
+                if consumed:
                     pend = (r_[1], ck, rows * pl, R * pl)
-            elif code == 6:
-                H.conv3_winograd(h2, _pack(w2, code)[2], out=new)
+                h2 = y1                                        # (placeholder in the saved list: the backward recomputes h2)
+                if DECISION_TAP is not None:
+                    _tap(H.bn_relu_ss(y1, R, m2, i2, g2, b2))
             else:
-                H.conv_fwd(h2, _pack(w2, 0)[0], 1, 1, out=new)
+                h2, m2, i2 = H.bn_fwd(y1, R, g2, b2, relu=True, eps=eps)
+                _tap(h2)
+                if code == 4:
+                    r_ = H.conv3_winograd(h2, _pack(w2, code)[2], out=new, drop=dr, stats_R=R if consumed and rec_ok else 0)
+                    if consumed and rec_ok:
+                        pend = (r_[1], ck, rows * pl, R * pl)
+                elif code == 6:
+                    H.conv3_winograd(h2, _pack(w2, code)[2], out=new)
+                else:
+                    H.conv_fwd(h2, _pack(w2, 0)[0], 1, 1, out=new)
             if consumed and pend is None:
                 H.bn_stats_fused(new, R, mean_t[:, ck:ck + G], invstd_t[:, ck:ck + G], eps)
             keep += [y1, m2, i2, h2]
+            fused2.append(fuse2)
         out_rec = None
         if tail_cb:
             gt, bt, wt = params[6 * n_layers:6 * n_layers + 3]
@@ -678,6 +694,7 @@ class DenseBlockFunction(Function):
             keep += [m5, i5]
             ctx.tail_out = out if tail_relu else None      # (its sign is the backward's ReLU decision)
         ctx.cfg = (R, c0, G, n_layers, drop_p, salt0, tail_cb, tail_relu)
+        ctx.fused2 = fused2
         ctx.gt = _tgt(*params)
         ctx.save_for_backward(buf, stats, seed if drop else stats, *keep, *params)
         if tail_cb:                                     # (next buffer, the records of its first channels)
@@ -731,13 +748,19 @@ class DenseBlockFunction(Function):
             y1, m2, i2, h2 = keep[4 * k:4 * k + 4]
             ck = c0 + k * G
             dnew = dbuf[:, :, ck:ck + G]                    # (its dropout mask was applied by the kernel that wrote it last)
-            grads[6 * k + 5] = _wgrad(dnew, h2, 3, 1, 1, tg[6 * k + 5])
+            f2 = ctx.fused2[k]
+            grads[6 * k + 5] = _wgrad(dnew, y1 if f2 else h2, 3, 1, 1, tg[6 * k + 5], {'xform': (m2, i2, g2, b2, R)} if f2 else None)
             code = _is_wino(w2, 1, 1)
             if code in (4, 6):
                 dh2 = H.conv3_winograd(dnew, _pack(w2, code)[3])
             else:
                 dh2 = H.conv_dgrad(dnew, _pack(w2, 0)[1], 1, 1, l)
-            dy1, grads[6 * k + 3], grads[6 * k + 4] = _bn_bwd(dh2, y1, R, m2, i2, g2, b2, 1, tg[6 * k + 3], tg[6 * k + 4], dx=dh2)
+            if f2:      # the ReLU decision of the form the forward applied (fused multiply-add), in place
+                ds2 = H.bn_bwd_ss(dh2, y1, R, m2, i2, g2, b2, 1, dh2)
+                fold(ds2, g2, b2, 6 * k + 3, 6 * k + 4)
+                dy1 = dh2
+            else:
+                dy1, grads[6 * k + 3], grads[6 * k + 4] = _bn_bwd(dh2, y1, R, m2, i2, g2, b2, 1, tg[6 * k + 3], tg[6 * k + 4], dx=dh2)
             xk, mk, ik = buf[:, :, :ck], mean_t[:, :ck], invstd_t[:, :ck]
             grads[6 * k + 2] = _wgrad(dy1, xk, 1, 1, 0, tg[6 * k + 2], {'xform': (mk, ik, g1, b1, R)})
             dh = H.conv_dgrad(dy1, _pack(w1, 0)[1], 1, 0, l)

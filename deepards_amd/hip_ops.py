@@ -181,6 +181,30 @@ def conv3_winograd(x, u, out=None, accumulate=False, drop=None, stats_R=0):
     return out
 
 
+def conv3_winograd_bn(x, u, R, rec, mean, invstd, gamma, beta, out, eps=1e-5, drop=None, want_records=False):
+    """The growth conv of a dense layer on the 1x1 conv's output x (rows, L, C <= 128, contiguous) with relu(norm2(x)) applied
+    while x is staged: the statistics of x come from ``rec`` (the records conv1x1_bn(want_records=True) wrote) and are
+    published to mean / invstd (W, C) for the backward; out: a (rows, L, N) channel slice of the block's buffer;
+    drop = (seed, salt, p): F.dropout in the epilogue; want_records: -> (out, records of the output, units = pairs)."""
+    _rlc32(x, 'x')
+    rows, l, c = x.shape
+    four, n, c2 = u.shape
+    if four != 4 or c2 != c or c % 32 or c > 128 or n % 32 or tuple(out.shape) != (rows, l, n) or rows % R:
+        raise ValueError('conv3_winograd_bn: unsupported shape x%s u%s out%s' % (tuple(x.shape), tuple(u.shape), tuple(out.shape)))
+    w = rows // R
+    if tuple(mean.shape) != (w, c) or tuple(invstd.shape) != (w, c) or not (mean.is_contiguous() and invstd.is_contiguous()):
+        raise ValueError('conv3_winograd_bn: mean / invstd must be contiguous (W, C)')
+    if rec.numel() != _lib.lib().da_stat_records_floats(rows * l, c):
+        raise ValueError('conv3_winograd_bn: the records do not have %d positions of %d channels' % (rows * l, c))
+    ldy = _pv(out, 'out')
+    seed, salt, p = drop if drop is not None and drop[2] > 0 else (None, 0, 0.0)
+    part = stat_records(rows * ((l + 1) // 2), n, x.device) if want_records else None
+    _chk(_lib.lib().da_conv3_winograd_bn(_p(x), _p(u), _p(out), rows, l, c, ldy, n, R, _p(rec), _p(mean), _p(invstd),
+                                         _p(_f32(gamma)), _p(_f32(beta)), eps, _p(seed), salt, p, _p(part), _stream()),
+         'da_conv3_winograd_bn')
+    return (out, part) if want_records else out
+
+
 def pack_conv3_bf16(w):
     """(Co, Ci, 3) fp32 conv weight -> (wf (3, Co, Ci), wd (3, Ci, Co)) bf16 tap packs for conv3_bf16."""
     _f32(w, 'w')
@@ -563,8 +587,12 @@ def conv_wgrad_multi(jobs):
         d.dy_stride, d.dy_off, d.src_stride, d.ntaps = 1, 0, stride, k
         d.winograd = wino
         if extra:
-            if wino or k != 1:
-                raise ValueError('conv_wgrad_multi: the dense-block operand forms belong to plain 1x1 jobs')
+            wino = 0                                     # (the operand forms run on the direct kernels)
+            _chk(L.da_conv_wgrad_plan(rows, lo, co, ci, k, 0, plan), 'da_conv_wgrad_plan')
+            ws = torch.empty((plan[2] * k * co * ci,), device=x.device, dtype=torch.float32)
+            d.workspace, d.winograd = ws.data_ptr(), 0
+            if stride != 1:
+                raise ValueError('conv_wgrad_multi: the dense-block operand forms belong to stride-1 jobs')
             d.dy_half = 1 if extra.get('dy_half') else 0
             if extra.get('xform') is not None:
                 mean_v, invstd_v, gamma, beta, R = extra['xform']

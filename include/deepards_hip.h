@@ -139,7 +139,7 @@ typedef struct {
   int winograd;   /* != 0: k3 s1 p1 job (N, C multiples of 64) in Winograd F(2,3) form; plan with winograd = 1;
                      16: bf16 operands; 49: split-bf16 (fp32-equivalent) products with dy AND x in the x3
                      format (see da_conv3_x3p; lddy == N, ldx == C), k3 s1 p1 only */
-  /* dense-block operand forms of plain 1x1 jobs (winograd == 0, ntaps == 1; see da_conv1x1_bn): xform = 1: X is
+  /* dense-block operand forms of stride-1 jobs on the direct kernels (winograd == 0; see da_conv1x1_bn): xform = 1: X is
      relu(BatchNorm(x)) recomputed while staged from the statistics tables [rows * Lm / Wn][ldstat] (Wn >= 32);
      dy_half = 1: dY has Ldy = Lm / 2 positions per row, position j reads dy[j / 2] / 2 */
   int xform, dy_half, Wn, ldstat; const float* mean; const float* invstd; const float* gamma; const float* beta;
@@ -263,6 +263,14 @@ int da_bn_bwd_ss(const float* dout, int ldd, const float* x, int ldx, const floa
 int da_conv1x1_bn(const float* x, int ldx, const float* w, float* y, int ldy, int rows, int R, int Lin, int C, int N, int pool,
                   float* mean, float* invstd, int ldstat, const float* gamma, const float* beta, const float* pend, int pend_c0,
                   long pend_units, int pend_Wu, float eps, float* out_part, da_stream_t stream);
+/* the growth conv on the 1x1 conv's OUTPUT x with relu(norm2(x)) applied while x is staged (densenet.py:27-32 norm2 -> relu2
+ * -> conv2: the activation is never stored): x [rows][L][C] contiguous, C <= 128; statistics of x from the records in_pend
+ * (da_conv1x1_bn out_part of the conv in front), published to in_mean / in_invstd [rows / R][C]; dropout / output records as
+ * da_conv3_winograd_drop.  R * ceil(L / 2) >= 64. */
+int da_conv3_winograd_bn(const float* x, const float* u, float* y, int rows, int L, int C, int ldy, int N, int R,
+                         const float* in_pend, float* in_mean, float* in_invstd, const float* gamma, const float* beta,
+                         float eps, const long long* drop_seed, unsigned drop_salt, float drop_p, float* stat_part,
+                         da_stream_t stream);
 /* Statistics records: a kernel that WRITES activation channels can hand their per-window BatchNorm statistics over from its
  * epilogue -- per 64-unit tile and window slot (a tile touches <= 2 windows) the count, mean and centred second moment of
  * each channel: floats [tiles][2][{mean, M2}][N] then counts [tiles][2] (da_stat_records_floats).  The consuming

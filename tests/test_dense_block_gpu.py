@@ -310,3 +310,56 @@ def test_statistics_records_from_the_transition_conv_epilogue(H, rows, R, L):
     close(m2_t[:, :N].cpu().numpy(), st2[0], tol=2e-6, name='published mean')
     assert np.abs(i2_t[:, :N].cpu().numpy() / st2[1] - 1).max() < 2e-5
     close(ncl(y), np_ref.conv1d_fwd(np_ref.relu(h2_ref), w1, 1, 0), tol=5e-6, name='first conv of the next block')
+
+
+@pytest.mark.parametrize('rows,R,L,drop', [(40, 20, 56, 0.2), (60, 20, 28, 0.0), (40, 20, 14, 0.2), (40, 20, 7, 0.0),
+                                            (1280, 20, 28, 0.2), (1280, 20, 7, 0.0)])
+def test_growth_conv_with_norm2_applied_while_staging(H, rows, R, L, drop):
+    """norm2 -> relu2 -> conv2 (+dropout) as one kernel: the 1x1 conv hands the statistics of its output over as records,
+    the Winograd growth conv merges them, normalises while it stages and publishes mean / invstd; the weight gradient of
+    conv2 recomputes relu(norm2(y1)) the same way (3-tap operand form), the BatchNorm backward takes its decisions."""
+    rng = np.random.RandomState(rows + L + 11)
+    C0, mid, G, cb = 64, 128, 32, 128
+    x0 = rng.randn(rows, C0, L) + rng.randn(1, C0, 1)
+    w1 = rng.randn(mid, C0, 1) / np.sqrt(C0)
+    w2 = rng.randn(G, mid, 3) * 0.08
+    g1, b1 = rng.rand(C0) + 0.5, rng.randn(C0) * 0.3
+    g2, b2 = rng.rand(mid) + 0.5, rng.randn(mid) * 0.3
+    buf, x0v = pitched(x0, cb)
+    mean_t, invstd_t = stat_tables(rows // R, cb)
+    H.bn_stats_fused(x0v, R, mean_t[:, :C0], invstd_t[:, :C0])
+    y1 = torch.empty(rows, L, mid, device='cuda')
+    _, rec1 = H.conv1x1_bn(x0v, cu(w1), R, mean_t[:, :C0], invstd_t[:, :C0], cu(g1), cu(b1), y1, want_records=True)
+    y1n = ncl(y1)
+    m2 = torch.full((rows // R, mid), float('nan'), device='cuda')
+    i2 = torch.full_like(m2, float('nan'))
+    seed = torch.tensor([99], dtype=torch.int64, device='cuda')
+    new = buf[:, :, C0:C0 + G]
+    _, rec2 = H.conv3_winograd_bn(y1, H.wino_weights(cu(w2)), R, rec1, m2, i2, cu(g2), cu(b2), new, drop=(seed, 4, drop) if drop else None,
+                                  want_records=True)
+    z2, st2 = np_ref.bn_window_fwd(y1n, g2, b2, R)
+    close(m2.cpu().numpy(), st2[0], tol=2e-6, name='published mean of y1')
+    assert np.abs(i2.cpu().numpy() / st2[1] - 1).max() < 2e-5
+    h2 = np_ref.relu(z2)
+    ref = np_ref.conv1d_fwd(h2, w2, 1, 1)
+    if drop:
+        ref = ref * ncl(H.dropout(torch.ones(rows, L, G, device='cuda'), seed, 4, drop))
+    close(ncl(new), ref, tol=1e-5, name='norm2 + growth conv')
+    # the records of the new channels feed the next 1x1 conv as before
+    C = C0 + G
+    w3 = rng.randn(128, C, 1) / np.sqrt(C)
+    g3, b3 = rng.rand(C) + 0.5, rng.randn(C) * 0.3
+    y3 = torch.empty(rows, L, 128, device='cuda')
+    pl = (L + 1) // 2
+    H.conv1x1_bn(buf[:, :, :C], cu(w3), R, mean_t[:, :C], invstd_t[:, :C], cu(g3), cu(b3), y3, pend=(rec2, C0, rows * pl, R * pl))
+    h3, st3 = np_ref.bn_window_fwd(ncl(buf[:, :, :C]), g3, b3, R)
+    close(mean_t[:, C0:C].cpu().numpy(), st3[0][:, C0:], tol=2e-6, name='published mean of the new channels')
+    close(ncl(y3), np_ref.conv1d_fwd(np_ref.relu(h3), w3, 1, 0), tol=5e-6, name='next 1x1 conv')
+    # backward pieces: dW of conv2 from (dnew, y1) with relu(norm2(y1)) recomputed; norm2 backward in the same decision form
+    dnew = rng.randn(rows, G, L)
+    _, dw_ref = np_ref.conv1d_bwd(h2, w2, dnew, 1, 1, need_dx=False)
+    _, dnv = pitched(dnew, cb, C0)
+    (slab,) = H.conv_wgrad_multi([(dnv, y1, 3, 1, 1, {'xform': (m2, i2, cu(g2), cu(b2), R)})])
+    dw = torch.zeros(G, mid, 3, device='cuda')
+    H.wgrad_reduce_multi([(slab, dw)], accumulate=False)
+    close(dw.cpu().numpy(), dw_ref, tol=2e-5, name='dW of the growth conv')
