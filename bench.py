@@ -46,6 +46,9 @@ def parse():
     ap.add_argument('--nb', type=int, default=20, help='sub-batch rows per window (BASELINE configs[4]: 40)')
     ap.add_argument('--seq-len', type=int, default=224, help='samples per row (BASELINE configs[4]: 512)')
     ap.add_argument('--batch', type=int, default=64, help='windows per GPU (BASELINE configs[1]: B=64)')
+    ap.add_argument('--global-batch', type=int, default=0,
+                    help='STRONG scaling: this many windows per step over ALL ranks (G / world per rank, as nn.DataParallel '
+                         'scatters a batch; BASELINE configs[3]: 16 or 64 over 4 GPUs) instead of --batch per rank')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -379,6 +382,11 @@ def main():
     else:
         model = M.CNNLinearNetwork(bb, 20, 0).to(dev)
     B = args.batch
+    if args.global_batch:                                # strong scaling: the global batch is fixed, a rank takes G / world
+        from deepards_amd.train import legal_batch_len
+        if args.global_batch % world or legal_batch_len(args.global_batch, args.global_batch, world) != args.global_batch:
+            raise SystemExit('--global-batch %d does not split into even shards over %d ranks' % (args.global_batch, world))
+        B = args.global_batch // world
     g = torch.Generator().manual_seed(1000 + rank)       # each rank its own shard of the global batch
     x = torch.randn(B, NB, 1, SL, generator=g).to(dev)
     t = torch.zeros(B, 2)
@@ -440,7 +448,7 @@ def main():
                    'breath-sequences/sec (train step) %s breath block + linear head nb%d seq%d' % (args.backbone, NB, SL)),
         'value': round(value, 1), 'unit': 'breath-sequences/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+        'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': (('%s breath block + Linear(F*NB, 2) head (stated, not mirrored: the reference cannot run this shape), '
                                  'synthetic (B=%d per GPU, %d, 1, %d) train step, %s (tile shape of BASELINE configs[4])' %
                                  (args.backbone, B, NB, SL, 'fp32' if args.dtype == 'f32' else 'fp32 via three-term bf16 splits (opt-in)' if args.dtype == 'f32x3p' else 'bf16 MFMA operands / fp32 sums in the residual-block convs, %s activation storage, fp32 statistics' % storage))
@@ -455,7 +463,10 @@ def main():
                                  'cnn_linear+%s, synthetic (B=%d per GPU, 20, 1, 224) train step, bf16 MFMA operands / fp32 sums in the '
                                  'residual-block convs (forward, data and weight gradient), ' + storage + ' activation storage, fp32 '
                                  'statistics / optimizer (BASELINE configs[2])') % (args.backbone, B)),
-                   'backbone': args.backbone, 'batch_per_gpu': B, 'global_batch': B * world, 'n_sub_batches': NB,
+                   'backbone': args.backbone, 'batch_per_gpu': B, 'global_batch': B * world,
+                   'batch_rule': ('--global-batch %d: fixed global batch, %d windows per rank (strong scaling)' % (args.global_batch, B)
+                                  if args.global_batch else '--batch %d per rank (weak scaling: the global batch grows with the ranks)' % B),
+                   'n_sub_batches': NB,
                    'seq_len': SL, 'optimizer': 'sgd-nesterov+clamp', 'parallelism': 'dp%d' % world,
                    'hipgraph': not args.no_graph},
         'final_loss': round(loss, 6),

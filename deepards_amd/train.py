@@ -57,24 +57,27 @@ def _capture_graph(graph, _ctx=None):
 
 
 def graph_branch_count(graph):
-    """Number of nodes of a captured ``torch.cuda.CUDAGraph`` (``enable_debug_mode()`` before the capture) with more than
-    one successor or predecessor -- 0 for the single chain every captured step of this package is meant to be; None when
-    the runtime's DOT dump cannot be produced or read.  (hipGraphDebugDotPrint: edges are lines ``"a" -> "b"``.)"""
-    import re
-    import tempfile
+    """Number of nodes of a captured ``torch.cuda.CUDAGraph(keep_graph=True)`` with more than one successor or predecessor
+    -- 0 for the single chain every captured step of this package is meant to be; None when the topology cannot be read.
+    (hipGraphGetEdges on the raw graph handle; this stack's hipGraphDebugDotPrint writes an empty file.)"""
+    import ctypes
     try:
-        with tempfile.NamedTemporaryFile(suffix='.dot', delete=True) as f:
-            graph.debug_dump(f.name)
-            txt = open(f.name).read()
+        raw = graph.raw_cuda_graph()
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
+        ne = ctypes.c_size_t(0)
+        if hip.hipGraphGetEdges(ctypes.c_void_p(raw), None, None, ctypes.byref(ne)) != 0:
+            return None
+        if ne.value == 0:
+            return 0
+        fr, to = (ctypes.c_void_p * ne.value)(), (ctypes.c_void_p * ne.value)()
+        if hip.hipGraphGetEdges(ctypes.c_void_p(raw), fr, to, ctypes.byref(ne)) != 0:
+            return None
     except Exception:                                    # noqa: BLE001
         return None
-    edges = re.findall(r'"?([\w.:]+)"?\s*->\s*"?([\w.:]+)"?', txt)
-    if not edges:
-        return None
     succ, pred = {}, {}
-    for a, b in set(edges):
-        succ[a] = succ.get(a, 0) + 1
-        pred[b] = pred.get(b, 0) + 1
+    for a_, b_ in set(zip(list(fr), list(to))):
+        succ[a_] = succ.get(a_, 0) + 1
+        pred[b_] = pred.get(b_, 0) + 1
     return sum(1 for v in succ.values() if v > 1) + sum(1 for v in pred.values() if v > 1)
 
 
@@ -366,11 +369,11 @@ class HotPathTrainer(object):
             #     single graph while its peer waits in an eager all-reduce would deadlock the exchange.
             ok, why = True, ''
             try:
-                graph = torch.cuda.CUDAGraph()
-                graph.enable_debug_mode()                # (keeps the hipGraph so that its topology can be dumped)
+                graph = torch.cuda.CUDAGraph(keep_graph=True)    # (keeps the hipGraph: its topology is read below)
                 with _capture_graph(graph):
                     static_out = self._eager_whole_step(*static)
                 branches = graph_branch_count(graph)
+                graph.instantiate()
                 if branches:
                     ok, why = False, 'the capture holds %d forked branch(es)' % branches
                 elif branches is None:

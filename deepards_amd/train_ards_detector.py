@@ -687,10 +687,11 @@ def main(argv=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world > 1:
         import torch.distributed as dist
-        local = int(os.environ.get('LOCAL_RANK', '0'))
-        torch.cuda.set_device(local)
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if not dist.is_initialized():                    # (a caller may bring its own group: the one-GPU rehearsals use gloo)
+            local = int(os.environ.get('LOCAL_RANK', '0'))
+            torch.cuda.set_device(local)
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     cls = network_map[args.network](args)
     results = cls.train_and_test()
     if world > 1:

@@ -1414,3 +1414,55 @@ def test_trainer_snapshot_restore_is_traceless(M, backbone):
     assert a[0] == b[0] and a[2] == b[2]
     for k in a[1]:
         assert torch.equal(a[1][k], b[1][k]), k
+
+
+def test_fold_groups_on_the_hip_path(tmp_path):
+    """BASELINE config C4 (k folds, each data-parallel over a group of GPUs) on the HIP path, as far as one GPU goes: FOUR
+    fresh processes share cuda:0 over gloo as 2 fold groups x 2 data-parallel ranks (--fold-groups 2, 4 folds: group 0
+    trains folds 0 and 2, group 1 folds 1 and 3, every step's gradients reduced inside the group).  Every rank must end
+    with every fold's patient results, and they must be those of the SAME folds trained one after the other by ONE
+    data-parallel pair (two processes, no fold groups): bit for bit -- a fold's numbers may not depend on which group ran it
+    or on what ran beside it.  (The single-process fold loop draws another epoch permutation -- a data-parallel group shares
+    ONE drawn by its leader -- so it is a different, equally valid trajectory: only the test windows per patient and the size
+    of the losses are compared with it.)"""
+    import subprocess
+    import sys
+    from deepards_amd import train_ards_detector as T
+    gold = os.path.join(os.path.dirname(__file__), 'golden', 'test_dataset.npz')
+    argv = ['--cuda-no-dp', '--train-from-pickle', gold, '--kfolds', '4', '-e', '1', '-b', '4', '--base-network', 'resnet18',
+            '--seed', '11', '--clip-grad']
+    _, ref = T.main(argv)                                         # one process, folds one after the other
+
+    def children(world, extra, tag):
+        port = 31500 + (os.getpid() * 11 + world * 17) % 3000
+        procs, outs = [], []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+            out = str(tmp_path / ('fg_%s_rank%d.npz' % (tag, r)))
+            outs.append(out)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), 'tools', 'fold_group_child.py'), out] +
+                                          argv + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        logs = []
+        for p_ in procs:
+            try:
+                o, _ = p_.communicate(timeout=420)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            logs.append(o.decode(errors='replace'))
+        for r, p_ in enumerate(procs):
+            assert p_.returncode == 0, 'rank %d failed:\n%s' % (r, logs[r][-4000:])
+        return [dict(np.load(o, allow_pickle=False)) for o in outs]
+
+    pair = children(2, [], 'pair')                                # one data-parallel pair, folds one after the other
+    groups = children(4, ['--fold-groups', '2'], 'groups')
+    keys = sorted(k for k in pair[0])
+    assert len([k for k in keys if k.startswith('votes/')]) == len(ref.patient_results) == 4
+    for got in pair[1:] + groups:
+        assert sorted(got) == keys
+        for k in keys:
+            assert np.array_equal(got[k], pair[0][k]), k
+    for (fold, ep), r_ in ref.patient_results.items():            # the same test windows per patient as the one-process loop
+        assert np.array_equal(pair[0]['votes/%d/%d' % (fold, ep)].sum(axis=1), np.asarray(r_['votes']).sum(axis=1)), fold
+        assert abs(float(pair[0]['loss/%d/%d' % (fold, ep)]) - float(r_['mean_loss'])) < 0.2, fold
