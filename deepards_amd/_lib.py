@@ -114,6 +114,7 @@ SIGNATURES = {
     'da_conv_bf16_multi': (_I, [ctypes.POINTER(ConvJob), _I, _P]),
     'da_wino_debug_tail': (_I, [_I]),
     'da_wino_debug_pchunk': (_I, [_I]),
+    'da_wino_debug_tapmod': (_I, [_I]),
     'da_wino_weights': (_I, [_P, _P, _I, _I, _I, _P]),
     'da_wino4_weights': (_I, [_P, _P, _I, _I, _I, _P]),
     'da_conv_wgrad_multi': (_I, [ctypes.POINTER(WgradJob), _I, _P]),

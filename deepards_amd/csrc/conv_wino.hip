@@ -50,6 +50,7 @@ struct WinoArgs {
   const float* in_beta;
   int in_tiles, in_Wu;
   float in_eps;
+  int tapmod;      // timing experiment only (da_wino_debug_tapmod): F(4,3) K-16 kernel reads its taps modulo this many channels
 };
 
 __device__ __forceinline__ uint32_t wino_mix32(uint32_t a, uint32_t b) {      // head_optim.hip mix32
@@ -656,7 +657,8 @@ __device__ __forceinline__ void conv3_wino4k_body(const WinoArgs& a, const int t
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
     const int idx = p * 64 + lr;
-    ub[p] = a.u + (size_t)(idx >> 5) * a.N * a.C + (size_t)(n_blk + (idx & 31)) * a.C + lq * 4;
+    const int nrow = n_blk + (idx & 31);
+    ub[p] = a.u + (size_t)(idx >> 5) * a.N * a.C + (size_t)(a.tapmod ? nrow % a.tapmod : nrow) * a.C + lq * 4;
   }
 
   f32x4 ra[NA], rb[3];
@@ -802,6 +804,8 @@ __global__ __launch_bounds__(256) void conv3_wino4_kernel(WinoArgs a, int nmini,
 
 static int g_wino_tail = 1;
 static int g_wino4_k16 = 1;
+static int g_wino4_tapmod = 0;   // TIMING EXPERIMENT ONLY (da_wino_debug_tapmod): F(4,3) taps read modulo this many output
+                                 // channels, so that the tap tensor fits one XCD's L2 -- results are then wrong by design
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient of the same convolution, Winograd form.  With dm = A dy = (dy0, dy0 + dy1, dy0 - dy1, -dy1) per
@@ -1051,6 +1055,8 @@ int da_conv3_winograd4(const float* x, const float* u, float* y, int rows, int L
   a.ldx = ldx; a.C = C; a.ldy = ldy; a.N = N; a.accumulate = accumulate;
   a.drop_seed = nullptr; a.drop_salt = 0u; a.drop_p = 0.f;
   a.stat_part = nullptr; a.stat_Wu = 1;
+  a.in_pend = nullptr; a.in_mean = a.in_invstd = nullptr; a.in_gamma = a.in_beta = nullptr; a.in_tiles = 0; a.in_Wu = 1; a.in_eps = 0.f;
+  a.tapmod = g_wino4_tapmod;
   a.divPL = make_fastdiv((uint32_t)a.PL);
   if ((uint64_t)a.MP * (uint64_t)a.PL >= 0xffffffffull) return DA_EINVAL;
   const int tiles = ((a.MP + 63) / 64) * (N / 32);
@@ -1102,6 +1108,7 @@ static int conv3_winograd_impl(const float* x, const float* u, float* y, int row
   a.stat_part = stat_part; a.stat_Wu = (stat_part || bn) ? stat_R * a.PL : 1;
   if ((stat_part || bn) && (stat_R < 1 || rows % stat_R || a.stat_Wu < 64 || accumulate)) return DA_EINVAL;
   a.in_pend = nullptr; a.in_mean = a.in_invstd = nullptr; a.in_gamma = a.in_beta = nullptr; a.in_tiles = 0; a.in_Wu = 1; a.in_eps = 0.f;
+  a.tapmod = 0;
   if (bn) {
     if (!bn->pend || !bn->mean || !bn->invstd || !bn->gamma || !bn->beta || C > 128 || ldx != C) return DA_EINVAL;
     a.in_pend = bn->pend; a.in_mean = bn->mean; a.in_invstd = bn->invstd; a.in_gamma = bn->gamma; a.in_beta = bn->beta;
@@ -1170,6 +1177,13 @@ int da_wino_debug_tail(int on) {
     return DA_OK;
   }
   g_wino_tail = on;
+  return DA_OK;
+}
+// TIMING EXPERIMENT ONLY: the F(4,3) kernel reads its transformed taps modulo `mod` output channels (0: off) -- the tap
+// tensor then fits one XCD's L2 and the launch shows what its re-reads through the fabric cost; results are wrong by design
+int da_wino_debug_tapmod(int mod) {
+  if (mod < 0 || mod % 32) return DA_EINVAL;
+  g_wino4_tapmod = mod;
   return DA_OK;
 }
 int da_wino_debug_pchunk(int pchunk) {

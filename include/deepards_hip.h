@@ -88,6 +88,7 @@ int da_conv3_winograd(const float* x, const float* u, float* y, int rows, int L,
 int da_wino_debug_tail(int on);
 /* tuning: pchunk > 0 = output pairs per split of the Winograd weight gradient (default 512); pchunk < 0 = -pchunk padded
    positions per split of the bf16 weight gradient (default 2048) */
+int da_wino_debug_tapmod(int mod);   /* timing experiment only: F(4,3) taps read modulo `mod` output channels (0: off) */
 int da_wino_debug_pchunk(int pchunk);
 /* u[4][co][ci] (transpose = 0, forward) or u[4][ci][co] (transpose = 1, data gradient) from w[co][ci][3] */
 int da_wino_weights(const float* w, float* u, int co, int ci, int transpose, da_stream_t stream);
