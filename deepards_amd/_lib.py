@@ -131,6 +131,9 @@ SIGNATURES = {
     'da_linear2_fwd': (_I, [_P, _P, _P, _P, _I, _I, _P]),
     'da_bce_logits': (_I, [_P, _P, _I, _F, _P, _P, _P]),
     'da_linear2_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'da_head_groups': (_I, [_I, _I]),
+    'da_head_fwd': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'da_head_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     'da_clamp_sgd_nesterov': (_I, [_P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _P]),
     'da_clamp_adam': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _F, _F, _P]),
     'da_clamp_adam_dev': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P, _F, _F, _P]),

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void linear2_bwd_input_kernel(const float* __r
 __global__ __launch_bounds__(256) void linear2_bwd_weight_kernel(const float* __restrict__ dl,
                                                                  const float* __restrict__ flat, float* __restrict__ dW,
                                                                  float* __restrict__ dbias, int B, int K,
-                                                                 int accumulate) {
+                                                                 int accumulate, const float* __restrict__ terms = nullptr,
+                                                                 float inv_n = 0.f, float* __restrict__ loss = nullptr) {
   __shared__ f32x4 red[2][16][16];
   const int kq = threadIdx.x & 15, slot = threadIdx.x >> 4;
   const int i = (blockIdx.x * 16 + kq) * 4;
@@ -136,7 +137,149 @@ __global__ __launch_bounds__(256) void linear2_bwd_weight_kernel(const float* __
       dbias[0] = accumulate ? dbias[0] + s0 : s0;
       dbias[1] = accumulate ? dbias[1] + s1 : s1;
     }
+    if (terms) {                                        // the fused head: the loss is the mean of the windows' BCE terms
+      float s = 0.f;
+      for (int b = threadIdx.x; b < B; b += 64) s += terms[b];
+      s = wave_sum(s);
+      if (threadIdx.x == 0) loss[0] = s * inv_n;
+    }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The head chain of CNNLinearNetwork in three launches instead of six (reference models/resnet.py:112,159-160 /
+// densenet.py:167,183-184 AvgPool1d(7,1) + view; torch_cnn_linear_network.py:102,110-112 linear_final on view(-1);
+// train_ards_detector.py:530 BCEWithLogitsLoss, and their backward):
+//   head_pool_dot_kernel  one block per (window, row group): global average pool of its rows -> flat (kept for dW) and its
+//                         share of the two dot products (a block per window could not pull its 287 KB fast enough: 12 us)
+//   head_bwd_kernel       logits from the partial dot products, the window's BCE terms and dlogits = (sigmoid - t) gscale / n
+//                         (n = 2 B elements), dx[row][l][f] = (dl[b][0] W[0][r F + f] + dl[b][1] W[1][r F + f]) / L
+//   linear2_bwd_weight_kernel (below, with `terms`): dW, dbias and loss = mean of the terms (fixed order)
+//   (forward only: head_finish_kernel = logits + loss)
+// ---------------------------------------------------------------------------------------------------------------------
+// block g of window b: 256 of the window's R * F / 4 (row, 4 features) items -- their pooled features -> flat, and the block's
+// share of the two dot products -> part[b][g]
+template <typename AT>
+__global__ __launch_bounds__(256) void head_pool_dot_kernel(const AT* __restrict__ x, int ldx, const float* __restrict__ W,
+                                                            float* __restrict__ flat, float* __restrict__ part, int R, int G,
+                                                            int L, int F) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.x, g = blockIdx.y, K = R * F, nq = F >> 2;
+  const int i = g * 256 + threadIdx.x;
+  float a0 = 0.f, a1 = 0.f;
+  if (i < R * nq) {
+    const int r = i / nq, q = i - r * nq;
+    const AT* xp = x + ((size_t)(b * R + r) * L) * ldx + q * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int l0 = 0; l0 < L; l0 += 8) {                           // 8 loads in flight (L = 7: all of them)
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = Act<AT>::ld4(xp + (size_t)min(l0 + j, L - 1) * ldx);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (l0 + j < L) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += v[j][e];
+        }
+    }
+    const float inv_l = 1.0f / (float)L;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] *= inv_l;                  // (avgpool_fwd_kernel's arithmetic)
+    const int k = r * F + q * 4;
+    *reinterpret_cast<f32x4*>(flat + (size_t)b * K + k) = acc;
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(W + k), w1 = *reinterpret_cast<const f32x4*>(W + K + k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a0 = fmaf(acc[e], w0[e], a0);
+      a1 = fmaf(acc[e], w1[e], a1);
+    }
+  }
+  a0 = wave_sum(a0);
+  a1 = wave_sum(a1);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a0;
+    red[1][threadIdx.x >> 6] = a1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) part[((size_t)b * G + g) * 2 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// logits of window b from the row groups' partial dot products (fixed order), its BCE terms and dBCE/dlogits
+__device__ __forceinline__ void head_logits(const float* __restrict__ part, const float* __restrict__ bias,
+                                            const float* __restrict__ target, int b, int G, float inv_n, float gscale,
+                                            float (&lg)[2], float (&dl)[2], float& term) {
+  term = 0.f;
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    float v = bias[o];
+    for (int g = 0; g < G; ++g) v += part[((size_t)b * G + g) * 2 + o];
+    const float tt = target[(size_t)b * 2 + o];
+    lg[o] = v;
+    term += fmaxf(v, 0.f) - v * tt + log1pf(expf(-fabsf(v)));      // (bce_kernel's)
+    dl[o] = (1.0f / (1.0f + expf(-v)) - tt) * inv_n * gscale;
+  }
+}
+
+// forward only: logits [B][2] and loss = mean of the terms, one block
+__global__ __launch_bounds__(256) void head_finish_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                          const float* __restrict__ target, float* __restrict__ logits,
+                                                          float* __restrict__ loss, int B, int G, float inv_n) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float lg[2], dl[2], term;
+    head_logits(part, bias, target, b, G, inv_n, 1.f, lg, dl, term);
+    logits[b * 2] = lg[0];
+    logits[b * 2 + 1] = lg[1];
+    acc += term;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
+}
+
+// backward, same (window, 256 items) blocks: the window's dlogits from the partials (two threads, through LDS), then every
+// thread writes the L positions of its (row, 4 features); block 0 of a window also publishes logits / dlogits / terms for the
+// weight kernel and the caller
+template <typename AT>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                       const float* __restrict__ target, const float* __restrict__ W,
+                                                       AT* __restrict__ dx, int lddx, float* __restrict__ logits,
+                                                       float* __restrict__ dlogits, float* __restrict__ terms, int R, int G,
+                                                       int L, int F, float inv_n, float gscale) {
+  __shared__ float sdl[2];
+  const int b = blockIdx.x, g = blockIdx.y, K = R * F, nq = F >> 2;
+  const int i = g * 256 + threadIdx.x;
+  f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+  int r = 0, q = 0;
+  if (i < R * nq) {
+    r = i / nq;
+    q = i - r * nq;
+    w0 = *reinterpret_cast<const f32x4*>(W + r * F + q * 4);
+    w1 = *reinterpret_cast<const f32x4*>(W + K + r * F + q * 4);
+  }
+  if (threadIdx.x == 0) {
+    float lg[2], dl[2], term;
+    head_logits(part, bias, target, b, G, inv_n, gscale, lg, dl, term);
+    sdl[0] = dl[0];
+    sdl[1] = dl[1];
+    if (g == 0) {
+      logits[b * 2] = lg[0];
+      logits[b * 2 + 1] = lg[1];
+      dlogits[b * 2] = dl[0];
+      dlogits[b * 2 + 1] = dl[1];
+      terms[b] = term;
+    }
+  }
+  __syncthreads();
+  if (i >= R * nq) return;
+  const float d0 = sdl[0], d1 = sdl[1], inv = 1.0f / (float)L;
+  f32x4 gq;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) gq[e] = (d0 * w0[e] + d1 * w1[e]) * inv;          // (linear2_bwd_input then avgpool_bwd)
+  AT* o = dx + ((size_t)(b * R + r) * L) * lddx + q * 4;
+  for (int l = 0; l < L; ++l) Act<AT>::st4(o + (size_t)l * lddx, gq);
 }
 
 // g <- clamp(g*gscale, +-clip); g += wd*p; buf = first ? g : mom*buf + g; p -= lr*(g + mom*buf)
@@ -703,6 +846,51 @@ int da_linear2_bwd(const float* dlogits, const float* flat, const float* W, floa
                        dbias, B, K, accumulate);
     DA_CHECK_LAUNCH();
   }
+  return DA_OK;
+}
+
+// The head of CNNLinearNetwork, forward: x [B * R][L][ldx] (the breath block's last map, activation storage type) -> flat
+// [B][R * F] (global average pool) and part [B][G][2], the shares of the two dot products of G = da_head_groups(R, F) blocks of 256 (row, 4 features) items a window.
+// finish != 0 (forward-only callers): also logits [B][2] and loss[0] (one more small launch); training callers continue
+// with da_head_bwd, which derives everything from `part`.  replaces AvgPool1d(7,1) + view + linear_final (+ BCEWithLogitsLoss)
+int da_head_groups(int R, int F) { return (R * (F / 4) + 255) / 256; }
+
+int da_head_fwd(const void* x, int ldx, const float* W, const float* bias, const float* target, float* flat, float* part,
+                float* logits, float* loss, int B, int R, int L, int F, int finish, hipStream_t stream) {
+  DA_ENTER();
+  if (!x || !W || !bias || !target || !flat || !part || F % 4 || ldx % 4 || R < 1 || L < 1 || (finish && (!logits || !loss)))
+    return DA_EINVAL;
+  if (B == 0) return DA_OK;
+  const int G = da_head_groups(R, F);
+  DA_ACT_DISPATCH(hipLaunchKernelGGL(head_pool_dot_kernel<AT>, dim3(B, G), dim3(256), 0, stream, (const AT*)x, ldx, W, flat, part,
+                                     R, G, L, F));
+  DA_CHECK_LAUNCH();
+  if (finish) {
+    hipLaunchKernelGGL(head_finish_kernel, dim3(1), dim3(256), 0, stream, part, bias, target, logits, loss, B, G,
+                       1.0f / (2.0f * (float)B));
+    DA_CHECK_LAUNCH();
+  }
+  return DA_OK;
+}
+
+// ... and the loss + backward: logits / dlogits [B][2], terms [B] from `part`; dx [B * R][L][lddx] (linear backward + pool
+// backward in one kernel); dW / dbias (+)= from dlogits and flat; loss[0] = mean of the terms.  gscale multiplies dlogits.
+int da_head_bwd(const float* part, const float* bias, const float* target, const float* flat, const float* W, void* dx, int lddx,
+                float* logits, float* dlogits, float* terms, float* dW, float* dbias, float* loss, int B, int R, int L, int F,
+                float gscale, int accumulate, hipStream_t stream) {
+  DA_ENTER();
+  if (!part || !bias || !target || !flat || !W || !dx || !logits || !dlogits || !terms || !dW || !dbias || !loss || F % 4 ||
+      lddx % 4 || R < 1 || L < 1)
+    return DA_EINVAL;
+  if (B == 0) return DA_OK;
+  const int K = R * F, G = da_head_groups(R, F);
+  const float inv_n = 1.0f / (2.0f * (float)B);
+  DA_ACT_DISPATCH(hipLaunchKernelGGL(head_bwd_kernel<AT>, dim3(B, G), dim3(256), 0, stream, part, bias, target, W, (AT*)dx, lddx,
+                                     logits, dlogits, terms, R, G, L, F, inv_n, gscale));
+  DA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(linear2_bwd_weight_kernel, dim3((K / 4 + 15) / 16), dim3(256), 0, stream, dlogits, flat, dW, dbias, B, K,
+                     accumulate, terms, inv_n, loss);
+  DA_CHECK_LAUNCH();
   return DA_OK;
 }
 

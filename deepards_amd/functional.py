@@ -898,6 +898,43 @@ class Linear2Function(Function):
         return dflat, None if direct else dw, None if direct else dbias
 
 
+class HeadLossFunction(Function):
+    """AvgPool1d(7,1) + view(-1) + linear_final + BCEWithLogitsLoss of CNNLinearNetwork as ONE autograd node in three launches
+    (H.head_fwd / head_bwd) instead of six: xmap (B * R, L, F) the breath block's last map, target (B, 2) -> (loss (1,), logits
+    (B, 2)).  In a training step the logits and the loss are FILLED BY THE BACKWARD (they are the first thing it needs, and
+    nothing reads them earlier: the forward kernel leaves the dot products as row-group partials); backward takes no upstream
+    gradient into account beyond d(loss) = 1: what the trainer's ``loss.backward()`` means.
+    reference models/resnet.py:112,159-160, densenet.py:167,183-184; torch_cnn_linear_network.py:102,110-112;
+    train_ards_detector.py:161-173,530."""
+
+    @staticmethod
+    def forward(ctx, xmap, w, bias, target, R, grad_mode):
+        # (grad mode is always off in here and needs_input_grad ignores no_grad: the caller passes torch.is_grad_enabled())
+        need_grad = grad_mode and any(ctx.needs_input_grad[:3])
+        target = target.contiguous()
+        flat, part, logits, loss = H.head_fwd(xmap.contiguous(), w, bias, target, R, finish=not need_grad)
+        ctx.save_for_backward(flat, part, w, bias, target, logits, loss)
+        ctx.R, ctx.l = R, xmap.shape[1]
+        ctx.gt = _tgt(w, bias)
+        ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)               # (or autograd fills a zero d(logits) every step: one more launch)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, _dloss, _dlogits=None):
+        flat, part, w, bias, target, logits, loss = ctx.saved_tensors
+        tw, tb = ctx.gt
+        direct = tw is not None and tb is not None
+        dx, dw, db = H.head_bwd(part, bias, target, flat, w, logits, loss, ctx.R, ctx.l, dw=tw if direct else None,
+                                dbias=tb if direct else None, accumulate=direct)
+        return dx, None if direct else dw, None if direct else db, None, None, None
+
+
+def head_loss(xmap, w, bias, target, R):
+    """(loss, logits) through HeadLossFunction; see its note on WHEN the two are filled."""
+    return HeadLossFunction.apply(xmap, w, bias, target, R, torch.is_grad_enabled())
+
+
 class WindowMeanFunction(Function):
     """torch.mean(outputs, dim=1) over the NB breaths of every window (CNNLinearToMean,
     models/torch_cnn_linear_network.py:25): (B*NB, F) -> (B, F)."""

@@ -1185,6 +1185,42 @@ def linear2_bwd(dlogits, flat, w, need_input=True, dw=None, dbias=None, accumula
     return dflat, dw, dbias
 
 
+def head_fwd(xmap, w, bias, target, R, finish=False):
+    """The head chain of CNNLinearNetwork, forward: xmap (B * R, L, F) the breath block's last map (activation storage type),
+    w (2, R * F), bias (2,), target (B, 2) -> flat (B, R * F), part (B, G, 2) the shares of the two dot products of the G blocks a window is pooled by,
+    logits (B, 2), loss (1,) -- the last two filled only with ``finish`` (forward-only callers; the training path gets them
+    from head_bwd)."""
+    _rlc(xmap, 'xmap')
+    rows, l, f = xmap.shape
+    b = rows // R
+    if rows % R or tuple(w.shape) != (2, R * f) or tuple(target.shape) != (b, 2):
+        raise ValueError('head_fwd: shapes x%s w%s target%s' % (tuple(xmap.shape), tuple(w.shape), tuple(target.shape)))
+    mk = lambda *shape: torch.empty(shape, device=xmap.device, dtype=torch.float32)
+    L = _lib.lib()
+    flat, part, logits, loss = mk(b, R * f), mk(b, L.da_head_groups(R, f), 2), mk(b, 2), mk(1)
+    _chk(L.da_head_fwd(_p(xmap), f, _p(_f32(w)), _p(_f32(bias)), _p(_f32(target)), _p(flat), _p(part), _p(logits), _p(loss), b, R,
+                       l, f, 1 if finish else 0, _stream()), 'da_head_fwd')
+    return flat, part, logits, loss
+
+
+def head_bwd(part, bias, target, flat, w, logits, loss, R, l, dw=None, dbias=None, accumulate=False, gscale=1.0):
+    """The loss and the backward of head_fwd: fills logits (B, 2) and loss (1,); -> dx (B * R, l, F) in the activation storage
+    type, dw (2, R * F), dbias (2,) (+= into the given ones with accumulate)."""
+    b, k = flat.shape
+    f = k // R
+    dx = torch.empty((b * R, l, f), device=flat.device, dtype=ACT)
+    dlogits = torch.empty((b, 2), device=flat.device, dtype=torch.float32)
+    terms = torch.empty((b,), device=flat.device, dtype=torch.float32)
+    if dw is None:
+        if accumulate:
+            raise ValueError('accumulate needs dw / dbias')
+        dw, dbias = torch.empty_like(w), torch.empty((2,), device=w.device, dtype=torch.float32)
+    _chk(_lib.lib().da_head_bwd(_p(part), _p(_f32(bias)), _p(_f32(target)), _p(flat), _p(_f32(w)), _p(dx), f, _p(logits), _p(dlogits),
+                                _p(terms), _p(dw), _p(dbias), _p(loss), b, R, l, f, gscale, 1 if accumulate else 0, _stream()),
+         'da_head_bwd')
+    return dx, dw, dbias
+
+
 def bce_logits(logits, target, want_grad=True, gscale=1.0):
     """-> loss (1,), dlogits (same shape as logits) or None."""
     _f32(logits, 'logits')

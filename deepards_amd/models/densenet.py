@@ -235,10 +235,15 @@ class DenseNet(nn.Module):
     def _features_rlc(self, x, R):
         return self.features.forward_rlc(x, R, True)
 
-    def forward_windows(self, x, rows_per_window):
+    def forward_windows(self, x, rows_per_window, pooled=True):
+        """pooled=False: the last map (rows, L, C) itself, for a head that pools it in its own kernel (CNNLinearNetwork.forward_loss)."""
         h = self._features_rlc(x, rows_per_window)
         if h.shape[1] < 7:
             raise ValueError('AvgPool1d(7, stride=1) needs a final length >= 7 (seq_len >= 224); got %d' % h.shape[1])
+        if not pooled:
+            if h.shape[1] != 7:
+                raise TypeError('the un-pooled map is only handed out at the 7-position length the fused head pools')
+            return h
         return F_.GlobalAvgPoolFunction.apply(h)
 
     def forward(self, x):

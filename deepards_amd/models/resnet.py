@@ -106,9 +106,10 @@ class ResNet(nn.Module):
         init_like_reference(self)
         self.n_out_filters = width
 
-    def forward_windows(self, x, rows_per_window):
+    def forward_windows(self, x, rows_per_window, pooled=True):
         """x: (rows, 1, L) with rows = windows * rows_per_window; BatchNorm statistics are taken per
-        window, exactly as when the reference feeds one (NB, 1, L) window at a time."""
+        window, exactly as when the reference feeds one (NB, 1, L) window at a time.  pooled=False: the last map
+        (rows, 7, C) itself, for a head that pools it in its own kernel (CNNLinearNetwork.forward_loss)."""
         _require_cuda(x, 'ResNet')
         if x.dim() != 3 or x.shape[1] != 1:
             raise ValueError('expected (rows, 1, L) input, got %s' % (tuple(x.shape),))
@@ -140,6 +141,10 @@ class ResNet(nn.Module):
                 h = blk.forward_rlc(h, rows_per_window, None, takes3[i + 1])
         if h.shape[1] < 7:
             raise ValueError('AvgPool1d(7, stride=1) needs a final length >= 7 (seq_len >= 224); got %d' % h.shape[1])
+        if not pooled:
+            if h.shape[1] != 7:
+                raise TypeError('the un-pooled map is only handed out at the 7-position length the fused head pools')
+            return h
         return F_.GlobalAvgPoolFunction.apply(h)
 
     def forward(self, x):

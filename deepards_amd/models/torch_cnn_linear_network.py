@@ -61,6 +61,26 @@ class CNNLinearNetwork(_WindowHead):
         self._no_metadata(self.metadata_features)
         return self._head(feat.view(b, nb * feat.shape[1]))                           # == view(-1) per window
 
+    def forward_loss(self, x, target):
+        """(loss (1,), logits (B, 2)) of BCEWithLogitsLoss()(self(x, None), target) with the head chain -- global average
+        pool, view(-1), linear_final, the loss and its first gradient -- as ONE autograd node in three launches
+        (functional.HeadLossFunction); ``loss.backward()`` then runs the whole backward.  With gradients required the
+        two returned tensors are FILLED BY THAT BACKWARD (its first kernel derives them from the forward's partial dot
+        products): read them after it; under no_grad they are complete on return.  None when the breath block's last
+        map is not the 7-position one the fused head pools (seq_len != 224 cannot happen here; a backbone without
+        ``forward_windows(..., pooled=False)``): the caller then takes forward() + the loss kernels."""
+        if x.shape[-1] != SEQ_LEN:
+            raise Exception('input breaths must have sequence length of 224')
+        if x.shape[0] == 0:
+            raise IndexError('index 0 is out of bounds for dimension 0 with size 0')
+        self._no_metadata(self.metadata_features)
+        b, nb, c, l = x.shape
+        try:
+            hmap = self.breath_block.forward_windows(x.reshape(b * nb, c, l), nb, pooled=False)
+        except TypeError:
+            return None
+        return F_.head_loss(hmap, self.linear_final.weight, self.linear_final.bias, target, nb)
+
 
 def _windows(model, x):
     return model._features(x)

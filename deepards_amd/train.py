@@ -177,6 +177,9 @@ def average_replica_buffers(model, world_size, group=None):
         dist.broadcast(b, src=src, group=group)
 
 
+_FUSED_HEAD = os.environ.get('DA_FUSED_HEAD', '1') != '0'      # 0: the six-launch head chain (A/B and the sibling heads' path)
+
+
 def _logits(out):
     """CNNLSTMNetwork returns (logits, (hx, cx)); every batch starts from a zero state here (the reference's stateful
     per-patient carry, train_ards_detector.py:845-849, is the caller's loop: pass hx_cx to the model yourself)."""
@@ -290,6 +293,13 @@ class HotPathTrainer(object):
     # ---- eager pieces ------------------------------------------------------------------------
     def _forward_backward(self, inputs, target):
         with F_.training_step(self.model):               # weights are constant within one step
+            fused = self.model.forward_loss(inputs, target) if _FUSED_HEAD and hasattr(self.model, 'forward_loss') else None
+            if fused is not None:                        # CNNLinearNetwork: pool + linear + loss (+ their backward) in 3 launches
+                loss, logits = fused
+                F_.flush_forward()
+                torch.autograd.backward(loss, grad_tensors=self._one(loss))
+                F_.flush_backward()
+                return loss, logits
             logits = _logits(self.model(inputs, None))
             F_.flush_forward()                           # batched BN running-statistics updates
             lg, tg = _loss_operands(logits.detach(), target)
@@ -297,6 +307,13 @@ class HotPathTrainer(object):
             logits.backward(dlogits.view(logits.shape))
             F_.flush_backward()                          # batched dgamma/dbeta folds + wgrad slab reductions
         return loss, logits.detach()
+
+    def _one(self, like):
+        """A constant 1 of the loss's shape (autograd would launch a fill kernel for an implicit one every step)."""
+        one = getattr(self, '_one_t', None)
+        if one is None or one.device != like.device or one.shape != like.shape:
+            one = self._one_t = torch.ones_like(like)
+        return one
 
     def _optimizer_step(self):
         b = self.bucket
@@ -528,6 +545,11 @@ class HotPathTrainer(object):
 
     def _test_forward(self, inputs, target):
         with torch.no_grad(), F_.training_step(self.model):      # packs / Winograd taps once, batched small kernels
+            fused = self.model.forward_loss(inputs, target) if _FUSED_HEAD and hasattr(self.model, 'forward_loss') else None
+            if fused is not None:
+                loss, logits = fused
+                F_.flush_forward()
+                return loss, logits, logits.argmax(dim=-1)
             logits = _logits(self.model(inputs, None))
             F_.flush_forward()                                   # train-mode forward: BN running statistics do move
             loss, _ = H.bce_logits(*_loss_operands(logits, target), want_grad=False)

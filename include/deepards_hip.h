@@ -350,6 +350,19 @@ int da_bce_logits(const float* logits, const float* target, int n, float gscale,
                   da_stream_t stream);
 int da_linear2_bwd(const float* dlogits, const float* flat, const float* W, float* dflat, float* dW, float* dbias,
                    int B, int K, int accumulate, da_stream_t stream);
+/* The head chain of CNNLinearNetwork in three launches instead of six: da_head_fwd = AvgPool1d(L,1) + view -> flat and the
+ * row groups' shares `part` [B][da_head_groups(R, F)][2] of linear_final's two dot products (finish != 0, forward-only callers:
+ * also logits and the BCEWithLogitsLoss mean); da_head_bwd = logits / loss terms / dlogits from `part`, linear + pool
+ * backward in one kernel, then dW / dbias and the loss mean (resnet.py:112,159-160 / densenet.py:167,183-184;
+ * torch_cnn_linear_network.py:102,110-112; train_ards_detector.py:530).  x / dx: the breath block's last map
+ * [B * R][L][ld] in the activation storage type. */
+int da_head_groups(int R, int F);
+int da_head_fwd(const da_act_t* x, int ldx, const float* W, const float* bias, const float* target, float* flat, float* part,
+                float* logits, float* loss, int B, int R, int L, int F, int finish, da_stream_t stream);
+int da_head_bwd(const float* part, const float* bias, const float* target, const float* flat, const float* W, da_act_t* dx,
+                int lddx, float* logits, float* dlogits, float* terms, float* dW, float* dbias, float* loss, int B, int R, int L,
+                int F, float gscale, int accumulate, da_stream_t stream);
+
 
 /* ---- optimiser: clamp hook + SGD(momentum .9, nesterov, weight decay) / Adam, fused ----------
  * train_ards_detector.py:474-476 (clamp), :419-421 (optimisers).  gscale = 1/world_size after the

@@ -166,3 +166,60 @@ def test_transition_norm_pool_head(Fn):
     cmp('dx', from_rlc(xd.grad), x.grad)
     for name, pd, p in zip(['g', 'b', 'w', 'g5', 'b5', 'wl', 'bl'], [dg, db, dw, dg5, db5, dwl, dbl], params):
         cmp('d' + name, pd.grad, p.grad, tol=5e-5)
+
+
+@pytest.mark.parametrize('backbone', ['resnet18', 'densenet18'])
+def test_fused_head_chain_against_the_oracle_and_the_six_launch_chain(backbone):
+    """functional.HeadLossFunction (global average pool + view(-1) + linear_final + BCEWithLogitsLoss and their backward in
+    three launches) against numpy (fp64) on the map, and -- through the trainer -- against the six-launch chain it replaces:
+    same losses, same parameters after three steps up to fp32 summation order."""
+    import numpy as np
+    import deepards_amd.functional as Fn
+    import deepards_amd.models as M
+    import deepards_amd.train as T
+    from oracle import np_ref
+    rng = np.random.RandomState(3)
+    B, R, L, F = 5, 20, 7, 128
+    xm = rng.randn(B * R, L, F)
+    w, bias = rng.randn(2, R * F) * 0.02, rng.randn(2) * 0.1
+    t = np.zeros((B, 2)); t[np.arange(B), rng.randint(0, 2, B)] = 1
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.float32)).cuda()
+    xt, wt, bt = cu(xm).requires_grad_(True), cu(w).requires_grad_(True), cu(bias).requires_grad_(True)
+    loss, logits = Fn.head_loss(xt, wt, bt, cu(t), R)
+    loss.backward()
+    flat = xm.mean(axis=1).reshape(B, R * F)
+    lg = flat @ w.T + bias
+    loss_ref, dl = np_ref.bce_with_logits(lg, t)
+    assert np.abs(logits.cpu().numpy() - lg).max() < 2e-6 * (1 + np.abs(lg).max())
+    assert abs(float(loss) - loss_ref) < 2e-6
+    dflat = dl @ w
+    dx_ref = np.repeat(dflat.reshape(B * R, 1, F), L, axis=1) / L
+    assert np.abs(xt.grad.cpu().numpy() - dx_ref).max() < 2e-6 * (1 + np.abs(dx_ref).max())
+    assert np.abs(wt.grad.cpu().numpy() - dl.T @ flat).max() < 2e-6 * (1 + np.abs(dl.T @ flat).max())
+    assert np.abs(bt.grad.cpu().numpy() - dl.sum(axis=0)).max() < 2e-6
+    # forward only (no_grad): the loss comes from the forward kernels
+    with torch.no_grad():
+        l2, lg2 = Fn.head_loss(xt, wt, bt, cu(t), R)
+    assert abs(float(l2) - loss_ref) < 2e-6 and torch.equal(lg2, logits)
+
+    def run(fused):
+        old = T._FUSED_HEAD
+        T._FUSED_HEAD = fused
+        try:
+            torch.manual_seed(5)
+            bb = M.resnet18() if backbone == 'resnet18' else M.densenet18(drop_rate=0.0)
+            m = M.CNNLinearNetwork(bb, 20, 0).cuda()
+            tr = T.HotPathTrainer(m, use_graph=True)
+            g = torch.Generator().manual_seed(1)
+            x = torch.randn(4, 20, 1, 224, generator=g).cuda()
+            tt = torch.zeros(4, 2).cuda(); tt[:, 0] = 1
+            ls = [float(tr.train_step(x, tt)) for _ in range(3)]
+            ts = tr.test_step(x, tt)
+            return ls, tr.bucket.p.clone(), float(ts[0]), ts[2].clone()
+        finally:
+            T._FUSED_HEAD = old
+    la, pa, ta, preda = run(True)
+    lb, pb, tb, predb = run(False)
+    # (three SGD steps apart: the two chains sum the loss and dW in another order, the steps compound the last-bit differences)
+    assert max(abs(a - b) for a, b in zip(la, lb)) < 1e-5, (la, lb)
+    assert float((pa - pb).abs().max()) < 5e-5 and abs(ta - tb) < 1e-5 and torch.equal(preda, predb)
