@@ -845,7 +845,7 @@ int da_bn_stats_partial(const void* x, int ld, int W, int Wn, int C, float* part
 // xrows (rows, Lin) float, wt (C, 1, 7); window = R rows of Lc = Lin / 2 conv outputs.  Records as da_bn_stats_partial's.
 int da_stem_stats_partial(const float* xrows, const float* wt, int rows, int R, int Lin, int C, float* part, hipStream_t stream) {
   DA_ENTER();
-  if (!xrows || !wt || !part || C % CG || R < 1 || rows % R || Lin < 2 || (Lin & 1) || g_act_bf16) return DA_EINVAL;
+  if (!xrows || !wt || !part || C % CG || R < 1 || rows % R || Lin < 2 || (Lin & 1)) return DA_EINVAL;
   if (rows == 0) return DA_OK;
   const int W = rows / R, Lc = Lin / 2, Wn = R * Lc;
   int P, chunk;

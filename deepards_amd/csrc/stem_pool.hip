@@ -193,9 +193,9 @@ struct StemBn4 {
   }
 };
 
-template <int OX3>
+template <typename AT, int OX3>
 __global__ __launch_bounds__(256) void stem_bn_relu_pool_fwd_kernel(const float* __restrict__ xrows, const float* __restrict__ wt,
-                                                                    float* __restrict__ out, int ldo, int rows, int R, int Lin,
+                                                                    AT* __restrict__ out, int ldo, int rows, int R, int Lin,
                                                                     int Lc, int Lp, int C, const float* __restrict__ mean,
                                                                     const float* __restrict__ invstd,
                                                                     const float* __restrict__ gamma,
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void stem_bn_relu_pool_fwd_kernel(const float*
       }
       const size_t po = (size_t)row * Lp + j;
       if constexpr (OX3) X3::st4(reinterpret_cast<__bf16*>(out) + po * (size_t)(3 * C), c0, o);
-      else Act<float>::st4(out + po * ldo + c0, o);
+      else Act<AT>::st4(out + po * ldo + c0, o);
       zm = zp;
     }
   }
@@ -330,8 +330,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const AT* __restrict__ do
 // per step two new conv outputs (2j, 2j+1; 2j-1 is the previous step's last) from a register window of 11 inputs that
 // advances by one ds_read_b128; position 2j-1 is finished by the step of window j (it also sat in window j-1, whose choice
 // the step before left in a carry -- a run recomputes the window in front of its first one for it), position 2j by its own.
-template <bool APPLY>
-__global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ dout, int ldd, const float* __restrict__ xrows,
+template <typename AT, bool APPLY>
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const AT* __restrict__ dout, int ldd, const float* __restrict__ xrows,
                                                        const float* __restrict__ wt, int rows, int R, int Lin, int Lc, int Lp,
                                                        int C, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
         t2n[e] = tot[C + c0 + e] * inv_n;
       }
     }
-    const float* drow = dout + (size_t)row * Lp * ldd + c0;
+    const AT* drow = dout + (size_t)row * Lp * ldd + c0;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     float xw[16];                                     // stem_xw_fill: position 2j-1 starts at xw[3], 2j at xw[5], 2j+1 at xw[7]
     // one finished position: its g (the windows' choices), its y, the window index of its first input
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
         const bool vm = j > 0, vp = 2 * j + 1 < Lc;
         const f32x4 y0 = stem_y4(sw, xw, 5), yp = stem_y4(sw, xw, 7);
         const f32x4 z0 = bn.z(y0), zp = bn.z(yp);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(drow + (size_t)j * ldd);
+        const f32x4 d = Act<AT>::ld4(drow + (size_t)j * ldd);
         f32x4 gm, g0, gp;
         choose(zm, z0, zp, vm, vp, d, gm, g0, gp);
         if (j >= j0) {
@@ -691,12 +691,13 @@ int da_bn_relu_pool_fwd(const void* y, int ldy, void* out, int ldo, int rows, in
 }
 
 // BN + ReLU + pool(3,2,1) of the default stem from the RAW rows (the conv output recomputed, never stored): xrows (rows, Lin),
-// wt (C, 1, 7) -> out (rows, Lp, C) float, or the x3 format when out_x3.  mean / invstd: da_stem_stats_partial + da_bn_stats_merge.
+// wt (C, 1, 7) -> out (rows, Lp, C) in the activation storage type, or the x3 format when out_x3 (float storage only).  mean / invstd: da_stem_stats_partial + da_bn_stats_merge.
 int da_stem_bn_relu_pool_fwd(const float* xrows, const float* wt, void* out, int ldo, int rows, int R, int Lin, int C,
                              const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode,
                              int out_x3, hipStream_t stream) {
   DA_ENTER();
-  if (!xrows || !wt || !out || C % 4 || (out_x3 ? C % 16 : ldo % 4) || R < 1 || rows % R || Lin < 2 || (Lin & 1) || g_act_bf16)
+  if (!xrows || !wt || !out || C % 4 || (out_x3 ? C % 16 : ldo % 4) || R < 1 || rows % R || Lin < 2 || (Lin & 1) ||
+      (g_act_bf16 && out_x3))
     return DA_EINVAL;
   if (rows == 0) return DA_OK;
   const int Lc = Lin / 2, Lp = (Lc - 1) / 2 + 1;
@@ -704,11 +705,11 @@ int da_stem_bn_relu_pool_fwd(const float* xrows, const float* wt, void* out, int
   const size_t shm = (size_t)stem_xs_floats(Lin) * sizeof(float);
   const int nblk = rows < 1024 ? rows : 1024;
   if (out_x3)
-    hipLaunchKernelGGL(stem_bn_relu_pool_fwd_kernel<1>, dim3(nblk), dim3(256), shm, stream, xrows, wt, (float*)out, ldo,
+    hipLaunchKernelGGL((stem_bn_relu_pool_fwd_kernel<float, 1>), dim3(nblk), dim3(256), shm, stream, xrows, wt, (float*)out, ldo,
                        rows, R, Lin, Lc, Lp, C, mean, invstd, gamma, beta, pool_mode);
   else
-    hipLaunchKernelGGL(stem_bn_relu_pool_fwd_kernel<0>, dim3(nblk), dim3(256), shm, stream, xrows, wt, (float*)out, ldo,
-                       rows, R, Lin, Lc, Lp, C, mean, invstd, gamma, beta, pool_mode);
+    DA_ACT_DISPATCH(hipLaunchKernelGGL((stem_bn_relu_pool_fwd_kernel<AT, 0>), dim3(nblk), dim3(256), shm, stream, xrows, wt,
+                                       (AT*)out, ldo, rows, R, Lin, Lc, Lp, C, mean, invstd, gamma, beta, pool_mode));
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -719,14 +720,14 @@ size_t da_stem_bwd_workspace(int rows, int C) {     // (one partial per block; a
 }
 
 // Backward of the default stem (conv k7 s2 p3 on one channel -> BN -> ReLU -> pool(3,2,1)) from the RAW rows: dout
-// (rows, Lp, C) float -> dw (C, 1, 7) (+= when accumulate) and ds (2, W, C): the BatchNorm's window sums of g / g xhat
+// (rows, Lp, C) in the activation storage type -> dw (C, 1, 7) (+= when accumulate) and ds (2, W, C): the BatchNorm's window sums of g / g xhat
 // (da_bn_param_grad_multi folds them into dgamma / dbeta).  Nothing at the stem's resolution is read or written.
-int da_stem_bwd(const float* dout, int ldd, const float* xrows, const float* wt, int rows, int R, int Lin, int C,
+int da_stem_bwd(const void* dout, int ldd, const float* xrows, const float* wt, int rows, int R, int Lin, int C,
                 const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode, float* ds,
                 float* dw, int accumulate, float* workspace, hipStream_t stream) {
   DA_ENTER();
   if (!dout || !xrows || !wt || !mean || !invstd || !gamma || !beta || !ds || !dw || !workspace || C % 4 || C < 4 ||
-      256 % (C / 4) || 2 * C > 256 || ldd % 4 || R < 1 || rows % R || Lin < 2 || (Lin & 1) || g_act_bf16)
+      256 % (C / 4) || 2 * C > 256 || ldd % 4 || R < 1 || rows % R || Lin < 2 || (Lin & 1))
     return DA_EINVAL;
   if (rows == 0) return DA_OK;
   const int Lc = Lin / 2, Lp = (Lc - 1) / 2 + 1, nruns = 256 / (C / 4);
@@ -742,11 +743,12 @@ int da_stem_bwd(const float* dout, int ldd, const float* xrows, const float* wt,
   const size_t shm1 = (xsn + 2 * C + (size_t)nruns * 2 * C) * sizeof(float);
   const size_t shm2 = (xsn + 2 * C + (size_t)nruns * 7 * C) * sizeof(float);
   if (shm2 > 64 * 1024) return DA_EINVAL;
-  hipLaunchKernelGGL(stem_bwd_kernel<false>, dim3(nblk), dim3(256), shm1, stream, dout, ldd, xrows, wt, rows, R, Lin, Lc, Lp, C, mean,
-                     invstd, gamma, beta, pool_mode, RPB, rowpart, (float*)nullptr, (float*)nullptr);
+  DA_ACT_DISPATCH(hipLaunchKernelGGL((stem_bwd_kernel<AT, false>), dim3(nblk), dim3(256), shm1, stream, (const AT*)dout, ldd, xrows,
+                                     wt, rows, R, Lin, Lc, Lp, C, mean, invstd, gamma, beta, pool_mode, RPB, rowpart,
+                                     (float*)nullptr, (float*)nullptr));
   DA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(stem_bwd_kernel<true>, dim3(nblk), dim3(256), shm2, stream, dout, ldd, xrows, wt, rows, R, Lin, Lc, Lp, C, mean,
-                     invstd, gamma, beta, pool_mode, RPB, rowpart, ds, partial);
+  DA_ACT_DISPATCH(hipLaunchKernelGGL((stem_bwd_kernel<AT, true>), dim3(nblk), dim3(256), shm2, stream, (const AT*)dout, ldd, xrows,
+                                     wt, rows, R, Lin, Lc, Lp, C, mean, invstd, gamma, beta, pool_mode, RPB, rowpart, ds, partial));
   DA_CHECK_LAUNCH();
   const int n = C * 7;
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((n + 7) / 8), dim3(256), 0, stream, partial, nblk, n, dw, accumulate);

@@ -322,7 +322,7 @@ class StemFunction(Function):
         # buffer, which its layers then fill (DenseBlockFunction); the buffer is what is returned
         # The default stem (one input channel) never stores its conv output -- 36.7 MB at B = 64 for 7 FMAs an element: the
         # statistics, the apply + pool pass and the whole backward recompute it from the raw rows (bit for bit the same
-        # forward values; H.stem_fused_fwd / stem_fused_bwd).  The other stems (FFT channels, bf16 storage) keep the stored map.
+        # forward values; H.stem_fused_fwd / stem_fused_bwd).  The stems with FFT channels keep the stored map.
         ctx.fused = _STEM_FUSED and H.stem_fused_ok(x2d, w, R)
         s_ = _Stats()
         c0 = w.shape[0]

@@ -1021,9 +1021,10 @@ def bn_relu_pool_fwd(y, R, mean, invstd, gamma, beta, pool_mode, out_x3=False, o
 
 def stem_fused_ok(x2d, w, R):
     """Whether the recomputing stem kernels take this stem: the default one (one input channel, k7 s2 p3, float storage,
-    even length, 32 / 64 / 128 channels, a window of R rows that the backward's row pairs / quads divide)."""
+    even length, 32 / 64 / 128 channels, a window of R rows that the backward's row pairs / quads divide).  Either activation
+    storage type: with bf16 storage only the pooled map and its gradient are bf16 -- the recomputed conv output never is."""
     lin = x2d.shape[-1]
-    ok = ACT == torch.float32 and (x2d.dim() == 2 or x2d.shape[1] == 1) and tuple(w.shape[1:]) == (1, 7) and \
+    ok = (x2d.dim() == 2 or x2d.shape[1] == 1) and tuple(w.shape[1:]) == (1, 7) and \
         lin % 2 == 0 and w.shape[0] in (32, 64, 128) and x2d.shape[0] % R == 0 and R % max(1, 128 // w.shape[0]) == 0
     if not ok or x2d.shape[0] == 0:
         return ok
@@ -1061,7 +1062,9 @@ def stem_fused_fwd(x2d, w, R, gamma, beta, pool_mode, eps=1e-5, out_x3=False, ou
             raise ValueError('stem_fused_fwd: bad out')
         ldo = _pv(out, 'out')
     else:
-        out = x3_empty(rows, lp, c, x.device) if out_x3 else torch.empty((rows, lp, c), device=x.device, dtype=torch.float32)
+        if out_x3 and ACT != torch.float32:
+            raise ValueError('stem_fused_fwd: the x3 format needs float storage')
+        out = x3_empty(rows, lp, c, x.device) if out_x3 else torch.empty((rows, lp, c), device=x.device, dtype=ACT)
     _chk(L.da_stem_bn_relu_pool_fwd(_p(x), _p(w), _p(out), ldo, rows, R, lin, c, _p(mean), _p(invstd), _p(gamma), _p(beta),
                                     pool_mode, 1 if out_x3 else 0, _stream()), 'da_stem_bn_relu_pool_fwd')
     return out, mean, invstd
@@ -1070,7 +1073,7 @@ def stem_fused_fwd(x2d, w, R, gamma, beta, pool_mode, eps=1e-5, out_x3=False, ou
 def stem_fused_bwd(dout, x2d, w, R, mean, invstd, gamma, beta, pool_mode, dw=None, accumulate=False):
     """Backward of stem_fused_fwd from dout (rows, Lp, C) float and the raw rows: -> dw (C, 1, 7) (+= into ``dw`` when
     accumulate), ds (2, W, C) = the BatchNorm's window sums (bn_param_grad_multi folds them into dgamma / dbeta)."""
-    ldd = _pv(dout, 'dout')
+    ldd = _pv(dout, 'dout') if ACT == torch.float32 else _rlc(dout, 'dout').shape[2]
     x = x2d.reshape(x2d.shape[0], x2d.shape[-1])
     rows, lin = x.shape
     c = w.shape[0]

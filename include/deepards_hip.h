@@ -310,14 +310,15 @@ int da_bn_relu_pool_fwd(const da_act_t* y, int ldy, da_act_t* out, int ldo, int 
  * it is needed instead of storing and re-reading it.  Forward: da_stem_stats_partial (chunk records as da_bn_stats_partial's
  * on the stored map, bit for bit) -> da_bn_stats_merge -> da_stem_bn_relu_pool_fwd (the pooled map, float or x3: bit for bit
  * da_stem_conv_fwd + da_bn_relu_pool_fwd).  Backward: da_stem_bwd = da_pool_bwd + da_bn_bwd + da_stem_conv_wgrad in two passes
- * over dout: dw (C, 1, 7) and ds (2, W, C) for da_bn_param_grad_multi; workspace da_stem_bwd_workspace() bytes.  Float
- * activation storage, Lin even, C a multiple of 32 (statistics) with 2 C <= 256. */
+ * over dout: dw (C, 1, 7) and ds (2, W, C) for da_bn_param_grad_multi; workspace da_stem_bwd_workspace() bytes.  out / dout
+ * in the activation storage type (with bf16 storage the conv output, being recomputed in fp32, is never rounded -- the
+ * stored-map stem rounds it); Lin even, C a multiple of 32 (statistics) with 2 C <= 256. */
 int da_stem_stats_partial(const float* xrows, const float* wt, int rows, int R, int Lin, int C, float* part, da_stream_t stream);
-int da_stem_bn_relu_pool_fwd(const float* xrows, const float* wt, void* out, int ldo, int rows, int R, int Lin, int C,
+int da_stem_bn_relu_pool_fwd(const float* xrows, const float* wt, da_act_t* out, int ldo, int rows, int R, int Lin, int C,
                              const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode,
                              int out_x3, da_stream_t stream);
 size_t da_stem_bwd_workspace(int rows, int C);
-int da_stem_bwd(const float* dout, int ldd, const float* xrows, const float* wt, int rows, int R, int Lin, int C,
+int da_stem_bwd(const da_act_t* dout, int ldd, const float* xrows, const float* wt, int rows, int R, int Lin, int C,
                 const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode, float* ds,
                 float* dw, int accumulate, float* workspace, da_stream_t stream);
 int da_bn_relu_pool_fwd_x(const float* y, int ldy, void* out, int rows, int R, int Lin, int C, const float* mean,

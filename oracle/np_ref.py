@@ -283,6 +283,22 @@ def _maxpool(t, x, name):
 
 
 def _stem(t, x, conv, bn, pool_type='max'):
+    if t.bf16_storage and getattr(t, 'stem_recomputed', False):
+        # the device's recomputing stem (deepards_amd/csrc/stem_pool.hip: stem_bn_relu_pool_fwd_kernel / stem_bwd_kernel) stores
+        # nothing at the stem's resolution: only the pooled map is rounded, and the backward keeps fp32 up to the weights
+        t.bf16_storage = False
+        try:
+            y3, bwd = _stem(t, x, conv, bn, pool_type)
+        finally:
+            t.bf16_storage = True
+
+        def bwd_unrounded(d):
+            t.bf16_storage = False
+            try:
+                return bwd(d)
+            finally:
+                t.bf16_storage = True
+        return round_bf16(y3), bwd_unrounded
     y0, b_conv = _conv(t, x, conv, 2, 3, need_dx=False)
     y1, b_bn = _bn(t, y0, bn)
     y2, b_relu = _relu(t, y1, bn + '.relu', store=False)       # relu -> pool inside one kernel
@@ -509,7 +525,7 @@ def lstm_bwd(x, w_ih, w_hh, tape, dh_all):
 
 def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_batches=20,
                                 first_pool_type='max', drop_masks=None, need_grads=True, head='linear',
-                                bf16_convs=False, bf16_storage=False, double_conv_first=False):
+                                bf16_convs=False, bf16_storage=False, double_conv_first=False, stem_recomputed=True):
     """CNNLinearNetwork.forward over a batch (torch_cnn_linear_network.py:104-113) + BCE loss
     (train_ards_detector.py:929-930) + backward.  x (B,NB,C,224); target (B,2) one-hot.
     params: dict name -> ndarray with the reference's state_dict keys.
@@ -532,6 +548,7 @@ def cnn_linear_forward_backward(params, x, target, backbone='resnet18', n_sub_ba
     t = _Tape(params, nb)
     t.bf16_convs = bf16_convs
     t.bf16_storage = bf16_storage            # resnets only (the device has no bf16-storage DenseNet)
+    t.stem_recomputed = stem_recomputed      # (bf16 storage only: which of the device's two stems is mirrored, see _stem)
     rows = x.reshape(b * nb, c, l)
     if backbone in RESNET_LAYERS:
         feat, fbwd = resnet18_features(t, rows, first_pool_type=first_pool_type, layers=RESNET_LAYERS[backbone],

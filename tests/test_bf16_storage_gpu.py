@@ -141,6 +141,28 @@ def test_stem_and_pool_kernels_bf16_storage(H, rows, lin, R, pool):
     assert float((dw16 - dw32).norm() / dw32.norm()) < 2e-2 and dw16.dtype == torch.float32
 
 
+@pytest.mark.parametrize('rows,lin,R,pool', [(40, 224, 20, 0), (12, 64, 4, 1)])
+def test_recomputing_stem_bf16_storage(H, rows, lin, R, pool):
+    """The recomputing stem under bf16 storage: nothing at the stem's resolution is stored, so the pooled map is EXACTLY the
+    float-storage one rounded once (same statistics, bit for bit), and the backward from a bf16 dout equals the float-storage
+    backward from the same (bf16-representable) values bit for bit."""
+    g = torch.Generator().manual_seed(rows * 3 + lin)
+    x2d = torch.randn(rows, lin, generator=g).cuda()
+    w = (torch.randn(64, 1, 7, generator=g) * 0.3).cuda()
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.3).cuda()
+    assert H.stem_fused_ok(x2d, w, R)
+    p32, m32, i32 = H.stem_fused_fwd(x2d, w, R, gamma, beta, pool)
+    dout = rnd(tuple(p32.shape), 5).bfloat16()
+    dw32, ds32 = H.stem_fused_bwd(dout.float(), x2d, w, R, m32, i32, gamma, beta, pool)
+    with storage(H, 'bf16'):
+        assert H.stem_fused_ok(x2d, w, R)
+        p16, m16, i16 = H.stem_fused_fwd(x2d, w, R, gamma, beta, pool)
+        dw16, ds16 = H.stem_fused_bwd(dout, x2d, w, R, m16, i16, gamma, beta, pool)
+    assert p16.dtype == torch.bfloat16 and torch.equal(m16, m32) and torch.equal(i16, i32)
+    assert torch.equal(p16, p32.bfloat16())
+    assert torch.equal(dw16, dw32) and torch.equal(ds16, ds32)
+
+
 @pytest.mark.parametrize('ci,co,L,rows', [(64, 64, 56, 40), (128, 128, 28, 23), (512, 512, 7, 40), (64, 64, 128, 9)])
 def test_conv_kernels_bf16_storage(H, ci, co, L, rows):
     """k3 s1 conv forward / data gradient (+accumulate), the stride-2 pair, and all three weight-gradient forms with bf16
@@ -338,7 +360,11 @@ def test_c5_tile_shape_at_its_benchmarked_arithmetic(H):
     t = np.zeros((B, 2), np.float32)
     t[0, 1] = t[1, 0] = 1
     p64 = {k: v.astype(np.float64) for k, v in p32.items()}
-    ref = _c5_reference(p64, x.astype(np.float64), t.astype(np.float64), nb, bf16_convs=True, bf16_storage=True)
+    # (which stem the device takes for this shape decides what the oracle rounds: the recomputing one stores no stem-resolution map)
+    recomputed = bool(F_._STEM_FUSED and H.stem_fused_ok(torch.from_numpy(x.reshape(B * nb, L)).cuda(),
+                                                         torch.from_numpy(p32['breath_block.conv1.weight']).cuda(), nb))
+    ref = _c5_reference(p64, x.astype(np.float64), t.astype(np.float64), nb, bf16_convs=True, bf16_storage=True,
+                        stem_recomputed=recomputed)
     exact = _c5_reference(p64, x.astype(np.float64), t.astype(np.float64), nb)
     F_.set_conv_dtype('bf16')
     try:
