@@ -94,7 +94,7 @@ SIGNATURES = {
     'da_bn_param_grad_multi': (_I, [ctypes.POINTER(BnPgradDesc), _I, _I, _P]),
     'da_bn_stats_fused': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _F, _P]),
     'da_bn_relu_ss': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
-    'da_bn_bwd_ss': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _I, _P, _U, _F, _I, _P, _P]),
+    'da_bn_bwd_ss': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _I, _P, _U, _F, _I, _P, _P, _I, _P]),
     'da_conv1x1_bn': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _I, ctypes.c_long, _I, _F, _P, _P]),
     'da_conv3_winograd_drop': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _U, _F, _P, _I, _P]),
     'da_stat_records_floats': (_Z, [ctypes.c_long, _I]),
@@ -105,6 +105,7 @@ SIGNATURES = {
     'da_conv3_winograd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'da_conv3_winograd4': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'da_conv3_bf16': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'da_conv3_bf16_bn': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P]),
     'da_pack_conv3_bf16': (_I, [_P, _P, _P, _I, _I, _P]),
     'da_conv3_x3p': (_I, [_P, _P, _P] + [_I] * 6 + [_P]),
     'da_conv_x3p_s2_fwd': (_I, [_P] * 5 + [_I] * 4 + [_P]),

@@ -440,6 +440,8 @@ struct BnBwdExt {
   const long long* seed;
   uint32_t salt;
   float p;
+  void* hout;          // mask_mode 4: the activation relu(fma(x, sc, sh)) the forward never stored, written here (activation
+  int ldh;             // storage type) for the weight gradient of the conv behind it -- or NULL
 };
 
 template <int NV, int NQ>
@@ -635,8 +637,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict
   for (int k = 0; k < NPOS; ++k) {
     const int p = slot + k * P;
     if (EXT && mask_mode == 4) {   // before xh overwrites the raw value
+      f32x4 h;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[k][e] = (fmaf(xh[k][e], sc[e], sh[e]) > 0.f) ? g[k][e] : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        h[e] = fmaf(xh[k][e], sc[e], sh[e]);
+        g[k][e] = (h[e] > 0.f) ? g[k][e] : 0.f;
+        h[e] = fmaxf(h[e], 0.f);
+      }
+      if (ext.hout && p < Wn)
+        Act<AT>::st4(reinterpret_cast<AT*>(ext.hout) + (base + p) * (size_t)ext.ldh + cg * CGB + q * 4, h);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) xh[k][e] = (xh[k][e] - mu[e]) * is[e];
@@ -1196,13 +1205,13 @@ int da_bn_relu_ss(const float* x, int ldx, float* out, int ldo, int W, int Wn, i
 //   dx = BatchNorm input gradient (+ add[:, 0:C], pitch ldadd -- dx may alias add: the in-place accumulation into the
 //   block's gradient buffer); then, with drop_p > 0, the dropout mask (seed, salt) of the contiguous [W Wn][drop_g]
 //   tensor on the channels [C - drop_g, C) of dx.  ds [2][W][C]: the window sums for da_bn_param_grad_multi.
-int da_bn_bwd_ss(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
-                 const float* add, int ldadd, int W, int Wn, int C, const float* mean, const float* invstd, int ldstat,
+int da_bn_bwd_ss(const void* dout, int ldd, const void* x, int ldx, const void* out, int ldo, void* dx, int lddx,
+                 const void* add, int ldadd, int W, int Wn, int C, const float* mean, const float* invstd, int ldstat,
                  const float* gamma, const float* beta, int relu, int half_dout, const long long* drop_seed, unsigned drop_salt, float drop_p, int drop_g, float* ds,
-                 hipStream_t stream) {
+                 void* hout, int ldh, hipStream_t stream) {
   DA_ENTER();
-  if (g_act_bf16) return DA_EINVAL;
   if (!dout || !x || !dx || !mean || !invstd || !gamma || !beta || !ds) return DA_EINVAL;
+  if (hout && (relu != 1 || ldh % 4 || ldh < C)) return DA_EINVAL;
   if (C % CG || ldd % 4 || ldx % 4 || lddx % 4 || (add && ldadd % 4) || ldstat % 4 || ldstat < C || Wn < 1) return DA_EINVAL;
   if (half_dout && (Wn & 1)) return DA_EINVAL;
   if (relu < 0 || relu > 2 || (relu == 2 && (!out || ldo % 4))) return DA_EINVAL;
@@ -1213,13 +1222,14 @@ int da_bn_bwd_ss(const float* dout, int ldd, const float* x, int ldx, const floa
   if (!threads) return DA_EINVAL;
   BnBwdExt ext;
   ext.ldstat = ldstat; ext.half_dout = half_dout ? 1 : 0; ext.drop_c0 = C - drop_g; ext.drop_g = drop_g;
-  ext.seed = drop_seed; ext.salt = drop_salt; ext.p = drop_p;
+  ext.seed = drop_seed; ext.salt = drop_salt; ext.p = drop_p; ext.hout = hout; ext.ldh = ldh;
   float* s1 = ds;
   float* s2 = ds + (size_t)W * C;
 #define BN_BWDSS_LAUNCH(QB, CH)                                                                                              \
-  hipLaunchKernelGGL((bn_bwd_fused_kernel<float, FUSED_NPOS, QB, 0, 1>), dim3(W, C / CH), dim3(threads), 0, stream, dout, ldd, x,  \
-                     ldx, out, ldo, dx, lddx, (float*)nullptr, 0, Wn, C, mean, invstd, gamma, beta,                                 \
-                     relu == 1 ? 4 : (relu == 2 ? 2 : 0), s1, s2, add, ldadd, (const unsigned long long*)nullptr, ext)
+  DA_ACT_DISPATCH(hipLaunchKernelGGL((bn_bwd_fused_kernel<AT, FUSED_NPOS, QB, 0, 1>), dim3(W, C / CH), dim3(threads), 0, stream,    \
+                                     (const AT*)dout, ldd, (const AT*)x, ldx, (const AT*)out, ldo, (AT*)dx, lddx, (AT*)nullptr, 0,  \
+                                     Wn, C, mean, invstd, gamma, beta, relu == 1 ? 4 : (relu == 2 ? 2 : 0), s1, s2,                 \
+                                     (const AT*)add, ldadd, (const unsigned long long*)nullptr, ext))
   if (cgb == 32) BN_BWDSS_LAUNCH(3, 32);
   else if (cgb == 16) BN_BWDSS_LAUNCH(2, 16);
   else BN_BWDSS_LAUNCH(1, 8);

@@ -190,7 +190,7 @@ __device__ __forceinline__ void bn_scale_shift(float mean, float invstd, float g
 // A tile whose first unit lies in front of the window started in the previous one: the window is its SECOND slot.
 // (Measured alternatives, whole densenet18 step at B = 64 / B = 16: this form 1.287 / 0.791 ms; a two-pass weighted mean
 // without divisions 1.311 / 0.813; the records staged through LDS by the whole block in one sweep 1.308 / 0.813.)
-#define MERGE_B 4
+template <int MERGE_B = 4>
 __device__ __forceinline__ void merge_stat_records(const float* __restrict__ part, int tiles, int nc, int Wu, int w, int c,
                                                    float eps, float& mean, float& invstd) {
   const int u0 = w * Wu;

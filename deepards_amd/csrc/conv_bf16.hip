@@ -29,6 +29,22 @@ struct ConvBf16Args {
   void* y;              // [M][ldy] activations, first N channels
   int M, L, ldx, C, ldy, N, accumulate;
   FastDiv divL;
+  // the BatchNorm in front of / behind the conv without a pass of its own (da_conv3_bf16_bn; resnet.py:27-33 conv1 -> bn1 ->
+  // relu -> conv2): windows of Wn positions.
+  //   stat_part != NULL: the statistics records (include/deepards_hip.h; units = positions, two records per 128-position tile)
+  //     of the STORED output, written by the epilogue;
+  //   in_pend != NULL: the input is a raw conv output whose records are in_pend -- every block merges the records of its
+  //     tile's (<= 2) windows into scale / shift tables, the tile holding a window's first position publishes (mean, invstd),
+  //     and relu(fma(x, sc, sh)) is what gets staged
+  int Wn;
+  float* stat_part;
+  const float* in_pend;
+  float* in_mean;
+  float* in_invstd;
+  const float* in_gamma;
+  const float* in_beta;
+  int in_tiles;
+  float in_eps;
 };
 
 #define CB_TM 128
@@ -52,12 +68,14 @@ template <> struct Stage<float> {
   static __device__ __forceinline__ reg zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
   static __device__ __forceinline__ reg ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
   static __device__ __forceinline__ f32x2v bits(const reg& v) { return cvt4_bf16(v); }
+  static __device__ __forceinline__ f32x4 wide(const reg& v) { return v; }
 };
 template <> struct Stage<__bf16> {
   typedef f32x2v reg;
   static __device__ __forceinline__ reg zero() { return f32x2v{0.f, 0.f}; }
   static __device__ __forceinline__ reg ld(const __bf16* p) { return *reinterpret_cast<const f32x2v*>(p); }
   static __device__ __forceinline__ f32x2v bits(const reg& v) { return v; }
+  static __device__ __forceinline__ f32x4 wide(const reg& v) { return X3::widen4(v); }
 };
 
 // activations in the x3 format (common.h): the three bf16 terms of 4 channels are 3 x 8 bytes, 32 bytes apart
@@ -79,9 +97,8 @@ __device__ __forceinline__ typename Stage<AT>::reg stage_ld(const void* base, si
   }
 }
 
-template <typename AT>
-__global__ __launch_bounds__(256) void conv3_bf16_kernel(ConvBf16Args a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[CB_LDS_BYTES];
+template <typename AT, bool STATS, bool XF>
+__device__ __forceinline__ void conv3_bf16_body(const ConvBf16Args& a, unsigned char* lds, float* xtab) {
   const AT* ax = reinterpret_cast<const AT*>(a.x);
   AT* ay = reinterpret_cast<AT*>(a.y);
   unsigned char* Xs = lds;                            // [130][80 B]: positions P0-1 .. P0+128
@@ -99,12 +116,15 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(ConvBf16Args a) {
   constexpr int NXP = (CB_XROWS + 31) / 32;           // 5 passes, the last one 2 rows
   long xoff[NXP];
   bool xok[NXP];
+  int xslot[NXP];                                     // XF: this row's scale / shift table (window w0 or w0 + 1), + the quad
+  const int w0 = XF ? P0 / a.Wn : 0;
 #pragma unroll
   for (int p = 0; p < NXP; ++p) {
     const int r = p * 32 + xrow;
     const long P = (long)P0 - 1 + r;
     xok[p] = r < CB_XROWS && P >= 0 && P < a.M;
     xoff[p] = (xok[p] ? P : 0) * a.ldx + xq * 4;
+    xslot[p] = (XF && P >= (long)(w0 + 1) * a.Wn ? 2 * a.C : 0) + xq * 4;
   }
   // W loader: 64 rows x 4 slots of 8 channels per pass (rows 4 apart per 8 lanes: ds_write_b128), 3 passes = 3 taps
   const int wm_ = tid >> 3, ws = tid & 3;
@@ -149,12 +169,41 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(ConvBf16Args a) {
 
   const int kc = a.C >> 5;
   gload(0);
+  if (XF) {   // the scale / shift vectors of this tile's two windows, from the records (first operand loads in flight)
+    const int nwin = a.M / a.Wn;
+    for (int i = tid; i < 2 * a.C; i += 256) {
+      const int ws_ = i >= a.C ? 1 : 0, c = i - ws_ * a.C, w = w0 + ws_;
+      float sc = 0.f, sh = 0.f;
+      if (w < nwin) {
+        float mu, is;
+        merge_stat_records<8>(a.in_pend, a.in_tiles, a.C, a.Wn, w, c, a.in_eps, mu, is);
+        const long wP = (long)w * a.Wn;               // the window's first position: its tile publishes
+        if (n_blk == 0 && wP >= P0 && wP < P0 + CB_TM) {
+          a.in_mean[(size_t)w * a.C + c] = mu;
+          a.in_invstd[(size_t)w * a.C + c] = is;
+        }
+        bn_scale_shift(mu, is, a.in_gamma[c], a.in_beta[c], sc, sh);
+      }
+      xtab[(ws_ * 2) * a.C + c] = sc;
+      xtab[(ws_ * 2 + 1) * a.C + c] = sh;
+    }
+  }
+  auto staged = [&](int p, int ks) -> f32x2v {            // the bf16 bits loader slot p puts into the image
+    if (!XF) return Stage<AT>::bits(rx[p]);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(&xtab[xslot[p] + (ks << 5)]);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(&xtab[xslot[p] + a.C + (ks << 5)]);
+    const f32x4 v = Stage<AT>::wide(rx[p]);
+    f32x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+    return xok[p] ? cvt4_bf16(h) : f32x2v{0.f, 0.f};      // rows outside the tensor stay zeros
+  };
   for (int ks = 0; ks < kc; ++ks) {
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < NXP; ++p) {
       const int r = p * 32 + xrow;
-      if (r < CB_XROWS) *reinterpret_cast<f32x2v*>(Xs + r * CB_PITCH + xq * 8) = Stage<AT>::bits(rx[p]);
+      if (r < CB_XROWS) *reinterpret_cast<f32x2v*>(Xs + r * CB_PITCH + xq * 8) = staged(p, ks);
     }
 #pragma unroll
     for (int t = 0; t < 3; ++t) *reinterpret_cast<f32x4*>(Ws + (t * CB_TN + wrow) * CB_PITCH + ws * 16) = rw[t];
@@ -177,18 +226,79 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(ConvBf16Args a) {
   }
 
   // lane holds output channel n_blk + wn*32 + l%32 of the positions (r & 3) + 8 (r >> 2) + 4 (l / 32) of each 32-row tile
+  // STATS: the wave's 64 positions x 32 channels are one record tile's share -- per channel (count, mean, centred M2) of the
+  // values AS STORED (rounded when the storage is bf16), single pass about a pivot (the chunk's first position), the window
+  // that starts inside the chunk in the second slot
+  const long Pf = (long)P0 + wm * 64;
+  long bound = 0;
+  float piv = 0.f, s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+  if (STATS) {
+    const uint32_t Pfc = (uint32_t)(Pf < a.M ? Pf : 0);
+    bound = ((long)(Pfc / (uint32_t)a.Wn) + 1) * a.Wn;
+    float v0 = acc[0][0];
+    if constexpr (__is_same(AT, __bf16)) v0 = (float)(__bf16)v0;
+    piv = __shfl(v0, frow, 64);
+  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const long P = (long)P0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      const long P = Pf + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
       if (P < a.M) {
         AT* o = ay + P * a.ldy + n_blk + wn * 32 + frow;
         float v = acc[mt][r];
         if (a.accumulate) v += Act<AT>::ld1(o);
         Act<AT>::st1(o, v);
+        if (STATS) {
+          if constexpr (__is_same(AT, __bf16)) v = (float)(__bf16)v;
+          const float d = v - piv;
+          const int sl = P >= bound ? 1 : 0;
+          s1[sl] += d;
+          s2[sl] = fmaf(d, d, s2[sl]);
+        }
       }
     }
+  if (STATS) {
+    const long nrt = ((long)a.M + 63) >> 6, rt = Pf >> 6;
+    if (rt < nrt) {
+      const long lastP = Pf + 63 < a.M ? Pf + 63 : (long)a.M - 1;
+      float cnt[2];
+      cnt[1] = lastP >= bound ? (float)(lastP - bound + 1) : 0.f;
+      cnt[0] = (float)(lastP - Pf + 1) - cnt[1];
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        s1[sl] += __shfl_xor(s1[sl], 32, 64);
+        s2[sl] += __shfl_xor(s2[sl], 32, 64);
+      }
+      if (kg == 0) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          const float inv = cnt[sl] > 0.f ? 1.f / cnt[sl] : 0.f;
+          float* rec = a.stat_part + ((size_t)(rt * 2 + sl) * 2) * a.N + n_blk + wn * 32 + frow;   // [tile][slot][{mean, M2}][N]
+          rec[0] = piv + s1[sl] * inv;
+          rec[a.N] = fmaxf(s2[sl] - s1[sl] * s1[sl] * inv, 0.f);
+        }
+        if (frow == 0 && n_blk == 0 && wn == 0) {
+          a.stat_part[(size_t)nrt * 4 * a.N + rt * 2] = cnt[0];
+          a.stat_part[(size_t)nrt * 4 * a.N + rt * 2 + 1] = cnt[1];
+        }
+      }
+    }
+  }
+}
+
+template <typename AT>
+__global__ __launch_bounds__(256) void conv3_bf16_kernel(ConvBf16Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[CB_LDS_BYTES];
+  conv3_bf16_body<AT, false, false>(a, lds, nullptr);
+}
+
+// ... with the output's statistics records from the epilogue and / or relu(BatchNorm(x)) applied while x is staged
+template <typename AT, bool STATS, bool XF>
+__global__ __launch_bounds__(256) void conv3_bf16_bn_kernel(ConvBf16Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[CB_LDS_BYTES];
+  extern __shared__ __attribute__((aligned(16))) float xtab_dyn[];     // XF: [2 windows][{sc, sh}][C]
+  conv3_bf16_body<AT, STATS, XF>(a, lds, xtab_dyn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -829,9 +939,47 @@ int da_conv3_bf16(const void* x, const void* wpk, void* y, int rows, int L, int 
   a.x = x; a.w = reinterpret_cast<const __bf16*>(wpk); a.y = y;
   a.M = (int)M; a.L = L; a.ldx = ldx; a.C = C; a.ldy = ldy; a.N = N; a.accumulate = accumulate;
   a.divL = make_fastdiv((uint32_t)L);
+  a.Wn = 1; a.stat_part = nullptr; a.in_pend = nullptr; a.in_mean = a.in_invstd = nullptr; a.in_gamma = a.in_beta = nullptr;
+  a.in_tiles = 0; a.in_eps = 0.f;
   const long tiles = ((M + CB_TM - 1) / CB_TM) * (N / CB_TN);
   if (tiles > 0x7fffffffl) return DA_EINVAL;
   DA_ACT_DISPATCH(hipLaunchKernelGGL(conv3_bf16_kernel<AT>, dim3((unsigned)tiles), dim3(256), 0, stream, a));
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// da_conv3_bf16 with a BatchNorm folded into either end (windows of R rows; resnet.py:27-33: conv1 -> bn1 -> relu -> conv2):
+//   stat_part != NULL: the statistics records of y (da_stat_records_floats(rows * L, N) floats; units = positions) written by
+//     the epilogue -- of the values as stored;
+//   in_pend != NULL: x is a raw conv output with records in_pend (rows * L positions, C channels): relu(gamma (x - mean)
+//     invstd + beta) is applied while x is staged, (mean, invstd) are published to in_mean / in_invstd [W][C].
+// A window needs >= 130 positions (a 128-position tile and its halo then touch two windows at most).  No accumulate.
+int da_conv3_bf16_bn(const void* x, const void* wpk, void* y, int rows, int L, int ldx, int C, int ldy, int N, int R,
+                     const float* in_pend, float* in_mean, float* in_invstd, const float* gamma, const float* beta, float eps,
+                     float* stat_part, hipStream_t stream) {
+  DA_ENTER();
+  if (!x || !wpk || !y || rows < 0 || L < 1 || C % 32 || N % CB_TN || C < 32 || N < CB_TN || ldx % 4 || ldx < C || ldy < N)
+    return DA_EINVAL;
+  if (R < 1 || rows % R || (long)R * L < CB_TM + 2 || (!stat_part && !in_pend)) return DA_EINVAL;
+  if (in_pend && (!in_mean || !in_invstd || !gamma || !beta || C > 1024)) return DA_EINVAL;
+  if (rows == 0) return DA_OK;
+  const long M = (long)rows * L;
+  if (M >= 0x7fffffffl) return DA_EINVAL;
+  ConvBf16Args a;
+  a.x = x; a.w = reinterpret_cast<const __bf16*>(wpk); a.y = y;
+  a.M = (int)M; a.L = L; a.ldx = ldx; a.C = C; a.ldy = ldy; a.N = N; a.accumulate = 0;
+  a.divL = make_fastdiv((uint32_t)L);
+  a.Wn = R * L; a.stat_part = stat_part; a.in_pend = in_pend; a.in_mean = in_mean; a.in_invstd = in_invstd;
+  a.in_gamma = gamma; a.in_beta = beta; a.in_tiles = (int)((M + 63) / 64); a.in_eps = eps;
+  const long tiles = ((M + CB_TM - 1) / CB_TM) * (N / CB_TN);
+  if (tiles > 0x7fffffffl) return DA_EINVAL;
+  const size_t shm = in_pend ? (size_t)4 * C * sizeof(float) : 0;
+#define CB_BN_LAUNCH(ST, XF_)                                                                                           \
+  DA_ACT_DISPATCH(hipLaunchKernelGGL((conv3_bf16_bn_kernel<AT, ST, XF_>), dim3((unsigned)tiles), dim3(256), shm, stream, a))
+  if (stat_part && in_pend) CB_BN_LAUNCH(true, true);
+  else if (in_pend) CB_BN_LAUNCH(false, true);
+  else CB_BN_LAUNCH(true, false);
+#undef CB_BN_LAUNCH
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

@@ -479,6 +479,12 @@ class BasicBlockFunction(Function):
             _is_wino(w1, stride, 1) == 16 and _is_wino(wd, stride, 0) == 16
         pair = bf16_pair or (wd is not None and stride == 2 and not _is_wino(w1, stride, 1))
         s2x = in3 and stride == 2
+        # conv dtype bf16, a stride-1 block: bn1 has no pass of its own (H.conv3_bf16_bn at both ends); a window must cover a
+        # 128-position tile and its halo
+        fuse1 = _BN1_FUSED and not in3 and stride == 1 and R * x.shape[1] >= 130 and x.shape[0] % R == 0 and \
+            _is_wino(w1, 1, 1) == 16 and _is_wino(w2, 1, 1) == 16 and \
+            H.bn_single_pass(x.shape[0] // R, R * x.shape[1], w1.shape[0])
+        ctx.fuse1 = fuse1
         if s2x:           # the stride-2 block entry on the pre-split input: conv1 and the downsample conv in one launch
             if not s2_x3_ok(w1, wd, x3.shape[1]):
                 raise ValueError('x3 input handed to a stride-2 block whose shape has no x3 kernels')
@@ -486,6 +492,8 @@ class BasicBlockFunction(Function):
             pair = True
         elif in3:         # k3 s1 conv on the pre-split input
             y1 = _conv_fwd(x3, w1, 1, 1)
+        elif fuse1:       # conv dtype bf16, stride 1: the statistics records of y1 come out of the conv's epilogue
+            y1, rec1 = H.conv3_bf16_bn(x, _pack(w1, 16)[2], R, want_records=True)
         elif bf16_pair:   # conv dtype bf16: the same shared launch on the bf16 kernel
             y1, yd = H.conv_fwd_bf16_s2(x, _pack(w1, 16)[2], _pack(wd, 16)[2])
         elif pair:    # the stride-2 conv and the 1x1 downsample read the same input: one launch
@@ -499,9 +507,19 @@ class BasicBlockFunction(Function):
         if (in3 or want_out3) and not mid3:
             raise ValueError('x3 input / output asked of a block whose shape has no x3 store forms')
         s1 = _Stats()
-        h1 = _bn_apply_x(y1, R, s1, st1, g1, b1, True) if mid3 else _bn_apply(y1, R, s1, st1, g1, b1, True)
-        _tap(h1)
-        y2 = _conv_fwd(h1, w2, 1, 1)
+        if fuse1:         # bn1 + ReLU applied while conv2 stages its operand: statistics from the records conv1's epilogue wrote
+            wn_ = y1.shape[0] // R
+            s1.mean = torch.empty((wn_, y1.shape[2]), device=y1.device, dtype=torch.float32)
+            s1.invstd = torch.empty_like(s1.mean)
+            y2 = H.conv3_bf16_bn(y1, _pack(w2, 16)[2], R, rec=rec1, mean=s1.mean, invstd=s1.invstd, gamma=g1, beta=b1, eps=st1.eps)
+            _running(y1, R, s1, st1)
+            h1 = y1                                     # (placeholder in the saved list: the backward rebuilds h1 for the weight gradient)
+            if DECISION_TAP is not None:
+                _tap(H.bn_fwd(y1, R, g1, b1, relu=True, eps=st1.eps)[0])
+        else:
+            h1 = _bn_apply_x(y1, R, s1, st1, g1, b1, True) if mid3 else _bn_apply(y1, R, s1, st1, g1, b1, True)
+            _tap(h1)
+            y2 = _conv_fwd(h1, w2, 1, 1)
         s2 = _Stats()
         if wd is not None:
             if not pair:
@@ -552,9 +570,26 @@ class BasicBlockFunction(Function):
                 dyd, dgd, dbd = _bn_bwd_x(g, yd, R, md, idd, gd, bd, 0, tgd, tbd)
             else:
                 dyd, dgd, dbd = _bn_bwd(g, yd, R, md, idd, gd, bd, 0, tgd, tbd, dx=g)
-        dw2 = _wgrad(dy2, h1, 3, 1, 1, tw2)
-        dh1 = _conv_dgrad(dy2, w2, 1, 1, y1.shape[1])
-        if in3:           # conv1 is a k3 s1 conv on x3 operands too
+        if ctx.fuse1:     # h1 was never stored: the BatchNorm backward rebuilds it (same fused multiply-add) for conv2's weight gradient
+            dh1 = _conv_dgrad(dy2, w2, 1, 1, y1.shape[1])
+            h1 = torch.empty_like(y1)
+            ds1 = H.bn_bwd_ss(dh1, y1, R, m1, i1, g1, b1, 1, dh1, hout=h1)
+            dy1, dg1, db1 = dh1, None, None
+            if tg1 is not None and tb1 is not None:
+                if _STEP['on']:
+                    _STEP['pgrad'].append((ds1, tg1, tb1))
+                else:
+                    H.bn_param_grad_multi([(ds1, tg1, tb1)], accumulate=True)
+            else:
+                dg1, db1 = torch.empty_like(g1), torch.empty_like(b1)
+                H.bn_param_grad_multi([(ds1, dg1, db1)], accumulate=False)
+            dw2 = _wgrad(dy2, h1, 3, 1, 1, tw2)
+        else:
+            dw2 = _wgrad(dy2, h1, 3, 1, 1, tw2)
+            dh1 = _conv_dgrad(dy2, w2, 1, 1, y1.shape[1])
+        if ctx.fuse1:
+            pass
+        elif in3:           # conv1 is a k3 s1 conv on x3 operands too
             dy1, dg1, db1 = _bn_bwd_x(dh1, y1, R, m1, i1, g1, b1, 1, tg1, tb1)
         else:
             dy1, dg1, db1 = _bn_bwd(dh1, y1, R, m1, i1, g1, b1, 1, tg1, tb1, dx=dh1)
@@ -574,6 +609,7 @@ class BasicBlockFunction(Function):
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None, None
 
 
+_BN1_FUSED = os.environ.get('DA_BN1_FUSED', '0') == '1'   # conv dtype bf16: bn1 of a stride-1 residual block without a pass of its own -- measured slower (profiles/r04_bf16_bn1_fusion.txt): opt-in
 _DENSE_BLOCK = os.environ.get('DA_DENSE_BLOCK', '1') != '0'   # 0: the per-layer Functions below (the path shapes without the block kernels take)
 
 

@@ -235,6 +235,30 @@ def conv3_bf16(x, wpk, out=None, accumulate=False):
     return out
 
 
+
+def conv3_bf16_bn(x, wpk, R, rec=None, mean=None, invstd=None, gamma=None, beta=None, eps=1e-5, want_records=False):
+    """conv3_bf16 with a BatchNorm (windows of R rows) folded into either end: rec (+ mean / invstd (W, C) tables to publish
+    into, gamma, beta): x is a raw conv output whose statistics records are ``rec`` -- relu(norm(x)) is applied while x is
+    staged; want_records: -> (out, records of the output as stored; units = positions)."""
+    _rlc(x, 'x')
+    rows, l, c = x.shape
+    three, n, c2 = wpk.shape
+    if three != 3 or c2 != c or c % 32 or n % 64 or wpk.dtype != torch.bfloat16 or not wpk.is_contiguous() or rows % R:
+        raise ValueError('conv3_bf16_bn: unsupported shape x%s w%s' % (tuple(x.shape), tuple(wpk.shape)))
+    L = _lib.lib()
+    if rec is not None:
+        w = rows // R
+        if rec.numel() != L.da_stat_records_floats(rows * l, c) or tuple(mean.shape) != (w, c) or tuple(invstd.shape) != (w, c) \
+                or not (mean.is_contiguous() and invstd.is_contiguous()):
+            raise ValueError('conv3_bf16_bn: records / tables do not fit x%s' % (tuple(x.shape),))
+    out = torch.empty((rows, l, n), device=x.device, dtype=ACT)
+    part = stat_records(rows * l, n, x.device) if want_records else None
+    _chk(L.da_conv3_bf16_bn(_p(x), _p(wpk), _p(out), rows, l, c, c, n, n, R, _p(rec), _p(mean), _p(invstd),
+                            _p(_f32(gamma)) if gamma is not None else None, _p(_f32(beta)) if beta is not None else None, eps,
+                            _p(part), _stream()), 'da_conv3_bf16_bn')
+    return (out, part) if want_records else out
+
+
 def is_x3(t):
     """An activation in the x3 format (exact three-term bf16 split, include/deepards_hip.h): (rows, L, C/16, 3, 16) bf16."""
     return t is not None and t.dtype == torch.bfloat16 and t.dim() == 5 and t.shape[3] == 3 and t.shape[4] == 16
@@ -897,6 +921,12 @@ def bn_param_grad_multi(items, accumulate=True):
 # the dense block as one design (include/deepards_hip.h "the dense block as one design"): a pitched buffer per block, one
 # pitched statistics table per block, relu(norm1(x)) never stored
 # ------------------------------------------------------------------------------------------------
+def bn_single_pass(w, wn, c):
+    """Whether a BatchNorm over W windows of wn positions x C channels has the single-pass geometry (a window slab in one
+    block's registers): what bn_bwd_ss and the block-fused forms need."""
+    return c % 32 == 0 and _lib.lib().da_bn_mask_words(w, wn, c) > 0
+
+
 def dense_fused_ok(rows, R, l, channels):
     """Whether BatchNorms over (rows, l, C) for every C in ``channels`` have the single-pass geometry the dense-block
     kernels need (float storage, a window slab in one block's registers, a conv tile within two windows)."""
@@ -934,13 +964,16 @@ def bn_relu_ss(xv, R, mean_v, invstd_v, gamma, beta):
     return out
 
 
-def bn_bwd_ss(dout, xv, R, mean_v, invstd_v, gamma, beta, relu, dx, add=None, half_dout=False, drop=None, out=None):
+def bn_bwd_ss(dout, xv, R, mean_v, invstd_v, gamma, beta, relu, dx, add=None, half_dout=False, drop=None, out=None, hout=None):
     """Backward of relu(norm(xv)) (relu: decision from the fused-multiply-add form) or norm(xv): dout (rows, L, C) -- or
     (rows, L / 2, C) with half_dout (a transition's pooling in front of its conv) --; relu = 1: decision of the fused
     multiply-add form, 2: the sign of ``out`` (the stored output of a bn_fwd forward), 0: none; dx a (rows, L, C) channel slice that
     receives the input gradient (+ ``add``, which may be dx itself: in-place accumulation into the block's gradient
-    buffer); drop = (seed, salt, p, g): the dropout mask on the last g channels of dx.  -> ds (2, W, C) window sums."""
-    ldd, ldx, lddx = _pv(dout, 'dout'), _pv(xv, 'x'), _pv(dx, 'dx')
+    buffer); drop = (seed, salt, p, g): the dropout mask on the last g channels of dx; hout (relu = 1): receives
+    relu(norm(xv)) itself (the activation the forward never stored).  -> ds (2, W, C) window sums.  Either storage type
+    (bf16: contiguous tensors)."""
+    _ld = _pv if ACT == torch.float32 else (lambda t, name: _rlc(t, name).shape[2])
+    ldd, ldx, lddx = _ld(dout, 'dout'), _ld(xv, 'x'), _ld(dx, 'dx')
     rows, l, c = xv.shape
     w = rows // R
     if rows % R or tuple(dx.shape) != (rows, l, c) or tuple(dout.shape) != (rows, l // 2 if half_dout else l, c) or \
@@ -953,17 +986,21 @@ def bn_bwd_ss(dout, xv, R, mean_v, invstd_v, gamma, beta, relu, dx, add=None, ha
     if add is not None:
         if tuple(add.shape) != (rows, l, c):
             raise ValueError('bn_bwd_ss: bad add operand')
-        ldadd = _pv(add, 'add')
+        ldadd = _ld(add, 'add')
     seed, salt, p, g = drop if drop is not None else (None, 0, 0.0, 0)
-    ldo = 0
+    ldo = ldh = 0
     if relu == 2:
         if out is None or tuple(out.shape) != (rows, l, c):
             raise ValueError('bn_bwd_ss: relu = 2 takes its decisions from the stored output')
-        ldo = _pv(out, 'out')
+        ldo = _ld(out, 'out')
+    if hout is not None:
+        if relu != 1 or tuple(hout.shape) != (rows, l, c):
+            raise ValueError('bn_bwd_ss: hout is the (rows, L, C) activation of the relu = 1 form')
+        ldh = _ld(hout, 'hout')
     ds = torch.empty((2, w, c), device=xv.device, dtype=torch.float32)
     _chk(_lib.lib().da_bn_bwd_ss(_p(dout), ldd, _p(xv), ldx, _p(out) if relu == 2 else None, ldo, _p(dx), lddx, _p(add), ldadd, w,
                                  R * l, c, _p(mean_v), _p(invstd_v), ldstat, _p(_f32(gamma)), _p(_f32(beta)), int(relu), 1 if half_dout else 0,
-                                 _p(seed) if p > 0 else None, salt, p, g, _p(ds), _stream()), 'da_bn_bwd_ss')
+                                 _p(seed) if p > 0 else None, salt, p, g, _p(ds), _p(hout), ldh, _stream()), 'da_bn_bwd_ss')
     return ds
 
 

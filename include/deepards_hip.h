@@ -104,6 +104,14 @@ int da_wino4_weights(const float* w, float* u, int co, int ci, int transpose, da
  * (reversed); either may be NULL. */
 int da_conv3_bf16(const da_act_t* x, const void* wpk, da_act_t* y, int rows, int L, int ldx, int C, int ldy, int N,
                   int accumulate, da_stream_t stream);
+/* da_conv3_bf16 with a BatchNorm (windows of R rows, R * L >= 130) folded into either end -- resnet.py:27-33 conv1 -> bn1 ->
+ * relu -> conv2 without a pass for bn1.  stat_part != NULL: the statistics records of y AS STORED
+ * (da_stat_records_floats(rows * L, N) floats, units = positions) from the epilogue.  in_pend != NULL: x is a raw conv output
+ * with records in_pend; relu(gamma (x - mean) invstd + beta) is applied while x is staged and (mean, invstd) are published to
+ * in_mean / in_invstd [rows / R][C] (the backward and the running statistics read them). */
+int da_conv3_bf16_bn(const da_act_t* x, const void* wpk, da_act_t* y, int rows, int L, int ldx, int C, int ldy, int N, int R,
+                     const float* in_pend, float* in_mean, float* in_invstd, const float* gamma, const float* beta, float eps,
+                     float* stat_part, da_stream_t stream);
 int da_pack_conv3_bf16(const float* w, void* wf, void* wd, int co, int ci, da_stream_t stream);
 /* ---- fp32 convolutions on the bf16 matrix cores with PRE-SPLIT operands (conv_x3p.hip; conv arithmetic 'f32x3p', opt-in) ----
  * Every operand is split exactly into three bf16 terms and a product taken as six bf16 MFMA products (the dropped ones
@@ -252,11 +260,13 @@ int da_bn_relu_ss(const float* x, int ldx, float* out, int ldo, int W, int Wn, i
  * relu = 2: from the sign of the stored output `out`, the forward of da_bn_fwd) or norm(x) (relu = 0): statistics from the
  * pitched tables; half_dout: dout has Wn / 2 positions per window, g[p] = dout[p / 2] / 2 (a transition's AvgPool1d(2,2) in
  * front of its conv); dx = input gradient (+ add[:, 0:C]; dx may alias add), then with drop_p > 0 the dropout mask
- * (da_dropout's, seed / salt, contiguous [W Wn][drop_g]) on dx's channels [C - drop_g, C); ds [2][W][C] window sums */
-int da_bn_bwd_ss(const float* dout, int ldd, const float* x, int ldx, const float* out, int ldo, float* dx, int lddx,
-                 const float* add, int ldadd, int W, int Wn, int C, const float* mean, const float* invstd, int ldstat,
-                 const float* gamma, const float* beta, int relu, int half_dout, const long long* drop_seed, unsigned drop_salt, float drop_p, int drop_g, float* ds,
-                 da_stream_t stream);
+ * (da_dropout's, seed / salt, contiguous [W Wn][drop_g]) on dx's channels [C - drop_g, C); ds [2][W][C] window sums;
+ * hout != NULL (relu = 1): the activation relu(norm(x)) itself, which the forward never stored, is written there for the
+ * weight gradient of the conv behind it (the residual blocks' bn1 under da_conv3_bf16_bn) */
+int da_bn_bwd_ss(const da_act_t* dout, int ldd, const da_act_t* x, int ldx, const da_act_t* out, int ldo, da_act_t* dx, int lddx,
+                 const da_act_t* add, int ldadd, int W, int Wn, int C, const float* mean, const float* invstd, int ldstat,
+                 const float* gamma, const float* beta, int relu, int half_dout, const long long* drop_seed, unsigned drop_salt,
+                 float drop_p, int drop_g, float* ds, da_act_t* hout, int ldh, da_stream_t stream);
 /* y[m][0:N] (pitch ldy) = sum_c w[n][c] relu(norm(x))[m][c], the activation applied while x (first C channels, pitch ldx) is
  * staged; pool != 0: the transition form, (h[2m] + h[2m+1]) / 2 in front of the conv (Lin even, Lin / 2 outputs per row).
  * w [N][C] = the torch weight of the k = 1 conv as it lies.  N % 64 == 0, C % 32 == 0, R * Lout >= 64.

@@ -163,6 +163,69 @@ def test_recomputing_stem_bf16_storage(H, rows, lin, R, pool):
     assert torch.equal(dw16, dw32) and torch.equal(ds16, ds32)
 
 
+@pytest.mark.parametrize('st', ['f32', 'bf16'])
+@pytest.mark.parametrize('C,L,R,W', [(64, 56, 20, 3), (128, 28, 20, 2), (512, 7, 20, 5), (256, 14, 20, 4)])
+def test_conv3_bf16_with_batchnorm_folded_in(H, C, L, R, W, st):
+    """H.conv3_bf16_bn (resnet.py:27-33 conv1 -> bn1 -> relu -> conv2 with no pass for bn1): (a) the conv output is
+    conv3_bf16's, bit for bit, and the statistics the records merge to are the per-window statistics of that STORED tensor
+    (np_ref.bn_window_fwd, fp64) to 2e-6 / 2e-5; (b) with the records as input, the published (mean, invstd) are those, and the
+    result is conv3_bf16 of relu(norm(y1)) computed by the same fused multiply-add (H.bn_relu_ss form) and rounded to bf16 --
+    up to the bf16 roundings that an fp32 last-bit difference in scale / shift moves (checked: <= 1e-2 of the scale, and
+    against the fp64 composition); (c) bn_bwd_ss(hout=) rebuilds exactly what conv2 staged, in the storage type."""
+    rows = R * W
+    g = torch.Generator().manual_seed(C + L)
+    x = bf(torch.randn(rows, L, C, generator=g)).cuda()
+    w1 = (torch.randn(C, C, 3, generator=g) * (2.0 / (3 * C)) ** 0.5).cuda()
+    w2 = (torch.randn(C, C, 3, generator=g) * (2.0 / (3 * C)) ** 0.5).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    p1, p2 = H.pack_conv3_bf16(w1)[0], H.pack_conv3_bf16(w2)[0]
+    with storage(H, st):
+        xs = x.bfloat16() if st == 'bf16' else x
+        y_plain = H.conv3_bf16(xs, p1)
+        y1, rec = H.conv3_bf16_bn(xs, p1, R, want_records=True)
+        assert torch.equal(y1, y_plain)
+        mean = torch.full((W, C), float('nan'), device='cuda')
+        invstd = torch.full((W, C), float('nan'), device='cuda')
+        y2, rec2 = H.conv3_bf16_bn(y1, p2, R, rec=rec, mean=mean, invstd=invstd, gamma=gamma, beta=beta, want_records=True)
+        y2b = H.conv3_bf16_bn(y1, p2, R, rec=rec, mean=mean.clone(), invstd=invstd.clone(), gamma=gamma, beta=beta)
+        assert torch.equal(y2, y2b)
+        # (c) the backward kernel's rebuilt activation
+        dout = rnd((rows, L, C), 9)
+        dout = dout.bfloat16() if st == 'bf16' else dout
+        h = torch.empty_like(y1)
+        dx = torch.empty_like(y1)
+        ds = H.bn_bwd_ss(dout, y1, R, mean, invstd, gamma, beta, 1, dx, hout=h)
+    y1f = y1.float().cpu().numpy().astype(np.float64).transpose(0, 2, 1)
+    _, stref = np_ref.bn_window_fwd(y1f, gamma.cpu().numpy().astype(np.float64), beta.cpu().numpy().astype(np.float64), R)
+    mref, iref = stref
+    assert np.abs(mean.cpu().numpy() - mref.reshape(W, C)).max() < 2e-6 * (1 + np.abs(mref).max())
+    assert np.abs(invstd.cpu().numpy() / iref.reshape(W, C) - 1).max() < 2e-5
+    # the staged activation, by the same arithmetic on the host (fp32 fma == a double multiply-add rounded once)
+    sc = (gamma * invstd)
+    sh = torch.from_numpy(np.float32(beta.cpu().numpy().astype(np.float64) - mean.cpu().numpy().astype(np.float64) * sc.cpu().numpy().astype(np.float64))).cuda()
+    yv = y1.float().view(W, R * L, C)
+    href = torch.clamp((yv.double() * sc.double()[:, None, :] + sh.double()[:, None, :]).float(), min=0).view(rows, L, C)
+    hb = href.bfloat16()
+    assert float((h.float() - (hb.float() if st == 'bf16' else href)).abs().max()) <= 1e-2 * float(href.abs().max())
+    with storage(H, st):
+        y2_ref = H.conv3_bf16(hb if st == 'bf16' else hb.float(), p2)
+    err = float((y2.float() - y2_ref.float()).abs().max())
+    assert err <= 1e-2 * float(y2_ref.float().abs().max()), err
+    # dx / ds against the fp64 BatchNorm backward on the same stored tensors
+    dref, dgr, dbr = np_ref.bn_window_bwd(y1f, gamma.cpu().numpy().astype(np.float64), stref,
+                                          (dout.float() * (h.float() > 0)).cpu().numpy().astype(np.float64).transpose(0, 2, 1), R)
+    tol = 2e-2 if st == 'bf16' else 2e-5
+    assert np.abs(dx.float().cpu().numpy().transpose(0, 2, 1) - dref).max() <= tol * (1 + np.abs(dref).max())
+    # records of the second conv: the statistics of its stored output
+    y2f = y2.float().cpu().numpy().astype(np.float64).transpose(0, 2, 1)
+    _, st2 = np_ref.bn_window_fwd(y2f, np.ones(C), np.zeros(C), R)
+    m2 = torch.empty((W, C), device='cuda'); i2 = torch.empty((W, C), device='cuda')
+    with storage(H, st):
+        H.conv3_bf16_bn(y2, p1, R, rec=rec2, mean=m2, invstd=i2, gamma=gamma, beta=beta)
+    m2r = st2[0]
+    assert np.abs(m2.cpu().numpy() - m2r.reshape(W, C)).max() < 2e-6 * (1 + np.abs(m2r).max())
+
+
 @pytest.mark.parametrize('ci,co,L,rows', [(64, 64, 56, 40), (128, 128, 28, 23), (512, 512, 7, 40), (64, 64, 128, 9)])
 def test_conv_kernels_bf16_storage(H, ci, co, L, rows):
     """k3 s1 conv forward / data gradient (+accumulate), the stride-2 pair, and all three weight-gradient forms with bf16
@@ -259,8 +322,11 @@ def test_feature_boundary_and_refusals_bf16_storage(H):
     assert H.act_dtype() == 'f32'
 
 
-def test_resnet18_bf16_storage_vs_rounding_oracle_and_training(H):
-    """cnn_linear + resnet18 with bf16 convs AND bf16 storage against the oracle with the same rounding model.  bf16 keeps
+@pytest.mark.parametrize('bn1_fused', [False, True])
+def test_resnet18_bf16_storage_vs_rounding_oracle_and_training(H, bn1_fused, monkeypatch):
+    """(bn1_fused: the opt-in form that folds bn1 of the stride-1 blocks into conv1's epilogue / conv2's loader,
+    functional._BN1_FUSED -- same rounding model: y1 and h1 are rounded where the unfused form stores them.)
+    cnn_linear + resnet18 with bf16 convs AND bf16 storage against the oracle with the same rounding model.  bf16 keeps
     8 significant bits and every stored tensor is rounded: an element near a rounding boundary lands on either side
     depending on the last bits of an fp32 sum, so agreement is statistical, not elementwise -- bounds (builder-stated,
     parity unpinned): logits within 3e-2 of the same-rounding oracle and 5e-2 of the exact one, loss within 2e-2, every
@@ -269,6 +335,7 @@ def test_resnet18_bf16_storage_vs_rounding_oracle_and_training(H):
     from deepards_amd import functional as F_
     from deepards_amd.functional import bce_with_logits
     from deepards_amd.train import HotPathTrainer
+    monkeypatch.setattr(F_, '_BN1_FUSED', bn1_fused)
     x, t = seeded_batch(3, 20, 11)
     xt, tt = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
     params = {k: v.astype(np.float64) for k, v in seeded_params('resnet18', 6).items()}
