@@ -185,50 +185,14 @@ __global__ __launch_bounds__(256) void bn_stats_merge_kernel(const float* __rest
 // updates them once per window, in window order (SURVEY.md finding 5); closed form of the W updates:
 //   r_W = (1-mom)^W r_0 + mom * sum_w (1-mom)^(W-1-w) stat_w      (unbiased variance n/(n-1))
 // block = 32 channels x 8 window slots, folded through LDS in a fixed order (deterministic).
-struct BnRunningDesc {
-  const float* mean;
-  const float* invstd;
-  float* rmean;
-  float* rvar;
-  long long* nbt;
-  int W, C, Wn;
-  float eps, momentum;
-};
+// (BnRunningDesc and the block's body: common.h -- a training step's tail launch carries these blocks too)
 struct BnRunningTable {
   BnRunningDesc d[32];
 };
 
 __global__ __launch_bounds__(256) void bn_running_multi_kernel(BnRunningTable t) {
-  const BnRunningDesc& d = t.d[blockIdx.y];
-  if ((int)blockIdx.x * 32 >= d.C) return;
   __shared__ float red[2][8][32];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), slot = threadIdx.x >> 5;
-  const int W = d.W, C = d.C;
-  const float keep = 1.f - d.momentum;
-  const float unb = d.Wn > 1 ? (float)d.Wn / (float)(d.Wn - 1) : 1.f;
-  float am = 0.f, av = 0.f;
-  if (c < C) {
-    for (int w = slot; w < W; w += 8) {
-      float wt = d.momentum * powf(keep, (float)(W - 1 - w));
-      float is = d.invstd[(size_t)w * C + c];
-      am = fmaf(wt, d.mean[(size_t)w * C + c], am);
-      av = fmaf(wt, (1.0f / (is * is) - d.eps) * unb, av);
-    }
-  }
-  red[0][slot][threadIdx.x & 31] = am;
-  red[1][slot][threadIdx.x & 31] = av;
-  __syncthreads();
-  if (threadIdx.x < 32 && c < C) {
-    float sm = 0.f, sv = 0.f;
-    for (int k = 0; k < 8; ++k) {
-      sm += red[0][k][threadIdx.x];
-      sv += red[1][k][threadIdx.x];
-    }
-    const float decay = powf(keep, (float)W);
-    d.rmean[c] = fmaf(decay, d.rmean[c], sm);
-    d.rvar[c] = fmaf(decay, d.rvar[c], sv);
-  }
-  if (d.nbt && blockIdx.x == 0 && threadIdx.x == 0) d.nbt[0] += W;
+  bn_running_block(t.d[blockIdx.y], blockIdx.x, red);
 }
 
 // out = act( (x-mean)*invstd*gamma + beta (+ res) )
@@ -644,7 +608,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict
         g[k][e] = (h[e] > 0.f) ? g[k][e] : 0.f;
         h[e] = fmaxf(h[e], 0.f);
       }
-      if (ext.hout && p < Wn)
+      if (EXT == 2 && p < Wn)       // (a template form of its own: the dense blocks' instantiation sits at the register limit)
         Act<AT>::st4(reinterpret_cast<AT*>(ext.hout) + (base + p) * (size_t)ext.ldh + cg * CGB + q * 4, h);
     }
 #pragma unroll
@@ -722,43 +686,15 @@ static int bn_fused_geometry(int W, int Wn, int C, int* cgb) {
 }
 
 // dbeta[c] (+)= sum_w s1[w][c];  dgamma[c] (+)= sum_w s2[w][c] for up to 32 BatchNorms in one launch
-// (blockIdx.y = which BN); block = 32 channels x 8 window slots, fixed order (deterministic).
-struct BnPgradDesc {
-  const float* s1;
-  const float* s2;
-  float* dgamma;
-  float* dbeta;
-  int W, C;
-};
+// (blockIdx.y = which BN); block = 32 channels x 8 window slots, fixed order (deterministic).  (BnPgradDesc and the block's
+// body: common.h -- the step's slab reduction carries the same folds as extra blocks, da_wgrad_reduce_pgrad_multi.)
 struct BnPgradTable {
   BnPgradDesc d[32];
 };
 
 __global__ __launch_bounds__(256) void bn_param_grad_multi_kernel(BnPgradTable t, int accumulate) {
-  const BnPgradDesc& d = t.d[blockIdx.y];
-  if ((int)blockIdx.x * 32 >= d.C) return;
   __shared__ float red[2][8][32];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), slot = threadIdx.x >> 5;
-  float a = 0.f, b = 0.f;
-  if (c < d.C) {
-    for (int w = slot; w < d.W; w += 8) {
-      a += d.s1[(size_t)w * d.C + c];
-      b += d.s2[(size_t)w * d.C + c];
-    }
-  }
-  red[0][slot][threadIdx.x & 31] = a;
-  red[1][slot][threadIdx.x & 31] = b;
-  __syncthreads();
-  if (threadIdx.x < 32 && c < d.C) {
-    a = 0.f;
-    b = 0.f;
-    for (int k = 0; k < 8; ++k) {
-      a += red[0][k][threadIdx.x];
-      b += red[1][k][threadIdx.x];
-    }
-    d.dbeta[c] = accumulate ? d.dbeta[c] + a : a;
-    d.dgamma[c] = accumulate ? d.dgamma[c] + b : b;
-  }
+  bn_param_grad_block(t.d[blockIdx.y], blockIdx.x, accumulate, red);
 }
 
 // out = max(fmaf(x, sc, sh), 0) with the statistics of a pitched table: the activation the dense-block path never stores
@@ -1226,10 +1162,18 @@ int da_bn_bwd_ss(const void* dout, int ldd, const void* x, int ldx, const void* 
   float* s1 = ds;
   float* s2 = ds + (size_t)W * C;
 #define BN_BWDSS_LAUNCH(QB, CH)                                                                                              \
-  DA_ACT_DISPATCH(hipLaunchKernelGGL((bn_bwd_fused_kernel<AT, FUSED_NPOS, QB, 0, 1>), dim3(W, C / CH), dim3(threads), 0, stream,    \
-                                     (const AT*)dout, ldd, (const AT*)x, ldx, (const AT*)out, ldo, (AT*)dx, lddx, (AT*)nullptr, 0,  \
-                                     Wn, C, mean, invstd, gamma, beta, relu == 1 ? 4 : (relu == 2 ? 2 : 0), s1, s2,                 \
-                                     (const AT*)add, ldadd, (const unsigned long long*)nullptr, ext))
+  do {                                                                                                                              \
+    if (hout)                                                                                                                       \
+      DA_ACT_DISPATCH(hipLaunchKernelGGL((bn_bwd_fused_kernel<AT, FUSED_NPOS, QB, 0, 2>), dim3(W, C / CH), dim3(threads), 0, stream, \
+                                         (const AT*)dout, ldd, (const AT*)x, ldx, (const AT*)out, ldo, (AT*)dx, lddx, (AT*)nullptr,  \
+                                         0, Wn, C, mean, invstd, gamma, beta, 4, s1, s2, (const AT*)add, ldadd,                      \
+                                         (const unsigned long long*)nullptr, ext));                                                  \
+    else                                                                                                                            \
+      DA_ACT_DISPATCH(hipLaunchKernelGGL((bn_bwd_fused_kernel<AT, FUSED_NPOS, QB, 0, 1>), dim3(W, C / CH), dim3(threads), 0, stream, \
+                                         (const AT*)dout, ldd, (const AT*)x, ldx, (const AT*)out, ldo, (AT*)dx, lddx, (AT*)nullptr,  \
+                                         0, Wn, C, mean, invstd, gamma, beta, relu == 1 ? 4 : (relu == 2 ? 2 : 0), s1, s2,           \
+                                         (const AT*)add, ldadd, (const unsigned long long*)nullptr, ext));                           \
+  } while (0)
   if (cgb == 32) BN_BWDSS_LAUNCH(3, 32);
   else if (cgb == 16) BN_BWDSS_LAUNCH(2, 16);
   else BN_BWDSS_LAUNCH(1, 8);

@@ -224,6 +224,84 @@ __device__ __forceinline__ void merge_stat_records(const float* __restrict__ par
   invstd = 1.0f / sqrtf(m2 / fmaxf(n, 1.f) + eps);
 }
 
+// One block of the dgamma / dbeta fold of a BatchNorm (bn.hip bn_param_grad_multi_kernel; conv_gemm.hip's slab reduction runs
+// the same blocks beside its own): channels [32 chunk, 32 chunk + 32), 8 window slots, fixed order.
+struct BnPgradDesc {
+  const float* s1;
+  const float* s2;
+  float* dgamma;
+  float* dbeta;
+  int W, C;
+};
+__device__ __forceinline__ void bn_param_grad_block(const BnPgradDesc& d, int chunk, int accumulate, float (*red)[8][32]) {
+  if (chunk * 32 >= d.C) return;                       // (block-uniform)
+  const int c = chunk * 32 + (threadIdx.x & 31), slot = threadIdx.x >> 5;
+  float a = 0.f, b = 0.f;
+  if (c < d.C) {
+    for (int w = slot; w < d.W; w += 8) {
+      a += d.s1[(size_t)w * d.C + c];
+      b += d.s2[(size_t)w * d.C + c];
+    }
+  }
+  red[0][slot][threadIdx.x & 31] = a;
+  red[1][slot][threadIdx.x & 31] = b;
+  __syncthreads();
+  if (threadIdx.x < 32 && c < d.C) {
+    a = 0.f;
+    b = 0.f;
+    for (int k = 0; k < 8; ++k) {
+      a += red[0][k][threadIdx.x];
+      b += red[1][k][threadIdx.x];
+    }
+    d.dbeta[c] = accumulate ? d.dbeta[c] + a : a;
+    d.dgamma[c] = accumulate ? d.dgamma[c] + b : b;
+  }
+}
+
+// One block of a BatchNorm's running-statistics update (bn.hip bn_running_multi_kernel): the reference updates them once per
+// window, in window order (SURVEY.md finding 5); closed form of the W updates
+//   r_W = (1-mom)^W r_0 + mom * sum_w (1-mom)^(W-1-w) stat_w      (unbiased variance n/(n-1))
+// channels [32 chunk, 32 chunk + 32) x 8 window slots, folded through LDS in a fixed order (deterministic).
+struct BnRunningDesc {
+  const float* mean;
+  const float* invstd;
+  float* rmean;
+  float* rvar;
+  long long* nbt;
+  int W, C, Wn;
+  float eps, momentum;
+};
+__device__ __forceinline__ void bn_running_block(const BnRunningDesc& d, int chunk, float (*red)[8][32]) {
+  if (chunk * 32 >= d.C) return;                       // (block-uniform)
+  const int c = chunk * 32 + (threadIdx.x & 31), slot = threadIdx.x >> 5;
+  const int W = d.W, C = d.C;
+  const float keep = 1.f - d.momentum;
+  const float unb = d.Wn > 1 ? (float)d.Wn / (float)(d.Wn - 1) : 1.f;
+  float am = 0.f, av = 0.f;
+  if (c < C) {
+    for (int w = slot; w < W; w += 8) {
+      float wt = d.momentum * powf(keep, (float)(W - 1 - w));
+      float is = d.invstd[(size_t)w * C + c];
+      am = fmaf(wt, d.mean[(size_t)w * C + c], am);
+      av = fmaf(wt, (1.0f / (is * is) - d.eps) * unb, av);
+    }
+  }
+  red[0][slot][threadIdx.x & 31] = am;
+  red[1][slot][threadIdx.x & 31] = av;
+  __syncthreads();
+  if (threadIdx.x < 32 && c < C) {
+    float sm = 0.f, sv = 0.f;
+    for (int k = 0; k < 8; ++k) {
+      sm += red[0][k][threadIdx.x];
+      sv += red[1][k][threadIdx.x];
+    }
+    const float decay = powf(keep, (float)W);
+    d.rmean[c] = fmaf(decay, d.rmean[c], sm);
+    d.rvar[c] = fmaf(decay, d.rvar[c], sv);
+  }
+  if (d.nbt && chunk == 0 && threadIdx.x == 0) d.nbt[0] += W;
+}
+
 // Winograd F(4,3) taps G g of one (output, input) channel pair, written at u[j * stride] (conv_wino.hip)
 __device__ __forceinline__ void wino4_taps(float g0, float g1, float g2, float* u, size_t stride) {
   const float s = g0 + g2;

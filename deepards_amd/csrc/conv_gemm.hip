@@ -1035,13 +1035,39 @@ struct WgradReduceDesc {
   float* dw;
   int splits, ntaps, N, C;
 };
+#define REDUCE_MAX_BN 24
 struct WgradReduceTable {
   WgradReduceDesc d[32];
 };
+// the BatchNorm dgamma / dbeta folds (row m of the same launch) and running-statistics updates (row m + 1) of the step
+struct ReducePgradTable {
+  BnPgradDesc p[REDUCE_MAX_BN];
+  BnRunningDesc r[REDUCE_MAX_BN];
+  int m, npg, nrun, chunks;    // chunks = ceil(max C / 32): block x of those rows = (BatchNorm x / chunks, channel chunk x % chunks)
+};
+
+__device__ __forceinline__ void wgrad_reduce_block(const WgradReduceDesc& d, int accumulate);
 
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgradReduceTable t, int accumulate) {
+  wgrad_reduce_block(t.d[blockIdx.y], accumulate);
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_pgrad_kernel(WgradReduceTable t, ReducePgradTable g, int accumulate) {
+  if ((int)blockIdx.y >= g.m) {
+    __shared__ float red[2][8][32];
+    const int bn = blockIdx.x / g.chunks, chunk = blockIdx.x - bn * g.chunks;
+    if ((int)blockIdx.y == g.m) {
+      if (bn < g.npg) bn_param_grad_block(g.p[bn], chunk, accumulate, red);
+    } else if (bn < g.nrun) {
+      bn_running_block(g.r[bn], chunk, red);
+    }
+    return;
+  }
+  wgrad_reduce_block(t.d[blockIdx.y], accumulate);
+}
+
+__device__ __forceinline__ void wgrad_reduce_block(const WgradReduceDesc& d, int accumulate) {
   // block = 256 consecutive slab elements (64 lanes x float4 = 1 KiB contiguous per split) x 4 split slots
-  const WgradReduceDesc& d = t.d[blockIdx.y];
   const int total = d.ntaps * d.N * d.C;          // multiple of 1024 (N, C multiples of 32)
   if ((int)blockIdx.x * 256 >= total) return;
   __shared__ f32x4 red[4][64];
@@ -1378,6 +1404,69 @@ typedef struct {
 } da_wgrad_reduce_desc;
 
 int da_sizeof_wgrad_reduce_desc(void) { return (int)sizeof(da_wgrad_reduce_desc); }
+
+typedef struct {          // (bn.hip's definitions; include/deepards_hip.h)
+  const float* s1;
+  const float* s2;
+  float* dgamma;
+  float* dbeta;
+  int W, C;
+} da_bn_pgrad_desc;
+typedef struct {
+  const float* mean;
+  const float* invstd;
+  float* running_mean;
+  float* running_var;
+  long long* num_batches_tracked;
+  int W, C, Wn;
+  float eps, momentum;
+} da_bn_running_desc;
+int da_bn_param_grad_multi(const da_bn_pgrad_desc* descs, int n, int accumulate, hipStream_t stream);
+int da_bn_running_multi(const da_bn_running_desc* descs, int n, hipStream_t stream);
+int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumulate, hipStream_t stream);
+
+// The tail of a training step in ONE launch: every slab reduction (da_wgrad_reduce_multi), every BatchNorm dgamma / dbeta
+// fold (da_bn_param_grad_multi) and every running-statistics update (da_bn_running_multi).  Up to 32 reductions and 24
+// BatchNorms of each kind share the launch; anything else runs as the three calls.
+int da_step_tail_multi(const da_wgrad_reduce_desc* descs, int n, const da_bn_pgrad_desc* pg, int npg,
+                       const da_bn_running_desc* run, int nrun, int accumulate, hipStream_t stream) {
+  DA_ENTER();
+  if (n < 0 || npg < 0 || nrun < 0 || (n && !descs) || (npg && !pg) || (nrun && !run)) return DA_EINVAL;
+  if (n == 0 || n > 32 || npg > REDUCE_MAX_BN || nrun > REDUCE_MAX_BN || npg + nrun == 0) {
+    int rc = nrun ? da_bn_running_multi(run, nrun, stream) : DA_OK;
+    if (!rc && npg) rc = da_bn_param_grad_multi(pg, npg, accumulate, stream);
+    if (!rc && n) rc = da_wgrad_reduce_multi(descs, n, accumulate, stream);
+    return rc;
+  }
+  WgradReduceTable t;
+  ReducePgradTable g;
+  int maxtot = 0, maxc = 0;
+  for (int i = 0; i < n; ++i) {
+    const da_wgrad_reduce_desc& s = descs[i];
+    if (!s.slab || !s.dw || s.splits < 1) return DA_EINVAL;
+    t.d[i] = {s.slab, s.dw, s.splits, s.ntaps, s.N, s.C};
+    const int tot = s.ntaps * s.N * s.C;
+    if (tot > maxtot) maxtot = tot;
+  }
+  for (int i = 0; i < npg; ++i) {
+    const da_bn_pgrad_desc& s = pg[i];
+    if (!s.s1 || !s.s2 || !s.dgamma || !s.dbeta) return DA_EINVAL;
+    g.p[i] = {s.s1, s.s2, s.dgamma, s.dbeta, s.W, s.C};
+    if (s.C > maxc) maxc = s.C;
+  }
+  for (int i = 0; i < nrun; ++i) {
+    const da_bn_running_desc& s = run[i];
+    if (!s.mean || !s.invstd || !s.running_mean || !s.running_var || s.Wn < 1) return DA_EINVAL;
+    g.r[i] = {s.mean, s.invstd, s.running_mean, s.running_var, s.num_batches_tracked, s.W, s.C, s.Wn, s.eps, s.momentum};
+    if (s.C > maxc) maxc = s.C;
+  }
+  g.m = n; g.npg = npg; g.nrun = nrun; g.chunks = (maxc + 31) / 32;
+  const int nb = (npg > nrun ? npg : nrun) * g.chunks;
+  const int gx = (maxtot + 255) / 256 > nb ? (maxtot + 255) / 256 : nb;
+  hipLaunchKernelGGL(wgrad_reduce_pgrad_kernel, dim3(gx, n + 2), dim3(256), 0, stream, t, g, accumulate);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
 
 // dW (+)= sum of slabs for n convolutions (descs: HOST array), 32 per launch.
 int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumulate, hipStream_t stream) {

@@ -55,18 +55,21 @@ def training_step(model=None):
         _STEP.update(on=False, pack={}, running=[], pgrad=[], wgrad=[], wslab=[])
 
 
-def flush_forward():
-    """Run the queued BN running-statistics updates (call after the forward of the step)."""
+def flush_forward(defer=False):
+    """Run the queued BN running-statistics updates (call after the forward of the step).  defer: a training step leaves
+    them queued for flush_backward, whose one launch carries them (nothing reads the running statistics in between)."""
+    if defer:
+        return
     H.bn_running_multi(_STEP['running'])
     _STEP['running'] = []
 
 
 def flush_backward():
     """Run the queued parameter-gradient folds (call after the backward, before the optimiser)."""
-    H.bn_param_grad_multi(_STEP['pgrad'], accumulate=True)
     _launch_wgrads()
-    H.wgrad_reduce_multi(_STEP['wslab'], accumulate=True)
-    _STEP['pgrad'], _STEP['wslab'] = [], []
+    # one launch: slab reductions + dgamma / dbeta folds + the running statistics a deferred flush_forward left queued
+    H.step_tail_multi(_STEP['wslab'], _STEP['pgrad'], _STEP['running'], accumulate=True)
+    _STEP['pgrad'], _STEP['wslab'], _STEP['running'] = [], [], []
 
 
 # The captured step is ONE chain of kernels on one stream.  Rounds 1-2 could fork the stem's backward (or a stage's weight

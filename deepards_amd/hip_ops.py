@@ -646,6 +646,39 @@ def wgrad_reduce_multi(items, accumulate=True):
     _chk(_lib.lib().da_wgrad_reduce_multi(arr, len(items), 1 if accumulate else 0, _stream()), 'da_wgrad_reduce_multi')
 
 
+def _running_descs(items):
+    arr = (_lib.BnRunningDesc * len(items))()
+    for d, (mean, invstd, wn, rm, rv, nbt, mom, eps) in zip(arr, items):
+        if nbt is not None and nbt.dtype != torch.int64:
+            raise ValueError('num_batches_tracked must be int64')
+        d.mean, d.invstd, d.running_mean, d.running_var = mean.data_ptr(), invstd.data_ptr(), rm.data_ptr(), rv.data_ptr()
+        d.num_batches_tracked = None if nbt is None else nbt.data_ptr()
+        d.W, d.C, d.Wn, d.eps, d.momentum = mean.shape[0], mean.shape[1], wn, eps, mom
+    return arr
+
+
+def step_tail_multi(items, pgrad, running, accumulate=True):
+    """The tail of a training step in ONE launch: wgrad_reduce_multi(items), bn_param_grad_multi(pgrad) and
+    bn_running_multi(running) (the library falls back to the three launches beyond 32 reductions / 24 BatchNorms)."""
+    if not items:
+        bn_running_multi(running)
+        bn_param_grad_multi(pgrad, accumulate)
+        return
+    arr = (_lib.WgradReduceDesc * len(items))()
+    for d, ((slab, splits, k, co, ci), dw) in zip(arr, items):
+        if tuple(dw.shape) != (co, ci, k):
+            raise ValueError('step_tail_multi: bad dw shape')
+        d.slab, d.dw, d.splits, d.ntaps, d.N, d.C = slab.data_ptr(), dw.data_ptr(), splits, k, co, ci
+    pg = (_lib.BnPgradDesc * max(1, len(pgrad)))()
+    for d, (ds, dg, db) in zip(pg, pgrad):
+        _, w, c = ds.shape
+        d.s1, d.s2 = ds.data_ptr(), ds.data_ptr() + 4 * w * c
+        d.dgamma, d.dbeta, d.W, d.C = dg.data_ptr(), db.data_ptr(), w, c
+    run = _running_descs(running) if running else None
+    _chk(_lib.lib().da_step_tail_multi(arr, len(items), pg if pgrad else None, len(pgrad), run, len(running),
+                                       1 if accumulate else 0, _stream()), 'da_step_tail_multi')
+
+
 def repack_multi(weights, winograd=None):
     """[(Co,Ci,K) weights] -> [(wf, wd, uf, ud)] with one launch per 32 weights.  winograd[i] (K == 3; True / 4:
     F(2,3), 6: F(4,3)): emit the Winograd taps uf (points,Co,Ci) / ud (points,Ci,Co) INSTEAD of the direct packs
@@ -746,14 +779,7 @@ def bn_running_multi(items):
     One launch per 32 BatchNorms: the reference's one momentum update per window, in window order."""
     if not items:
         return
-    arr = (_lib.BnRunningDesc * len(items))()
-    for d, (mean, invstd, wn, rm, rv, nbt, mom, eps) in zip(arr, items):
-        if nbt is not None and nbt.dtype != torch.int64:
-            raise ValueError('num_batches_tracked must be int64')
-        d.mean, d.invstd, d.running_mean, d.running_var = mean.data_ptr(), invstd.data_ptr(), rm.data_ptr(), rv.data_ptr()
-        d.num_batches_tracked = None if nbt is None else nbt.data_ptr()
-        d.W, d.C, d.Wn, d.eps, d.momentum = mean.shape[0], mean.shape[1], wn, eps, mom
-    _chk(_lib.lib().da_bn_running_multi(arr, len(items), _stream()), 'da_bn_running_multi')
+    _chk(_lib.lib().da_bn_running_multi(_running_descs(items), len(items), _stream()), 'da_bn_running_multi')
 
 
 def bn_stats(x, R, eps=1e-5, running_mean=None, running_var=None, num_batches_tracked=None, momentum=0.1):

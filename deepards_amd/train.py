@@ -296,12 +296,12 @@ class HotPathTrainer(object):
             fused = self.model.forward_loss(inputs, target) if _FUSED_HEAD and hasattr(self.model, 'forward_loss') else None
             if fused is not None:                        # CNNLinearNetwork: pool + linear + loss (+ their backward) in 3 launches
                 loss, logits = fused
-                F_.flush_forward()
+                F_.flush_forward(defer=True)        # (the running-statistics updates ride on the tail launch)
                 torch.autograd.backward(loss, grad_tensors=self._one(loss))
                 F_.flush_backward()
                 return loss, logits
             logits = _logits(self.model(inputs, None))
-            F_.flush_forward()                           # batched BN running-statistics updates
+            F_.flush_forward(defer=True)                 # BN running-statistics updates: on flush_backward's launch
             lg, tg = _loss_operands(logits.detach(), target)
             loss, dlogits = H.bce_logits(lg, tg, want_grad=True)
             logits.backward(dlogits.view(logits.shape))

@@ -161,6 +161,13 @@ int da_conv_wgrad_splits(int rows, int Lm, int N, int C, int ntaps);
 int da_conv_wgrad_plan(int rows, int Lm, int N, int C, int ntaps, int winograd, int* out);
 typedef struct { const float* slab; float* dw; int splits, ntaps, N, C; } da_wgrad_reduce_desc;
 int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumulate, da_stream_t stream);
+/* The tail of a training step in ONE launch: the slab reductions, every BatchNorm's dgamma / dbeta fold
+   (da_bn_param_grad_multi) and running-statistics update (da_bn_running_multi).  n <= 32 reductions and <= 24 BatchNorms
+   of each kind share the launch, anything else runs as the three calls. */
+struct da_bn_pgrad_desc_;
+struct da_bn_running_desc_;
+int da_step_tail_multi(const da_wgrad_reduce_desc* descs, int n, const struct da_bn_pgrad_desc_* pg, int npg,
+                       const struct da_bn_running_desc_* run, int nrun, int accumulate, da_stream_t stream);
 
 /* torch [Co][Ci][K] -> Wf [K][Co][Ci] (forward) and Wd [K][Ci][Co] (data gradient). */
 int da_repack_conv_weight(const float* W, float* Wf, float* Wd, int Co, int Ci, int K, da_stream_t stream);
@@ -190,11 +197,11 @@ int da_stem_conv_wgrad_g(const da_act_t* dy, int lddy, const float* x, float* dw
  * resnet.py:27-38,143,152 ; densenet.py:23-29,72-74,146 ; per-window statistics because
  * torch_cnn_linear_network.py:108-113 calls breath_block(x[i]) one window at a time. */
 /* descriptors for the batched small kernels: HOST arrays of these are passed, 32 served per launch */
-typedef struct {
+typedef struct da_bn_running_desc_ {
   const float* mean; const float* invstd; float* running_mean; float* running_var;
   long long* num_batches_tracked; int W, C, Wn; float eps, momentum;
 } da_bn_running_desc;
-typedef struct { const float* s1; const float* s2; float* dgamma; float* dbeta; int W, C; } da_bn_pgrad_desc;
+typedef struct da_bn_pgrad_desc_ { const float* s1; const float* s2; float* dgamma; float* dbeta; int W, C; } da_bn_pgrad_desc;
 
 /* two-stage statistics: P chunks of `chunk` positions per window so that W*C/32*P blocks fill the chip */
 void da_bn_chunks(int W, int Wn, int C, int* P, int* chunk);

@@ -197,6 +197,21 @@ def test_fused_head_chain_against_the_oracle_and_the_six_launch_chain(backbone):
     assert np.abs(xt.grad.cpu().numpy() - dx_ref).max() < 2e-6 * (1 + np.abs(dx_ref).max())
     assert np.abs(wt.grad.cpu().numpy() - dl.T @ flat).max() < 2e-6 * (1 + np.abs(dl.T @ flat).max())
     assert np.abs(bt.grad.cpu().numpy() - dl.sum(axis=0)).max() < 2e-6
+    # a window's share is the same whether it is trained alone or in a batch (the data-parallel step relies on it): logits
+    # bit for bit, dx / dW / dbias up to the factor 1 / B (exact for the powers of two the data-parallel step divides by)
+    def alone(i):
+        xa = cu(xm[i * R:(i + 1) * R]).requires_grad_(True)
+        wa, ba = cu(w).requires_grad_(True), cu(bias).requires_grad_(True)
+        la, lga = Fn.head_loss(xa, wa, ba, cu(t[i:i + 1]), R)
+        la.backward()
+        return lga, xa.grad, wa.grad, ba.grad
+    parts = [alone(i) for i in range(B)]
+    for i, (lga, dxa, _, _) in enumerate(parts):
+        assert torch.equal(lga[0], logits[i])
+        assert float((dxa / B - xt.grad[i * R:(i + 1) * R]).abs().max()) <= 2e-7 * float(xt.grad.abs().max())   # (B = 5: 1 / B is not exact)
+    if backbone == 'resnet18':          # (B = 5: the sum of five shares in another order -- one rounding)
+        dw_sum = sum(p_[2] for p_ in parts) / B
+        assert float((dw_sum - wt.grad).abs().max()) <= 2e-7 * float(wt.grad.abs().max())
     # forward only (no_grad): the loss comes from the forward kernels
     with torch.no_grad():
         l2, lg2 = Fn.head_loss(xt, wt, bt, cu(t), R)

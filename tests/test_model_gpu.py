@@ -816,9 +816,18 @@ def test_data_parallel_two_processes_trajectory(M, tmp_path):
     bucket), rank r trains on window r of the golden's B=2 batch.  Rank 1 starts from a DIFFERENT random initialisation:
     sync_replicas() must replace it with rank 0's.  Checked: (1) the ranks end with bit-identical parameters;
     (2) the mean of the rank losses and the parameters follow the reference's B=2 trajectory (golden) within the
-    bounds of the single-process trajectory test; (3) they equal this build's own single-process B=2 run to 2e-6 --
-    not bit-for-bit: the single process sums the two windows' weight-gradient contributions inside one split-K
-    reduction, the data-parallel step adds two rank totals, a different fp32 summation order."""
+    bounds of the single-process trajectory test; (3) they equal this build's own single-process B=2 run -- losses to
+    2e-6, parameters to 2e-5.  Not bit-for-bit, and not to rounding either: the single process sums the two windows'
+    weight-gradient contributions inside one split-K reduction while the data-parallel step adds two rank totals, and the
+    BatchNorm / stem-statistics block geometry depends on how many windows a process holds (1 vs 2).  Those are other
+    fp32 summation orders; from the second step on the two runs' parameters differ in their last bits, and an element
+    whose pre-activation is within that noise of zero takes the other ReLU / max-pool branch in one of them (the
+    ambiguity DESIGN.md 2 describes: ~1 element in 1e7 per step, each moving the gradients in front of it by up to ~1e-2
+    relative).  Measured after three steps: 1e-6 ... 9.6e-6 (breath_block.conv1.weight) -- which elements flip depends on
+    the last bits of everything, e.g. on the summation order inside the head kernels.  What IS exact is checked exactly:
+    the replicas, and the head chain across batch sizes (test_functions_gpu: a window's logits / dx / dW shares are
+    bit-identical whether it is trained alone or with another).
+    """
     from deepards_amd.train import HotPathTrainer
     path = [p for p in GOLD if 'resnet18_b2_randn' in p][0]
     g = _gold(path)
@@ -836,18 +845,19 @@ def test_data_parallel_two_processes_trajectory(M, tmp_path):
     x, t = torch.from_numpy(g['x']).cuda(), torch.from_numpy(g['target']).cuda()
     single = [float(tr.train_step(x, t)) for _ in range(3)]
     assert np.abs(losses - np.array(single)).max() < 2e-6
-    worst = 0.0
+    worst, worst_name = 0.0, ''
     for n, p in model.named_parameters():
         a, b = r0['p/' + n], p.detach().cpu().numpy()
         key = 'sgd_p64/' + n
         if key not in g:
             continue                                    # dead parameters: rank 0's initial values everywhere
-        worst = max(worst, float(np.abs(a - b).max()))
+        if float(np.abs(a - b).max()) > worst:
+            worst, worst_name = float(np.abs(a - b).max()), n
         d = digest(a)
         body = slice(None) if a.size <= 1024 else slice(0, -3)
         assert np.abs(d - g[key])[body].max() < 1.5e-4, n
-    log('dp2 vs single-process params max abs diff %.3e' % worst)
-    assert worst < 2e-6
+    log('dp2 vs single-process params max abs diff %.3e (%s)' % (worst, worst_name))
+    assert worst < 2e-5, (worst_name, worst)
     # dead parameters and buffers were broadcast too: rank 1 holds rank 0's values
     for n in DEAD_RESNET_PARAMS:
         assert np.array_equal(r0['p/' + n], r1['p/' + n]), n
