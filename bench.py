@@ -760,7 +760,7 @@ def main():
                   'final_loss': round(float(l4), 6),
                   'note': 'cnn_linear+resnet18, same workload as the headline under conv arithmetic f32x3p: activations stored pre-split '
                           '[h|m|l] by the BatchNorm / pool kernels, every residual-block conv (k3 s1, the stride-2 block entries, their '
-                          'data and weight gradients) on v_mfma_f32_32x32x16_bf16; opt-in (DESIGN.md 7c: the 2.7 ms bar for making it '
+                          'data and weight gradients) on v_mfma_f32_32x32x16_bf16; opt-in (DESIGN_APPENDIX.md 7c: the 2.7 ms bar for making it '
                           'the default was not met)'}
           except Exception as e:                     # an opt-in extra never takes the headline line down with it
             out.setdefault('extra', {})['resnet18_f32x3p'] = {'error': '%s: %s' % (type(e).__name__, e)}

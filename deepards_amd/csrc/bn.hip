@@ -988,7 +988,7 @@ int da_bn_debug_two_stage(int on) {
   return DA_OK;
 }
 
-// tuning: blocks per launch the single-pass geometry aims for (default 256; swept in DESIGN.md section 8)
+// tuning: blocks per launch the single-pass geometry aims for (default 256; swept in DESIGN_APPENDIX.md section 8)
 int da_bn_debug_target_blocks(int blocks) {
   if (blocks < 1) return DA_EINVAL;
   g_bn_target_blocks = blocks;

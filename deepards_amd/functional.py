@@ -74,7 +74,7 @@ def flush_backward():
 
 # The captured step is ONE chain of kernels on one stream.  Rounds 1-2 could fork the stem's backward (or a stage's weight
 # gradients) onto a side stream inside the capture; that never paid once the weight gradients took the Winograd form
-#  and a hipGraphExec with parallel branches owns streams that die with ANOTHER such exec (segfault in
+# (DESIGN_APPENDIX.md 7a) and a hipGraphExec with parallel branches owns streams that die with ANOTHER such exec (segfault in
 # hip::Graph::UpdateStreams) -- so the forked paths and their switches are gone, not just off.
 def _launch_wgrads():
     """Launch the queued weight-gradient GEMMs ((dy, x, k, stride, pad, target) jobs), all in one batched call."""
