@@ -572,6 +572,8 @@ def main():
             'da_bn_bwd_add': 'bn_bwd_fused_kernel<*> (BatchNorm backward + concat pass-through)',
             'da_pool_bwd': 'pool_bwd_kernel (stem max/avg pool + ReLU backward)',
             'da_conv_wgrad_multi[code1]': 'wino_wgrad_multi_kernel (k3 s1 weight gradients, Winograd F(2,3) form on v_mfma_f32_32x32x2_f32)',
+            'da_conv_wgrad_multi[code6]': 'wino4_wgrad_multi_kernel (512-channel k3 s1 weight gradients, Winograd F(4,3) form: 6 contractions '
+                                          'over output quads, 1/2 of the direct FLOPs executed)',
             'da_conv_wgrad_multi[code49]': 'wgrad_x3p_multi_kernel (k3 s1 weight gradients on pre-split (x3) operands, six v_mfma_f32_32x32x16_bf16 '
                                            'products per multiply)',
             'da_conv_wgrad_multi[code16]': 'wgrad_bf16_multi_kernel<*, 1> (weight gradients, bf16 operands)',

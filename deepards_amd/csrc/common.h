@@ -321,7 +321,7 @@ typedef struct {
   float* workspace;      // splits * ntaps*N*C floats: receives the split-K slabs
   int rows, Lm, Ldy, lddy, N, Lx, ldx, C, dy_stride, dy_off, src_stride, ntaps;
   int src_off[3];
-  int winograd;          // k3 s1 p1, N and C multiples of 64 -- 1: Winograd F(2,3) form (fp32), 16: bf16 operands /
+  int winograd;          // k3 s1 p1, N and C multiples of 64 -- 1: Winograd F(2,3) form (fp32), 6: F(4,3) form (fp32), 16: bf16 operands /
                          // fp32 sums, 49: split-bf16 fp32-equivalent products on x3 operands (both conv_bf16.hip; also
                          // the stride-2 jobs); the matching da_conv_wgrad_plan(winograd = 1 / 16 / 49) sizes the workspace
   // dense-block operand forms of stride-1 jobs on the direct kernels (winograd == 0; conv_gemm.hip WgradArgs): xform = 1: X is
@@ -338,6 +338,8 @@ typedef struct {
 bool wino_wgrad_eligible(const da_wgrad_job& j);
 void wino_wgrad_plan(int rows, int L, int* splits, int* pchunk);
 int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream);
+void wino4_wgrad_plan(int rows, int L, int* splits, int* qchunk);               // winograd == 6: the F(4,3) form (quads)
+int wino4_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream);
 
 // conv_bf16.hip: jobs with winograd == 16 (the same eligibility; bf16 operands, padded-position K)
 bool bf16_wgrad_eligible(const da_wgrad_job& j);

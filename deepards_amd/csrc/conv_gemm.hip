@@ -1338,6 +1338,7 @@ int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
         (j.winograd == 49 && (j.lddy != j.N || j.ldx != j.C)))
       return DA_EINVAL;
     if ((uint64_t)j.rows * j.Lm * (uint64_t)j.Lm >= 0xffffffffull) return DA_EINVAL;
+    if (j.winograd != 0 && j.winograd != 1 && j.winograd != 6 && j.winograd != 16 && j.winograd != 49) return DA_EINVAL;
     if ((j.xform || j.dy_half) && (j.winograd || j.src_stride != 1 || j.dy_stride != 1 || j.dy_off || j.Lm != j.Lx ||
                                    (j.dy_half && j.ntaps != 1)))
       return DA_EINVAL;                                       // the dense-block operand forms: stride-1 jobs on the direct kernels
@@ -1353,7 +1354,8 @@ int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
       return DA_EINVAL;
   }
   int rc;
-  if ((rc = wino_wgrad_launch(jobs, n, stream))) return rc;   // the heaviest blocks first
+  if ((rc = wino4_wgrad_launch(jobs, n, stream))) return rc;  // the heaviest blocks first
+  if ((rc = wino_wgrad_launch(jobs, n, stream))) return rc;
   if ((rc = bf16_wgrad_launch(jobs, n, 49, stream))) return rc;      // x3 operands (dy / x are x3 tensors; ld* = channel counts)
   if ((rc = bf16_wgrad_launch(jobs, n, 16, stream))) return rc;
   if ((rc = launch_wgrad_group<2, 2, 2, 2>(jobs, n, 128, 128, stream))) return rc;
@@ -1389,6 +1391,7 @@ int da_conv_wgrad_plan(int rows, int Lm, int N, int C, int ntaps, int winograd, 
     if ((ntaps != 3 && winograd != 16 && winograd != 49) || N % 64 || C % 64) return DA_EINVAL;
     out[0] = 64; out[1] = 64;
     if (winograd == 16 || winograd == 49) bf16_wgrad_plan(rows, Lm, &out[2], &out[3]);     // kchunk counts padded positions
+    else if (winograd == 6) wino4_wgrad_plan(rows, Lm, &out[2], &out[3]);                  // ... quads
     else wino_wgrad_plan(rows, Lm, &out[2], &out[3]);
     return DA_OK;
   }

@@ -961,7 +961,10 @@ bool wino_wgrad_eligible(const da_wgrad_job& j) {
          j.N >= 64 && j.C >= 64;
 }
 
-static int g_ww_pchunk = 512;
+#ifndef WW_PCHUNK
+#define WW_PCHUNK 640      // (whole fp32 step at B = 64, ms, rows = pairs per split 416 / 512 / 640 / 768 / 1024 with 320 quads: 2.927 / 2.944 / 2.912 / 2.955 / 2.970)
+#endif
+static int g_ww_pchunk = WW_PCHUNK;
 
 // pairs per split: every block of every job carries the same work (16 K steps), slab traffic 48 KB per block
 void wino_wgrad_plan(int rows, int L, int* splits, int* pchunk) {
@@ -996,6 +999,200 @@ int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s) {
     a.dy = j.dy; a.x = j.x; a.slab = j.workspace;
     a.L = j.Lm; a.PL = (j.Lm + 1) / 2; a.MP = j.rows * a.PL;
     a.lddy = j.lddy; a.N = j.N; a.ldx = j.ldx; a.C = j.C; a.pchunk = pchunk;
+    a.divPL = make_fastdiv((uint32_t)a.PL);
+    t.first_block[cnt] = blocks;
+    blocks += (j.N / 64) * (j.C / 64) * splits;
+    if (++cnt == 24) {
+      int rc = flush();
+      if (rc) return rc;
+    }
+  }
+  return flush();
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same weight gradient in the F(4,3) form (job flag winograd == 6; the 512-channel convs, like the forward's
+// conv3_wino4k_kernel): K runs over output QUADS.  With dy0..dy3 the quad's outputs, d0..d5 = x[4q-1 .. 4q+4] and
+//   dm = A dy = (dy0, dy0+dy1+dy2+dy3, dy0-dy1+dy2-dy3, dy0+2dy1+4dy2+8dy3, dy0-2dy1+4dy2-8dy3, dy3),   D = B^T d (as forward)
+//   M_j[n][c] = sum over quads dm_j[n] D_j[c]              (6 contractions over quads: 3/4 of F(2,3)'s 8 over pairs)
+//   dW0 = M0/4 - (M1+M2)/6 + (M3+M4)/24    dW1 = (M2-M1)/6 + (M3-M4)/12    dW2 = -(M1+M2)/6 + (M3+M4)/6 + M5      (= G^T M)
+// Block = 64 co x 64 ci, 4 waves of 32 x 32 with six accumulators; K step = 16 quads: dY in four phase panels [quad][channel],
+// X in four ([quad - 1 ..] for phase 3, [.. quad + 1] for phase 0: d0 = X3[q-1], d1..d4 = X0..X3[q], d5 = X0[q+1]); sequence
+// edges (d0 of a row's first quad, d5 of its last) from two 16-bit masks per K step, positions past L are zeros of the
+// loader.  Slabs in the direct kernel's layout, shared reduction.
+// ---------------------------------------------------------------------------------------------
+#ifndef WW4_KQ
+#define WW4_KQ 16         // quads per K step (16 or 32)
+#endif
+#ifndef WW4_MIN_WAVES
+#define WW4_MIN_WAVES 3   // waves per SIMD the register allocation must allow
+#endif
+#ifndef WW4_UNROLL
+#define WW4_UNROLL 4      // (8: 39 spilled registers at 3 waves/SIMD, 346 us for the three 512-channel jobs at B = 64 against 280)
+#endif
+#define WW4_LDS_FLOATS ((4 * WW4_KQ + 4 * WW4_KQ + 2) * 64)
+
+__device__ __forceinline__ void wino4_wgrad_body(const WinoWgradArgs& a, const int block_id, const int nblocks, float* lds) {
+  constexpr int KQ = WW4_KQ, NRB = KQ / 16;
+  float* Y = lds;                         // [4 phases][KQ][64]
+  float* X0 = lds + 4 * KQ * 64;          // [KQ + 1][64]: quads k0 .. k0 + KQ
+  float* X1 = X0 + (KQ + 1) * 64;         // [KQ][64]
+  float* X2 = X1 + KQ * 64;               // [KQ][64]
+  float* X3 = X2 + KQ * 64;               // [KQ + 1][64]: quads k0 - 1 .. k0 + KQ - 1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntc = a.C >> 6, tiles = (a.N >> 6) * ntc;
+  const int lin = xcd_chunked(block_id, nblocks);
+  const int bx = lin % tiles, split = lin / tiles;
+  const int n_blk = (bx / ntc) * 64, c_blk = (bx % ntc) * 64;
+  const int QL = a.PL;                    // quads per row (the args' PL / MP / divPL count quads here)
+  const int k_beg = split * a.pchunk, k_end = min(a.MP, k_beg + a.pchunk);
+
+  const int lrow = tid >> 4, lq = tid & 15;             // loader: 16 quads x 16 channel quads per pass
+  f32x4 ry[4 * NRB], rx[4 * NRB + 1];
+  auto gload = [&](int k0) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      const int Q = k0 + lrow + 16 * rb;
+      const bool ok = Q < a.MP;
+      const uint32_t r = fdiv((uint32_t)(ok ? Q : 0), a.divPL);
+      const int i = (ok ? Q : 0) - (int)r * QL;
+      const size_t pos = (size_t)r * a.L + 4 * i;
+      const bool okk = ok && Q < k_end;                 // dY only inside this split's quads; X neighbours beyond it are real
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        const bool in = 4 * i + ph < a.L;
+        ry[4 * rb + ph] = (okk && in) ? *reinterpret_cast<const f32x4*>(a.dy + (pos + ph) * a.lddy + n_blk + lq * 4) : z;
+        rx[4 * rb + ph] = (ok && in) ? *reinterpret_cast<const f32x4*>(a.x + (pos + ph) * a.ldx + c_blk + lq * 4) : z;
+      }
+    }
+    if (tid < 32) {                                     // halo: phase 3 of quad k0 - 1 (tid < 16), phase 0 of quad k0 + KQ
+      const int Qh = tid < 16 ? k0 - 1 : k0 + KQ;
+      const bool okh = Qh >= 0 && Qh < a.MP;
+      const uint32_t rh = fdiv((uint32_t)(okh ? Qh : 0), a.divPL);
+      const int ih = (okh ? Qh : 0) - (int)rh * QL;
+      const int pp = 4 * ih + (tid < 16 ? 3 : 0);
+      f32x4 v = z;
+      if (okh && pp < a.L) v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)rh * a.L + pp) * a.ldx + c_blk + lq * 4);
+      rx[4 * NRB] = v;
+    }
+  };
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int frow = lane & 31, fh = lane >> 5;
+  if (k_beg < k_end) gload(k_beg);
+  for (int k0 = k_beg; k0 < k_end; k0 += KQ) {
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      const int row = lrow + 16 * rb;
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) *reinterpret_cast<f32x4*>(&Y[(ph * KQ + row) * 64 + lq * 4]) = ry[4 * rb + ph];
+      *reinterpret_cast<f32x4*>(&X0[row * 64 + lq * 4]) = rx[4 * rb];
+      *reinterpret_cast<f32x4*>(&X1[row * 64 + lq * 4]) = rx[4 * rb + 1];
+      *reinterpret_cast<f32x4*>(&X2[row * 64 + lq * 4]) = rx[4 * rb + 2];
+      *reinterpret_cast<f32x4*>(&X3[(row + 1) * 64 + lq * 4]) = rx[4 * rb + 3];
+    }
+    if (tid < 16) *reinterpret_cast<f32x4*>(&X3[lq * 4]) = rx[4 * NRB];
+    else if (tid < 32) *reinterpret_cast<f32x4*>(&X0[KQ * 64 + lq * 4]) = rx[4 * NRB];
+    // sequence-edge masks of this step's quads (bit p: quad k0 + p is the first / last of its sequence)
+    const int Qm = k0 + (lane & (KQ - 1));
+    const int im = Qm - (int)fdiv((uint32_t)(Qm < a.MP ? Qm : 0), a.divPL) * QL;
+    const uint32_t fmask = (uint32_t)__ballot(Qm < a.MP && im == 0);          // (bits >= KQ repeat the low ones: never read)
+    const uint32_t lmask = (uint32_t)__ballot(Qm < a.MP && im == QL - 1);
+    __syncthreads();
+#pragma unroll WW4_UNROLL
+    for (int kk = 0; kk < KQ / 2; ++kk) {
+      if (kk == KQ / 4) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + KQ < k_end) gload(k0 + KQ);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int p = 2 * kk + fh;
+      const int yo = p * 64 + wm * 32 + frow, xo = p * 64 + wn * 32 + frow;
+      const float y0 = Y[yo], y1 = Y[KQ * 64 + yo], y2 = Y[2 * KQ * 64 + yo], y3 = Y[3 * KQ * 64 + yo];
+      float d0 = X3[xo];
+      const float d1 = X0[xo], d2 = X1[xo], d3 = X2[xo], d4 = X3[xo + 64];
+      float d5 = X0[xo + 64];
+      if ((fmask >> p) & 1) d0 = 0.f;
+      if ((lmask >> p) & 1) d5 = 0.f;
+      const float ya = y0 + y2, yb = y1 + y3, yc = fmaf(4.f, y2, y0), yd = 2.f * fmaf(4.f, y3, y1);
+      const float e1 = fmaf(-4.f, d2, d4), e2 = fmaf(-4.f, d1, d3), f1 = d4 - d2, f2 = d3 - d1;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, fmaf(4.f, d0, fmaf(-5.f, d2, d4)), acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya + yb, e1 + e2, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya - yb, e1 - e2, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(yc + yd, fmaf(2.f, f2, f1), acc[3], 0, 0, 0);
+      acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(yc - yd, fmaf(-2.f, f2, f1), acc[4], 0, 0, 0);
+      acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(y3, fmaf(4.f, d1, fmaf(-5.f, d3, d5)), acc[5], 0, 0, 0);
+    }
+  }
+
+  float* out = a.slab + (size_t)split * 3 * a.N * a.C;
+  const size_t plane = (size_t)a.N * a.C;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n_blk + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+    const int c = c_blk + wn * 32 + frow;
+    const float s12 = acc[1][r] + acc[2][r], s34 = acc[3][r] + acc[4][r];
+    float* o = out + (size_t)n * a.C + c;
+    o[0] = fmaf(0.25f, acc[0][r], fmaf(1.0f / 24.0f, s34, -(1.0f / 6.0f) * s12));
+    o[plane] = fmaf(1.0f / 6.0f, acc[2][r] - acc[1][r], (1.0f / 12.0f) * (acc[3][r] - acc[4][r]));
+    o[2 * plane] = fmaf(1.0f / 6.0f, s34 - s12, acc[5][r]);
+  }
+}
+
+__global__ __launch_bounds__(256, WW4_MIN_WAVES) void wino4_wgrad_multi_kernel(WinoWgradTable t) {
+  __shared__ float lds[WW4_LDS_FLOATS];
+  int i = 0;
+  while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
+  wino4_wgrad_body(t.d[i], blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i], lds);
+}
+
+#ifndef WW4_QCHUNK
+#define WW4_QCHUNK 320     // (quads per split 192 / 256 / 320 / 384 / 448 with 640 pairs: 2.959 / 2.934 / 2.912 / 2.990 (768 pairs) / 2.987: block counts that fill whole rounds)
+#endif
+static int g_ww4_qchunk = WW4_QCHUNK;
+
+// quads per split (a multiple of the K step)
+void wino4_wgrad_plan(int rows, int L, int* splits, int* qchunk) {
+  const int MQ = rows * ((L + 3) / 4);
+  int sp = (MQ + g_ww4_qchunk - 1) / g_ww4_qchunk;
+  if (sp < 1) sp = 1;
+  int qc = ((MQ + sp - 1) / sp + WW4_KQ - 1) / WW4_KQ * WW4_KQ;
+  if (qc < WW4_KQ) qc = WW4_KQ;
+  *splits = (MQ + qc - 1) / qc > 0 ? (MQ + qc - 1) / qc : 1;
+  *qchunk = qc;
+}
+
+int wino4_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s) {
+  WinoWgradTable t;
+  int cnt = 0, blocks = 0;
+  auto flush = [&]() -> int {
+    if (!cnt) return DA_OK;
+    t.n = cnt;
+    t.first_block[cnt] = blocks;
+    hipLaunchKernelGGL(wino4_wgrad_multi_kernel, dim3(blocks), dim3(256), 0, s, t);
+    DA_CHECK_LAUNCH();
+    cnt = 0;
+    blocks = 0;
+    return DA_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    const da_wgrad_job& j = jobs[i];
+    if (j.winograd != 6) continue;
+    int splits, qchunk;
+    wino4_wgrad_plan(j.rows, j.Lm, &splits, &qchunk);
+    WinoWgradArgs& a = t.d[cnt];
+    a.dy = j.dy; a.x = j.x; a.slab = j.workspace;
+    a.L = j.Lm; a.PL = (j.Lm + 3) / 4; a.MP = j.rows * a.PL;
+    a.lddy = j.lddy; a.N = j.N; a.ldx = j.ldx; a.C = j.C; a.pchunk = qchunk;
     a.divPL = make_fastdiv((uint32_t)a.PL);
     t.first_block[cnt] = blocks;
     blocks += (j.N / 64) * (j.C / 64) * splits;

@@ -554,12 +554,14 @@ def _conv_wgrad_taps(dy, x, src_off, stride):
 
 WINOGRAD_WGRAD = os.environ.get('DA_WINOGRAD', '1') != '0'     # 0: the direct fp32 kernels (as functional._WINOGRAD)
 WGRAD_BF16 = False        # set by functional.set_conv_dtype('bf16'): k3 s1 weight gradients on the bf16 matrix cores
+WINO4_WGRAD_MIN_C = 512  # channels from which the F(4,3) weight-gradient form replaces F(2,3) (the 512-channel stage, as the forward)
 
 
 def conv_wgrad_multi(jobs):
     """jobs: [(dy, x, k, stride, pad)] -> [(slab, splits, k, co, ci)]: every weight-gradient GEMM of the list in
     one launch per tile shape (slabs only; reduce with wgrad_reduce_multi).  k3 s1 p1 jobs with 64-multiple
-    channel counts take the Winograd F(2,3) form, or the bf16-operand kernel while WGRAD_BF16 is set."""
+    channel counts take the Winograd F(2,3) form (F(4,3) from WINO4_WGRAD_MIN_C channels), or the bf16-operand kernel
+    while WGRAD_BF16 is set."""
     if not jobs:
         return []
     L = _lib.lib()
@@ -596,6 +598,8 @@ def conv_wgrad_multi(jobs):
         if rows != rows2 or lo != conv_out_len(l, k, stride, pad) or k > 3 or ci % 32 or co % 32:
             raise ValueError('conv_wgrad_multi: unsupported shape')
         wino = 1 if (WINOGRAD_WGRAD and k == 3 and stride == 1 and pad == 1 and co % 64 == 0 and ci % 64 == 0) else 0
+        if wino and min(co, ci) >= WINO4_WGRAD_MIN_C:
+            wino = 6                                 # F(4,3) form: 6 contractions over quads instead of 8 over pairs
         if WGRAD_BF16 and co % 64 == 0 and ci % 64 == 0 and (
                 (k == 3 and stride == 1 and pad == 1) or
                 (stride == 2 and l % 2 == 0 and ((k == 3 and pad == 1) or (k == 1 and pad == 0)))):
