@@ -23,6 +23,18 @@ class BnRunningDesc(ctypes.Structure):
                 ('W', _I), ('C', _I), ('Wn', _I), ('eps', _F), ('momentum', _F)]
 
 
+class BnFwdDesc(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('ldx', ctypes.c_int), ('res', ctypes.c_void_p), ('ldr', ctypes.c_int),
+                ('out', ctypes.c_void_p), ('ldo', ctypes.c_int), ('mean', ctypes.c_void_p), ('invstd', ctypes.c_void_p),
+                ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p), ('relu', ctypes.c_int), ('mask', ctypes.c_void_p)]
+
+
+class BnBwdDesc(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('ldx', ctypes.c_int), ('dx', ctypes.c_void_p), ('lddx', ctypes.c_int),
+                ('mean', ctypes.c_void_p), ('invstd', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p),
+                ('ds', ctypes.c_void_p)]
+
+
 class BnPgradDesc(ctypes.Structure):
     _fields_ = [('s1', _P), ('s2', _P), ('dgamma', _P), ('dbeta', _P), ('W', _I), ('C', _I)]
 
@@ -92,6 +104,8 @@ SIGNATURES = {
     'da_bn_bwd_mask': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'da_bn_bwd_add': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P]),
     'da_bn_param_grad_multi': (_I, [ctypes.POINTER(BnPgradDesc), _I, _I, _P]),
+    'da_bn_fwd_pair': (_I, [ctypes.POINTER(BnFwdDesc), _I, _I, _I, _F, _P]),
+    'da_bn_bwd_pair': (_I, [_P, _I, ctypes.POINTER(BnBwdDesc), _I, _I, _I, _P, _P]),
     'da_bn_stats_fused': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _F, _P]),
     'da_bn_relu_ss': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     'da_bn_bwd_ss': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _I, _P, _U, _F, _I, _P, _P, _I, _P]),

@@ -443,17 +443,13 @@ __device__ __forceinline__ void quad_block_sum(f32x4 (&v)[NV], float* red) {
 // RX3 / OX3: the residual is read / the output is stored in the x3 format (common.h: exact three-term bf16 split, 3 C bf16
 // per position; float activations only) -- the producers of the k3 s1 convs' inputs under conv arithmetic 'f32x3'.
 template <typename AT, int NPOS, int QB, int RX3 = 0, int OX3 = 0>
-__global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const AT* __restrict__ x, int ldx,
-                                                            const AT* __restrict__ res, int ldr,
-                                                            AT* __restrict__ out, int ldo, int Wn, int C,
-                                                            const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, int relu, float eps,
-                                                            float* __restrict__ mean_out,
-                                                            float* __restrict__ invstd_out,
-                                                            unsigned long long* __restrict__ mask, int ldstat) {
+__device__ __forceinline__ void bn_fwd_fused_body(const AT* __restrict__ x, int ldx, const AT* __restrict__ res, int ldr,
+                                                  AT* __restrict__ out, int ldo, int Wn, int C,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                                                  float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                  unsigned long long* __restrict__ mask, int ldstat, float* red) {
   // ldstat: pitch of mean_out / invstd_out ([W][ldstat], >= C: a dense block keeps ONE table for its whole buffer);
   // out == nullptr: statistics only (da_bn_stats_fused)
-  __shared__ float red[16 * CG];
   constexpr int NQ = 1 << QB, CGB = 4 * NQ;            // channel quads / channels per block (32 or 16)
   const int w = row_xcd_chunk(blockIdx.x, gridDim.x), cg = blockIdx.y, P = blockDim.x >> QB;
   const int q = threadIdx.x & (NQ - 1), slot = threadIdx.x >> QB;
@@ -532,22 +528,54 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const AT* __restrict
   if (mask) mask[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x] = bits;
 }
 
+template <typename AT, int NPOS, int QB, int RX3 = 0, int OX3 = 0>
+__global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const AT* __restrict__ x, int ldx,
+                                                            const AT* __restrict__ res, int ldr,
+                                                            AT* __restrict__ out, int ldo, int Wn, int C,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int relu, float eps,
+                                                            float* __restrict__ mean_out,
+                                                            float* __restrict__ invstd_out,
+                                                            unsigned long long* __restrict__ mask, int ldstat) {
+  __shared__ float red[16 * CG];
+  bn_fwd_fused_body<AT, NPOS, QB, RX3, OX3>(x, ldx, res, ldr, out, ldo, Wn, C, gamma, beta, relu, eps, mean_out, invstd_out, mask,
+                                            ldstat, red);
+}
+
+// Two BatchNorms of ONE geometry (W, Wn, C) in one launch, blockIdx.z = which: the two that follow a stride-2 block entry's
+// shared conv launch (bn1 + ReLU on the conv output, the downsample's BatchNorm on the 1x1 output; resnet.py:27-29,36-37)
+template <typename AT>
+struct BnFwdOne {
+  const AT* x;
+  const AT* res;
+  AT* out;
+  const float* gamma;
+  const float* beta;
+  float* mean;
+  float* invstd;
+  unsigned long long* mask;
+  int ldx, ldr, ldo, relu;
+};
+template <typename AT, int NPOS, int QB>
+__global__ __launch_bounds__(1024) void bn_fwd_pair_kernel(BnFwdOne<AT> a, BnFwdOne<AT> b, int Wn, int C, float eps) {
+  __shared__ float red[16 * CG];
+  const BnFwdOne<AT>& s = blockIdx.z ? b : a;
+  bn_fwd_fused_body<AT, NPOS, QB, 0, 0>(s.x, s.ldx, s.res, s.ldr, s.out, s.ldo, Wn, C, s.gamma, s.beta, s.relu, eps, s.mean,
+                                        s.invstd, s.mask, C, red);
+}
+
 // same arithmetic as bn_bwd_reduce_kernel + bn_bwd_apply_kernel with the slab held in registers
 // DX3: dx (the gradient w.r.t. the BatchNorm input = the conv output: the data-gradient and weight-gradient convs' operand)
 // is stored in the x3 format; gout stays float (the convs accumulate the branch gradient into it).
 template <typename AT, int NPOS, int QB, int DX3 = 0, int EXT = 0>
-__global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict__ dout, int ldd,
-                                                            const AT* __restrict__ x, int ldx,
-                                                            const AT* __restrict__ outp, int ldo,
-                                                            AT* __restrict__ dx, int lddx, AT* __restrict__ gout,
-                                                            int ldg, int Wn, int C, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd,
-                                                            const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, int mask_mode,
-                                                            float* __restrict__ ds1, float* __restrict__ ds2,
-                                                            const AT* __restrict__ add, int ldadd,
-                                                            const unsigned long long* __restrict__ mask, BnBwdExt ext) {
-  __shared__ float red[16 * 2 * CG];
+__device__ __forceinline__ void bn_bwd_fused_body(const AT* __restrict__ dout, int ldd, const AT* __restrict__ x, int ldx,
+                                                  const AT* __restrict__ outp, int ldo, AT* __restrict__ dx, int lddx,
+                                                  AT* __restrict__ gout, int ldg, int Wn, int C,
+                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  int mask_mode, float* __restrict__ ds1, float* __restrict__ ds2,
+                                                  const AT* __restrict__ add, int ldadd,
+                                                  const unsigned long long* __restrict__ mask, const BnBwdExt& ext, float* red) {
   constexpr int NQ = 1 << QB, CGB = 4 * NQ;            // channel quads / channels per block (32 or 16)
   const int w = row_xcd_chunk(blockIdx.x, gridDim.x), cg = blockIdx.y, P = blockDim.x >> QB;
   const int q = threadIdx.x & (NQ - 1), slot = threadIdx.x >> QB;
@@ -669,6 +697,47 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict
   }
 }
 
+template <typename AT, int NPOS, int QB, int DX3 = 0, int EXT = 0>
+__global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict__ dout, int ldd,
+                                                            const AT* __restrict__ x, int ldx,
+                                                            const AT* __restrict__ outp, int ldo,
+                                                            AT* __restrict__ dx, int lddx, AT* __restrict__ gout,
+                                                            int ldg, int Wn, int C, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int mask_mode,
+                                                            float* __restrict__ ds1, float* __restrict__ ds2,
+                                                            const AT* __restrict__ add, int ldadd,
+                                                            const unsigned long long* __restrict__ mask, BnBwdExt ext) {
+  __shared__ float red[16 * 2 * CG];
+  bn_bwd_fused_body<AT, NPOS, QB, DX3, EXT>(dout, ldd, x, ldx, outp, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta,
+                                            mask_mode, ds1, ds2, add, ldadd, mask, ext, red);
+}
+
+// ... and their backward: the block-output BatchNorm (bn2) and the downsample's BatchNorm take the SAME masked gradient
+// dout * [out > 0] (ReLU decisions as the bit mask of the forward), so neither waits for the other (resnet.py:33-38 backward)
+template <typename AT>
+struct BnBwdOne {
+  const AT* x;
+  AT* dx;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  float* ds;           // [2][W][C]
+  int ldx, lddx;
+};
+template <typename AT, int NPOS, int QB>
+__global__ __launch_bounds__(1024) void bn_bwd_pair_kernel(const AT* __restrict__ dout, int ldd, BnBwdOne<AT> a, BnBwdOne<AT> b,
+                                                           int W, int Wn, int C, const unsigned long long* __restrict__ mask) {
+  __shared__ float red[16 * 2 * CG];
+  const BnBwdOne<AT>& s = blockIdx.z ? b : a;
+  BnBwdExt ext = {};
+  bn_bwd_fused_body<AT, NPOS, QB, 0, 0>(dout, ldd, s.x, s.ldx, (const AT*)nullptr, 0, s.dx, s.lddx, (AT*)nullptr, 0, Wn, C,
+                                        s.mean, s.invstd, s.gamma, s.beta, 3, s.ds, s.ds + (size_t)W * C, (const AT*)nullptr, 0,
+                                        mask, ext, red);
+}
+
 // geometry of the single-pass kernels for W windows of Wn positions: channels per block (32, or 16 when 32 would
 // leave CUs without a block or the window too long for one block) and block size; 0: use the two-stage path
 static int g_bn_target_blocks = 256;   // blocks a launch should have before the channel group per block stops shrinking
@@ -737,6 +806,42 @@ static void bn_chunks(int W, int Wn, int C, int* P, int* chunk) {
   int ch = ((Wn + p - 1) / p + 31) / 32 * 32;
   *P = (Wn + ch - 1) / ch;
   *chunk = ch;
+}
+
+typedef struct {
+  const void* x; int ldx;
+  const void* res; int ldr;
+  void* out; int ldo;
+  float* mean; float* invstd;
+  const float* gamma; const float* beta;
+  int relu;
+  unsigned long long* mask;
+} da_bn_fwd_desc;
+typedef struct {
+  const void* x; int ldx;
+  void* dx; int lddx;
+  const float* mean; const float* invstd;
+  const float* gamma; const float* beta;
+  float* ds;
+} da_bn_bwd_desc;
+
+template <typename AT, int QB>
+static void launch_bn_fwd_pair(const da_bn_fwd_desc* d, int W, int Wn, int C, int CH, int threads, float eps, hipStream_t stream) {
+  BnFwdOne<AT> s[2];
+  for (int i = 0; i < 2; ++i)
+    s[i] = BnFwdOne<AT>{(const AT*)d[i].x, (const AT*)d[i].res, (AT*)d[i].out, d[i].gamma, d[i].beta, d[i].mean, d[i].invstd,
+                        d[i].mask, d[i].ldx, d[i].ldr, d[i].ldo, d[i].relu};
+  hipLaunchKernelGGL((bn_fwd_pair_kernel<AT, FUSED_NPOS, QB>), dim3(W, C / CH, 2), dim3(threads), 0, stream, s[0], s[1], Wn, C, eps);
+}
+
+template <typename AT, int QB>
+static void launch_bn_bwd_pair(const void* dout, int ldd, const da_bn_bwd_desc* d, int W, int Wn, int C, int CH, int threads,
+                               const unsigned long long* mask, hipStream_t stream) {
+  BnBwdOne<AT> s[2];
+  for (int i = 0; i < 2; ++i)
+    s[i] = BnBwdOne<AT>{(const AT*)d[i].x, (AT*)d[i].dx, d[i].mean, d[i].invstd, d[i].gamma, d[i].beta, d[i].ds, d[i].ldx, d[i].lddx};
+  hipLaunchKernelGGL((bn_bwd_pair_kernel<AT, FUSED_NPOS, QB>), dim3(W, C / CH, 2), dim3(threads), 0, stream, (const AT*)dout, ldd,
+                     s[0], s[1], W, Wn, C, mask);
 }
 
 extern "C" {
@@ -1091,6 +1196,61 @@ int da_bn_bwd_add(const void* dout, int ldd, const void* x, int ldx, const void*
   if (!add) return DA_EINVAL;
   return bn_bwd_impl(dout, ldd, x, ldx, out, ldo, dx, lddx, gout, ldg, W, Wn, C, mean, invstd, gamma, beta, mask_mode,
                      scratch, ds, dgamma, dbeta, accumulate, add, ldadd, nullptr, stream);
+}
+
+// Two BatchNorm forwards of one geometry in ONE launch (a stride-2 block entry: bn1 + ReLU on conv1's output and the
+// downsample's BatchNorm; resnet.py:27-29,36-37): d[0], d[1] as da_bn_fwd / da_bn_fwd_mask take them (mask may be NULL).
+// Single-pass geometry only (da_bn_mask_words(W, Wn, C) > 0; -1 otherwise: the caller runs the two calls).
+int da_bn_fwd_pair(const da_bn_fwd_desc* d, int W, int Wn, int C, float eps, hipStream_t stream) {
+  DA_ENTER();
+  if (!d || C % CG || Wn < 1) return DA_EINVAL;
+  for (int i = 0; i < 2; ++i)
+    if (!d[i].x || !d[i].out || !d[i].mean || !d[i].invstd || !d[i].gamma || !d[i].beta || d[i].ldx % 4 || d[i].ldo % 4 ||
+        (d[i].res && d[i].ldr % 4) || (d[i].mask && !d[i].relu))
+      return DA_EINVAL;
+  if (W == 0) return DA_OK;
+  int cgb = 0;
+  const int threads = bn_fused_geometry(W, Wn, C, &cgb);
+  if (!threads) return DA_EINVAL;
+#define BN_FWDP_LAUNCH(QB, CH)                                                          \
+  do {                                                                                  \
+    if (g_act_bf16) launch_bn_fwd_pair<__bf16, QB>(d, W, Wn, C, CH, threads, eps, stream); \
+    else launch_bn_fwd_pair<float, QB>(d, W, Wn, C, CH, threads, eps, stream);          \
+  } while (0)
+  if (cgb == 32) BN_FWDP_LAUNCH(3, 32);
+  else if (cgb == 16) BN_FWDP_LAUNCH(2, 16);
+  else BN_FWDP_LAUNCH(1, 8);
+#undef BN_FWDP_LAUNCH
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// ... and the two backwards that share one masked gradient (the block-output BatchNorm and the downsample's; the ReLU
+// decisions of the block output as the bit mask of da_bn_fwd_mask): dx_i = BatchNorm_i backward of dout * mask, ds_i
+// [2][W][C] the window sums for da_bn_param_grad_multi.  Single-pass geometry only.
+int da_bn_bwd_pair(const void* dout, int ldd, const da_bn_bwd_desc* d, int W, int Wn, int C, const unsigned long long* mask,
+                   hipStream_t stream) {
+  DA_ENTER();
+  if (!dout || !d || !mask || C % CG || Wn < 1 || ldd % 4) return DA_EINVAL;
+  for (int i = 0; i < 2; ++i)
+    if (!d[i].x || !d[i].dx || !d[i].mean || !d[i].invstd || !d[i].gamma || !d[i].beta || !d[i].ds || d[i].ldx % 4 ||
+        d[i].lddx % 4)
+      return DA_EINVAL;
+  if (W == 0) return DA_OK;
+  int cgb = 0;
+  const int threads = bn_fused_geometry(W, Wn, C, &cgb);
+  if (!threads) return DA_EINVAL;
+#define BN_BWDP_LAUNCH(QB, CH)                                                                 \
+  do {                                                                                         \
+    if (g_act_bf16) launch_bn_bwd_pair<__bf16, QB>(dout, ldd, d, W, Wn, C, CH, threads, mask, stream); \
+    else launch_bn_bwd_pair<float, QB>(dout, ldd, d, W, Wn, C, CH, threads, mask, stream);     \
+  } while (0)
+  if (cgb == 32) BN_BWDP_LAUNCH(3, 32);
+  else if (cgb == 16) BN_BWDP_LAUNCH(2, 16);
+  else BN_BWDP_LAUNCH(1, 8);
+#undef BN_BWDP_LAUNCH
+  DA_CHECK_LAUNCH();
+  return DA_OK;
 }
 
 // ---- dense-block forms (reference models/densenet.py:18-44,46-66,68-81; float activations, single-pass geometry only) ----

@@ -447,6 +447,20 @@ def _bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, tg, tb, out=None, dx=No
     return res + (g,) if want_g else res
 
 
+def _bn_pgrad(ds, gamma, beta, tg, tb):
+    """dgamma / dbeta from a BatchNorm backward's window sums ``ds``: queued for (or run as) the batched fold into the trainer's
+    destinations (-> (None, None)), or returned."""
+    if tg is not None and tb is not None:
+        if _STEP['on']:
+            _STEP['pgrad'].append((ds, tg, tb))
+        else:
+            H.bn_param_grad_multi([(ds, tg, tb)], accumulate=True)
+        return None, None
+    dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+    H.bn_param_grad_multi([(ds, dg, db)], accumulate=False)
+    return dg, db
+
+
 def _wgrad(dy, x, k, stride, pad, tw, extra=None):
     """Weight gradient of a conv: queued for the step's batched launch (a trainer's gradient destination ``tw``), or run now.
     ``extra``: the dense-block operand forms of H.conv_wgrad_multi (x recomputed as relu(norm(x)), dy at half resolution);
@@ -503,14 +517,29 @@ class BasicBlockFunction(Function):
             y1, yd = H.conv_fwd_multi([(x, _pack(w1, False)[0], stride, 1), (x, _pack(wd, False)[0], stride, 0)])
         else:
             y1 = _conv_fwd(x, w1, stride, 1)
-        if pair:          # the downsample BatchNorm first: yd is still in L2 / MALL right after the shared launch
-            sd = _Stats()   # (forking it beside bn1 / conv2 on another stream was measured slower)
-            res = _bn_apply(yd, R, sd, std, gd, bd, False)
         mid3 = x3_block_ok(y1.shape[0], y1.shape[1], y1.shape[2], R) and _is_wino(w2, 1, 1) == 49
         if (in3 or want_out3) and not mid3:
             raise ValueError('x3 input / output asked of a block whose shape has no x3 store forms')
         s1 = _Stats()
-        if fuse1:         # bn1 + ReLU applied while conv2 stages its operand: statistics from the records conv1's epilogue wrote
+        # the two BatchNorms behind the shared conv launch (the downsample's and bn1) in ONE launch when the shape has the
+        # single-pass geometry: two ~10 us latency chains side by side instead of one after the other
+        bn_pair = pair and not mid3 and not fuse1 and _BN_PAIR and std.eps == st1.eps and \
+            y1.shape[0] % R == 0 and H.bn_single_pass(y1.shape[0] // R, R * y1.shape[1], y1.shape[2])
+        ctx.bn_pair = bn_pair
+        if bn_pair:
+            sd = _Stats()
+            (res, sd.mean, sd.invstd, _), (h1, s1.mean, s1.invstd, _) = H.bn_fwd_pair(
+                [(yd, gd, bd, False, None, False), (y1, g1, b1, True, None, False)], R, st1.eps)
+            _running(yd, R, sd, std)
+            _running(y1, R, s1, st1)
+            _tap(h1)
+            y2 = _conv_fwd(h1, w2, 1, 1)
+        elif pair:        # the downsample BatchNorm first: yd is still in L2 / MALL right after the shared launch
+            sd = _Stats()   # (forking it beside bn1 / conv2 on another stream was measured slower)
+            res = _bn_apply(yd, R, sd, std, gd, bd, False)
+        if bn_pair:
+            pass
+        elif fuse1:         # bn1 + ReLU applied while conv2 stages its operand: statistics from the records conv1's epilogue wrote
             wn_ = y1.shape[0] // R
             s1.mean = torch.empty((wn_, y1.shape[2]), device=y1.device, dtype=torch.float32)
             s1.invstd = torch.empty_like(s1.mean)
@@ -563,11 +592,18 @@ class BasicBlockFunction(Function):
         in3, mid3 = ctx.in3, ctx.mid3
         dout = dout.contiguous()
         # relu + residual add + bn2
-        if mid3:          # dy2 feeds the k3 s1 data-gradient and weight-gradient convs: stored pre-split
+        bwd_pair = ctx.has_ds and ctx.bn_pair and ctx.relu_mask is not None and not mid3 and not ctx.s2x
+        if bwd_pair:      # bn2 and the downsample's BatchNorm take the same masked gradient: one launch, no g tensor
+            wd, gd, bd, yd, md, idd = s[15:]
+            (dy2, ds2), (dyd, dsd) = H.bn_bwd_pair(dout, [(y2, m2, i2, g2, b2, None), (yd, md, idd, gd, bd, None)], R, ctx.relu_mask)
+            dg2, db2 = _bn_pgrad(ds2, g2, b2, tg2, tb2)
+            dgd, dbd = _bn_pgrad(dsd, gd, bd, tgd, tbd)
+            g = None
+        elif mid3:        # dy2 feeds the k3 s1 data-gradient and weight-gradient convs: stored pre-split
             dy2, dg2, db2, g = _bn_bwd_x(dout, y2, R, m2, i2, g2, b2, 3, tg2, tb2, want_g=True, mask=ctx.relu_mask)
         else:
             dy2, dg2, db2, g = _bn_bwd(dout, y2, R, m2, i2, g2, b2, 2, tg2, tb2, out=out, want_g=True, mask=ctx.relu_mask)
-        if ctx.has_ds:    # the downsample BatchNorm's backward right away: g is still cache-resident
+        if ctx.has_ds and not bwd_pair:    # the downsample BatchNorm's backward right away: g is still cache-resident
             wd, gd, bd, yd, md, idd = s[15:]
             if ctx.s2x:       # x3: it feeds the stride-2 data-gradient and weight-gradient kernels
                 dyd, dgd, dbd = _bn_bwd_x(g, yd, R, md, idd, gd, bd, 0, tgd, tbd)
@@ -612,6 +648,7 @@ class BasicBlockFunction(Function):
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None, None
 
 
+_BN_PAIR = True           # a block entry's two independent BatchNorms (forward: bn1 | downsample; backward: bn2 | downsample) share a launch
 _BN1_FUSED = os.environ.get('DA_BN1_FUSED', '0') == '1'   # conv dtype bf16: bn1 of a stride-1 residual block without a pass of its own -- measured slower (profiles/r04_bf16_bn1_fusion.txt): opt-in
 _DENSE_BLOCK = os.environ.get('DA_DENSE_BLOCK', '1') != '0'   # 0: the per-layer Functions below (the path shapes without the block kernels take)
 

@@ -846,6 +846,61 @@ def bn_fwd(x, R, gamma, beta, relu=True, res=None, eps=1e-5, out=None, want_mask
     return (out, mean, invstd, mask) if want_mask else (out, mean, invstd)
 
 
+def bn_fwd_pair(items, R, eps=1e-5):
+    """Two BatchNorm forwards of ONE shape in one launch (a stride-2 block entry: bn1 + ReLU on conv1's output and the
+    downsample's BatchNorm): items = two (x, gamma, beta, relu, res | None, want_mask) -> [(out, mean, invstd, mask | None)].
+    Single-pass geometry only (bn_single_pass)."""
+    (x0, x1) = items[0][0], items[1][0]
+    _rlc(x0, 'x')
+    _rlc(x1, 'x')
+    rows, l, c = x0.shape
+    if len(items) != 2 or tuple(x1.shape) != (rows, l, c) or rows % R:
+        raise ValueError('bn_fwd_pair: two tensors of one (rows, L, C) shape, rows a multiple of rows_per_window')
+    w = rows // R
+    L = _lib.lib()
+    words = L.da_bn_mask_words(w, R * l, c)
+    arr = (_lib.BnFwdDesc * 2)()
+    outs = []
+    for d, (x, gamma, beta, relu, res, want_mask) in zip(arr, items):
+        if res is not None and tuple(res.shape) != (rows, l, c):
+            raise ValueError('residual shape mismatch')
+        out = torch.empty_like(x)
+        mean = torch.empty((w, c), device=x.device, dtype=torch.float32)
+        invstd = torch.empty((w, c), device=x.device, dtype=torch.float32)
+        mask = torch.empty((words,), device=x.device, dtype=torch.int64) if (want_mask and relu and words) else None
+        d.x, d.ldx, d.res, d.ldr, d.out, d.ldo = x.data_ptr(), c, (res.data_ptr() if res is not None else None), c, out.data_ptr(), c
+        d.mean, d.invstd, d.gamma, d.beta = mean.data_ptr(), invstd.data_ptr(), _f32(gamma).data_ptr(), _f32(beta).data_ptr()
+        d.relu, d.mask = (1 if relu else 0), (mask.data_ptr() if mask is not None else None)
+        outs.append((out, mean, invstd, mask))
+    _chk(L.da_bn_fwd_pair(arr, w, R * l, c, eps, _stream()), 'da_bn_fwd_pair')
+    return outs
+
+
+def bn_bwd_pair(dout, items, R, mask):
+    """The two BatchNorm backwards that share one masked gradient dout * [out > 0] (a block entry's bn2 and its downsample's
+    BatchNorm; ``mask``: the ReLU bit mask of the block output's bn_fwd(want_mask=True)) in one launch: items = two
+    (x, mean, invstd, gamma, beta, dx | None) -> [(dx, ds (2, W, C))]."""
+    _rlc(dout, 'dout')
+    rows, l, c = dout.shape
+    if len(items) != 2 or rows % R or mask is None:
+        raise ValueError('bn_bwd_pair: two items, rows a multiple of rows_per_window, a ReLU bit mask')
+    w = rows // R
+    arr = (_lib.BnBwdDesc * 2)()
+    outs = []
+    for d, (x, mean, invstd, gamma, beta, dx) in zip(arr, items):
+        _rlc(x, 'x')
+        if tuple(x.shape) != (rows, l, c):
+            raise ValueError('bn_bwd_pair: shape mismatch')
+        if dx is None:
+            dx = torch.empty_like(x)
+        ds = torch.empty((2, w, c), device=x.device, dtype=torch.float32)
+        d.x, d.ldx, d.dx, d.lddx = x.data_ptr(), c, dx.data_ptr(), c
+        d.mean, d.invstd, d.gamma, d.beta, d.ds = mean.data_ptr(), invstd.data_ptr(), _f32(gamma).data_ptr(), _f32(beta).data_ptr(), ds.data_ptr()
+        outs.append((dx, ds))
+    _chk(_lib.lib().da_bn_bwd_pair(_p(dout), c, arr, w, R * l, c, _p(mask), _stream()), 'da_bn_bwd_pair')
+    return outs
+
+
 def bn_x3_ok(rows, l, c, R):
     """Whether the BatchNorm of a (rows, L, C) tensor in windows of R rows has the single-pass geometry the x3 store forms
     exist for (a window slab fits one block's registers: R * L <= 1280 at the usual channel counts)."""

@@ -304,6 +304,22 @@ int da_conv3_winograd_drop(const float* x, const float* u, float* y, int rows, i
                            da_stream_t stream);     /* stat_part != NULL: + the records of y for windows of R rows */
 
 int da_bn_param_grad_multi(const da_bn_pgrad_desc* descs, int n, int accumulate, da_stream_t stream);
+/* Two BatchNorms of ONE geometry (W, Wn, C) in one launch -- a stride-2 BasicBlock entry (resnet.py:27-29,33-38,126-128):
+ * forward: bn1 + ReLU on conv1's output and the downsample's BatchNorm on the 1x1 conv's (d[0], d[1] as da_bn_fwd /
+ * da_bn_fwd_mask take them); backward: the block-output BatchNorm (bn2) and the downsample's take the SAME masked gradient
+ * dout * [out > 0] (mask = the ReLU bit mask of da_bn_fwd_mask), ds_i [2][W][C] for da_bn_param_grad_multi.
+ * Single-pass geometry only (da_bn_mask_words(W, Wn, C) > 0, else -1: the caller issues the two calls). */
+typedef struct {
+  const da_act_t* x; int ldx; const da_act_t* res; int ldr; da_act_t* out; int ldo; float* mean; float* invstd;
+  const float* gamma; const float* beta; int relu; unsigned long long* mask;
+} da_bn_fwd_desc;
+typedef struct {
+  const da_act_t* x; int ldx; da_act_t* dx; int lddx; const float* mean; const float* invstd; const float* gamma;
+  const float* beta; float* ds;
+} da_bn_bwd_desc;
+int da_bn_fwd_pair(const da_bn_fwd_desc* d, int W, int Wn, int C, float eps, da_stream_t stream);
+int da_bn_bwd_pair(const da_act_t* dout, int ldd, const da_bn_bwd_desc* d, int W, int Wn, int C,
+                   const unsigned long long* mask, da_stream_t stream);
 /* The same BatchNorm forward / backward (resnet.py:27-38) in front of an x3 consumer (conv arithmetic 'f32x3', see
  * da_conv3_x3p): float in, and res_x3 / out_x3 / dx_x3 say which of `res`, `out`, `dx` are in the x3 format (their pitches are
  * ignored).  Single-pass geometry only (da_bn_mask_words() > 0; -1 otherwise); mask may be NULL (no ReLU bit mask wanted /

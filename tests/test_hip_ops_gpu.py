@@ -100,6 +100,31 @@ def test_conv_wgrad_multi_matches_single_jobs(H):
     assert H.conv_wgrad_multi([]) == []
 
 
+@pytest.mark.parametrize('C,L,R,W', [(128, 28, 20, 64), (256, 14, 20, 3), (512, 7, 20, 5), (64, 56, 20, 2)])
+def test_batchnorm_pair_launches_equal_the_single_ones(H, C, L, R, W):
+    """A stride-2 block entry's two independent BatchNorms in one launch (da_bn_fwd_pair: bn1 + ReLU | the downsample's;
+    da_bn_bwd_pair: bn2 | the downsample's from the same masked gradient) == the single launches, bit for bit (the same
+    body on the same geometry; oracle parity of those: test_bn_*)."""
+    rows = R * W
+    g = torch.Generator().manual_seed(C + L + W)
+    mk = lambda *sh: torch.randn(*sh, generator=g).cuda()
+    y1, yd, y2, res_in = mk(rows, L, C), mk(rows, L, C), mk(rows, L, C), mk(rows, L, C)
+    g1, b1, gd, bd, g2, b2 = (torch.rand(C, generator=g).cuda() + 0.5 for _ in range(6))
+    assert H.bn_single_pass(W, R * L, C)
+    (res, md, idd, _), (h1, m1, i1, _) = H.bn_fwd_pair([(yd, gd, bd, False, None, False), (y1, g1, b1, True, None, False)], R)
+    res_s, md_s, id_s = H.bn_fwd(yd, R, gd, bd, relu=False)
+    h1_s, m1_s, i1_s = H.bn_fwd(y1, R, g1, b1, relu=True)
+    for a, b in ((res, res_s), (md, md_s), (idd, id_s), (h1, h1_s), (m1, m1_s), (i1, i1_s)):
+        assert torch.equal(a, b)
+    out, m2, i2, mask = H.bn_fwd(y2, R, g2, b2, relu=True, res=res, want_mask=True)
+    dout = mk(rows, L, C)
+    (dy2, ds2), (dyd, dsd) = H.bn_bwd_pair(dout, [(y2, m2, i2, g2, b2, None), (yd, md, idd, gd, bd, None)], R, mask)
+    dy2_s, _, _, g_s, ds2_s = H.bn_bwd(dout, y2, R, m2, i2, g2, b2, 2, out=out, want_g=True, mask=mask, defer_param_grads=True)
+    dyd_s, _, _, _, dsd_s = H.bn_bwd(g_s, yd, R, md, idd, gd, bd, 0, defer_param_grads=True)
+    for a, b in ((dy2, dy2_s), (ds2, ds2_s), (dyd, dyd_s), (dsd, dsd_s)):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('ci,co,L,rows', [(512, 512, 7, 40), (512, 512, 14, 23), (512, 1024, 7, 33), (512, 512, 5, 9),
                                           (512, 512, 1, 70), (512, 512, 4, 64), (512, 512, 8, 1), (1024, 512, 9, 300)])
 def test_conv3_wgrad_winograd4(H, ci, co, L, rows):
