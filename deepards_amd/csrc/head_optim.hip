@@ -283,10 +283,29 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 }
 
 // g <- clamp(g*gscale, +-clip); g += wd*p; buf = first ? g : mom*buf + g; p -= lr*(g + mom*buf)
+// (four elements a thread: the flat buffers are 256-B aligned segments, n4 = n / 4 quads + a scalar tail)
 __global__ __launch_bounds__(256) void clamp_sgd_nesterov_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                                  float* __restrict__ buf, size_t n, float lr, float mom,
                                                                  float wd, float clip, float gscale, int first) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(buf)) & 15) == 0;
+  const size_t n4 = al ? n >> 2 : 0, stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = t0; i < n4; i += stride) {
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i], bv = {0.f, 0.f, 0.f, 0.f};
+    if (!first) bv = reinterpret_cast<const f32x4*>(buf)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gi = gv[e] * gscale;
+      if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+      gi = fmaf(wd, pv[e], gi);
+      const float bi = first ? gi : fmaf(mom, bv[e], gi);
+      bv[e] = bi;
+      pv[e] = pv[e] - lr * fmaf(mom, bi, gi);
+    }
+    reinterpret_cast<f32x4*>(buf)[i] = bv;
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+  }
+  for (size_t i = (n4 << 2) + t0; i < n; i += stride) {
     float gi = g[i] * gscale;
     if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
     float pi = p[i];
@@ -899,7 +918,7 @@ int da_clamp_sgd_nesterov(float* p, const float* g, float* buf, size_t n, float 
   DA_ENTER();
   if (!p || !g || !buf) return DA_EINVAL;
   if (n == 0) return DA_OK;
-  hipLaunchKernelGGL(clamp_sgd_nesterov_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, p, g, buf, n, lr,
+  hipLaunchKernelGGL(clamp_sgd_nesterov_kernel, dim3(grid_for((n + 3) / 4, 256, 4096)), dim3(256), 0, stream, p, g, buf, n, lr,
                      momentum, weight_decay, clip, gscale, first);
   DA_CHECK_LAUNCH();
   return DA_OK;
