@@ -85,7 +85,7 @@ __device__ __forceinline__ int wino_row(int i) {
 //               conv_gemm.hip "Tail tiles": a half tile holds its CU for a quarter of a full tile's time.
 #define WINO_STAT_FLOATS (4 * 2 * 2 * 32 + 8)           // the records' fold area behind the operand panels
 #define WINO_XF_FLOATS (2 * 2 * 128)                  // [2 window slots][{sc, sh}][C <= 128] behind that
-template <bool MINI, bool STATS = false, bool XFW = false>
+template <bool MINI, bool STATS = false, bool XFW = false, bool DROP = false>
 __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int tile, const int sub, float* lds) {
   constexpr int PITCH = WINO_PITCH, PAIRS = MINI ? 32 : 64, AR = PAIRS + 2;
   float* Es = lds;                      // [AR][PITCH] even positions of pairs P0-1 .. P0+PAIRS
@@ -274,7 +274,7 @@ __device__ __forceinline__ void conv3_wino_body(const WinoArgs& a, const int til
   }
 
   // output transform + store: lane holds channel n = nt*16 + wino_row(l%16) of the pairs wino_row(4*(l/16) + r)
-  const bool drop = a.drop_p > 0.f;
+  const bool drop = (DROP || STATS || XFW) && a.drop_p > 0.f;      // (the plain kernel carries no dropout code: DROP = a form of its own)
   uint32_t dkey = 0u, dthr = 0u;
   float dscale = 1.f;
   if (drop) {
@@ -400,6 +400,12 @@ __global__ __launch_bounds__(256) void conv3_wino_kernel(WinoArgs a, int nmini, 
     return;
   }
   conv3_wino_body<false>(a, xcd_chunked(blockIdx.x - nmini_pad, full), 0, lds);
+}
+
+// ... with F.dropout in the epilogue and no statistics records (a dense layer outside the fused block path)
+__global__ __launch_bounds__(256) void conv3_wino_drop_kernel(WinoArgs a, int full) {
+  __shared__ float lds[WINO_LDS_FLOATS];
+  conv3_wino_body<false, false, false, true>(a, xcd_chunked(blockIdx.x, full), 0, lds);
 }
 
 // the same tiles (whole ones only) with the statistics records of the output written from the epilogue (WinoArgs.stat_part)
@@ -1317,7 +1323,8 @@ static int conv3_winograd_impl(const float* x, const float* u, float* y, int row
   const int tiles = ((a.MP + 63) / 64) * (N / 32);
   const int R = tiles % 256;
   int nmini = 0, full = tiles;
-  if (g_wino_tail && !stat_part && !bn && tiles > 256 && R >= 1 && R <= 128) {
+  const bool dropping = drop_p > 0.f;
+  if (g_wino_tail && !stat_part && !bn && !dropping && tiles > 256 && R >= 1 && R <= 128) {
     nmini = 2 * R;
     full = tiles - R;
   }
@@ -1325,6 +1332,7 @@ static int conv3_winograd_impl(const float* x, const float* u, float* y, int row
   if (bn && stat_part) hipLaunchKernelGGL(conv3_wino_bn_kernel<true>, dim3(full), dim3(256), 0, stream, a, full);
   else if (bn) hipLaunchKernelGGL(conv3_wino_bn_kernel<false>, dim3(full), dim3(256), 0, stream, a, full);
   else if (stat_part) hipLaunchKernelGGL(conv3_wino_stats_kernel, dim3(full), dim3(256), 0, stream, a, full);
+  else if (dropping) hipLaunchKernelGGL(conv3_wino_drop_kernel, dim3(full), dim3(256), 0, stream, a, full);
   else hipLaunchKernelGGL(conv3_wino_kernel, dim3(nmini_pad + full), dim3(256), 0, stream, a, nmini, nmini_pad, full);
   DA_CHECK_LAUNCH();
   return DA_OK;
