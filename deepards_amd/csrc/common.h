@@ -224,6 +224,24 @@ __device__ __forceinline__ void merge_stat_records(const float* __restrict__ par
   invstd = 1.0f / sqrtf(m2 / fmaxf(n, 1.f) + eps);
 }
 
+// One block of the fold of the stem's weight-gradient partials [nblk][n] -> dw[n] (stem_pool.hip stem_wgrad_reduce_kernel):
+// 8 outputs x 32 slots, fixed order.
+__device__ __forceinline__ void stem_wgrad_reduce_block(const float* __restrict__ partial, int nblk, int n,
+                                                        float* __restrict__ dw, int accumulate, int blk, float (*red)[8]) {
+  const int o = threadIdx.x & 7, slot = threadIdx.x >> 3;
+  const int i = blk * 8 + o;
+  float s = 0.f;
+  if (i < n)
+    for (int b = slot; b < nblk; b += 32) s += partial[(size_t)b * n + i];
+  red[slot][o] = s;
+  __syncthreads();
+  if (threadIdx.x < 8 && i < n) {
+    s = 0.f;
+    for (int k = 0; k < 32; ++k) s += red[k][threadIdx.x];
+    dw[i] = accumulate ? dw[i] + s : s;
+  }
+}
+
 // One block of the dgamma / dbeta fold of a BatchNorm (bn.hip bn_param_grad_multi_kernel; conv_gemm.hip's slab reduction runs
 // the same blocks beside its own): channels [32 chunk, 32 chunk + 32), 8 window slots, fixed order.
 struct BnPgradDesc {

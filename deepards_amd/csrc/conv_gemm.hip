@@ -1044,6 +1044,9 @@ struct ReducePgradTable {
   BnPgradDesc p[REDUCE_MAX_BN];
   BnRunningDesc r[REDUCE_MAX_BN];
   int m, npg, nrun, chunks;    // chunks = ceil(max C / 32): block x of those rows = (BatchNorm x / chunks, channel chunk x % chunks)
+  const float* stem_partial;   // row m + 2: the stem's weight-gradient partials [stem_nblk][stem_n] -> stem_dw (or NULL)
+  float* stem_dw;
+  int stem_nblk, stem_n;
 };
 
 __device__ __forceinline__ void wgrad_reduce_block(const WgradReduceDesc& d, int accumulate);
@@ -1058,8 +1061,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_pgrad_kernel(WgradReduceTabl
     const int bn = blockIdx.x / g.chunks, chunk = blockIdx.x - bn * g.chunks;
     if ((int)blockIdx.y == g.m) {
       if (bn < g.npg) bn_param_grad_block(g.p[bn], chunk, accumulate, red);
-    } else if (bn < g.nrun) {
-      bn_running_block(g.r[bn], chunk, red);
+    } else if ((int)blockIdx.y == g.m + 1) {
+      if (bn < g.nrun) bn_running_block(g.r[bn], chunk, red);
+    } else if ((int)blockIdx.x * 8 < g.stem_n) {
+      stem_wgrad_reduce_block(g.stem_partial, g.stem_nblk, g.stem_n, g.stem_dw, accumulate, blockIdx.x,
+                              reinterpret_cast<float (*)[8]>(&red[0][0][0]));
     }
     return;
   }
@@ -1431,12 +1437,16 @@ int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumula
 // The tail of a training step in ONE launch: every slab reduction (da_wgrad_reduce_multi), every BatchNorm dgamma / dbeta
 // fold (da_bn_param_grad_multi) and every running-statistics update (da_bn_running_multi).  Up to 32 reductions and 24
 // BatchNorms of each kind share the launch; anything else runs as the three calls.
+int da_stem_wgrad_reduce(const float* partial, int nblk, int n, float* dw, int accumulate, hipStream_t stream);
 int da_step_tail_multi(const da_wgrad_reduce_desc* descs, int n, const da_bn_pgrad_desc* pg, int npg,
-                       const da_bn_running_desc* run, int nrun, int accumulate, hipStream_t stream) {
+                       const da_bn_running_desc* run, int nrun, const float* stem_partial, int stem_nblk, int stem_n,
+                       float* stem_dw, int accumulate, hipStream_t stream) {
   DA_ENTER();
   if (n < 0 || npg < 0 || nrun < 0 || (n && !descs) || (npg && !pg) || (nrun && !run)) return DA_EINVAL;
-  if (n == 0 || n > 32 || npg > REDUCE_MAX_BN || nrun > REDUCE_MAX_BN || npg + nrun == 0) {
+  if (stem_partial && (!stem_dw || stem_nblk < 1 || stem_n < 1)) return DA_EINVAL;
+  if (n == 0 || n > 32 || npg > REDUCE_MAX_BN || nrun > REDUCE_MAX_BN || (npg + nrun == 0 && !stem_partial)) {
     int rc = nrun ? da_bn_running_multi(run, nrun, stream) : DA_OK;
+    if (!rc && stem_partial) rc = da_stem_wgrad_reduce(stem_partial, stem_nblk, stem_n, stem_dw, accumulate, stream);
     if (!rc && npg) rc = da_bn_param_grad_multi(pg, npg, accumulate, stream);
     if (!rc && n) rc = da_wgrad_reduce_multi(descs, n, accumulate, stream);
     return rc;
@@ -1463,10 +1473,12 @@ int da_step_tail_multi(const da_wgrad_reduce_desc* descs, int n, const da_bn_pgr
     g.r[i] = {s.mean, s.invstd, s.running_mean, s.running_var, s.num_batches_tracked, s.W, s.C, s.Wn, s.eps, s.momentum};
     if (s.C > maxc) maxc = s.C;
   }
-  g.m = n; g.npg = npg; g.nrun = nrun; g.chunks = (maxc + 31) / 32;
-  const int nb = (npg > nrun ? npg : nrun) * g.chunks;
+  g.m = n; g.npg = npg; g.nrun = nrun; g.chunks = (maxc + 31) / 32 > 0 ? (maxc + 31) / 32 : 1;
+  g.stem_partial = stem_partial; g.stem_dw = stem_dw; g.stem_nblk = stem_nblk; g.stem_n = stem_n;
+  int nb = (npg > nrun ? npg : nrun) * g.chunks;
+  if (stem_partial && (stem_n + 7) / 8 > nb) nb = (stem_n + 7) / 8;
   const int gx = (maxtot + 255) / 256 > nb ? (maxtot + 255) / 256 : nb;
-  hipLaunchKernelGGL(wgrad_reduce_pgrad_kernel, dim3(gx, n + 2), dim3(256), 0, stream, t, g, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_pgrad_kernel, dim3(gx, n + (stem_partial ? 3 : 2)), dim3(256), 0, stream, t, g, accumulate);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

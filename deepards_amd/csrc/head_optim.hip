@@ -81,14 +81,13 @@ __global__ __launch_bounds__(256) void linear2_bwd_input_kernel(const float* __r
 // dW[o][i] (+)= sum_b dl[b][o] flat[b][i];  dbias[o] (+)= sum_b dl[b][o].  Block = 64 columns (16 float4 lanes) x 16 row
 // slots folded through LDS in a fixed order (deterministic); rows = windows for cnn_linear, window*breath rows for the
 // per-breath heads (1280 at B = 64: the one-thread-per-column loop over all rows took hundreds of microseconds there).
-__global__ __launch_bounds__(256) void linear2_bwd_weight_kernel(const float* __restrict__ dl,
-                                                                 const float* __restrict__ flat, float* __restrict__ dW,
-                                                                 float* __restrict__ dbias, int B, int K,
-                                                                 int accumulate, const float* __restrict__ terms = nullptr,
-                                                                 float inv_n = 0.f, float* __restrict__ loss = nullptr) {
-  __shared__ f32x4 red[2][16][16];
+// (dl / terms may live in LDS: the fused head's backward kernel runs these blocks itself)
+__device__ __forceinline__ void linear2_bwd_weight_block(const float* dl, const float* __restrict__ flat,
+                                                         float* __restrict__ dW, float* __restrict__ dbias, int B, int K,
+                                                         int accumulate, const float* terms, float inv_n,
+                                                         float* __restrict__ loss, int blk, f32x4 (*red)[16][16]) {
   const int kq = threadIdx.x & 15, slot = threadIdx.x >> 4;
-  const int i = (blockIdx.x * 16 + kq) * 4;
+  const int i = (blk * 16 + kq) * 4;
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
   if (i < K) {
     for (int b = slot; b < B; b += 16) {
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(256) void linear2_bwd_weight_kernel(const float* __
     *reinterpret_cast<f32x4*>(dW + i) = a0;
     *reinterpret_cast<f32x4*>(dW + K + i) = a1;
   }
-  if (blockIdx.x == 0 && threadIdx.x < 64) {          // first wave: the two bias gradients (fixed shuffle tree)
+  if (blk == 0 && threadIdx.x < 64) {                 // first wave: the two bias gradients (fixed shuffle tree)
     float s0 = 0.f, s1 = 0.f;
     for (int b = threadIdx.x; b < B; b += 64) {
       s0 += dl[b * 2];
@@ -146,15 +145,25 @@ __global__ __launch_bounds__(256) void linear2_bwd_weight_kernel(const float* __
   }
 }
 
+__global__ __launch_bounds__(256) void linear2_bwd_weight_kernel(const float* __restrict__ dl,
+                                                                 const float* __restrict__ flat, float* __restrict__ dW,
+                                                                 float* __restrict__ dbias, int B, int K,
+                                                                 int accumulate, const float* __restrict__ terms = nullptr,
+                                                                 float inv_n = 0.f, float* __restrict__ loss = nullptr) {
+  __shared__ f32x4 red[2][16][16];
+  linear2_bwd_weight_block(dl, flat, dW, dbias, B, K, accumulate, terms, inv_n, loss, blockIdx.x, red);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
-// The head chain of CNNLinearNetwork in three launches instead of six (reference models/resnet.py:112,159-160 /
+// The head chain of CNNLinearNetwork in TWO launches instead of six (reference models/resnet.py:112,159-160 /
 // densenet.py:167,183-184 AvgPool1d(7,1) + view; torch_cnn_linear_network.py:102,110-112 linear_final on view(-1);
 // train_ards_detector.py:530 BCEWithLogitsLoss, and their backward):
 //   head_pool_dot_kernel  one block per (window, row group): global average pool of its rows -> flat (kept for dW) and its
 //                         share of the two dot products (a block per window could not pull its 287 KB fast enough: 12 us)
 //   head_bwd_kernel       logits from the partial dot products, the window's BCE terms and dlogits = (sigmoid - t) gscale / n
 //                         (n = 2 B elements), dx[row][l][f] = (dl[b][0] W[0][r F + f] + dl[b][1] W[1][r F + f]) / L
-//   linear2_bwd_weight_kernel (below, with `terms`): dW, dbias and loss = mean of the terms (fixed order)
+//                         ... and, in further blocks of the SAME launch (they recompute every window's dlogits / term from
+//                         the partials into LDS), dW, dbias and loss = mean of the terms (linear2_bwd_weight_block, fixed order)
 //   (forward only: head_finish_kernel = logits + loss)
 // ---------------------------------------------------------------------------------------------------------------------
 // block g of window b: 256 of the window's R * F / 4 (row, 4 features) items -- their pooled features -> flat, and the block's
@@ -242,12 +251,31 @@ __global__ __launch_bounds__(256) void head_finish_kernel(const float* __restric
 // backward, same (window, 256 items) blocks: the window's dlogits from the partials (two threads, through LDS), then every
 // thread writes the L positions of its (row, 4 features); block 0 of a window also publishes logits / dlogits / terms for the
 // weight kernel and the caller
+#define HEAD_MAXB 512     // windows whose dlogits / terms the weight blocks of head_bwd_kernel keep in LDS (more: two launches)
 template <typename AT>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                        const float* __restrict__ target, const float* __restrict__ W,
                                                        AT* __restrict__ dx, int lddx, float* __restrict__ logits,
                                                        float* __restrict__ dlogits, float* __restrict__ terms, int R, int G,
-                                                       int L, int F, float inv_n, float gscale) {
+                                                       int L, int F, float inv_n, float gscale, const float* __restrict__ flat,
+                                                       float* __restrict__ dW, float* __restrict__ dbias,
+                                                       float* __restrict__ loss, int accumulate, int wblocks) {
+  if ((int)blockIdx.y >= G) {                           // the weight-gradient blocks (wblocks > 0 only)
+    __shared__ float wdl[2 * HEAD_MAXB], wterm[HEAD_MAXB];
+    __shared__ f32x4 red[2][16][16];
+    const int B = gridDim.x, blk = ((int)blockIdx.y - G) * B + (int)blockIdx.x;
+    if (blk >= wblocks) return;
+    for (int b = threadIdx.x; b < B; b += 256) {
+      float lg[2], dl[2], term;
+      head_logits(part, bias, target, b, G, inv_n, gscale, lg, dl, term);
+      wdl[2 * b] = dl[0];
+      wdl[2 * b + 1] = dl[1];
+      wterm[b] = term;
+    }
+    __syncthreads();
+    linear2_bwd_weight_block(wdl, flat, dW, dbias, B, R * F, accumulate, wterm, inv_n, loss, blk, red);
+    return;
+  }
   __shared__ float sdl[2];
   const int b = blockIdx.x, g = blockIdx.y, K = R * F, nq = F >> 2;
   const int i = g * 256 + threadIdx.x;
@@ -904,12 +932,18 @@ int da_head_bwd(const float* part, const float* bias, const float* target, const
   if (B == 0) return DA_OK;
   const int K = R * F, G = da_head_groups(R, F);
   const float inv_n = 1.0f / (2.0f * (float)B);
-  DA_ACT_DISPATCH(hipLaunchKernelGGL(head_bwd_kernel<AT>, dim3(B, G), dim3(256), 0, stream, part, bias, target, W, (AT*)dx, lddx,
-                                     logits, dlogits, terms, R, G, L, F, inv_n, gscale));
+  const int wblocks = (K / 4 + 15) / 16;
+  const bool one = B <= HEAD_MAXB;                      // the weight gradient as further blocks of the same launch
+  const int wrows = one ? (wblocks + B - 1) / B : 0;
+  DA_ACT_DISPATCH(hipLaunchKernelGGL(head_bwd_kernel<AT>, dim3(B, G + wrows), dim3(256), 0, stream, part, bias, target, W, (AT*)dx,
+                                     lddx, logits, dlogits, terms, R, G, L, F, inv_n, gscale, flat, dW, dbias, loss, accumulate,
+                                     one ? wblocks : 0));
   DA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(linear2_bwd_weight_kernel, dim3((K / 4 + 15) / 16), dim3(256), 0, stream, dlogits, flat, dW, dbias, B, K,
-                     accumulate, terms, inv_n, loss);
-  DA_CHECK_LAUNCH();
+  if (!one) {
+    hipLaunchKernelGGL(linear2_bwd_weight_kernel, dim3(wblocks), dim3(256), 0, stream, dlogits, flat, dW, dbias, B, K, accumulate,
+                       terms, inv_n, loss);
+    DA_CHECK_LAUNCH();
+  }
   return DA_OK;
 }
 

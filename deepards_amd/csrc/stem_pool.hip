@@ -88,18 +88,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const AT* __restrict__ 
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int n,
                                                                 float* __restrict__ dw, int accumulate) {
   __shared__ float red[32][8];
-  const int o = threadIdx.x & 7, slot = threadIdx.x >> 3;
-  const int i = blockIdx.x * 8 + o;
-  float s = 0.f;
-  if (i < n)
-    for (int b = slot; b < nblk; b += 32) s += partial[(size_t)b * n + i];
-  red[slot][o] = s;
-  __syncthreads();
-  if (threadIdx.x < 8 && i < n) {
-    s = 0.f;
-    for (int k = 0; k < 32; ++k) s += red[k][threadIdx.x];
-    dw[i] = accumulate ? dw[i] + s : s;
-  }
+  stem_wgrad_reduce_block(partial, nblk, n, dw, accumulate, blockIdx.x, red);      // (common.h: the step's tail launch runs these too)
 }
 
 // out[row][j][c] = pool_{l in {2j-1,2j,2j+1}} relu(bn(y[row][l][c]));  pool_mode 0 = max (-inf pad),
@@ -714,9 +703,32 @@ int da_stem_bn_relu_pool_fwd(const float* xrows, const float* wt, void* out, int
   return DA_OK;
 }
 
+// where da_stem_bwd(dw = NULL) leaves its weight-gradient partials: offset (floats) into the workspace and their count --
+// [nblk][C * 7], to be summed over nblk into dw (C, 1, 7) by da_step_tail_multi (or da_stem_wgrad_reduce)
+int da_stem_bwd_partials(int rows, int R, int C, size_t* offset, int* nblk) {
+  if (!offset || !nblk || C % 4 || C < 4 || 256 % (C / 4) || R < 1 || rows % R) return DA_EINVAL;
+  const int nruns = 256 / (C / 4), NRUN = nruns < 8 ? nruns : 8, RS = nruns / NRUN;
+  if (R % RS) return DA_EINVAL;
+  int RPB = RS;
+  for (int d = RS; d <= 5; d += RS)
+    if (R % d == 0) RPB = d;
+  *offset = (size_t)rows * 2 * C;
+  *nblk = rows / RPB;
+  return DA_OK;
+}
+
 // floats of scratch da_stem_bwd needs: the row records (rows x 2 C) and the weight-gradient partials (blocks x 7 C)
 size_t da_stem_bwd_workspace(int rows, int C) {     // (one partial per block; a block owns >= 1 row)
   return ((size_t)rows * 2 * C + (size_t)rows * 7 * C) * sizeof(float);
+}
+
+// dw[n] (+)= sum over nblk of partial[nblk][n]: the fold da_stem_bwd(dw = NULL) left out
+int da_stem_wgrad_reduce(const float* partial, int nblk, int n, float* dw, int accumulate, hipStream_t stream) {
+  DA_ENTER();
+  if (!partial || !dw || nblk < 1 || n < 1) return DA_EINVAL;
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((n + 7) / 8), dim3(256), 0, stream, partial, nblk, n, dw, accumulate);
+  DA_CHECK_LAUNCH();
+  return DA_OK;
 }
 
 // Backward of the default stem (conv k7 s2 p3 on one channel -> BN -> ReLU -> pool(3,2,1)) from the RAW rows: dout
@@ -726,7 +738,7 @@ int da_stem_bwd(const void* dout, int ldd, const float* xrows, const float* wt, 
                 const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode, float* ds,
                 float* dw, int accumulate, float* workspace, hipStream_t stream) {
   DA_ENTER();
-  if (!dout || !xrows || !wt || !mean || !invstd || !gamma || !beta || !ds || !dw || !workspace || C % 4 || C < 4 ||
+  if (!dout || !xrows || !wt || !mean || !invstd || !gamma || !beta || !ds || !workspace || C % 4 || C < 4 ||
       256 % (C / 4) || 2 * C > 256 || ldd % 4 || R < 1 || rows % R || Lin < 2 || (Lin & 1))
     return DA_EINVAL;
   if (rows == 0) return DA_OK;
@@ -750,6 +762,7 @@ int da_stem_bwd(const void* dout, int ldd, const float* xrows, const float* wt, 
   DA_ACT_DISPATCH(hipLaunchKernelGGL((stem_bwd_kernel<AT, true>), dim3(nblk), dim3(256), shm2, stream, (const AT*)dout, ldd, xrows,
                                      wt, rows, R, Lin, Lc, Lp, C, mean, invstd, gamma, beta, pool_mode, RPB, rowpart, ds, partial));
   DA_CHECK_LAUNCH();
+  if (!dw) return DA_OK;       // the caller folds the partials later (da_step_tail_multi: da_stem_bwd_partials() says where they are)
   const int n = C * 7;
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((n + 7) / 8), dim3(256), 0, stream, partial, nblk, n, dw, accumulate);
   DA_CHECK_LAUNCH();

@@ -35,12 +35,12 @@ class BNState(object):
 #   * the ~60 tiny per-layer launches -- BN running statistics, BN dgamma/dbeta folds, split-K slab
 #     reductions of the weight gradients -- are queued and served by three batched launches.
 # Outside it (plain autograd use, tests) everything runs immediately.
-_STEP = {'on': False, 'pack': {}, 'running': [], 'pgrad': [], 'wgrad': [], 'wslab': []}
+_STEP = {'on': False, 'pack': {}, 'running': [], 'pgrad': [], 'wgrad': [], 'wslab': [], 'stemred': None}
 
 
 @contextlib.contextmanager
 def training_step(model=None):
-    _STEP.update(on=True, pack={}, running=[], pgrad=[], wgrad=[], wslab=[])
+    _STEP.update(on=True, pack={}, running=[], pgrad=[], wgrad=[], wslab=[], stemred=None)
     try:
         if model is not None:
             ms = [m for m in model.modules()
@@ -52,7 +52,7 @@ def training_step(model=None):
                 _STEP['pack'][(w.data_ptr(), int(c))] = e
         yield
     finally:
-        _STEP.update(on=False, pack={}, running=[], pgrad=[], wgrad=[], wslab=[])
+        _STEP.update(on=False, pack={}, running=[], pgrad=[], wgrad=[], wslab=[], stemred=None)
 
 
 def flush_forward(defer=False):
@@ -68,8 +68,8 @@ def flush_backward():
     """Run the queued parameter-gradient folds (call after the backward, before the optimiser)."""
     _launch_wgrads()
     # one launch: slab reductions + dgamma / dbeta folds + the running statistics a deferred flush_forward left queued
-    H.step_tail_multi(_STEP['wslab'], _STEP['pgrad'], _STEP['running'], accumulate=True)
-    _STEP['pgrad'], _STEP['wslab'], _STEP['running'] = [], [], []
+    H.step_tail_multi(_STEP['wslab'], _STEP['pgrad'], _STEP['running'], accumulate=True, stem=_STEP.get('stemred'))
+    _STEP['pgrad'], _STEP['wslab'], _STEP['running'], _STEP['stemred'] = [], [], [], None
 
 
 # The captured step is ONE chain of kernels on one stream.  Rounds 1-2 could fork the stem's backward (or a stage's weight
@@ -370,8 +370,14 @@ class StemFunction(Function):
         if ctx.c0:                                      # the gradient of a pitched buffer: the stem's channels are its first C0
             dout = dout[:, :, :ctx.c0]
         if ctx.fused:                                   # y0 holds the conv weight here
-            dw, ds = H.stem_fused_bwd(dout, x2d, y0, ctx.R, mean, invstd, gamma, beta, ctx.pool_mode, dw=tw,
-                                      accumulate=tw is not None)
+            if _STEM_TAIL and tw is not None and _STEP['on'] and _STEP.get('stemred') is None:
+                # inside a training step: the last fold of the weight gradient rides on the step's tail launch
+                (part, nblk, n), ds = H.stem_fused_bwd(dout, x2d, y0, ctx.R, mean, invstd, gamma, beta, ctx.pool_mode, defer=True)
+                _STEP['stemred'] = (part, nblk, n, tw)
+                dw = None
+            else:
+                dw, ds = H.stem_fused_bwd(dout, x2d, y0, ctx.R, mean, invstd, gamma, beta, ctx.pool_mode, dw=tw,
+                                          accumulate=tw is not None)
             dgamma = dbeta = None
             if tg is not None and tb is not None:
                 if _STEP['on']:
@@ -648,6 +654,7 @@ class BasicBlockFunction(Function):
         return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None, None
 
 
+_STEM_TAIL = True         # inside a training step the stem's last weight-gradient fold rides on the tail launch
 _BN_PAIR = True           # a block entry's two independent BatchNorms (forward: bn1 | downsample; backward: bn2 | downsample) share a launch
 _BN1_FUSED = os.environ.get('DA_BN1_FUSED', '0') == '1'   # conv dtype bf16: bn1 of a stride-1 residual block without a pass of its own -- measured slower (profiles/r04_bf16_bn1_fusion.txt): opt-in
 _DENSE_BLOCK = os.environ.get('DA_DENSE_BLOCK', '1') != '0'   # 0: the per-layer Functions below (the path shapes without the block kernels take)

@@ -661,12 +661,16 @@ def _running_descs(items):
     return arr
 
 
-def step_tail_multi(items, pgrad, running, accumulate=True):
+def step_tail_multi(items, pgrad, running, accumulate=True, stem=None):
     """The tail of a training step in ONE launch: wgrad_reduce_multi(items), bn_param_grad_multi(pgrad) and
-    bn_running_multi(running) (the library falls back to the three launches beyond 32 reductions / 24 BatchNorms)."""
+    bn_running_multi(running) (the library falls back to the three launches beyond 32 reductions / 24 BatchNorms).
+    stem = (partial, nblk, n, dw): the partials a deferred stem_fused_bwd left, folded into dw by the same launch."""
     if not items:
         bn_running_multi(running)
         bn_param_grad_multi(pgrad, accumulate)
+        if stem is not None:
+            part, nblk, n, dw = stem
+            _chk(_lib.lib().da_stem_wgrad_reduce(_p(part), nblk, n, _p(dw), 1 if accumulate else 0, _stream()), 'da_stem_wgrad_reduce')
         return
     arr = (_lib.WgradReduceDesc * len(items))()
     for d, ((slab, splits, k, co, ci), dw) in zip(arr, items):
@@ -679,7 +683,8 @@ def step_tail_multi(items, pgrad, running, accumulate=True):
         d.s1, d.s2 = ds.data_ptr(), ds.data_ptr() + 4 * w * c
         d.dgamma, d.dbeta, d.W, d.C = dg.data_ptr(), db.data_ptr(), w, c
     run = _running_descs(running) if running else None
-    _chk(_lib.lib().da_step_tail_multi(arr, len(items), pg if pgrad else None, len(pgrad), run, len(running),
+    sp, snb, sn, sdw = (None, 0, 0, None) if stem is None else (_p(stem[0]), stem[1], stem[2], _p(stem[3]))
+    _chk(_lib.lib().da_step_tail_multi(arr, len(items), pg if pgrad else None, len(pgrad), run, len(running), sp, snb, sn, sdw,
                                        1 if accumulate else 0, _stream()), 'da_step_tail_multi')
 
 
@@ -1192,16 +1197,17 @@ def stem_fused_fwd(x2d, w, R, gamma, beta, pool_mode, eps=1e-5, out_x3=False, ou
     return out, mean, invstd
 
 
-def stem_fused_bwd(dout, x2d, w, R, mean, invstd, gamma, beta, pool_mode, dw=None, accumulate=False):
-    """Backward of stem_fused_fwd from dout (rows, Lp, C) float and the raw rows: -> dw (C, 1, 7) (+= into ``dw`` when
-    accumulate), ds (2, W, C) = the BatchNorm's window sums (bn_param_grad_multi folds them into dgamma / dbeta)."""
+def stem_fused_bwd(dout, x2d, w, R, mean, invstd, gamma, beta, pool_mode, dw=None, accumulate=False, defer=False):
+    """Backward of stem_fused_fwd from dout (rows, Lp, C) and the raw rows: -> dw (C, 1, 7) (+= into ``dw`` when
+    accumulate), ds (2, W, C) = the BatchNorm's window sums (bn_param_grad_multi folds them into dgamma / dbeta).
+    defer: the last fold of the weight gradient is left to the caller -> ((partial, nblk, n), ds) for step_tail_multi(stem=)."""
     ldd = _pv(dout, 'dout') if ACT == torch.float32 else _rlc(dout, 'dout').shape[2]
     x = x2d.reshape(x2d.shape[0], x2d.shape[-1])
     rows, lin = x.shape
     c = w.shape[0]
     if dout.shape[2] != c:
         raise ValueError('stem_fused_bwd: dout must have the stem\'s %d channels' % c)
-    if dw is None:
+    if dw is None and not defer:
         if accumulate:
             raise ValueError('accumulate needs dw')
         dw = torch.empty((c, 1, 7), device=x.device, dtype=torch.float32)
@@ -1209,7 +1215,11 @@ def stem_fused_bwd(dout, x2d, w, R, mean, invstd, gamma, beta, pool_mode, dw=Non
     ds = torch.empty((2, rows // R, c), device=x.device, dtype=torch.float32)
     ws = torch.empty((L.da_stem_bwd_workspace(rows, c) // 4,), device=x.device, dtype=torch.float32)
     _chk(L.da_stem_bwd(_p(dout), ldd, _p(x), _p(w), rows, R, lin, c, _p(mean), _p(invstd), _p(gamma), _p(beta), pool_mode, _p(ds),
-                       _p(dw), 1 if accumulate else 0, _p(ws), _stream()), 'da_stem_bwd')
+                       None if defer else _p(dw), 1 if accumulate else 0, _p(ws), _stream()), 'da_stem_bwd')
+    if defer:
+        off, nblk = ctypes.c_size_t(), ctypes.c_int()
+        _chk(L.da_stem_bwd_partials(rows, R, c, ctypes.byref(off), ctypes.byref(nblk)), 'da_stem_bwd_partials')
+        return (ws[off.value:], nblk.value, c * 7), ds
     return dw, ds
 
 

@@ -291,7 +291,10 @@ class HotPathTrainer(object):
         self.allreduce_calls += 1
 
     # ---- eager pieces ------------------------------------------------------------------------
-    def _forward_backward(self, inputs, target):
+    def _forward_backward(self, inputs, target, zero_grad=False):
+        """zero_grad: clear the flat gradient bucket first (optimizer.zero_grad(), train_ards_detector.py:164)."""
+        if zero_grad:
+            self.bucket.zero_grad()
         with F_.training_step(self.model):               # weights are constant within one step
             fused = self.model.forward_loss(inputs, target) if _FUSED_HEAD and hasattr(self.model, 'forward_loss') else None
             if fused is not None:                        # CNNLinearNetwork: pool + linear + loss (+ their backward) in 3 launches
@@ -349,8 +352,7 @@ class HotPathTrainer(object):
         return loss, logits
 
     def _eager_step(self, inputs, target):
-        self.bucket.zero_grad()
-        loss, logits = self._forward_backward(inputs, target)
+        loss, logits = self._forward_backward(inputs, target, zero_grad=True)
         if self.world_size > 1:
             self._allreduce()
         self._optimizer_step()
@@ -367,8 +369,7 @@ class HotPathTrainer(object):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self.bucket.zero_grad()
-            self._forward_backward(*static)
+            self._forward_backward(*static, zero_grad=True)
             for b, c in zip(self.model.buffers(), saved):
                 b.copy_(c)
         torch.cuda.current_stream().wait_stream(s)
@@ -438,15 +439,13 @@ class HotPathTrainer(object):
 
     def _eager_whole_step(self, inputs, target):
         """zero-grad, forward, loss, backward, gradient all-reduce, update: the data-parallel step as one capturable chain."""
-        self.bucket.zero_grad()
-        loss, logits = self._forward_backward(inputs, target)
+        loss, logits = self._forward_backward(inputs, target, zero_grad=True)
         self.bucket.allreduce(self.group)
         self._optimizer_step()
         return loss, logits
 
     def _eager_single_gpu_parts(self, inputs, target):
-        self.bucket.zero_grad()
-        loss, logits = self._forward_backward(inputs, target)
+        loss, logits = self._forward_backward(inputs, target, zero_grad=True)
         if self.world_size == 1:
             self._optimizer_step()
         return loss, logits

@@ -162,12 +162,14 @@ int da_conv_wgrad_plan(int rows, int Lm, int N, int C, int ntaps, int winograd, 
 typedef struct { const float* slab; float* dw; int splits, ntaps, N, C; } da_wgrad_reduce_desc;
 int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumulate, da_stream_t stream);
 /* The tail of a training step in ONE launch: the slab reductions, every BatchNorm's dgamma / dbeta fold
-   (da_bn_param_grad_multi) and running-statistics update (da_bn_running_multi).  n <= 32 reductions and <= 24 BatchNorms
-   of each kind share the launch, anything else runs as the three calls. */
+   (da_bn_param_grad_multi) and running-statistics update (da_bn_running_multi), and -- stem_partial != NULL -- the fold of
+   the stem's weight-gradient partials that da_stem_bwd(dw = NULL) left behind (da_stem_bwd_partials says where).  n <= 32
+   reductions and <= 24 BatchNorms of each kind share the launch, anything else runs as the separate calls. */
 struct da_bn_pgrad_desc_;
 struct da_bn_running_desc_;
 int da_step_tail_multi(const da_wgrad_reduce_desc* descs, int n, const struct da_bn_pgrad_desc_* pg, int npg,
-                       const struct da_bn_running_desc_* run, int nrun, int accumulate, da_stream_t stream);
+                       const struct da_bn_running_desc_* run, int nrun, const float* stem_partial, int stem_nblk, int stem_n,
+                       float* stem_dw, int accumulate, da_stream_t stream);
 
 /* torch [Co][Ci][K] -> Wf [K][Co][Ci] (forward) and Wd [K][Ci][Co] (data gradient). */
 int da_repack_conv_weight(const float* W, float* Wf, float* Wd, int Co, int Ci, int K, da_stream_t stream);
@@ -351,6 +353,10 @@ int da_stem_bn_relu_pool_fwd(const float* xrows, const float* wt, da_act_t* out,
                              const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode,
                              int out_x3, da_stream_t stream);
 size_t da_stem_bwd_workspace(int rows, int C);
+/* da_stem_bwd with dw == NULL leaves its weight-gradient partials [nblk][C * 7] at workspace + *offset (floats): fold them
+   with da_step_tail_multi (the step's tail launch) or da_stem_wgrad_reduce */
+int da_stem_bwd_partials(int rows, int R, int C, size_t* offset, int* nblk);
+int da_stem_wgrad_reduce(const float* partial, int nblk, int n, float* dw, int accumulate, da_stream_t stream);
 int da_stem_bwd(const da_act_t* dout, int ldd, const float* xrows, const float* wt, int rows, int R, int Lin, int C,
                 const float* mean, const float* invstd, const float* gamma, const float* beta, int pool_mode, float* ds,
                 float* dw, int accumulate, float* workspace, da_stream_t stream);
