@@ -982,7 +982,7 @@ class Linear2Function(Function):
 
 
 class HeadLossFunction(Function):
-    """AvgPool1d(7,1) + view(-1) + linear_final + BCEWithLogitsLoss of CNNLinearNetwork as ONE autograd node in three launches
+    """AvgPool1d(7,1) + view(-1) + linear_final + BCEWithLogitsLoss of CNNLinearNetwork as ONE autograd node in two launches
     (H.head_fwd / head_bwd) instead of six: xmap (B * R, L, F) the breath block's last map, target (B, 2) -> (loss (1,), logits
     (B, 2)).  In a training step the logits and the loss are FILLED BY THE BACKWARD (they are the first thing it needs, and
     nothing reads them earlier: the forward kernel leaves the dot products as row-group partials); backward takes no upstream

@@ -63,7 +63,7 @@ class CNNLinearNetwork(_WindowHead):
 
     def forward_loss(self, x, target):
         """(loss (1,), logits (B, 2)) of BCEWithLogitsLoss()(self(x, None), target) with the head chain -- global average
-        pool, view(-1), linear_final, the loss and its first gradient -- as ONE autograd node in three launches
+        pool, view(-1), linear_final, the loss and its first gradient -- as ONE autograd node in two launches
         (functional.HeadLossFunction); ``loss.backward()`` then runs the whole backward.  With gradients required the
         two returned tensors are FILLED BY THAT BACKWARD (its first kernel derives them from the forward's partial dot
         products): read them after it; under no_grad they are complete on return.  None when the breath block's last

@@ -297,7 +297,7 @@ class HotPathTrainer(object):
             self.bucket.zero_grad()
         with F_.training_step(self.model):               # weights are constant within one step
             fused = self.model.forward_loss(inputs, target) if _FUSED_HEAD and hasattr(self.model, 'forward_loss') else None
-            if fused is not None:                        # CNNLinearNetwork: pool + linear + loss (+ their backward) in 3 launches
+            if fused is not None:                        # CNNLinearNetwork: pool + linear + loss (+ their backward) in 2 launches
                 loss, logits = fused
                 F_.flush_forward(defer=True)        # (the running-statistics updates ride on the tail launch)
                 torch.autograd.backward(loss, grad_tensors=self._one(loss))

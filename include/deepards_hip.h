@@ -390,7 +390,7 @@ int da_bce_logits(const float* logits, const float* target, int n, float gscale,
                   da_stream_t stream);
 int da_linear2_bwd(const float* dlogits, const float* flat, const float* W, float* dflat, float* dW, float* dbias,
                    int B, int K, int accumulate, da_stream_t stream);
-/* The head chain of CNNLinearNetwork in three launches instead of six: da_head_fwd = AvgPool1d(L,1) + view -> flat and the
+/* The head chain of CNNLinearNetwork in two launches instead of six: da_head_fwd = AvgPool1d(L,1) + view -> flat and the
  * row groups' shares `part` [B][da_head_groups(R, F)][2] of linear_final's two dot products (finish != 0, forward-only callers:
  * also logits and the BCEWithLogitsLoss mean); da_head_bwd = logits / loss terms / dlogits from `part`, linear + pool
  * backward in one kernel, then dW / dbias and the loss mean (resnet.py:112,159-160 / densenet.py:167,183-184;

@@ -171,7 +171,7 @@ def test_transition_norm_pool_head(Fn):
 @pytest.mark.parametrize('backbone', ['resnet18', 'densenet18'])
 def test_fused_head_chain_against_the_oracle_and_the_six_launch_chain(backbone):
     """functional.HeadLossFunction (global average pool + view(-1) + linear_final + BCEWithLogitsLoss and their backward in
-    three launches) against numpy (fp64) on the map, and -- through the trainer -- against the six-launch chain it replaces:
+    two launches) against numpy (fp64) on the map, and -- through the trainer -- against the six-launch chain it replaces:
     same losses, same parameters after three steps up to fp32 summation order."""
     import numpy as np
     import deepards_amd.functional as Fn

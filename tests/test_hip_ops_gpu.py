@@ -100,6 +100,47 @@ def test_conv_wgrad_multi_matches_single_jobs(H):
     assert H.conv_wgrad_multi([]) == []
 
 
+@pytest.mark.parametrize('n_red,n_bn,with_stem', [(3, 4, True), (3, 0, True), (33, 4, True), (3, 25, False), (0, 3, True), (2, 2, False)])
+def test_step_tail_launch_equals_its_parts(H, n_red, n_bn, with_stem):
+    """da_step_tail_multi (slab reductions + BatchNorm dgamma / dbeta folds + running-statistics updates + the stem's
+    weight-gradient fold in ONE launch) == the separate entry points, bit for bit -- also where the library falls back to
+    separate launches (more than 32 reductions / 24 BatchNorms, no reductions at all)."""
+    g = torch.Generator().manual_seed(n_red * 100 + n_bn)
+    mk = lambda *sh: torch.randn(*sh, generator=g).cuda()
+    def build():
+        red = []
+        for i in range(n_red):
+            co, ci, k, splits = (64, 32, 3, 5) if i % 2 else (32, 64, 1, 9)
+            red.append(((mk(splits * k * co * ci), splits, k, co, ci), mk(co, ci, k)))
+        pg, run = [], []
+        for i in range(n_bn):
+            c, w = (64, 7) if i % 2 else (96, 64)
+            pg.append((mk(2, w, c), mk(c), mk(c)))
+            run.append((mk(w, c), torch.rand(w, c, generator=g).cuda() + 0.5, 140, mk(c), torch.rand(c, generator=g).cuda() + 0.5,
+                        torch.zeros((), dtype=torch.int64, device='cuda'), 0.1, 1e-5))
+        stem = (mk(40, 448), 40, 448, mk(64, 1, 7)) if with_stem else None
+        return red, pg, run, stem
+    g.manual_seed(5)
+    red_a, pg_a, run_a, stem_a = build()
+    g.manual_seed(5)
+    red_b, pg_b, run_b, stem_b = build()
+    H.step_tail_multi(red_a, pg_a, run_a, accumulate=True, stem=stem_a)
+    H.wgrad_reduce_multi(red_b, accumulate=True)
+    H.bn_param_grad_multi(pg_b, accumulate=True)
+    H.bn_running_multi(run_b)
+    if stem_b is not None:
+        from deepards_amd import _lib
+        H._chk(_lib.lib().da_stem_wgrad_reduce(H._p(stem_b[0]), stem_b[1], stem_b[2], H._p(stem_b[3]), 1, H._stream()), 'reduce')
+    for (_, da), (_, db) in zip(red_a, red_b):
+        assert torch.equal(da, db)
+    for (_, ga, ba), (_, gb, bb) in zip(pg_a, pg_b):
+        assert torch.equal(ga, gb) and torch.equal(ba, bb)
+    for ra, rb in zip(run_a, run_b):
+        assert torch.equal(ra[3], rb[3]) and torch.equal(ra[4], rb[4]) and int(ra[5]) == int(rb[5]) > 0
+    if stem_a is not None:
+        assert torch.equal(stem_a[3], stem_b[3])
+
+
 @pytest.mark.parametrize('C,L,R,W', [(128, 28, 20, 64), (256, 14, 20, 3), (512, 7, 20, 5), (64, 56, 20, 2)])
 def test_batchnorm_pair_launches_equal_the_single_ones(H, C, L, R, W):
     """A stride-2 block entry's two independent BatchNorms in one launch (da_bn_fwd_pair: bn1 + ReLU | the downsample's;
