@@ -532,20 +532,16 @@ class BasicBlockFunction(Function):
         bn_pair = pair and not mid3 and not fuse1 and _BN_PAIR and std.eps == st1.eps and \
             y1.shape[0] % R == 0 and H.bn_single_pass(y1.shape[0] // R, R * y1.shape[1], y1.shape[2])
         ctx.bn_pair = bn_pair
-        if bn_pair:
+        if pair:
             sd = _Stats()
+        if bn_pair:
             (res, sd.mean, sd.invstd, _), (h1, s1.mean, s1.invstd, _) = H.bn_fwd_pair(
                 [(yd, gd, bd, False, None, False), (y1, g1, b1, True, None, False)], R, st1.eps)
             _running(yd, R, sd, std)
             _running(y1, R, s1, st1)
-            _tap(h1)
-            y2 = _conv_fwd(h1, w2, 1, 1)
         elif pair:        # the downsample BatchNorm first: yd is still in L2 / MALL right after the shared launch
-            sd = _Stats()   # (forking it beside bn1 / conv2 on another stream was measured slower)
-            res = _bn_apply(yd, R, sd, std, gd, bd, False)
-        if bn_pair:
-            pass
-        elif fuse1:         # bn1 + ReLU applied while conv2 stages its operand: statistics from the records conv1's epilogue wrote
+            res = _bn_apply(yd, R, sd, std, gd, bd, False)   # (forking it beside bn1 / conv2 on another stream was measured slower)
+        if fuse1:         # bn1 + ReLU applied while conv2 stages its operand: statistics from the records conv1's epilogue wrote
             wn_ = y1.shape[0] // R
             s1.mean = torch.empty((wn_, y1.shape[2]), device=y1.device, dtype=torch.float32)
             s1.invstd = torch.empty_like(s1.mean)
@@ -555,7 +551,8 @@ class BasicBlockFunction(Function):
             if DECISION_TAP is not None:
                 _tap(H.bn_fwd(y1, R, g1, b1, relu=True, eps=st1.eps)[0])
         else:
-            h1 = _bn_apply_x(y1, R, s1, st1, g1, b1, True) if mid3 else _bn_apply(y1, R, s1, st1, g1, b1, True)
+            if not bn_pair:
+                h1 = _bn_apply_x(y1, R, s1, st1, g1, b1, True) if mid3 else _bn_apply(y1, R, s1, st1, g1, b1, True)
             _tap(h1)
             y2 = _conv_fwd(h1, w2, 1, 1)
         s2 = _Stats()
@@ -619,25 +616,16 @@ class BasicBlockFunction(Function):
             dh1 = _conv_dgrad(dy2, w2, 1, 1, y1.shape[1])
             h1 = torch.empty_like(y1)
             ds1 = H.bn_bwd_ss(dh1, y1, R, m1, i1, g1, b1, 1, dh1, hout=h1)
-            dy1, dg1, db1 = dh1, None, None
-            if tg1 is not None and tb1 is not None:
-                if _STEP['on']:
-                    _STEP['pgrad'].append((ds1, tg1, tb1))
-                else:
-                    H.bn_param_grad_multi([(ds1, tg1, tb1)], accumulate=True)
-            else:
-                dg1, db1 = torch.empty_like(g1), torch.empty_like(b1)
-                H.bn_param_grad_multi([(ds1, dg1, db1)], accumulate=False)
+            dy1 = dh1
+            dg1, db1 = _bn_pgrad(ds1, g1, b1, tg1, tb1)
             dw2 = _wgrad(dy2, h1, 3, 1, 1, tw2)
         else:
             dw2 = _wgrad(dy2, h1, 3, 1, 1, tw2)
             dh1 = _conv_dgrad(dy2, w2, 1, 1, y1.shape[1])
-        if ctx.fuse1:
-            pass
-        elif in3:           # conv1 is a k3 s1 conv on x3 operands too
-            dy1, dg1, db1 = _bn_bwd_x(dh1, y1, R, m1, i1, g1, b1, 1, tg1, tb1)
-        else:
-            dy1, dg1, db1 = _bn_bwd(dh1, y1, R, m1, i1, g1, b1, 1, tg1, tb1, dx=dh1)
+            if in3:       # conv1 is a k3 s1 conv on x3 operands too
+                dy1, dg1, db1 = _bn_bwd_x(dh1, y1, R, m1, i1, g1, b1, 1, tg1, tb1)
+            else:
+                dy1, dg1, db1 = _bn_bwd(dh1, y1, R, m1, i1, g1, b1, 1, tg1, tb1, dx=dh1)
         dw1 = _wgrad(dy1, x, 3, stride, 1, tw1)
         if ctx.has_ds:
             dwd = _wgrad(dyd, x, 1, stride, 0, twd)
