@@ -352,12 +352,140 @@ typedef struct {
   const float* beta;
 } da_wgrad_job;
 
+// dW[co][ci][k] (torch layout) (+)= sum over the split-K slabs slab[split][k][co][ci] of one convolution
+struct WgradReduceDesc {
+  const float* slab;
+  float* dw;
+  int splits, ntaps, N, C;
+};
+
+// One block of that reduction = 1 024 consecutive slab elements, a float4 per thread: every thread walks ALL splits of its four
+// elements with eight 16-byte loads in flight and one fixed summation tree (deterministic; no LDS, no barrier).
+__device__ __forceinline__ void wgrad_reduce_block(const WgradReduceDesc& d, int blk, int accumulate) {
+  const int total = d.ntaps * d.N * d.C;          // a multiple of 4 (the host checks); of 1024 for N, C multiples of 32
+  const int i = blk * 1024 + threadIdx.x * 4;
+  if (i >= total) return;
+  const float* p = d.slab + i;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int sp = 0;
+  for (; sp + 8 <= d.splits; sp += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(p + (size_t)(sp + j) * total);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] += ((v[0][e] + v[1][e]) + (v[2][e] + v[3][e])) + ((v[4][e] + v[5][e]) + (v[6][e] + v[7][e]));
+  }
+  if (sp + 4 <= d.splits) {
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(p + (size_t)(sp + j) * total);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] += (v[0][e] + v[1][e]) + (v[2][e] + v[3][e]);
+    sp += 4;
+  }
+  for (; sp < d.splits; ++sp) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + (size_t)sp * total);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] += v[e];
+  }
+  // slab order [tap][co][ci] -> torch order [co][ci][tap] (the four elements share a tap: N C is a multiple of 4)
+  const int nc = d.N * d.C;
+  const int tap = i / nc, rem = i - tap * nc;
+  float* o = d.dw + (size_t)rem * d.ntaps + tap;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float* q = o + (size_t)e * d.ntaps;
+    *q = accumulate ? *q + s[e] : s[e];
+  }
+}
+
+// Slab reductions that ride on the next weight-gradient launch (da_conv_wgrad_multi_reduce): the slabs the previous launch
+// of the same call wrote are folded by `nblocks` further blocks of this one -- memory-bound blocks beside matrix-bound ones
+// (the step's one reduction launch behind all weight gradients found 165 MB of slabs cold: 54 us at B = 64).
+#define WGRAD_PRE_MAX 14
+struct WgradPreTable {
+  WgradReduceDesc d[WGRAD_PRE_MAX];
+  int first_block[WGRAD_PRE_MAX + 1];
+  int n, nblocks, accumulate;      // nblocks = first_block[n] rounded up to a multiple of 8 (block id % 8 stays the XCD)
+  int own;                         // the launch's own blocks, rounded up to a multiple of 8: the reductions come BEHIND them;
+                                   // -1: in FRONT of them
+};
+// Where the reduction blocks sit in the launch, measured on the resnet18 step (B = 64; the F(2,3) launch carrying 75 MB of
+// F(4,3) slabs, 267 us alone): in FRONT of the own blocks +15 us (they run alone before any matrix block starts); spread
+// evenly in groups of 8 +53 us (the own blocks' whole-round balance is gone); BEHIND them: the own blocks end in a partly
+// filled round (1 232 blocks on 1 024 slots) and the reductions fill its idle slots.
+// -> -1: this block ran a reduction (or is padding); else its index among the launch's own blocks (may lie past their count:
+// padding -- the caller returns)
+__device__ __forceinline__ int wgrad_pre_dispatch(const WgradPreTable& p) {
+  const int bid = blockIdx.x;
+  if (p.nblocks == 0) return bid;
+  if (p.own < 0) {                 // in front
+    if (bid >= p.nblocks) return bid - p.nblocks;
+  } else if (bid < p.own) {
+    return bid;
+  }
+  const int pb = p.own < 0 ? bid : bid - p.own;
+  if (pb < p.first_block[p.n]) {
+    int i = 0;
+    while (i + 1 < p.n && pb >= p.first_block[i + 1]) ++i;      // block-uniform
+    wgrad_reduce_block(p.d[i], pb - p.first_block[i], p.accumulate);
+  }
+  return -1;
+}
+// grid of a launch of `blocks` own blocks that carries `pre` (sets pre.own); front: the reductions as the FIRST blocks -- for
+// a launch whose own blocks already end in short ones (the direct kernels sort theirs longest first)
+static inline int wgrad_pre_grid(WgradPreTable& pre, int blocks, bool front = false) {
+  if (pre.nblocks == 0) return blocks;
+  pre.own = front ? -1 : (blocks + 7) & ~7;
+  return (front ? blocks : pre.own) + pre.nblocks;
+}
+
+// host side of the chain: `pre` = what the NEXT launch carries (with the jobs it belongs to), `next` = what the launch being
+// assembled offers to the one after it
+struct WgradChain {
+  WgradPreTable pre, next;
+  int pre_job[WGRAD_PRE_MAX], next_job[WGRAD_PRE_MAX];
+  float* const* dws;       // per job: the gradient destination, or NULL (slabs only)
+  int* reduced;            // per job: set to 1 once a launch carries its reduction
+};
+static inline void wgrad_chain_init(WgradChain* c, float* const* dws, int accumulate, int* reduced) {
+  c->pre.n = c->pre.nblocks = c->pre.own = 0;
+  c->pre.first_block[0] = 0;
+  c->pre.accumulate = accumulate;
+  c->next = c->pre;
+  c->dws = dws;
+  c->reduced = reduced;
+}
+// the launch being assembled writes job `job`'s slabs
+static inline void wgrad_chain_offer(WgradChain* c, int job, const da_wgrad_job& j, int splits) {
+  if (!c || !c->dws || !c->dws[job] || c->next.n >= WGRAD_PRE_MAX) return;
+  WgradPreTable& t = c->next;
+  t.d[t.n] = {j.workspace, c->dws[job], splits, j.ntaps, j.N, j.C};
+  c->next_job[t.n] = job;
+  t.first_block[t.n + 1] = t.first_block[t.n] + (j.ntaps * j.N * j.C + 1023) / 1024;
+  ++t.n;
+  t.nblocks = (t.first_block[t.n] + 7) & ~7;
+}
+// the table a launch carries (empty without a chain); call once per launch, right before it
+static inline WgradPreTable wgrad_chain_take(WgradChain* c) {
+  WgradPreTable t;
+  t.n = t.nblocks = t.accumulate = t.own = 0;
+  t.first_block[0] = 0;
+  if (!c) return t;
+  t = c->pre;
+  for (int i = 0; i < t.n; ++i) c->reduced[c->pre_job[i]] = 1;
+  c->pre = c->next;
+  for (int i = 0; i < c->next.n; ++i) c->pre_job[i] = c->next_job[i];
+  c->next.n = c->next.nblocks = 0;
+  return t;
+}
+
 // conv_wino.hip
 bool wino_wgrad_eligible(const da_wgrad_job& j);
 void wino_wgrad_plan(int rows, int L, int* splits, int* pchunk);
-int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream);
+int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream, WgradChain* chain = nullptr);
 void wino4_wgrad_plan(int rows, int L, int* splits, int* qchunk);               // winograd == 6: the F(4,3) form (quads)
-int wino4_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream);
+int wino4_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream, WgradChain* chain = nullptr);
 
 // conv_bf16.hip: jobs with winograd == 16 (the same eligibility; bf16 operands, padded-position K)
 bool bf16_wgrad_eligible(const da_wgrad_job& j);

@@ -993,18 +993,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 // All weight gradients of a step that share a tile shape in ONE launch.  They are independent of each other and of
 // the rest of the backward pass, and each alone has only 1-2 blocks per CU at B = 64 -- too few to hide its own
 // ramp-up and tail (the same kernel runs ~20 % faster with 8 tiles per CU than with 4, scripts/balance_probe.py).
+#define WGRAD_TABLE_MAX 20
 struct WgradTable {
-  WgradArgs d[24];
-  int first_block[25];
+  WgradArgs d[WGRAD_TABLE_MAX];
+  int first_block[WGRAD_TABLE_MAX + 1];
   int n;
 };
+static_assert(sizeof(WgradTable) + sizeof(WgradPreTable) <= 4096, "kernel arguments: 4 KB");
 
+// pre: the slab reductions of the previous launch's jobs, as this launch's first blocks (common.h WgradPreTable)
 template <int TM, int TN, int WGM, int WGN, int XF = 0>
-__global__ __launch_bounds__(256) void conv_wgrad_multi_kernel(WgradTable t) {
+__global__ __launch_bounds__(256) void conv_wgrad_multi_kernel(WgradTable t, WgradPreTable pre) {
   __shared__ float lds[32 * (TM * WGM * 32 + TN * WGN * 32)];
+  const int b = wgrad_pre_dispatch(pre);
+  if (b < 0 || b >= t.first_block[t.n]) return;
   int i = 0;
-  while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
-  wgrad_body<TM, TN, WGM, WGN, XF>(t.d[i], blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i], lds);
+  while (i + 1 < t.n && b >= t.first_block[i + 1]) ++i;      // wave-uniform
+  wgrad_body<TM, TN, WGM, WGN, XF>(t.d[i], b - t.first_block[i], t.first_block[i + 1] - t.first_block[i], lds);
 }
 
 // dW[co][ci][k] (torch layout) (+)= sum_split slab[split][k][co][ci]
@@ -1029,88 +1034,58 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-// the same reduction for up to 32 convolutions in one launch (blockIdx.y = which conv)
-struct WgradReduceDesc {
-  const float* slab;
-  float* dw;
-  int splits, ntaps, N, C;
-};
+// the same reduction (common.h wgrad_reduce_block) for up to 32 convolutions in one launch
 #define REDUCE_MAX_BN 24
+// first_block[i]: the launch's first block of conv i (1 024 slab elements a block, ONE dimension: no block without work --
+// with blockIdx.y = which conv and the largest conv's width, 24 k of the step's 67 k blocks found nothing to do)
 struct WgradReduceTable {
   WgradReduceDesc d[32];
+  int first_block[33];
+  int n;
 };
-// the BatchNorm dgamma / dbeta folds (row m of the same launch) and running-statistics updates (row m + 1) of the step
+// the BatchNorm dgamma / dbeta folds, the running-statistics updates and the stem's weight-gradient fold of the step: three
+// further runs of `nb` blocks behind the reductions
 struct ReducePgradTable {
   BnPgradDesc p[REDUCE_MAX_BN];
   BnRunningDesc r[REDUCE_MAX_BN];
-  int m, npg, nrun, chunks;    // chunks = ceil(max C / 32): block x of those rows = (BatchNorm x / chunks, channel chunk x % chunks)
-  const float* stem_partial;   // row m + 2: the stem's weight-gradient partials [stem_nblk][stem_n] -> stem_dw (or NULL)
+  int nb, nsmall, npg, nrun, chunks;   // nsmall = 2 or 3 runs of nb blocks; chunks = ceil(max C / 32): block x of those runs = (BatchNorm x / chunks, channel chunk x % chunks)
+  const float* stem_partial;   // third run: the stem's weight-gradient partials [stem_nblk][stem_n] -> stem_dw (or NULL)
   float* stem_dw;
   int stem_nblk, stem_n;
 };
 
-__device__ __forceinline__ void wgrad_reduce_block(const WgradReduceDesc& d, int accumulate);
+__device__ __forceinline__ int wgrad_reduce_find(const WgradReduceTable& t, int b) {      // block-uniform
+  int i = 0;
+  while (i + 1 < t.n && b >= t.first_block[i + 1]) ++i;
+  return i;
+}
 
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgradReduceTable t, int accumulate) {
-  wgrad_reduce_block(t.d[blockIdx.y], accumulate);
+  const int i = wgrad_reduce_find(t, blockIdx.x);
+  wgrad_reduce_block(t.d[i], (int)blockIdx.x - t.first_block[i], accumulate);
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_pgrad_kernel(WgradReduceTable t, ReducePgradTable g, int accumulate) {
-  if ((int)blockIdx.y >= g.m) {
+  // the small folds FIRST: each is a dependent chain (load -> LDS fold -> store) of a few us that the slab reductions behind
+  // them hide; as the launch's last blocks they were its tail
+  const int nsmall = g.nsmall;
+  if ((int)blockIdx.x < nsmall) {
     __shared__ float red[2][8][32];
-    const int bn = blockIdx.x / g.chunks, chunk = blockIdx.x - bn * g.chunks;
-    if ((int)blockIdx.y == g.m) {
+    const int x = (int)blockIdx.x % g.nb, run = (int)blockIdx.x / g.nb;
+    const int bn = x / g.chunks, chunk = x - bn * g.chunks;
+    if (run == 0) {
       if (bn < g.npg) bn_param_grad_block(g.p[bn], chunk, accumulate, red);
-    } else if ((int)blockIdx.y == g.m + 1) {
+    } else if (run == 1) {
       if (bn < g.nrun) bn_running_block(g.r[bn], chunk, red);
-    } else if ((int)blockIdx.x * 8 < g.stem_n) {
-      stem_wgrad_reduce_block(g.stem_partial, g.stem_nblk, g.stem_n, g.stem_dw, accumulate, blockIdx.x,
+    } else if (x * 8 < g.stem_n) {
+      stem_wgrad_reduce_block(g.stem_partial, g.stem_nblk, g.stem_n, g.stem_dw, accumulate, x,
                               reinterpret_cast<float (*)[8]>(&red[0][0][0]));
     }
     return;
   }
-  wgrad_reduce_block(t.d[blockIdx.y], accumulate);
-}
-
-__device__ __forceinline__ void wgrad_reduce_block(const WgradReduceDesc& d, int accumulate) {
-  // block = 256 consecutive slab elements (64 lanes x float4 = 1 KiB contiguous per split) x 4 split slots
-  const int total = d.ntaps * d.N * d.C;          // multiple of 1024 (N, C multiples of 32)
-  if ((int)blockIdx.x * 256 >= total) return;
-  __shared__ f32x4 red[4][64];
-  const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
-  const int i = blockIdx.x * 256 + lane * 4;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  int sp = slot;
-  for (; sp + 12 < d.splits; sp += 16) {             // four slabs in flight per lane (fixed order: deterministic)
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(d.slab + (size_t)sp * total + i);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(d.slab + (size_t)(sp + 4) * total + i);
-    const f32x4 v2 = *reinterpret_cast<const f32x4*>(d.slab + (size_t)(sp + 8) * total + i);
-    const f32x4 v3 = *reinterpret_cast<const f32x4*>(d.slab + (size_t)(sp + 12) * total + i);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) s[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
-  }
-  for (; sp < d.splits; sp += 4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(d.slab + (size_t)sp * total + i);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) s[e] += v[e];
-  }
-  red[slot][lane] = s;
-  __syncthreads();
-  if (slot == 0) {
-#pragma unroll
-    for (int k = 1; k < 4; ++k)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) s[e] += red[k][lane][e];
-    // slab order [tap][co][ci] -> torch order [co][ci][tap]
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      int ii = i + e;
-      int tap = ii / (d.N * d.C);
-      int rem = ii - tap * d.N * d.C;
-      size_t o = (size_t)rem * d.ntaps + tap;
-      d.dw[o] = accumulate ? d.dw[o] + s[e] : s[e];
-    }
-  }
+  const int b = (int)blockIdx.x - nsmall;
+  const int i = wgrad_reduce_find(t, b);
+  wgrad_reduce_block(t.d[i], b - t.first_block[i], accumulate);
 }
 
 template <int TM, int TN, int WGM, int WGN>
@@ -1170,7 +1145,7 @@ static WgradPlan wgrad_plan(int M, int N, int C, int ntaps) {
 // =============================================================================================
 
 template <int TM, int TN, int WGM, int WGN, int XF = 0>
-static int launch_wgrad_group(const da_wgrad_job* jobs, int n, int tn, int tc, hipStream_t s) {
+static int launch_wgrad_group(const da_wgrad_job* jobs, int n, int tn, int tc, hipStream_t s, WgradChain* chain = nullptr) {
   constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32;
   WgradTable t;
   int cnt = 0, blocks = 0;
@@ -1178,7 +1153,8 @@ static int launch_wgrad_group(const da_wgrad_job* jobs, int n, int tn, int tc, h
     if (!cnt) return DA_OK;
     t.n = cnt;
     t.first_block[cnt] = blocks;
-    hipLaunchKernelGGL((conv_wgrad_multi_kernel<TM, TN, WGM, WGN, XF>), dim3(blocks), dim3(256), 0, s, t);
+    WgradPreTable pre = wgrad_chain_take(chain);
+    hipLaunchKernelGGL((conv_wgrad_multi_kernel<TM, TN, WGM, WGN, XF>), dim3(wgrad_pre_grid(pre, blocks, true)), dim3(256), 0, s, t, pre);
     DA_CHECK_LAUNCH();
     cnt = 0;
     blocks = 0;
@@ -1210,7 +1186,8 @@ static int launch_wgrad_group(const da_wgrad_job* jobs, int n, int tn, int tc, h
     a.divWn = make_fastdiv((uint32_t)(j.Wn > 0 ? j.Wn : 1));
     t.first_block[cnt] = blocks;
     blocks += (j.N / BM) * (j.C / BN) * j.ntaps * pl.splits;
-    if (++cnt == 24) {
+    wgrad_chain_offer(chain, o.second, j, pl.splits);
+    if (++cnt == WGRAD_TABLE_MAX) {
       int rc = flush();
       if (rc) return rc;
     }
@@ -1335,7 +1312,11 @@ size_t da_conv_wgrad_workspace(int rows, int Lm, int N, int C, int ntaps) {
 
 // Slabs of n weight gradients (jobs: HOST array) with one launch per tile shape; reduce them afterwards with
 // da_wgrad_reduce_multi (da_conv_wgrad_splits() slabs per job).
-int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
+// dws != NULL: dws[i] is job i's gradient destination (or NULL); the slab reduction dws[i] (+)= sum of job i's slabs then rides
+// in front of the NEXT launch of this call (common.h WgradPreTable) where there is one, and reduced[i] says whether it did
+// (1) or the caller still owes it (0: da_wgrad_reduce_multi / da_step_tail_multi) -- the jobs of the call's last launch always.
+static int conv_wgrad_multi_impl(const da_wgrad_job* jobs, int n, float* const* dws, int accumulate, int* reduced,
+                                 hipStream_t stream) {
   DA_ENTER();
   if (n < 0 || (n && !jobs)) return DA_EINVAL;
   for (int i = 0; i < n; ++i) {
@@ -1360,27 +1341,44 @@ int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
       return DA_EINVAL;
   }
   int rc;
-  if ((rc = wino4_wgrad_launch(jobs, n, stream))) return rc;  // the heaviest blocks first
-  if ((rc = wino_wgrad_launch(jobs, n, stream))) return rc;
+  WgradChain chain_, *chain = nullptr;
+  if (dws) {
+    if (!reduced) return DA_EINVAL;
+    for (int i = 0; i < n; ++i) reduced[i] = 0;
+    wgrad_chain_init(&chain_, dws, accumulate, reduced);
+    chain = &chain_;
+  }
+  if ((rc = wino4_wgrad_launch(jobs, n, stream, chain))) return rc;  // the heaviest blocks first
+  if ((rc = wino_wgrad_launch(jobs, n, stream, chain))) return rc;
   if ((rc = bf16_wgrad_launch(jobs, n, 49, stream))) return rc;      // x3 operands (dy / x are x3 tensors; ld* = channel counts)
   if ((rc = bf16_wgrad_launch(jobs, n, 16, stream))) return rc;
-  if ((rc = launch_wgrad_group<2, 2, 2, 2>(jobs, n, 128, 128, stream))) return rc;
-  if ((rc = launch_wgrad_group<2, 1, 2, 2>(jobs, n, 128, 64, stream))) return rc;
-  if ((rc = launch_wgrad_group<1, 2, 2, 2>(jobs, n, 64, 128, stream))) return rc;
-  if ((rc = launch_wgrad_group<1, 1, 2, 2>(jobs, n, 64, 64, stream))) return rc;
-  if ((rc = launch_wgrad_group<1, 1, 4, 1>(jobs, n, 128, 32, stream))) return rc;
-  if ((rc = launch_wgrad_group<1, 1, 1, 4>(jobs, n, 32, 128, stream))) return rc;
+  if ((rc = launch_wgrad_group<2, 2, 2, 2>(jobs, n, 128, 128, stream, chain))) return rc;
+  if ((rc = launch_wgrad_group<2, 1, 2, 2>(jobs, n, 128, 64, stream, chain))) return rc;
+  if ((rc = launch_wgrad_group<1, 2, 2, 2>(jobs, n, 64, 128, stream, chain))) return rc;
+  if ((rc = launch_wgrad_group<1, 1, 2, 2>(jobs, n, 64, 64, stream, chain))) return rc;
+  if ((rc = launch_wgrad_group<1, 1, 4, 1>(jobs, n, 128, 32, stream, chain))) return rc;
+  if ((rc = launch_wgrad_group<1, 1, 1, 4>(jobs, n, 32, 128, stream, chain))) return rc;
   bool any_xf = false;
   for (int i = 0; i < n; ++i) any_xf = any_xf || jobs[i].xform || jobs[i].dy_half;
   if (any_xf) {                                           // dense-block operand forms (conv1x1_bn_kernel's weight gradients)
-    if ((rc = launch_wgrad_group<2, 2, 2, 2, 1>(jobs, n, 128, 128, stream))) return rc;
-    if ((rc = launch_wgrad_group<2, 1, 2, 2, 1>(jobs, n, 128, 64, stream))) return rc;
-    if ((rc = launch_wgrad_group<1, 2, 2, 2, 1>(jobs, n, 64, 128, stream))) return rc;
-    if ((rc = launch_wgrad_group<1, 1, 2, 2, 1>(jobs, n, 64, 64, stream))) return rc;
-    if ((rc = launch_wgrad_group<1, 1, 4, 1, 1>(jobs, n, 128, 32, stream))) return rc;
-    if ((rc = launch_wgrad_group<1, 1, 1, 4, 1>(jobs, n, 32, 128, stream))) return rc;
+    if ((rc = launch_wgrad_group<2, 2, 2, 2, 1>(jobs, n, 128, 128, stream, chain))) return rc;
+    if ((rc = launch_wgrad_group<2, 1, 2, 2, 1>(jobs, n, 128, 64, stream, chain))) return rc;
+    if ((rc = launch_wgrad_group<1, 2, 2, 2, 1>(jobs, n, 64, 128, stream, chain))) return rc;
+    if ((rc = launch_wgrad_group<1, 1, 2, 2, 1>(jobs, n, 64, 64, stream, chain))) return rc;
+    if ((rc = launch_wgrad_group<1, 1, 4, 1, 1>(jobs, n, 128, 32, stream, chain))) return rc;
+    if ((rc = launch_wgrad_group<1, 1, 1, 4, 1>(jobs, n, 32, 128, stream, chain))) return rc;
   }
   return DA_OK;
+}
+
+int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
+  return conv_wgrad_multi_impl(jobs, n, nullptr, 0, nullptr, stream);
+}
+
+int da_conv_wgrad_multi_reduce(const da_wgrad_job* jobs, int n, float* const* dws, int accumulate, int* reduced,
+                               hipStream_t stream) {
+  if (n && (!dws || !reduced)) return DA_EINVAL;
+  return conv_wgrad_multi_impl(jobs, n, dws, accumulate, reduced, stream);
 }
 
 // number of slabs da_conv_wgrad writes for this shape (workspace = splits * ntaps*N*C floats)
@@ -1453,14 +1451,17 @@ int da_step_tail_multi(const da_wgrad_reduce_desc* descs, int n, const da_bn_pgr
   }
   WgradReduceTable t;
   ReducePgradTable g;
-  int maxtot = 0, maxc = 0;
+  int maxc = 0, nred = 0;
   for (int i = 0; i < n; ++i) {
     const da_wgrad_reduce_desc& s = descs[i];
     if (!s.slab || !s.dw || s.splits < 1) return DA_EINVAL;
+    if (s.ntaps < 1 || s.N < 1 || s.C < 1 || (s.N * s.C) % 4) return DA_EINVAL;
     t.d[i] = {s.slab, s.dw, s.splits, s.ntaps, s.N, s.C};
-    const int tot = s.ntaps * s.N * s.C;
-    if (tot > maxtot) maxtot = tot;
+    t.first_block[i] = nred;
+    nred += (s.ntaps * s.N * s.C + 1023) / 1024;
   }
+  t.first_block[n] = nred;
+  t.n = n;
   for (int i = 0; i < npg; ++i) {
     const da_bn_pgrad_desc& s = pg[i];
     if (!s.s1 || !s.s2 || !s.dgamma || !s.dbeta) return DA_EINVAL;
@@ -1473,12 +1474,13 @@ int da_step_tail_multi(const da_wgrad_reduce_desc* descs, int n, const da_bn_pgr
     g.r[i] = {s.mean, s.invstd, s.running_mean, s.running_var, s.num_batches_tracked, s.W, s.C, s.Wn, s.eps, s.momentum};
     if (s.C > maxc) maxc = s.C;
   }
-  g.m = n; g.npg = npg; g.nrun = nrun; g.chunks = (maxc + 31) / 32 > 0 ? (maxc + 31) / 32 : 1;
+  g.npg = npg; g.nrun = nrun; g.chunks = (maxc + 31) / 32 > 0 ? (maxc + 31) / 32 : 1;
   g.stem_partial = stem_partial; g.stem_dw = stem_dw; g.stem_nblk = stem_nblk; g.stem_n = stem_n;
   int nb = (npg > nrun ? npg : nrun) * g.chunks;
   if (stem_partial && (stem_n + 7) / 8 > nb) nb = (stem_n + 7) / 8;
-  const int gx = (maxtot + 255) / 256 > nb ? (maxtot + 255) / 256 : nb;
-  hipLaunchKernelGGL(wgrad_reduce_pgrad_kernel, dim3(gx, n + (stem_partial ? 3 : 2)), dim3(256), 0, stream, t, g, accumulate);
+  g.nb = nb > 0 ? nb : 1;
+  g.nsmall = (stem_partial ? 3 : 2) * g.nb;
+  hipLaunchKernelGGL(wgrad_reduce_pgrad_kernel, dim3(nred + g.nsmall), dim3(256), 0, stream, t, g, accumulate);
   DA_CHECK_LAUNCH();
   return DA_OK;
 }
@@ -1489,15 +1491,18 @@ int da_wgrad_reduce_multi(const da_wgrad_reduce_desc* descs, int n, int accumula
   if (n < 0 || (n && !descs)) return DA_EINVAL;
   for (int base = 0; base < n; base += 32) {
     WgradReduceTable t;
-    int m = n - base < 32 ? n - base : 32, maxtot = 0;
+    int m = n - base < 32 ? n - base : 32, nred = 0;
     for (int i = 0; i < m; ++i) {
       const da_wgrad_reduce_desc& s = descs[base + i];
       if (!s.slab || !s.dw || s.splits < 1) return DA_EINVAL;
+      if (s.ntaps < 1 || s.N < 1 || s.C < 1 || (s.N * s.C) % 4) return DA_EINVAL;
       t.d[i] = {s.slab, s.dw, s.splits, s.ntaps, s.N, s.C};
-      int tot = s.ntaps * s.N * s.C;
-      if (tot > maxtot) maxtot = tot;
+      t.first_block[i] = nred;
+      nred += (s.ntaps * s.N * s.C + 1023) / 1024;
     }
-    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((maxtot + 255) / 256, m), dim3(256), 0, stream, t, accumulate);
+    t.first_block[m] = nred;
+    t.n = m;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(nred), dim3(256), 0, stream, t, accumulate);
     DA_CHECK_LAUNCH();
   }
   return DA_OK;

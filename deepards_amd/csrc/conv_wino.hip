@@ -953,12 +953,16 @@ struct WinoWgradTable {
   int first_block[25];
   int n;
 };
+static_assert(sizeof(WinoWgradTable) + sizeof(WgradPreTable) <= 4096, "kernel arguments: 4 KB");
 
-__global__ __launch_bounds__(256, WW_MIN_WAVES) void wino_wgrad_multi_kernel(WinoWgradTable t) {
+// pre: the slab reductions of the previous weight-gradient launch's jobs, as this launch's first blocks (common.h)
+__global__ __launch_bounds__(256, WW_MIN_WAVES) void wino_wgrad_multi_kernel(WinoWgradTable t, WgradPreTable pre) {
   __shared__ float lds[WW_LDS_FLOATS];
+  const int b = wgrad_pre_dispatch(pre);
+  if (b < 0 || b >= t.first_block[t.n]) return;
   int i = 0;
-  while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
-  wino_wgrad_body(t.d[i], blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i], lds);
+  while (i + 1 < t.n && b >= t.first_block[i + 1]) ++i;      // wave-uniform
+  wino_wgrad_body(t.d[i], b - t.first_block[i], t.first_block[i + 1] - t.first_block[i], lds);
 }
 
 bool wino_wgrad_eligible(const da_wgrad_job& j) {
@@ -983,14 +987,15 @@ void wino_wgrad_plan(int rows, int L, int* splits, int* pchunk) {
   *pchunk = pc;
 }
 
-int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s) {
+int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s, WgradChain* chain) {
   WinoWgradTable t;
   int cnt = 0, blocks = 0;
   auto flush = [&]() -> int {
     if (!cnt) return DA_OK;
     t.n = cnt;
     t.first_block[cnt] = blocks;
-    hipLaunchKernelGGL(wino_wgrad_multi_kernel, dim3(blocks), dim3(256), 0, s, t);
+    WgradPreTable pre = wgrad_chain_take(chain);
+    hipLaunchKernelGGL(wino_wgrad_multi_kernel, dim3(wgrad_pre_grid(pre, blocks)), dim3(256), 0, s, t, pre);
     DA_CHECK_LAUNCH();
     cnt = 0;
     blocks = 0;
@@ -1008,6 +1013,7 @@ int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s) {
     a.divPL = make_fastdiv((uint32_t)a.PL);
     t.first_block[cnt] = blocks;
     blocks += (j.N / 64) * (j.C / 64) * splits;
+    wgrad_chain_offer(chain, i, j, splits);
     if (++cnt == 24) {
       int rc = flush();
       if (rc) return rc;
@@ -1154,11 +1160,13 @@ __device__ __forceinline__ void wino4_wgrad_body(const WinoWgradArgs& a, const i
   }
 }
 
-__global__ __launch_bounds__(256, WW4_MIN_WAVES) void wino4_wgrad_multi_kernel(WinoWgradTable t) {
+__global__ __launch_bounds__(256, WW4_MIN_WAVES) void wino4_wgrad_multi_kernel(WinoWgradTable t, WgradPreTable pre) {
   __shared__ float lds[WW4_LDS_FLOATS];
+  const int b = wgrad_pre_dispatch(pre);
+  if (b < 0 || b >= t.first_block[t.n]) return;
   int i = 0;
-  while (i + 1 < t.n && (int)blockIdx.x >= t.first_block[i + 1]) ++i;      // wave-uniform
-  wino4_wgrad_body(t.d[i], blockIdx.x - t.first_block[i], t.first_block[i + 1] - t.first_block[i], lds);
+  while (i + 1 < t.n && b >= t.first_block[i + 1]) ++i;      // wave-uniform
+  wino4_wgrad_body(t.d[i], b - t.first_block[i], t.first_block[i + 1] - t.first_block[i], lds);
 }
 
 #ifndef WW4_QCHUNK
@@ -1177,14 +1185,15 @@ void wino4_wgrad_plan(int rows, int L, int* splits, int* qchunk) {
   *qchunk = qc;
 }
 
-int wino4_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s) {
+int wino4_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s, WgradChain* chain) {
   WinoWgradTable t;
   int cnt = 0, blocks = 0;
   auto flush = [&]() -> int {
     if (!cnt) return DA_OK;
     t.n = cnt;
     t.first_block[cnt] = blocks;
-    hipLaunchKernelGGL(wino4_wgrad_multi_kernel, dim3(blocks), dim3(256), 0, s, t);
+    WgradPreTable pre = wgrad_chain_take(chain);
+    hipLaunchKernelGGL(wino4_wgrad_multi_kernel, dim3(wgrad_pre_grid(pre, blocks)), dim3(256), 0, s, t, pre);
     DA_CHECK_LAUNCH();
     cnt = 0;
     blocks = 0;
@@ -1202,6 +1211,7 @@ int wino4_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s) {
     a.divPL = make_fastdiv((uint32_t)a.PL);
     t.first_block[cnt] = blocks;
     blocks += (j.N / 64) * (j.C / 64) * splits;
+    wgrad_chain_offer(chain, i, j, splits);
     if (++cnt == 24) {
       int rc = flush();
       if (rc) return rc;

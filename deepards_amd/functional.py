@@ -81,11 +81,18 @@ def _launch_wgrads():
     jobs = _STEP['wgrad']
     if not jobs:
         return
-    slabs = H.conv_wgrad_multi([j[:5] + (j[6],) for j in jobs])
-    _STEP['wslab'] += [(sl, j[5]) for sl, j in zip(slabs, jobs)]
+    # the slab reductions chained: each launch of the call folds, as its first blocks, the slabs the launch before it wrote
+    # (still in the Infinity Cache, and memory-bound blocks beside matrix-bound ones); the step's tail keeps the last launch's
+    specs = [j[:5] + (j[6],) for j in jobs]
+    if _WGRAD_CHAIN:
+        slabs, reduced = H.conv_wgrad_multi(specs, dws=[j[5] for j in jobs], accumulate=True)
+    else:
+        slabs, reduced = H.conv_wgrad_multi(specs), [False] * len(jobs)
+    _STEP['wslab'] += [(sl, j[5]) for sl, j, r in zip(slabs, jobs, reduced) if not r]
     _STEP['wgrad'] = []
 
 
+_WGRAD_CHAIN = os.environ.get('DA_WGRAD_CHAIN', '1') != '0'       # (tests switch it off to compare with the one reduction launch behind all weight gradients)
 _WINOGRAD = os.environ.get('DA_WINOGRAD', '1') != '0'   # 0: the direct fp32 kernels (the second fp32 implementation the tests compare)
 _WINO4_MIN_C = 512        # channels from which F(4,3) beats F(2,3) (scripts/bench_wino.py; DESIGN appendix)
 

@@ -557,13 +557,17 @@ WGRAD_BF16 = False        # set by functional.set_conv_dtype('bf16'): k3 s1 weig
 WINO4_WGRAD_MIN_C = 512  # channels from which the F(4,3) weight-gradient form replaces F(2,3) (the 512-channel stage, as the forward)
 
 
-def conv_wgrad_multi(jobs):
+def conv_wgrad_multi(jobs, dws=None, accumulate=True):
     """jobs: [(dy, x, k, stride, pad)] -> [(slab, splits, k, co, ci)]: every weight-gradient GEMM of the list in
     one launch per tile shape (slabs only; reduce with wgrad_reduce_multi).  k3 s1 p1 jobs with 64-multiple
     channel counts take the Winograd F(2,3) form (F(4,3) from WINO4_WGRAD_MIN_C channels), or the bf16-operand kernel
-    while WGRAD_BF16 is set."""
+    while WGRAD_BF16 is set.
+    dws (one (co, ci, k) gradient destination per job, or None entries): the slab reductions are chained
+    (da_conv_wgrad_multi_reduce) -- every launch of the call carries, as its first blocks, the reduction of the slabs the
+    launch before it wrote; -> (slabs, reduced) with reduced[i] False for the jobs whose reduction the caller still owes
+    (those of the call's last launch)."""
     if not jobs:
-        return []
+        return [] if dws is None else ([], [])
     L = _lib.lib()
     arr = (_lib.WgradJob * len(jobs))()
     plan = (ctypes.c_int * 4)()
@@ -634,6 +638,18 @@ def conv_wgrad_multi(jobs):
         for t in range(3):
             d.src_off[t] = t - pad if t < k else 0
         outs.append((ws, plan[2], k, co, ci))
+    if dws is not None:
+        if len(dws) != len(jobs):
+            raise ValueError('conv_wgrad_multi: one destination (or None) per job')
+        ptrs = (ctypes.c_void_p * len(jobs))()
+        for i, (dw, (_, _, k, co, ci)) in enumerate(zip(dws, outs)):
+            if dw is not None:
+                if tuple(dw.shape) != (co, ci, k) or not dw.is_contiguous():
+                    raise ValueError('conv_wgrad_multi: bad dw shape')
+                ptrs[i] = _f32(dw, 'dw').data_ptr()
+        red = (ctypes.c_int * len(jobs))()
+        _chk(L.da_conv_wgrad_multi_reduce(arr, len(jobs), ptrs, 1 if accumulate else 0, red, _stream()), 'da_conv_wgrad_multi_reduce')
+        return outs, [bool(r) for r in red]
     _chk(L.da_conv_wgrad_multi(arr, len(jobs), _stream()), 'da_conv_wgrad_multi')
     return outs
 

@@ -154,6 +154,13 @@ typedef struct {
   int xform, dy_half, Wn, ldstat; const float* mean; const float* invstd; const float* gamma; const float* beta;
 } da_wgrad_job;
 int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, da_stream_t stream);  /* winograd == 16 jobs: dy / x are da_act_t tensors (the only kind accepted while bf16 is selected) */
+/* the same call with the slab reductions chained: dws[i] = job i's gradient destination dW[co][ci][k] (or NULL); the
+   reduction dws[i] (+)= sum of job i's slabs rides as the FIRST blocks of the NEXT launch of this call (memory-bound blocks
+   beside matrix-bound ones, on slabs still in the Infinity Cache) and reduced[i] = 1; reduced[i] = 0: the caller still
+   owes it (the jobs of the call's last launch, always) -- da_wgrad_reduce_multi / da_step_tail_multi.  The sums are the
+   ones da_wgrad_reduce_multi forms, bit for bit.  (replaces nothing of its own in the reference: the reduction of
+   loss.backward()'s conv weight gradients, train_ards_detector.py:161-173) */
+int da_conv_wgrad_multi_reduce(const da_wgrad_job* jobs, int n, float* const* dws, int accumulate, int* reduced, da_stream_t stream);
 /* deferred slab reduction: da_conv_wgrad with dw == NULL leaves da_conv_wgrad_splits() slabs in the workspace */
 int da_conv_wgrad_splits(int rows, int Lm, int N, int C, int ntaps);
 /* host only: out[4] = {tile_n, tile_c, splits, positions per split} the plan of da_conv_wgrad and

@@ -100,6 +100,33 @@ def test_conv_wgrad_multi_matches_single_jobs(H):
     assert H.conv_wgrad_multi([]) == []
 
 
+@pytest.mark.parametrize('accumulate', [True, False])
+def test_chained_slab_reductions_equal_the_reduction_launch(H, accumulate):
+    """da_conv_wgrad_multi_reduce: every launch of the call folds, as its first blocks, the slabs the launch before it wrote;
+    the gradients are bit for bit those of da_conv_wgrad_multi + da_wgrad_reduce_multi, the jobs of the last launch (and jobs
+    without a destination) are handed back, more than WGRAD_PRE_MAX jobs of one launch too."""
+    rng = np.random.default_rng(5)
+    cases = [(512, 512, 3, 1, 1, 7, 40)] * 2 + [(64, 64, 3, 1, 1, 56, 20)] * 17 + [(128, 128, 3, 1, 1, 28, 20),
+             (64, 128, 3, 2, 1, 56, 20), (64, 128, 1, 2, 0, 56, 20), (128, 32, 3, 1, 1, 7, 40), (96, 128, 1, 1, 0, 7, 40)]
+    jobs, a, b = [], [], []
+    for ci, co, k, stride, pad, L, rows in cases:
+        lo = (L + 2 * pad - k) // stride + 1
+        jobs.append((rlc(rng.standard_normal((rows, co, lo))), rlc(rng.standard_normal((rows, ci, L))), k, stride, pad))
+        init = torch.from_numpy(rng.standard_normal((co, ci, k)).astype(np.float32)).cuda()
+        a.append(init.clone())
+        b.append(init.clone())
+    a[3] = None                                     # a job without a destination: slabs only
+    slabs, reduced = H.conv_wgrad_multi(jobs, dws=a, accumulate=accumulate)
+    assert not reduced[3] and not all(reduced) and sum(reduced) >= 17, reduced
+    assert not reduced[-1] or not reduced[-2]       # (the last launch's jobs are the caller's)
+    a[3] = b[3].clone()
+    H.wgrad_reduce_multi([(sl, dw) for sl, dw, r in zip(slabs, a, reduced) if not r], accumulate=accumulate)
+    H.wgrad_reduce_multi(list(zip(H.conv_wgrad_multi(jobs), b)), accumulate=accumulate)
+    for n, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), 'job %d' % n
+    assert H.conv_wgrad_multi([], dws=[]) == ([], [])
+
+
 @pytest.mark.parametrize('n_red,n_bn,with_stem', [(3, 4, True), (3, 0, True), (33, 4, True), (3, 25, False), (0, 3, True), (2, 2, False)])
 def test_step_tail_launch_equals_its_parts(H, n_red, n_bn, with_stem):
     """da_step_tail_multi (slab reductions + BatchNorm dgamma / dbeta folds + running-statistics updates + the stem's
