@@ -133,7 +133,7 @@ SIGNATURES = {
     'da_wino_weights': (_I, [_P, _P, _I, _I, _I, _P]),
     'da_wino4_weights': (_I, [_P, _P, _I, _I, _I, _P]),
     'da_conv_wgrad_multi': (_I, [ctypes.POINTER(WgradJob), _I, _P]),
-    'da_conv_wgrad_multi_reduce': (_I, [ctypes.POINTER(WgradJob), _I, ctypes.POINTER(ctypes.c_void_p), _I, ctypes.POINTER(ctypes.c_int), _P]),
+    'da_conv_wgrad_multi_reduce': (_I, [ctypes.POINTER(WgradJob), _I, ctypes.POINTER(ctypes.c_void_p), _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), _P]),
     'da_wgrad_reduce_multi': (_I, [ctypes.POINTER(WgradReduceDesc), _I, _I, _P]),
     'da_step_tail_multi': (_I, [ctypes.POINTER(WgradReduceDesc), _I, ctypes.POINTER(BnPgradDesc), _I, ctypes.POINTER(BnRunningDesc), _I, _P, _I, _I, _P, _I, _P]),
     'da_stem_bwd_partials': (_I, [_I, _I, _I, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(_I)]),

@@ -799,6 +799,7 @@ struct WgradArgs {
   // tables; dy_half = 1: dY sits at half resolution (a transition's pooling folded in front of its conv): position j
   // reads dy[j / 2] / 2
   int xform, dy_half, ldstat;
+  int kind;              // conv_wgrad_any_kernel: which tile shape's body runs the job
   const float* mean;
   const float* invstd;
   const float* gamma;
@@ -826,7 +827,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block_i
   const int t = bx / (ntm * ntn);
   bx -= t * ntm * ntn;
   const int n_blk = (bx / ntn) * BM, c_blk = (bx % ntn) * BN;
-  const int so = t == 0 ? a.so0 : (t == 1 ? a.so1 : a.so2);
+  // (values first: a conditional between the MEMBERS is an lvalue -- a computed address into `a`, which keeps a local copy of
+  // the arguments in scratch memory, conv_wgrad_any_kernel)
+  const int so0_ = a.so0, so1_ = a.so1, so2_ = a.so2;
+  const int so = t == 0 ? so0_ : (t == 1 ? so1_ : so2_);
   const int Lm = (int)a.divLm.d;
   const int k_beg = split * a.kchunk;
   const int k_end = min(a.M, k_beg + a.kchunk);
@@ -1034,6 +1038,44 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// ... and the jobs of DIFFERENT tile shapes in one launch (kind[i] = which body): a step's direct weight gradients as one
+// grid of blocks sorted longest first, instead of one launch per tile shape each with its own ramp and partly filled last
+// round (densenet18 at B = 64: five launches of 140 ... 3 180 blocks, 254 us).  The 128 x 128 tile stays a launch of its own
+// (152 registers: it would halve the occupancy of all the others).
+struct WgradAnyTable {
+  WgradArgs d[WGRAD_TABLE_MAX];
+  int first_block[WGRAD_TABLE_MAX + 1];
+  int n;                                    // d[i].kind: 0: 128 x 64, 1: 64 x 128, 2: 64 x 64, 3: 128 x 32, 4: 32 x 128 (co x ci)
+};
+static_assert(sizeof(WgradAnyTable) + sizeof(WgradPreTable) <= 4096, "kernel arguments: 4 KB");
+
+template <int XF>
+__global__ __launch_bounds__(256, 4) void conv_wgrad_any_kernel(WgradAnyTable t, WgradPreTable pre) {
+  __shared__ float lds[32 * 192];
+  const int b = wgrad_pre_dispatch(pre);
+  if (b < 0 || b >= t.first_block[t.n]) return;
+  int i = 0;
+  while (i + 1 < t.n && b >= t.first_block[i + 1]) ++i;      // wave-uniform
+  const int blk = b - t.first_block[i], nblk = t.first_block[i + 1] - t.first_block[i];
+  // a COPY of the job's arguments (with a reference to t.d[i] in five inlined bodies the compiler parked the table in scratch
+  // memory and re-read it inside the K loops: 1 689 us for 254)
+  const WgradArgs& j = t.d[i];
+  WgradArgs a;
+  a.dy = j.dy; a.x = j.x; a.slab = j.slab;
+  a.M = j.M; a.Ldy = j.Ldy; a.lddy = j.lddy; a.N = j.N; a.Lx = j.Lx; a.ldx = j.ldx; a.C = j.C;
+  a.dy_stride = j.dy_stride; a.dy_off = j.dy_off; a.src_stride = j.src_stride;
+  a.ntaps = j.ntaps; a.so0 = j.so0; a.so1 = j.so1; a.so2 = j.so2; a.kchunk = j.kchunk; a.divLm = j.divLm;
+  a.xform = j.xform; a.dy_half = j.dy_half; a.ldstat = j.ldstat; a.kind = j.kind;
+  a.mean = j.mean; a.invstd = j.invstd; a.gamma = j.gamma; a.beta = j.beta; a.divWn = j.divWn;
+  switch (a.kind) {                                           // block-uniform
+    case 0: wgrad_body<2, 1, 2, 2, XF>(a, blk, nblk, lds); break;
+    case 1: wgrad_body<1, 2, 2, 2, XF>(a, blk, nblk, lds); break;
+    case 2: wgrad_body<1, 1, 2, 2, XF>(a, blk, nblk, lds); break;
+    case 3: wgrad_body<1, 1, 4, 1, XF>(a, blk, nblk, lds); break;
+    default: wgrad_body<1, 1, 1, 4, XF>(a, blk, nblk, lds); break;
+  }
+}
+
 // the same reduction (common.h wgrad_reduce_block) for up to 32 convolutions in one launch
 #define REDUCE_MAX_BN 24
 // first_block[i]: the launch's first block of conv i (1 024 slab elements a block, ONE dimension: no block without work --
@@ -1105,7 +1147,9 @@ struct WgradPlan {
   int tn, tc, splits, kchunk;
 };
 
-static WgradPlan wgrad_plan(int M, int N, int C, int ntaps) {
+// batch_target > 0: the job shares its launch with many others (launch_wgrad_any): that many blocks per job instead of a grid
+// that fills the chip by itself
+static WgradPlan wgrad_plan(int M, int N, int C, int ntaps, int batch_target = 0) {
   static const int opts[] = {128, 64, 32};
   WgradPlan best = {0, 0, 1, ((M + 31) / 32) * 32};
   double best_t = 1e30;
@@ -1115,7 +1159,7 @@ static WgradPlan wgrad_plan(int M, int N, int C, int ntaps) {
     if (N % tn) continue;
     for (int tc : opts) {
       if (C % tc) continue;
-      int target = g_wgrad_target_blocks > 0 ? g_wgrad_target_blocks : target0;
+      int target = g_wgrad_target_blocks > 0 ? g_wgrad_target_blocks : (batch_target > 0 ? batch_target : target0);
       // kernels exist for these pairs only
       bool ok = (tn == 128 && tc == 128) || (tn == 128 && tc == 64) || (tn == 64 && tc == 128) ||
                 (tn == 64 && tc == 64) || (tn == 128 && tc == 32) || (tn == 32 && tc == 128);
@@ -1145,7 +1189,7 @@ static WgradPlan wgrad_plan(int M, int N, int C, int ntaps) {
 // =============================================================================================
 
 template <int TM, int TN, int WGM, int WGN, int XF = 0>
-static int launch_wgrad_group(const da_wgrad_job* jobs, int n, int tn, int tc, hipStream_t s, WgradChain* chain = nullptr) {
+static int launch_wgrad_group(const da_wgrad_job* jobs, int n, int tn, int tc, hipStream_t s, WgradChain* chain = nullptr, int tgt = 0) {
   constexpr int BM = TM * WGM * 32, BN = TN * WGN * 32;
   WgradTable t;
   int cnt = 0, blocks = 0;
@@ -1165,13 +1209,13 @@ static int launch_wgrad_group(const da_wgrad_job* jobs, int n, int tn, int tc, h
   for (int i = 0; i < n; ++i) {
     if (jobs[i].winograd) continue;                       // conv_wino.hip
     if ((XF != 0) != (jobs[i].xform != 0 || jobs[i].dy_half != 0)) continue;      // the operand forms have kernels of their own
-    WgradPlan pl = wgrad_plan(jobs[i].rows * jobs[i].Lm, jobs[i].N, jobs[i].C, jobs[i].ntaps);
+    WgradPlan pl = wgrad_plan(jobs[i].rows * jobs[i].Lm, jobs[i].N, jobs[i].C, jobs[i].ntaps, tgt);
     if (pl.tn == tn && pl.tc == tc) order.push_back({-pl.kchunk, i});
   }
   std::stable_sort(order.begin(), order.end());
   for (const auto& o : order) {
     const da_wgrad_job& j = jobs[o.second];
-    WgradPlan pl = wgrad_plan(j.rows * j.Lm, j.N, j.C, j.ntaps);
+    WgradPlan pl = wgrad_plan(j.rows * j.Lm, j.N, j.C, j.ntaps, tgt);
     WgradArgs& a = t.d[cnt];
     a.dy = j.dy; a.x = j.x; a.slab = j.workspace;
     a.M = j.rows * j.Lm; a.Ldy = j.Ldy; a.lddy = j.lddy; a.N = j.N;
@@ -1195,15 +1239,76 @@ static int launch_wgrad_group(const da_wgrad_job* jobs, int n, int tn, int tc, h
   return flush();
 }
 
+static void wgrad_fill_args(WgradArgs& a, const da_wgrad_job& j, const WgradPlan& pl) {
+  a.dy = j.dy; a.x = j.x; a.slab = j.workspace;
+  a.M = j.rows * j.Lm; a.Ldy = j.Ldy; a.lddy = j.lddy; a.N = j.N;
+  a.Lx = j.Lx; a.ldx = j.ldx; a.C = j.C;
+  a.dy_stride = j.dy_stride; a.dy_off = j.dy_off; a.src_stride = j.src_stride;
+  a.ntaps = j.ntaps;
+  a.so0 = j.src_off[0]; a.so1 = j.ntaps > 1 ? j.src_off[1] : 0; a.so2 = j.ntaps > 2 ? j.src_off[2] : 0;
+  a.kchunk = pl.kchunk;
+  a.divLm = make_fastdiv((uint32_t)j.Lm);
+  a.xform = j.xform; a.dy_half = j.dy_half; a.ldstat = j.ldstat;
+  a.kind = 0;
+  a.mean = j.mean; a.invstd = j.invstd; a.gamma = j.gamma; a.beta = j.beta;
+  a.divWn = make_fastdiv((uint32_t)(j.Wn > 0 ? j.Wn : 1));
+}
+
+static int g_wgrad_any = 1;     // da_debug_set(key 7): 0 = one launch per tile shape (the form the tests compare with)
+
+// every direct job of the operand kind XF whose plan is not the 128 x 128 tile, in one launch (conv_wgrad_any_kernel)
+template <int XF>
+static int launch_wgrad_any(const da_wgrad_job* jobs, int n, hipStream_t s, WgradChain* chain, int tgt) {
+  WgradAnyTable t;
+  int cnt = 0, blocks = 0;
+  auto flush = [&]() -> int {
+    if (!cnt) return DA_OK;
+    t.n = cnt;
+    t.first_block[cnt] = blocks;
+    WgradPreTable pre = wgrad_chain_take(chain);
+    hipLaunchKernelGGL((conv_wgrad_any_kernel<XF>), dim3(wgrad_pre_grid(pre, blocks, true)), dim3(256), 0, s, t, pre);
+    DA_CHECK_LAUNCH();
+    cnt = 0;
+    blocks = 0;
+    return DA_OK;
+  };
+  // longest blocks first (block time ~ positions per split x 32 x 32 products per wave): short ones fill the launch's tail
+  std::vector<std::pair<long, int>> order;
+  for (int i = 0; i < n; ++i) {
+    if (jobs[i].winograd) continue;
+    if ((XF != 0) != (jobs[i].xform != 0 || jobs[i].dy_half != 0)) continue;
+    const WgradPlan pl = wgrad_plan(jobs[i].rows * jobs[i].Lm, jobs[i].N, jobs[i].C, jobs[i].ntaps, tgt);
+    if (pl.tn == 128 && pl.tc == 128) continue;
+    order.push_back({-(long)pl.kchunk * (pl.tn * pl.tc / 4096), i});
+  }
+  std::stable_sort(order.begin(), order.end());
+  for (const auto& o : order) {
+    const da_wgrad_job& j = jobs[o.second];
+    const WgradPlan pl = wgrad_plan(j.rows * j.Lm, j.N, j.C, j.ntaps, tgt);
+    wgrad_fill_args(t.d[cnt], j, pl);
+    t.d[cnt].kind = pl.tn == 128 ? (pl.tc == 64 ? 0 : 3) : (pl.tn == 64 ? (pl.tc == 128 ? 1 : 2) : 4);
+    t.first_block[cnt] = blocks;
+    blocks += (j.N / pl.tn) * (j.C / pl.tc) * j.ntaps * pl.splits;
+    wgrad_chain_offer(chain, o.second, j, pl.splits);
+    if (++cnt == WGRAD_TABLE_MAX) {
+      int rc = flush();
+      if (rc) return rc;
+    }
+  }
+  return flush();
+}
+
 extern "C" {
 
 // Benchmark-only tuning knobs.  key 0: force the conv GEMM tile (0 auto, 1 128x128, 2 64x128, 3 128x64,
-// 4 64x64, 5 128x32, 6 32x128).  key 1: wgrad target block count (0 = 1024).
+// 4 64x64, 5 128x32, 6 32x128).  key 1: wgrad target block count (0 = 1024).  key 7: 0 = the dense-block weight gradients as
+// one launch per tile shape instead of one launch for all shapes (conv_wgrad_any_kernel).
 int da_debug_set(int key, int value) {
   if (key == 0) g_force_conv_tile = value;
   else if (key == 1) g_wgrad_target_blocks = value;
   else if (key == 2) g_use_halo = value;
   else if (key == 3) g_use_tail = value;
+  else if (key == 7) g_wgrad_any = value;
   else return DA_EINVAL;
   return DA_OK;
 }
@@ -1315,8 +1420,13 @@ size_t da_conv_wgrad_workspace(int rows, int Lm, int N, int C, int ntaps) {
 // dws != NULL: dws[i] is job i's gradient destination (or NULL); the slab reduction dws[i] (+)= sum of job i's slabs then rides
 // in front of the NEXT launch of this call (common.h WgradPreTable) where there is one, and reduced[i] says whether it did
 // (1) or the caller still owes it (0: da_wgrad_reduce_multi / da_step_tail_multi) -- the jobs of the call's last launch always.
+// splits_out != NULL: the number of slabs every job wrote (what its reduction must be told) -- with it the dense-block jobs
+// of a call that has 8 or more of them are planned as a batch (one launch, conv_wgrad_any_kernel: ~2 560 blocks over all of
+// them instead of 512 ... 1 024 per job; never more slabs than da_conv_wgrad_plan's figure, which sizes the workspace).
+// densenet18 at B = 64, per-job target 0 (the plan alone) / 64 / 128 / 192 / 256 / 384 / 512: 1.215 / 1.249 / 1.187 / 1.194 /
+// 1.199 / 1.206 / 1.213 ms a step.
 static int conv_wgrad_multi_impl(const da_wgrad_job* jobs, int n, float* const* dws, int accumulate, int* reduced,
-                                 hipStream_t stream) {
+                                 int* splits_out, hipStream_t stream) {
   DA_ENTER();
   if (n < 0 || (n && !jobs)) return DA_EINVAL;
   for (int i = 0; i < n; ++i) {
@@ -1358,10 +1468,22 @@ static int conv_wgrad_multi_impl(const da_wgrad_job* jobs, int n, float* const* 
   if ((rc = launch_wgrad_group<1, 1, 2, 2>(jobs, n, 64, 64, stream, chain))) return rc;
   if ((rc = launch_wgrad_group<1, 1, 4, 1>(jobs, n, 128, 32, stream, chain))) return rc;
   if ((rc = launch_wgrad_group<1, 1, 1, 4>(jobs, n, 32, 128, stream, chain))) return rc;
-  bool any_xf = false;
-  for (int i = 0; i < n; ++i) any_xf = any_xf || jobs[i].xform || jobs[i].dy_half;
-  if (any_xf) {                                           // dense-block operand forms (conv1x1_bn_kernel's weight gradients)
-    if ((rc = launch_wgrad_group<2, 2, 2, 2, 1>(jobs, n, 128, 128, stream, chain))) return rc;
+  int n_xf = 0;
+  for (int i = 0; i < n; ++i) n_xf += (jobs[i].xform || jobs[i].dy_half) ? 1 : 0;
+  const int tgt = (splits_out && g_wgrad_any && n_xf >= 8) ? (2560 / n_xf < 96 ? 96 : 2560 / n_xf) : 0;
+  if (splits_out)
+    for (int i = 0; i < n; ++i) {
+      const da_wgrad_job& j = jobs[i];
+      int sp = 0, kc = 0;
+      if (j.winograd == 16 || j.winograd == 49) bf16_wgrad_plan(j.rows, j.Lm, &sp, &kc);
+      else if (j.winograd == 6) wino4_wgrad_plan(j.rows, j.Lm, &sp, &kc);
+      else if (j.winograd) wino_wgrad_plan(j.rows, j.Lm, &sp, &kc);
+      else sp = wgrad_plan(j.rows * j.Lm, j.N, j.C, j.ntaps, (j.xform || j.dy_half) ? tgt : 0).splits;
+      splits_out[i] = sp;
+    }
+  if (n_xf) {                                             // dense-block operand forms (conv1x1_bn_kernel's weight gradients)
+    if ((rc = launch_wgrad_group<2, 2, 2, 2, 1>(jobs, n, 128, 128, stream, chain, tgt))) return rc;
+    if (g_wgrad_any) return launch_wgrad_any<1>(jobs, n, stream, chain, tgt);
     if ((rc = launch_wgrad_group<2, 1, 2, 2, 1>(jobs, n, 128, 64, stream, chain))) return rc;
     if ((rc = launch_wgrad_group<1, 2, 2, 2, 1>(jobs, n, 64, 128, stream, chain))) return rc;
     if ((rc = launch_wgrad_group<1, 1, 2, 2, 1>(jobs, n, 64, 64, stream, chain))) return rc;
@@ -1372,13 +1494,13 @@ static int conv_wgrad_multi_impl(const da_wgrad_job* jobs, int n, float* const* 
 }
 
 int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, hipStream_t stream) {
-  return conv_wgrad_multi_impl(jobs, n, nullptr, 0, nullptr, stream);
+  return conv_wgrad_multi_impl(jobs, n, nullptr, 0, nullptr, nullptr, stream);
 }
 
 int da_conv_wgrad_multi_reduce(const da_wgrad_job* jobs, int n, float* const* dws, int accumulate, int* reduced,
-                               hipStream_t stream) {
-  if (n && (!dws || !reduced)) return DA_EINVAL;
-  return conv_wgrad_multi_impl(jobs, n, dws, accumulate, reduced, stream);
+                               int* splits, hipStream_t stream) {
+  if (n && (!dws || !reduced || !splits)) return DA_EINVAL;
+  return conv_wgrad_multi_impl(jobs, n, dws, accumulate, reduced, splits, stream);
 }
 
 // number of slabs da_conv_wgrad writes for this shape (workspace = splits * ntaps*N*C floats)

@@ -647,8 +647,12 @@ def conv_wgrad_multi(jobs, dws=None, accumulate=True):
                 if tuple(dw.shape) != (co, ci, k) or not dw.is_contiguous():
                     raise ValueError('conv_wgrad_multi: bad dw shape')
                 ptrs[i] = _f32(dw, 'dw').data_ptr()
-        red = (ctypes.c_int * len(jobs))()
-        _chk(L.da_conv_wgrad_multi_reduce(arr, len(jobs), ptrs, 1 if accumulate else 0, red, _stream()), 'da_conv_wgrad_multi_reduce')
+        red, spl = (ctypes.c_int * len(jobs))(), (ctypes.c_int * len(jobs))()
+        _chk(L.da_conv_wgrad_multi_reduce(arr, len(jobs), ptrs, 1 if accumulate else 0, red, spl, _stream()), 'da_conv_wgrad_multi_reduce')
+        for i, (ws, planned, k, co, ci) in enumerate(outs):       # the slabs actually written (a batch plan may use fewer)
+            if not 1 <= spl[i] <= planned:
+                raise RuntimeError('conv_wgrad_multi: job %d wrote %d slabs into a workspace of %d' % (i, spl[i], planned))
+            outs[i] = (ws, spl[i], k, co, ci)
         return outs, [bool(r) for r in red]
     _chk(L.da_conv_wgrad_multi(arr, len(jobs), _stream()), 'da_conv_wgrad_multi')
     return outs

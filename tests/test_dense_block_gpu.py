@@ -187,6 +187,51 @@ def test_wgrad_with_the_recomputed_activation_against_the_oracle(H, rows, R, L, 
     assert torch.equal(dwb, dw)
 
 
+def test_one_launch_for_all_tile_shapes_and_the_batch_plan(H):
+    """The dense-block weight gradients of a step: (a) all tile shapes in ONE launch (conv_wgrad_any_kernel) == one launch per
+    tile shape, bit for bit (da_debug_set(7, 0)); (b) planned as a batch (da_conv_wgrad_multi_reduce with 8 or more such jobs:
+    fewer slabs per job, the count reported back) == the oracle, and the chained reductions equal the reduction launch."""
+    from deepards_amd import _lib
+    rng = np.random.RandomState(3)
+    R, cb = 20, 160
+    jobs, refs = [], []
+    for rows, L, C, N, k in [(40, 56, 96, 128, 1), (40, 56, 64, 128, 1), (40, 28, 128, 64, 1), (40, 7, 128, 128, 1), (40, 56, 128, 32, 3),
+                             (60, 28, 128, 32, 3), (40, 14, 96, 128, 1), (40, 14, 128, 32, 3), (1280, 56, 96, 128, 1), (640, 14, 96, 128, 1)]:
+        x = rng.randn(rows, C, L) + rng.randn(1, C, 1)
+        gamma, beta = rng.rand(C) + 0.5, rng.randn(C) * 0.3
+        h_ref = np_ref.relu(np_ref.bn_window_fwd(x, gamma, beta, R)[0])
+        dy = rng.randn(rows, N, L)
+        refs.append(np_ref.conv1d_bwd(h_ref, np.zeros((N, C, k)), dy, 1, k // 2, need_dx=False)[1])
+        _, xv = pitched(x, cb)
+        mean_t, invstd_t = stat_tables(rows // R, cb)
+        H.bn_stats_fused(xv, R, mean_t[:, :C], invstd_t[:, :C])
+        _, dyv = pitched(dy, N + 32)
+        jobs.append((dyv, xv, k, 1, k // 2, {'xform': (mean_t[:, :C], invstd_t[:, :C], cu(gamma), cu(beta), R)}))
+    def run(**kw):
+        dws = [torch.zeros(r.shape, device='cuda') for r in refs]
+        if kw:
+            slabs, reduced = H.conv_wgrad_multi(jobs, dws=dws, accumulate=False)
+            H.wgrad_reduce_multi([(sl, dw) for sl, dw, r in zip(slabs, dws, reduced) if not r], accumulate=False)
+        else:
+            slabs = H.conv_wgrad_multi(jobs)
+            H.wgrad_reduce_multi(list(zip(slabs, dws)), accumulate=False)
+        return dws, [sl[1] for sl in slabs]
+    a, sa = run()
+    _lib.lib().da_debug_set(7, 0)
+    try:
+        b, sb = run()
+    finally:
+        _lib.lib().da_debug_set(7, 1)
+    assert sa == sb
+    for n, (x, y, r) in enumerate(zip(a, b, refs)):
+        assert torch.equal(x, y), 'job %d' % n
+        close(x.cpu().numpy(), r, tol=2e-5, name='dW %d' % n)
+    c, sc = run(batch=True)
+    assert all(q <= p for p, q in zip(sa, sc)) and sum(sc) < sum(sa), (sa, sc)
+    for n, (x, r) in enumerate(zip(c, refs)):
+        close(x.cpu().numpy(), r, tol=2e-5, name='batched dW %d' % n)
+
+
 @pytest.mark.parametrize('rows,L', [(40, 56), (40, 7), (300, 28), (1280, 14)])
 def test_winograd_growth_conv_with_dropout_in_the_epilogue(H, rows, L):
     """The growth conv (128 -> 32, k3) writing at a channel offset of a pitched buffer with F.dropout applied in its
