@@ -68,7 +68,10 @@ def flush_backward():
     """Run the queued parameter-gradient folds (call after the backward, before the optimiser)."""
     _launch_wgrads()
     # one launch: slab reductions + dgamma / dbeta folds + the running statistics a deferred flush_forward left queued
-    H.step_tail_multi(_STEP['wslab'], _STEP['pgrad'], _STEP['running'], accumulate=True, stem=_STEP.get('stemred'))
+    dst = [dw.data_ptr() for _, dw in _STEP['wslab']] + [t.data_ptr() for _, tg, tb in _STEP['pgrad'] for t in (tg, tb)]
+    if len(set(dst)) != len(dst):                   # a destination written twice in one step (shared parameters)
+        _plain_writer()
+    H.step_tail_multi(_STEP['wslab'], _STEP['pgrad'], _STEP['running'], accumulate=_acc(), stem=_STEP.get('stemred'))
     _STEP['pgrad'], _STEP['wslab'], _STEP['running'], _STEP['stemred'] = [], [], [], None
 
 
@@ -85,7 +88,9 @@ def _launch_wgrads():
     # (still in the Infinity Cache, and memory-bound blocks beside matrix-bound ones); the step's tail keeps the last launch's
     specs = [j[:5] + (j[6],) for j in jobs]
     if _WGRAD_CHAIN:
-        slabs, reduced = H.conv_wgrad_multi(specs, dws=[j[5] for j in jobs], accumulate=True)
+        if len({j[5].data_ptr() for j in jobs}) != len(jobs):
+            _plain_writer()
+        slabs, reduced = H.conv_wgrad_multi(specs, dws=[j[5] for j in jobs], accumulate=_acc())
     else:
         slabs, reduced = H.conv_wgrad_multi(specs), [False] * len(jobs)
     _STEP['wslab'] += [(sl, j[5]) for sl, j, r in zip(slabs, jobs, reduced) if not r]
@@ -229,6 +234,29 @@ def _conv_dgrad(dy, w, stride, pad, l_in, out=None, accumulate=False):
     if code:
         return H.conv3_winograd(dy, _pack(w, code)[3], out=out, accumulate=accumulate)
     return H.conv_dgrad(dy, _pack(w, 0)[1], stride, pad, l_in, out=out, accumulate=accumulate)
+
+
+# A captured training step may run WITHOUT the zero-fill of the gradient bucket: every gradient destination is then written
+# exactly once, by a writer that has an overwrite form (the step's queued folds / slab reductions, the fused head).  The
+# trainer learns whether that holds from the eager warm-up pass in front of the capture (_OV['ok'] stays True) and switches
+# the form on for the capture only (grad_overwrite); a writer that can only accumulate refuses to run in such a step.
+_OV = {'on': False, 'ok': True}
+
+
+def grad_overwrite(on):
+    _OV['on'] = bool(on)
+
+
+def _acc():
+    """accumulate flag of the writers that have an overwrite form."""
+    return not _OV['on']
+
+
+def _plain_writer():
+    """A backward is about to ACCUMULATE into a trainer's gradient destination (no overwrite form)."""
+    _OV['ok'] = False
+    if _OV['on']:
+        raise RuntimeError('a gradient writer without an overwrite form ran in a step captured without the gradient zero-fill')
 
 
 def _tgt(*params):
@@ -383,6 +411,8 @@ class StemFunction(Function):
                 _STEP['stemred'] = (part, nblk, n, tw)
                 dw = None
             else:
+                if tw is not None:
+                    _plain_writer()
                 dw, ds = H.stem_fused_bwd(dout, x2d, y0, ctx.R, mean, invstd, gamma, beta, ctx.pool_mode, dw=tw,
                                           accumulate=tw is not None)
             dgamma = dbeta = None
@@ -390,6 +420,7 @@ class StemFunction(Function):
                 if _STEP['on']:
                     _STEP['pgrad'].append((ds, tg, tb))
                 else:
+                    _plain_writer()
                     H.bn_param_grad_multi([(ds, tg, tb)], accumulate=True)
             else:
                 dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
@@ -397,6 +428,8 @@ class StemFunction(Function):
             return None, None if tw is not None else dw, dgamma, dbeta, None, None, None, None, None
         dz = H.pool_bwd(dout, y0, ctx.R, mean, invstd, gamma, beta, ctx.pool_mode)
         dy0, dgamma, dbeta = _bn_bwd(dz, y0, ctx.R, mean, invstd, gamma, beta, 1, tg, tb, dx=dz)
+        if tw is not None:
+            _plain_writer()
         dw = H.stem_conv_wgrad(dy0, x2d, out=tw, accumulate=tw is not None)
         return None, None if tw is not None else dw, dgamma, dbeta, None, None, None, None, None
 
@@ -436,6 +469,8 @@ class DoubleStemFunction(Function):
         x2d, ya, m1, i1, g1, b1, h, wd, y2, m2, i2, g2, b2 = ctx.saved_tensors
         twa, tg1, tb1, tw2, tg2, tb2 = ctx.gt
         R = ctx.R
+        if twa is not None or tw2 is not None:
+            _plain_writer()
         dz = H.pool_bwd(dout.contiguous(), y2, R, m2, i2, g2, b2, ctx.pool_mode)
         dy2, dg2, db2 = _bn_bwd(dz, y2, R, m2, i2, g2, b2, 1, tg2, tb2, dx=dz)
         dw2 = H.conv_wgrad(dy2, h, 7, 2, 3, out=tw2, accumulate=tw2 is not None)
@@ -451,6 +486,8 @@ def _bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, tg, tb, out=None, dx=No
     add = (tensor, channel offset): that slice is added to dx in the same pass (a concatenation's pass-through)."""
     direct = tg is not None and tb is not None
     defer = direct and _STEP['on']
+    if direct and not defer:
+        _plain_writer()
     dx, dg, db, g, ds = H.bn_bwd(dout, x, R, mean, invstd, gamma, beta, mode, out=out, want_g=want_g, dx=dx,
                                  dgamma=tg if direct else None, dbeta=tb if direct else None, accumulate=direct,
                                  defer_param_grads=defer, add=add, mask=mask)
@@ -467,6 +504,7 @@ def _bn_pgrad(ds, gamma, beta, tg, tb):
         if _STEP['on']:
             _STEP['pgrad'].append((ds, tg, tb))
         else:
+            _plain_writer()
             H.bn_param_grad_multi([(ds, tg, tb)], accumulate=True)
         return None, None
     dg, db = torch.empty_like(gamma), torch.empty_like(beta)
@@ -481,6 +519,8 @@ def _wgrad(dy, x, k, stride, pad, tw, extra=None):
     if tw is not None and _STEP['on']:
         _STEP['wgrad'].append((dy, x, k, stride, pad, tw, extra))     # launched with all the others by flush_backward()
         return None
+    if tw is not None:
+        _plain_writer()
     if H.WGRAD_BF16 or H.act_dtype() == 'bf16' or H.is_x3(dy) or extra or not (dy.is_contiguous() and x.is_contiguous()):
         # (the bf16-pipe kernels, the operand forms and pitched operands exist in the batched form only)
         (slab,) = H.conv_wgrad_multi([(dy, x, k, stride, pad, extra)])
@@ -801,6 +841,7 @@ class DenseBlockFunction(Function):
                 if _STEP['on']:
                     _STEP['pgrad'].append((ds, tg[ig], tg[ib]))
                 else:
+                    _plain_writer()
                     H.bn_param_grad_multi([(ds, tg[ig], tg[ib])], accumulate=True)
             else:
                 grads[ig], grads[ib] = torch.empty_like(gamma), torch.empty_like(beta)
@@ -971,6 +1012,8 @@ class Linear2Function(Function):
         flat, w = ctx.saved_tensors
         tw, tb = ctx.gt
         direct = tw is not None and tb is not None
+        if direct:
+            _plain_writer()
         dflat, dw, dbias = H.linear2_bwd(dlogits.contiguous(), flat, w, need_input=ctx.needs_input_grad[0],
                                          dw=tw if direct else None, dbias=tb if direct else None, accumulate=direct)
         return dflat, None if direct else dw, None if direct else dbias
@@ -1004,7 +1047,7 @@ class HeadLossFunction(Function):
         tw, tb = ctx.gt
         direct = tw is not None and tb is not None
         dx, dw, db = H.head_bwd(part, bias, target, flat, w, logits, loss, ctx.R, ctx.l, dw=tw if direct else None,
-                                dbias=tb if direct else None, accumulate=direct)
+                                dbias=tb if direct else None, accumulate=direct and _acc())
         return dx, None if direct else dw, None if direct else db, None, None, None
 
 
@@ -1080,6 +1123,8 @@ class LSTMFunction(Function):
         dg3 = dgates.view(rows, 1, g4)
         dfeat = H.conv_dgrad(dg3, H.repack_weight(w_ih.view(g4, f, 1), False, True)[1], 1, 0, 1)
         direct = tih is not None
+        if direct:
+            _plain_writer()
         dw_ih = H.conv_wgrad(dg3, x3, 1, 1, 0, out=tih.view(g4, f, 1) if direct else None, accumulate=direct)
         dw_hh = H.reduce_rows(part, out=thh if direct else None, accumulate=direct)
         db = H.reduce_rows(dgates.view(rows, g4), out=tbi if direct else None, accumulate=direct)

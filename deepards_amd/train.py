@@ -177,6 +177,7 @@ def average_replica_buffers(model, world_size, group=None):
         dist.broadcast(b, src=src, group=group)
 
 
+_GRAD_OVERWRITE = os.environ.get('DA_GRAD_OVERWRITE', '1') != '0'   # 0: every captured step zero-fills the gradient bucket and its writers accumulate
 _FUSED_HEAD = os.environ.get('DA_FUSED_HEAD', '1') != '0'      # 0: the six-launch head chain (A/B and the sibling heads' path)
 
 
@@ -256,6 +257,7 @@ class HotPathTrainer(object):
         # data parallel: DA_DP_CAPTURE_ALLREDUCE=1 tries to capture the all-reduce INSIDE the step graph (opt-in, see _capture)
         self._capture_allreduce = os.environ.get('DA_DP_CAPTURE_ALLREDUCE', '0') == '1'
         self.allreduce_in_graph = False
+        self.grad_overwrite = False         # the form of the step being captured (set per capture)
 
     # ---- replicas ----------------------------------------------------------------------------
     def sync_replicas(self):
@@ -368,11 +370,22 @@ class HotPathTrainer(object):
         saved = [b.clone() for b in self.model.buffers()]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        F_._OV['ok'] = True
         with torch.cuda.stream(s):
             self._forward_backward(*static, zero_grad=True)
             for b, c in zip(self.model.buffers(), saved):
                 b.copy_(c)
         torch.cuda.current_stream().wait_stream(s)
+        # Did every gradient destination get exactly one write, by a writer with an overwrite form (functional._OV)?  Then
+        # the captured step needs no zero-fill of the gradient bucket: its writers overwrite (6 us a step at B = 64).
+        self.grad_overwrite = _GRAD_OVERWRITE and F_._OV['ok']
+        try:
+            F_.grad_overwrite(self.grad_overwrite)
+            return self._capture_forms(inputs, static)
+        finally:
+            F_.grad_overwrite(False)
+
+    def _capture_forms(self, inputs, static):
         graph, static_out, graph_opt = None, None, None
         if self.world_size > 1 and self._capture_allreduce and self._collectives_capturable():
             # Data parallel, OPT-IN form (DA_DP_CAPTURE_ALLREDUCE=1): ONE graph holds backward | all-reduce | update.  RCCL
@@ -439,13 +452,13 @@ class HotPathTrainer(object):
 
     def _eager_whole_step(self, inputs, target):
         """zero-grad, forward, loss, backward, gradient all-reduce, update: the data-parallel step as one capturable chain."""
-        loss, logits = self._forward_backward(inputs, target, zero_grad=True)
+        loss, logits = self._forward_backward(inputs, target, zero_grad=not self.grad_overwrite)
         self.bucket.allreduce(self.group)
         self._optimizer_step()
         return loss, logits
 
     def _eager_single_gpu_parts(self, inputs, target):
-        loss, logits = self._forward_backward(inputs, target, zero_grad=True)
+        loss, logits = self._forward_backward(inputs, target, zero_grad=not self.grad_overwrite)
         if self.world_size == 1:
             self._optimizer_step()
         return loss, logits

@@ -888,6 +888,41 @@ def test_data_parallel_two_processes_epochs_from_store(tmp_path):
     assert np.isfinite(r0['losses']).all() and np.isfinite(r1['losses']).all()
 
 
+@pytest.mark.parametrize('backbone,drop', [('resnet18', 0.0), ('densenet18', 0.2)])
+def test_captured_step_without_the_gradient_zero_fill(M, backbone, drop, monkeypatch):
+    """A captured step whose every gradient destination has ONE writer with an overwrite form runs without the zero-fill of
+    the gradient bucket (functional._OV, HotPathTrainer.grad_overwrite): parameters, momentum and the gradient bucket are bit
+    for bit those of the zero-fill + accumulate form over 4 steps and two batch shapes; a writer that can only accumulate
+    (the six-launch head chain) keeps the zero-fill form."""
+    import deepards_amd.train as T
+    from deepards_amd.train import HotPathTrainer
+    x = torch.randn(6, 20, 1, 224, device='cuda')
+    t = torch.zeros(6, 2, device='cuda')
+    t[:3, 0] = 1
+    t[3:, 1] = 1
+
+    def run(overwrite):
+        monkeypatch.setattr(T, '_GRAD_OVERWRITE', overwrite)
+        tr = HotPathTrainer(build(M, backbone, 11, drop_rate=drop), use_graph=True)
+        for n in (6, 6, 4, 6, 4):
+            tr.train_step(x[:n].contiguous(), t[:n].contiguous())
+        torch.cuda.synchronize()
+        out = (tr.grad_overwrite, tr.bucket.p.clone(), tr.bucket.g.clone(), tr.state['buf'].clone())
+        tr.release_graphs()
+        return out
+    a, b = run(True), run(False)
+    assert a[0] and not b[0]
+    for u, v in zip(a[1:], b[1:]):
+        assert torch.equal(u, v)
+    monkeypatch.setattr(T, '_GRAD_OVERWRITE', True)
+    monkeypatch.setattr(T, '_FUSED_HEAD', False)
+    tr = HotPathTrainer(build(M, backbone, 11, drop_rate=drop), use_graph=True)
+    for _ in range(3):
+        loss = tr.train_step(x, t)
+    assert not tr.grad_overwrite and np.isfinite(float(loss))
+    tr.release_graphs()
+
+
 def test_recapture_on_shape_change_with_garbage_pending(M):
     """Pins the capture-window ownership rule (deepards_amd.train._capture_graph): cyclic garbage
     that owns captured graphs and device tensors is pending when a NEW shape is captured; it must be finalised before
