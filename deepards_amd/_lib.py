@@ -102,6 +102,9 @@ SIGNATURES = {
     'da_bn_mask_words': (_Z, [_I, _I, _I]),
     'da_bn_fwd_mask': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P]),
     'da_bn_bwd_mask': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'da_bn_pool_ok': (_I, [_I, _I, _I, _I]),
+    'da_bn_fwd_pool': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P]),
+    'da_bn_bwd_pool': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     'da_bn_bwd_add': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P]),
     'da_bn_param_grad_multi': (_I, [ctypes.POINTER(BnPgradDesc), _I, _I, _P]),
     'da_bn_fwd_pair': (_I, [ctypes.POINTER(BnFwdDesc), _I, _I, _I, _F, _P]),
@@ -153,6 +156,8 @@ SIGNATURES = {
     'da_head_groups': (_I, [_I, _I]),
     'da_head_fwd': (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'da_head_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    'da_head_flat_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'da_head_flat_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     'da_clamp_sgd_nesterov': (_I, [_P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _P]),
     'da_clamp_adam': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _I, _F, _F, _P]),
     'da_clamp_adam_dev': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _P, _F, _F, _P]),

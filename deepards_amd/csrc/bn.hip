@@ -400,6 +400,8 @@ __device__ __forceinline__ uint32_t bn_mix32(uint32_t a, uint32_t b) {
 // (those channels are the previous layer's new features: this kernel is the last to add to their gradient, and what
 // its data / weight gradient convs want is the gradient in front of F.dropout, densenet.py:37-39).
 struct BnBwdExt {
+  int pool_L;          // DPOOL: dout is the gradient of the POOLED features, float [rows][ldd]: position p of a window reads
+  FastDiv pool_div;    //        row p / pool_L, scaled by 1 / pool_L (the backward of bn_fwd_pool_kernel's average)
   int ldstat, half_dout, drop_c0, drop_g;
   const long long* seed;
   uint32_t salt;
@@ -442,12 +444,18 @@ __device__ __forceinline__ void quad_block_sum(f32x4 (&v)[NV], float* red) {
 // mean / invstd of the window (two-pass from registers), published, and out = act(bn(x) (+res))
 // RX3 / OX3: the residual is read / the output is stored in the x3 format (common.h: exact three-term bf16 split, 3 C bf16
 // per position; float activations only) -- the producers of the k3 s1 convs' inputs under conv arithmetic 'f32x3'.
-template <typename AT, int NPOS, int QB, int RX3 = 0, int OX3 = 0>
+// POOL: the output is not stored -- only its average over the L positions of every row, pool_out[row][C] (float): the
+// block-output BatchNorm of the LAST residual block, whose map only the head's AvgPool1d(7) reads (resnet.py:112,159-160).
+// The values pooled are the ones the activation storage type would have held, summed in position order and scaled by 1 / L
+// last (head_pool_dot_kernel's arithmetic: bit for bit the pooled features of the stored map).
+#define BN_POOL_MAX_WN 160
+template <typename AT, int NPOS, int QB, int RX3 = 0, int OX3 = 0, int POOL = 0>
 __device__ __forceinline__ void bn_fwd_fused_body(const AT* __restrict__ x, int ldx, const AT* __restrict__ res, int ldr,
                                                   AT* __restrict__ out, int ldo, int Wn, int C,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
                                                   float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                                  unsigned long long* __restrict__ mask, int ldstat, float* red) {
+                                                  unsigned long long* __restrict__ mask, int ldstat, float* red,
+                                                  float* __restrict__ pool_out = nullptr, int pool_L = 1, float* pool_s = nullptr) {
   // ldstat: pitch of mean_out / invstd_out ([W][ldstat], >= C: a dense block keeps ONE table for its whole buffer);
   // out == nullptr: statistics only (da_bn_stats_fused)
   constexpr int NQ = 1 << QB, CGB = 4 * NQ;            // channel quads / channels per block (32 or 16)
@@ -494,7 +502,7 @@ __device__ __forceinline__ void bn_fwd_fused_body(const AT* __restrict__ x, int 
     *reinterpret_cast<f32x4*>(mean_out + (size_t)w * ldstat + c0) = mu;
     *reinterpret_cast<f32x4*>(invstd_out + (size_t)w * ldstat + c0) = is;
   }
-  if (!out) return;                                  // (block-uniform)
+  if (!POOL && !out) return;                         // (block-uniform)
   const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
   const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c0);
   unsigned long long bits = 0ull;
@@ -519,8 +527,20 @@ __device__ __forceinline__ void bn_fwd_fused_body(const AT* __restrict__ x, int 
           o[e] = fmaxf(o[e], 0.f);
         }
       }
-      if constexpr (OX3) X3::st4(reinterpret_cast<__bf16*>(out) + (base + p) * (size_t)(3 * C), c0, o);
+      if constexpr (POOL) *reinterpret_cast<f32x4*>(&pool_s[p * CGB + q * 4]) = act_round4<AT>(o);
+      else if constexpr (OX3) X3::st4(reinterpret_cast<__bf16*>(out) + (base + p) * (size_t)(3 * C), c0, o);
       else Act<AT>::st4(ob + (uint32_t)(p * ldo + q * 4), o);
+    }
+  }
+  if constexpr (POOL) {
+    __syncthreads();
+    const int R = Wn / pool_L;
+    const float inv_l = 1.0f / (float)pool_L;
+    for (int i = threadIdx.x; i < R * CGB; i += blockDim.x) {
+      const int r = i / CGB, c = i - r * CGB;
+      float acc = 0.f;
+      for (int l = 0; l < pool_L; ++l) acc += pool_s[(r * pool_L + l) * CGB + c];
+      pool_out[((size_t)w * R + r) * C + cg * CGB + c] = acc * inv_l;
     }
   }
   // ReLU decisions of this thread's 4 x NPOS elements: the backward kernel (same geometry, same thread -> element map)
@@ -540,6 +560,19 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const AT* __restrict
   __shared__ float red[16 * CG];
   bn_fwd_fused_body<AT, NPOS, QB, RX3, OX3>(x, ldx, res, ldr, out, ldo, Wn, C, gamma, beta, relu, eps, mean_out, invstd_out, mask,
                                             ldstat, red);
+}
+
+template <typename AT, int NPOS, int QB>
+__global__ __launch_bounds__(1024) void bn_fwd_pool_kernel(const AT* __restrict__ x, int ldx, const AT* __restrict__ res,
+                                                           int ldr, int Wn, int C, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                           unsigned long long* __restrict__ mask,
+                                                           float* __restrict__ pool_out, int pool_L) {
+  __shared__ float red[16 * CG];
+  __shared__ float pool_s[BN_POOL_MAX_WN * 32];
+  bn_fwd_fused_body<AT, NPOS, QB, 0, 0, 1>(x, ldx, res, ldr, (AT*)nullptr, 0, Wn, C, gamma, beta, 1, eps, mean_out, invstd_out,
+                                           mask, C, red, pool_out, pool_L, pool_s);
 }
 
 // Two BatchNorms of ONE geometry (W, Wn, C) in one launch, blockIdx.z = which: the two that follow a stride-2 block entry's
@@ -567,7 +600,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_pair_kernel(BnFwdOne<AT> a, BnFwd
 // same arithmetic as bn_bwd_reduce_kernel + bn_bwd_apply_kernel with the slab held in registers
 // DX3: dx (the gradient w.r.t. the BatchNorm input = the conv output: the data-gradient and weight-gradient convs' operand)
 // is stored in the x3 format; gout stays float (the convs accumulate the branch gradient into it).
-template <typename AT, int NPOS, int QB, int DX3 = 0, int EXT = 0>
+template <typename AT, int NPOS, int QB, int DX3 = 0, int EXT = 0, int DPOOL = 0>
 __device__ __forceinline__ void bn_bwd_fused_body(const AT* __restrict__ dout, int ldd, const AT* __restrict__ x, int ldx,
                                                   const AT* __restrict__ outp, int ldo, AT* __restrict__ dx, int lddx,
                                                   AT* __restrict__ gout, int ldg, int Wn, int C,
@@ -600,7 +633,10 @@ __device__ __forceinline__ void bn_bwd_fused_body(const AT* __restrict__ dout, i
     g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     xh[k] = mu;
     if (p < Wn) {
-      if (EXT && ext.half_dout) {
+      if constexpr (DPOOL) {
+        const float* df = reinterpret_cast<const float*>(dout) + ((size_t)w * (Wn / ext.pool_L)) * ldd + cg * CGB;
+        g[k] = *reinterpret_cast<const f32x4*>(df + (size_t)fdiv((uint32_t)p, ext.pool_div) * ldd + q * 4);
+      } else if (EXT && ext.half_dout) {
         g[k] = Act<AT>::ld4(db + (uint32_t)((p >> 1) * ldd + q * 4));
 #pragma unroll
         for (int e = 0; e < 4; ++e) g[k][e] *= 0.5f;
@@ -625,9 +661,16 @@ __device__ __forceinline__ void bn_bwd_fused_body(const AT* __restrict__ dout, i
   f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   const unsigned long long mbits =
       mask ? mask[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x] : 0ull;
+  const float pool_inv = DPOOL ? 1.0f / (float)ext.pool_L : 1.0f;
 #pragma unroll
   for (int k = 0; k < NPOS; ++k) {
     const int p = slot + k * P;
+    if constexpr (DPOOL) {         // (here, not behind the load: a VALU op on a fresh register serialises the loads)
+      f32x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = g[k][e] * pool_inv;
+      g[k] = act_round4<AT>(t);    // what head_bwd_kernel would have stored in the activation type
+    }
     if (EXT && mask_mode == 4) {   // before xh overwrites the raw value
       f32x4 h;
 #pragma unroll
@@ -712,6 +755,21 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const AT* __restrict
   __shared__ float red[16 * 2 * CG];
   bn_bwd_fused_body<AT, NPOS, QB, DX3, EXT>(dout, ldd, x, ldx, outp, ldo, dx, lddx, gout, ldg, Wn, C, mean, invstd, gamma, beta,
                                             mask_mode, ds1, ds2, add, ldadd, mask, ext, red);
+}
+
+// the backward of bn_fwd_pool_kernel: dout = the gradient of the pooled features [rows][ldd] (float), ReLU decisions from the mask
+template <typename AT, int NPOS, int QB>
+__global__ __launch_bounds__(1024) void bn_bwd_pool_kernel(const float* __restrict__ dflat, int ldd, const AT* __restrict__ x,
+                                                           int ldx, AT* __restrict__ dx, int lddx, AT* __restrict__ gout, int ldg,
+                                                           int Wn, int C, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ ds1,
+                                                           float* __restrict__ ds2, const unsigned long long* __restrict__ mask,
+                                                           BnBwdExt ext) {
+  __shared__ float red[16 * 2 * CG];
+  bn_bwd_fused_body<AT, NPOS, QB, 0, 0, 1>(reinterpret_cast<const AT*>(dflat), ldd, x, ldx, (const AT*)nullptr, 0, dx, lddx, gout,
+                                           ldg, Wn, C, mean, invstd, gamma, beta, 3, ds1, ds2, (const AT*)nullptr, 0, mask, ext,
+                                           red);
 }
 
 // ... and their backward: the block-output BatchNorm (bn2) and the downsample's BatchNorm take the SAME masked gradient
@@ -1160,6 +1218,64 @@ int da_bn_bwd(const void* dout, int ldd, const void* x, int ldx, const void* out
                      scratch, ds, dgamma, dbeta, accumulate, nullptr, 0, nullptr, stream);
 }
 
+// The block-output BatchNorm of the LAST residual block with the head's global average pool folded in (resnet.py:33-38 into
+// :112,159-160 AvgPool1d(7) + view): da_bn_fwd_mask(relu) whose output is not stored -- flat[W * Wn / L][C] (float) receives the
+// average over the L positions of every row, bit for bit what da_head_fwd pools from the stored map; and its backward,
+// da_bn_bwd_mask with dout = dflat[rows][ldd] (float), the gradient of those pooled features.  Single-pass geometry, L | Wn,
+// Wn <= 160 (da_bn_pool_ok); mask: da_bn_mask_words() words.
+int da_bn_pool_ok(int W, int Wn, int C, int L) {
+  int cgb = 0;
+  return L >= 1 && Wn % L == 0 && Wn <= BN_POOL_MAX_WN && C % CG == 0 && bn_fused_geometry(W, Wn, C, &cgb) != 0;
+}
+
+int da_bn_fwd_pool(const void* x, int ldx, const void* res, int ldr, float* flat, int W, int Wn, int C, int L, float* mean,
+                   float* invstd, const float* gamma, const float* beta, float eps, unsigned long long* mask,
+                   hipStream_t stream) {
+  DA_ENTER();
+  if (!x || !flat || !mean || !invstd || !gamma || !beta || !mask || ldx % 4 || (res && ldr % 4)) return DA_EINVAL;
+  if (!da_bn_pool_ok(W, Wn, C, L)) return DA_EINVAL;
+  if (W == 0) return DA_OK;
+  int cgb = 0;
+  const int threads = bn_fused_geometry(W, Wn, C, &cgb);
+#define BN_FWDP_LAUNCH(QB, CH)                                                                                            \
+  DA_ACT_DISPATCH(hipLaunchKernelGGL((bn_fwd_pool_kernel<AT, FUSED_NPOS, QB>), dim3(W, C / CH), dim3(threads), 0, stream,    \
+                                     (const AT*)x, ldx, (const AT*)res, ldr, Wn, C, gamma, beta, eps, mean, invstd, mask, flat, L))
+  if (cgb == 32) BN_FWDP_LAUNCH(3, 32);
+  else if (cgb == 16) BN_FWDP_LAUNCH(2, 16);
+  else BN_FWDP_LAUNCH(1, 8);
+#undef BN_FWDP_LAUNCH
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+int da_bn_bwd_pool(const float* dflat, int ldd, const void* x, int ldx, void* dx, int lddx, void* gout, int ldg, int W, int Wn,
+                   int C, int L, const float* mean, const float* invstd, const float* gamma, const float* beta, float* ds,
+                   const unsigned long long* mask, hipStream_t stream) {
+  DA_ENTER();
+  if (!dflat || !x || !dx || !mean || !invstd || !gamma || !beta || !ds || !mask || ldd % 4 || ldx % 4 || lddx % 4 ||
+      (gout && ldg % 4))
+    return DA_EINVAL;
+  if (!da_bn_pool_ok(W, Wn, C, L)) return DA_EINVAL;
+  if (W == 0) return DA_OK;
+  int cgb = 0;
+  const int threads = bn_fused_geometry(W, Wn, C, &cgb);
+  BnBwdExt ext = {};
+  ext.pool_L = L;
+  ext.pool_div = make_fastdiv((uint32_t)L);
+  float* s1 = ds;
+  float* s2 = ds + (size_t)W * C;
+#define BN_BWDP_LAUNCH(QB, CH)                                                                                            \
+  DA_ACT_DISPATCH(hipLaunchKernelGGL((bn_bwd_pool_kernel<AT, FUSED_NPOS, QB>), dim3(W, C / CH), dim3(threads), 0, stream,    \
+                                     dflat, ldd, (const AT*)x, ldx, (AT*)dx, lddx, (AT*)gout, ldg, Wn, C, mean, invstd, gamma,   \
+                                     beta, s1, s2, mask, ext))
+  if (cgb == 32) BN_BWDP_LAUNCH(3, 32);
+  else if (cgb == 16) BN_BWDP_LAUNCH(2, 16);
+  else BN_BWDP_LAUNCH(1, 8);
+#undef BN_BWDP_LAUNCH
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
 // 64-bit words a ReLU mask of da_bn_fwd_mask / da_bn_bwd_mask has for this shape (one per thread of the single-pass
 // kernel); 0: the shape takes the two-stage kernels, no mask form.
 size_t da_bn_mask_words(int W, int Wn, int C) {
@@ -1316,7 +1432,7 @@ int da_bn_bwd_ss(const void* dout, int ldd, const void* x, int ldx, const void* 
   int cgb = 0;
   const int threads = bn_fused_geometry(W, Wn, C, &cgb);
   if (!threads) return DA_EINVAL;
-  BnBwdExt ext;
+  BnBwdExt ext = {};
   ext.ldstat = ldstat; ext.half_dout = half_dout ? 1 : 0; ext.drop_c0 = C - drop_g; ext.drop_g = drop_g;
   ext.seed = drop_seed; ext.salt = drop_salt; ext.p = drop_p; ext.hout = hout; ext.ldh = ldh;
   float* s1 = ds;

@@ -98,6 +98,13 @@ struct X3 {
   }
 };
 
+// a value as the activation storage type would hold it (float: itself; bf16: rounded to nearest even and widened back)
+template <typename AT>
+__device__ __forceinline__ f32x4 act_round4(const f32x4& v) {
+  if constexpr (sizeof(AT) == 4) return v;
+  else return X3::widen4(X3::cvt4(v));
+}
+
 // The default stem (conv k7 s2 p3 on ONE input channel: reference models/resnet.py:86-87, densenet.py:118-119) costs 7 FMAs per
 // output and its output is 36.7 MB at B = 64 -- the "recomputing stem" kernels never store it: they take the raw rows and the
 // 64 x 7 weights and recompute an output wherever one is needed.  This is stem_conv_fwd_kernel's value BIT FOR BIT: the same

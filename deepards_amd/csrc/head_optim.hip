@@ -947,6 +947,49 @@ int da_head_bwd(const float* part, const float* bias, const float* target, const
   return DA_OK;
 }
 
+// The same two calls on features that are pooled already (da_bn_fwd_pool wrote them): flat_in [B * R][F] float takes the place
+// of the map (a "map" of ONE position: the pool is the identity, bit for bit), dflat [B * R][F] float that of dx -- whatever
+// the activation storage type.
+int da_head_flat_fwd(const float* flat_in, const float* W, const float* bias, const float* target, float* flat, float* part,
+                     float* logits, float* loss, int B, int R, int F, int finish, hipStream_t stream) {
+  DA_ENTER();
+  if (!flat_in || !W || !bias || !target || !flat || !part || F % 4 || R < 1 || (finish && (!logits || !loss))) return DA_EINVAL;
+  if (B == 0) return DA_OK;
+  const int G = da_head_groups(R, F);
+  hipLaunchKernelGGL(head_pool_dot_kernel<float>, dim3(B, G), dim3(256), 0, stream, flat_in, F, W, flat, part, R, G, 1, F);
+  DA_CHECK_LAUNCH();
+  if (finish) {
+    hipLaunchKernelGGL(head_finish_kernel, dim3(1), dim3(256), 0, stream, part, bias, target, logits, loss, B, G,
+                       1.0f / (2.0f * (float)B));
+    DA_CHECK_LAUNCH();
+  }
+  return DA_OK;
+}
+
+int da_head_flat_bwd(const float* part, const float* bias, const float* target, const float* flat, const float* W, float* dflat,
+                     float* logits, float* dlogits, float* terms, float* dW, float* dbias, float* loss, int B, int R, int F,
+                     float gscale, int accumulate, hipStream_t stream) {
+  DA_ENTER();
+  if (!part || !bias || !target || !flat || !W || !dflat || !logits || !dlogits || !terms || !dW || !dbias || !loss || F % 4 ||
+      R < 1)
+    return DA_EINVAL;
+  if (B == 0) return DA_OK;
+  const int K = R * F, G = da_head_groups(R, F);
+  const float inv_n = 1.0f / (2.0f * (float)B);
+  const int wblocks = (K / 4 + 15) / 16;
+  const bool one = B <= HEAD_MAXB;
+  const int wrows = one ? (wblocks + B - 1) / B : 0;
+  hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(B, G + wrows), dim3(256), 0, stream, part, bias, target, W, dflat, F, logits,
+                     dlogits, terms, R, G, 1, F, inv_n, gscale, flat, dW, dbias, loss, accumulate, one ? wblocks : 0);
+  DA_CHECK_LAUNCH();
+  if (!one) {
+    hipLaunchKernelGGL(linear2_bwd_weight_kernel, dim3(wblocks), dim3(256), 0, stream, dlogits, flat, dW, dbias, B, K, accumulate,
+                       terms, inv_n, loss);
+    DA_CHECK_LAUNCH();
+  }
+  return DA_OK;
+}
+
 int da_clamp_sgd_nesterov(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float weight_decay,
                           float clip, float gscale, int first, hipStream_t stream) {
   DA_ENTER();

@@ -543,7 +543,10 @@ class BasicBlockFunction(Function):
     shape has the store forms.  Returns ``out`` or ``(handle, out3)``."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, R, st1, st2, std, x3=None, want_out3=False):
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, R, st1, st2, std, x3=None, want_out3=False, pool_out=False):
+        # pool_out (the LAST block in front of a head that pools its map, CNNLinearNetwork.forward_loss): the block's output
+        # is never stored -- bn2 + residual + ReLU hand over the pooled features (rows, C) float (H.bn_fwd_pool), and the
+        # backward takes their gradient (H.bn_bwd_pool): two 18 MB passes and the pooling launch less at B = 64
         in3 = x3 is not None
         bf16_pair = wd is not None and stride == 2 and x.shape[1] % 2 == 0 and \
             _is_wino(w1, stride, 1) == 16 and _is_wino(wd, stride, 0) == 16
@@ -612,11 +615,20 @@ class BasicBlockFunction(Function):
         else:
             yd = md = idd = None
             res = x3 if in3 else x
-        if mid3:          # x3 residual and / or x3 output: the store forms (always with the ReLU bit mask)
+        ctx.pool_out = bool(pool_out)
+        if pool_out:
+            if mid3 or want_out3 or wd is not None or not H.bn_pool_ok(y2, R):
+                raise ValueError('pool_out: an identity block on a map with the pooled BatchNorm form (pool_out_ok)')
+            out, s2.mean, s2.invstd, s2.mask = H.bn_fwd_pool(y2, R, g2, b2, res=res, eps=st2.eps)
+            _running(y2, R, s2, st2)
+            if DECISION_TAP is not None:
+                _tap(H.bn_fwd(y2, R, g2, b2, relu=True, res=res, eps=st2.eps)[0])
+        elif mid3:        # x3 residual and / or x3 output: the store forms (always with the ReLU bit mask)
             out = _bn_apply_x(y2, R, s2, st2, g2, b2, True, res=res, want_mask=True, out_x3=want_out3)
+            _tap(out)
         else:
             out = _bn_apply(y2, R, s2, st2, g2, b2, True, res=res, want_mask=True)
-        _tap(out)
+            _tap(out)
         m1, i1, m2, i2 = s1.mean, s1.invstd, s2.mean, s2.invstd
         ctx.relu_mask = s2.mask     # 8 bytes per thread instead of re-reading `out` for its sign (None: two-stage geometry)
         ctx.has_ds, ctx.in3, ctx.mid3, ctx.s2x = wd is not None, in3, mid3, s2x
@@ -649,6 +661,9 @@ class BasicBlockFunction(Function):
             dg2, db2 = _bn_pgrad(ds2, g2, b2, tg2, tb2)
             dgd, dbd = _bn_pgrad(dsd, gd, bd, tgd, tbd)
             g = None
+        elif ctx.pool_out:  # dout = the gradient of the pooled features (rows, C)
+            dy2, g, ds2 = H.bn_bwd_pool(dout, y2, R, m2, i2, g2, b2, ctx.relu_mask, want_g=True)
+            dg2, db2 = _bn_pgrad(ds2, g2, b2, tg2, tb2)
         elif mid3:        # dy2 feeds the k3 s1 data-gradient and weight-gradient convs: stored pre-split
             dy2, dg2, db2, g = _bn_bwd_x(dout, y2, R, m2, i2, g2, b2, 3, tg2, tb2, want_g=True, mask=ctx.relu_mask)
         else:
@@ -686,7 +701,7 @@ class BasicBlockFunction(Function):
         else:
             dwd = dgd = dbd = None
             dx = _conv_dgrad(dy1, w1, stride, 1, lin, out=g, accumulate=True)   # identity grad + conv path
-        return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None, None
+        return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None, None, None
 
 
 _STEM_TAIL = True         # inside a training step the stem's last weight-gradient fold rides on the tail launch
@@ -1031,11 +1046,17 @@ class HeadLossFunction(Function):
     @staticmethod
     def forward(ctx, xmap, w, bias, target, R, grad_mode):
         # (grad mode is always off in here and needs_input_grad ignores no_grad: the caller passes torch.is_grad_enabled())
+        # xmap (B * R, F) float: features the last block pooled already (BasicBlockFunction pool_out) -- the same two launches
+        # on a "map" of one position, their gradient (B * R, F) float
         need_grad = grad_mode and any(ctx.needs_input_grad[:3])
         target = target.contiguous()
-        flat, part, logits, loss = H.head_fwd(xmap.contiguous(), w, bias, target, R, finish=not need_grad)
+        ctx.pooled = xmap.dim() == 2
+        if ctx.pooled:
+            flat, part, logits, loss = H.head_flat_fwd(xmap.contiguous(), w, bias, target, R, finish=not need_grad)
+        else:
+            flat, part, logits, loss = H.head_fwd(xmap.contiguous(), w, bias, target, R, finish=not need_grad)
         ctx.save_for_backward(flat, part, w, bias, target, logits, loss)
-        ctx.R, ctx.l = R, xmap.shape[1]
+        ctx.R, ctx.l = R, 1 if ctx.pooled else xmap.shape[1]
         ctx.gt = _tgt(w, bias)
         ctx.mark_non_differentiable(logits)
         ctx.set_materialize_grads(False)               # (or autograd fills a zero d(logits) every step: one more launch)
@@ -1046,8 +1067,12 @@ class HeadLossFunction(Function):
         flat, part, w, bias, target, logits, loss = ctx.saved_tensors
         tw, tb = ctx.gt
         direct = tw is not None and tb is not None
-        dx, dw, db = H.head_bwd(part, bias, target, flat, w, logits, loss, ctx.R, ctx.l, dw=tw if direct else None,
-                                dbias=tb if direct else None, accumulate=direct and _acc())
+        if ctx.pooled:
+            dx, dw, db = H.head_flat_bwd(part, bias, target, flat, w, logits, loss, ctx.R, dw=tw if direct else None,
+                                         dbias=tb if direct else None, accumulate=direct and _acc())
+        else:
+            dx, dw, db = H.head_bwd(part, bias, target, flat, w, logits, loss, ctx.R, ctx.l, dw=tw if direct else None,
+                                    dbias=tb if direct else None, accumulate=direct and _acc())
         return dx, None if direct else dw, None if direct else db, None, None, None
 
 

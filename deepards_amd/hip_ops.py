@@ -1014,6 +1014,49 @@ def bn_bwd(dout, x, R, mean, invstd, gamma, beta, mask_mode, out=None, want_g=Fa
     return dx, dgamma, dbeta, g, ds
 
 
+def bn_pool_ok(x, R):
+    """Whether bn_fwd_pool / bn_bwd_pool take this (rows, L, C) map with windows of R rows."""
+    rows, l, c = x.shape
+    return rows % R == 0 and rows > 0 and bool(_lib.lib().da_bn_pool_ok(rows // R, R * l, c, l))
+
+
+def bn_fwd_pool(x, R, gamma, beta, res=None, eps=1e-5):
+    """relu(bn(x) (+res)) WITHOUT storing it: -> flat (rows, C) float, the average over the L positions of every row (what
+    head_fwd / global_avgpool_fwd pool from the stored map, bit for bit), mean, invstd (W, C), mask (the ReLU decisions for
+    bn_bwd_pool).  The block-output BatchNorm of the last residual block in front of the head."""
+    _rlc(x, 'x')
+    rows, l, c = x.shape
+    if not bn_pool_ok(x, R):
+        raise ValueError('bn_fwd_pool: shape %s / R %d has no pooled form' % (tuple(x.shape), R))
+    if res is not None and tuple(res.shape) != tuple(x.shape):
+        raise ValueError('residual shape mismatch')
+    w = rows // R
+    mk = lambda *sh: torch.empty(sh, device=x.device, dtype=torch.float32)
+    flat, mean, invstd = mk(rows, c), mk(w, c), mk(w, c)
+    mask = torch.empty((_lib.lib().da_bn_mask_words(w, R * l, c),), device=x.device, dtype=torch.int64)
+    _chk(_lib.lib().da_bn_fwd_pool(_p(x), c, _p(res), c, _p(flat), w, R * l, c, l, _p(mean), _p(invstd), _p(_f32(gamma)),
+                                   _p(_f32(beta)), eps, _p(mask), _stream()), 'da_bn_fwd_pool')
+    return flat, mean, invstd, mask
+
+
+def bn_bwd_pool(dflat, x, R, mean, invstd, gamma, beta, mask, want_g=False, dx=None):
+    """The backward of bn_fwd_pool: dflat (rows, C) float = the gradient of the pooled features -> dx, g (the masked upstream
+    gradient, activation storage type; only with want_g), ds (2, W, C)."""
+    _rlc(x, 'x')
+    _f32(dflat, 'dflat')
+    rows, l, c = x.shape
+    if tuple(dflat.shape) != (rows, c) or not bn_pool_ok(x, R):
+        raise ValueError('bn_bwd_pool: shapes dflat%s x%s' % (tuple(dflat.shape), tuple(x.shape)))
+    w = rows // R
+    if dx is None:
+        dx = torch.empty_like(x)
+    g = torch.empty_like(x) if want_g else None
+    ds = torch.empty((2, w, c), device=x.device, dtype=torch.float32)
+    _chk(_lib.lib().da_bn_bwd_pool(_p(dflat), c, _p(x), c, _p(dx), c, _p(g), c, w, R * l, c, l, _p(mean), _p(invstd),
+                                   _p(_f32(gamma)), _p(_f32(beta)), _p(ds), _p(mask), _stream()), 'da_bn_bwd_pool')
+    return dx, g, ds
+
+
 def bn_param_grad_multi(items, accumulate=True):
     """items: (ds (2,W,C), dgamma (C,), dbeta (C,)) -- one launch per 32 BatchNorms."""
     if not items:
@@ -1374,6 +1417,38 @@ def head_bwd(part, bias, target, flat, w, logits, loss, R, l, dw=None, dbias=Non
                                 _p(terms), _p(dw), _p(dbias), _p(loss), b, R, l, f, gscale, 1 if accumulate else 0, _stream()),
          'da_head_bwd')
     return dx, dw, dbias
+
+
+def head_flat_fwd(feat, w, bias, target, R, finish=False):
+    """head_fwd on features that are pooled already (bn_fwd_pool): feat (B * R, F) float -> flat, part, logits, loss."""
+    _f32(feat, 'feat')
+    rows, f = feat.shape
+    b = rows // R
+    if rows % R or tuple(w.shape) != (2, R * f) or tuple(target.shape) != (b, 2):
+        raise ValueError('head_flat_fwd: shapes feat%s w%s target%s' % (tuple(feat.shape), tuple(w.shape), tuple(target.shape)))
+    mk = lambda *shape: torch.empty(shape, device=feat.device, dtype=torch.float32)
+    L = _lib.lib()
+    flat, part, logits, loss = mk(b, R * f), mk(b, L.da_head_groups(R, f), 2), mk(b, 2), mk(1)
+    _chk(L.da_head_flat_fwd(_p(feat), _p(_f32(w)), _p(_f32(bias)), _p(_f32(target)), _p(flat), _p(part), _p(logits), _p(loss), b, R,
+                            f, 1 if finish else 0, _stream()), 'da_head_flat_fwd')
+    return flat, part, logits, loss
+
+
+def head_flat_bwd(part, bias, target, flat, w, logits, loss, R, dw=None, dbias=None, accumulate=False, gscale=1.0):
+    """head_bwd for head_flat_fwd: -> dfeat (B * R, F) float (the gradient of the pooled features), dw, dbias."""
+    b, k = flat.shape
+    f = k // R
+    dfeat = torch.empty((b * R, f), device=flat.device, dtype=torch.float32)
+    dlogits = torch.empty((b, 2), device=flat.device, dtype=torch.float32)
+    terms = torch.empty((b,), device=flat.device, dtype=torch.float32)
+    if dw is None:
+        if accumulate:
+            raise ValueError('accumulate needs dw / dbias')
+        dw, dbias = torch.empty_like(w), torch.empty((2,), device=w.device, dtype=torch.float32)
+    _chk(_lib.lib().da_head_flat_bwd(_p(part), _p(_f32(bias)), _p(_f32(target)), _p(flat), _p(_f32(w)), _p(dfeat), _p(logits),
+                                     _p(dlogits), _p(terms), _p(dw), _p(dbias), _p(loss), b, R, f, gscale, 1 if accumulate else 0,
+                                     _stream()), 'da_head_flat_bwd')
+    return dfeat, dw, dbias
 
 
 def bce_logits(logits, target, want_grad=True, gscale=1.0):

@@ -9,6 +9,8 @@ containers here: ``forward`` runs the hand-written HIP kernels through
 """
 import math
 
+import os
+
 import torch.nn as nn
 
 from .. import functional as F_
@@ -49,14 +51,14 @@ class BasicBlock(nn.Module):
             self.add_module(name, mod)
         self.downsample, self.stride = downsample, stride
 
-    def forward_rlc(self, x, R, x3=None, want_out3=False):
+    def forward_rlc(self, x, R, x3=None, want_out3=False, pool_out=False):
         """x: (rows, L, C) channels-last; R rows per BatchNorm window.  Conv arithmetic 'f32x3p': ``x3`` = the input in the
         x3 format (``x`` is then the autograd handle) and ``want_out3`` asks for ``(handle, out3)`` (functional: the x3 flow)."""
         ds = self.downsample
         dsw = (None, None, None, None) if ds is None else (ds[0].weight, ds[1].weight, ds[1].bias, F_.BNState(ds[1]))
         return F_.BasicBlockFunction.apply(
             x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias,
-            dsw[0], dsw[1], dsw[2], self.stride, R, F_.BNState(self.bn1), F_.BNState(self.bn2), dsw[3], x3, want_out3)
+            dsw[0], dsw[1], dsw[2], self.stride, R, F_.BNState(self.bn1), F_.BNState(self.bn2), dsw[3], x3, want_out3, pool_out)
 
     def takes_x3(self, rows, l_in, R):
         """Whether this block's conv1 reads the x3 format under the current conv arithmetic: a k3 s1 conv (no downsample)
@@ -69,12 +71,15 @@ class BasicBlock(nn.Module):
 
 
 _POOLS = {'max': nn.MaxPool1d, 'avg': nn.AvgPool1d}
+_FUSED_TAIL = os.environ.get('DA_FUSED_TAIL', '1') != '0'   # the last block's BatchNorm pools for the head (0: its map is stored and the head pools it)
 
 
 class ResNet(nn.Module):
     """Four stages of BasicBlocks behind a k7 s2 stem.  The module tree (names, order, shapes -- including the stem's
     unused conv1_alt / conv2 / bn2, SURVEY finding 6) is the reference's (resnet.py:81-135): 129 state_dict keys for
     cnn_linear + resnet18."""
+
+    fused_tail = True     # forward_windows(pooled='fused')
 
     def __init__(self, block, layers, initial_planes=64, first_pool_type='max', double_conv_first=False):
         super(ResNet, self).__init__()
@@ -109,7 +114,8 @@ class ResNet(nn.Module):
     def forward_windows(self, x, rows_per_window, pooled=True):
         """x: (rows, 1, L) with rows = windows * rows_per_window; BatchNorm statistics are taken per
         window, exactly as when the reference feeds one (NB, 1, L) window at a time.  pooled=False: the last map
-        (rows, 7, C) itself, for a head that pools it in its own kernel (CNNLinearNetwork.forward_loss)."""
+        (rows, 7, C) itself, for a head that pools it in its own kernel; pooled='fused' (CNNLinearNetwork.forward_loss):
+        that map, or -- where the last block can pool it itself -- the pooled features (rows, C) without the map."""
         _require_cuda(x, 'ResNet')
         if x.dim() != 3 or x.shape[1] != 1:
             raise ValueError('expected (rows, 1, L) input, got %s' % (tuple(x.shape),))
@@ -134,11 +140,19 @@ class ResNet(nn.Module):
             h = F_.StemFunction.apply(x2d, self.conv1.weight, self.bn1.weight, self.bn1.bias, rows_per_window, pool,
                                       F_.BNState(self.bn1), takes3[0])
         for i, blk in enumerate(blocks):
+            # pooled='fused' (CNNLinearNetwork.forward_loss): the last block hands over its POOLED output (rows, C) -- its map
+            # is never stored (BasicBlockFunction pool_out) -- when it is an identity block on the 7-position map
+            pool_out = pooled == 'fused' and _FUSED_TAIL and i == len(blocks) - 1 and not takes3[i] and \
+                blk.downsample is None and blk.stride == 1 and lens[i] == 7 and F_.H.bn_pool_ok(h, rows_per_window)
             if takes3[i]:
                 h, h3 = h
                 h = blk.forward_rlc(h, rows_per_window, h3, takes3[i + 1])
             else:
-                h = blk.forward_rlc(h, rows_per_window, None, takes3[i + 1])
+                h = blk.forward_rlc(h, rows_per_window, None, takes3[i + 1], pool_out)
+        if pooled == 'fused':
+            if h.dim() == 3 and h.shape[1] != 7:
+                raise TypeError('the un-pooled map is only handed out at the 7-position length the fused head pools')
+            return h
         if h.shape[1] < 7:
             raise ValueError('AvgPool1d(7, stride=1) needs a final length >= 7 (seq_len >= 224); got %d' % h.shape[1])
         if not pooled:

@@ -75,8 +75,9 @@ class CNNLinearNetwork(_WindowHead):
             raise IndexError('index 0 is out of bounds for dimension 0 with size 0')
         self._no_metadata(self.metadata_features)
         b, nb, c, l = x.shape
-        try:
-            hmap = self.breath_block.forward_windows(x.reshape(b * nb, c, l), nb, pooled=False)
+        try:       # ('fused': a backbone whose last block can pool for the head hands over (rows, F) features instead of the map)
+            hmap = self.breath_block.forward_windows(x.reshape(b * nb, c, l), nb,
+                                                     pooled='fused' if getattr(self.breath_block, 'fused_tail', False) else False)
         except TypeError:
             return None
         return F_.head_loss(hmap, self.linear_final.weight, self.linear_final.bias, target, nb)

@@ -256,6 +256,17 @@ int da_bn_bwd_mask(const da_act_t* dout, int ldd, const da_act_t* x, int ldx, da
                    int Wn, int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
                    float* scratch, float* ds, float* dgamma, float* dbeta, int accumulate,
                    const unsigned long long* mask, da_stream_t stream);
+/* The block-output BatchNorm of the LAST BasicBlock with the head's AvgPool1d(L) folded in (resnet.py:33-38 into
+   :112,159-160): da_bn_fwd_mask(relu) whose output map is never stored -- flat[W * Wn / L][C] (always float) receives the
+   average over the L positions of every row, bit for bit what da_head_fwd pools from the stored map -- and its backward,
+   da_bn_bwd_mask whose dout is dflat[rows][ldd] (float), the gradient of those pooled features.  da_bn_pool_ok: single-pass
+   geometry, L | Wn, Wn <= 160. */
+int da_bn_pool_ok(int W, int Wn, int C, int L);
+int da_bn_fwd_pool(const da_act_t* x, int ldx, const da_act_t* res, int ldr, float* flat, int W, int Wn, int C, int L, float* mean,
+                   float* invstd, const float* gamma, const float* beta, float eps, unsigned long long* mask, da_stream_t stream);
+int da_bn_bwd_pool(const float* dflat, int ldd, const da_act_t* x, int ldx, da_act_t* dx, int lddx, da_act_t* gout, int ldg, int W,
+                   int Wn, int C, int L, const float* mean, const float* invstd, const float* gamma, const float* beta, float* ds,
+                   const unsigned long long* mask, da_stream_t stream);
 /* da_bn_bwd with dx = input gradient + add[pos][0:C] (pitch ldadd): a concatenation's pass-through gradient
    (densenet.py:41) joins in the same pass */
 int da_bn_bwd_add(const da_act_t* dout, int ldd, const da_act_t* x, int ldx, const da_act_t* out, int ldo, da_act_t* dx, int lddx,
@@ -412,6 +423,13 @@ int da_head_fwd(const da_act_t* x, int ldx, const float* W, const float* bias, c
 int da_head_bwd(const float* part, const float* bias, const float* target, const float* flat, const float* W, da_act_t* dx,
                 int lddx, float* logits, float* dlogits, float* terms, float* dW, float* dbias, float* loss, int B, int R, int L,
                 int F, float gscale, int accumulate, da_stream_t stream);
+/* the same two calls on features da_bn_fwd_pool pooled already: flat_in [B * R][F] (float) in the place of the map (a map of
+   ONE position), dflat [B * R][F] (float) in the place of dx -- whatever the activation storage type */
+int da_head_flat_fwd(const float* flat_in, const float* W, const float* bias, const float* target, float* flat, float* part,
+                     float* logits, float* loss, int B, int R, int F, int finish, da_stream_t stream);
+int da_head_flat_bwd(const float* part, const float* bias, const float* target, const float* flat, const float* W, float* dflat,
+                     float* logits, float* dlogits, float* terms, float* dW, float* dbias, float* loss, int B, int R, int F,
+                     float gscale, int accumulate, da_stream_t stream);
 
 
 /* ---- optimiser: clamp hook + SGD(momentum .9, nesterov, weight decay) / Adam, fused ----------

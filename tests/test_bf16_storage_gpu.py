@@ -70,6 +70,46 @@ def rnd(shape, seed, scale=1.0):
     return bf(torch.randn(shape, generator=g) * scale).cuda()
 
 
+@pytest.mark.parametrize('store', ['f32', 'bf16'])
+@pytest.mark.parametrize('C,L,R,W', [(512, 7, 20, 5), (512, 7, 20, 64), (128, 7, 20, 3), (64, 7, 8, 2), (32, 5, 20, 2)])
+def test_batchnorm_with_the_heads_pool_folded_in(H, store, C, L, R, W):
+    """bn_fwd_pool / bn_bwd_pool (the last block's bn2 + residual + ReLU whose map is never stored; its backward from the
+    gradient of the pooled features) == bn_fwd(mask) -> head_fwd's pooling and head_bwd's broadcast -> bn_bwd(mask), bit for
+    bit, in both activation storage types; head_flat_fwd / head_flat_bwd == head_fwd / head_bwd on the stored map."""
+    with storage(H, store):
+        dt = torch.bfloat16 if store == 'bf16' else torch.float32
+        rows = W * R
+        x, res = rnd((rows, L, C), 1).to(dt), rnd((rows, L, C), 2).to(dt)
+        g = torch.Generator().manual_seed(3)
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+        w, bias = (torch.randn(2, R * C, generator=g) * 0.02).cuda(), torch.randn(2, generator=g).cuda()
+        target = torch.zeros(W, 2).cuda()
+        target[::2, 0] = 1
+        target[1::2, 1] = 1
+        assert H.bn_pool_ok(x, R)
+        # the stored-map chain
+        out, mean, invstd, mask = H.bn_fwd(x, R, gamma, beta, relu=True, res=res, want_mask=True)
+        flat, part, logits, loss = H.head_fwd(out, w, bias, target, R, finish=False)
+        dw, db = torch.zeros_like(w), torch.zeros(2).cuda()
+        dx, _, _ = H.head_bwd(part, bias, target, flat, w, logits, loss, R, L, dw=dw, dbias=db, accumulate=True)
+        dy, _, _, gq, ds = H.bn_bwd(dx, x, R, mean, invstd, gamma, beta, 2, want_g=True, defer_param_grads=True, mask=mask)
+        # the pooled chain
+        feat, mean2, invstd2, mask2 = H.bn_fwd_pool(x, R, gamma, beta, res=res)
+        flat2, part2, logits2, loss2 = H.head_flat_fwd(feat, w, bias, target, R, finish=False)
+        dw2, db2 = torch.zeros_like(w), torch.zeros(2).cuda()
+        dfeat, _, _ = H.head_flat_bwd(part2, bias, target, flat2, w, logits2, loss2, R, dw=dw2, dbias=db2, accumulate=True)
+        dy2, gq2, ds2 = H.bn_bwd_pool(dfeat, x, R, mean2, invstd2, gamma, beta, mask2, want_g=True)
+        assert feat.dtype == torch.float32 and dfeat.dtype == torch.float32 and dy2.dtype == dt
+        for name, a, b in (('mean', mean, mean2), ('invstd', invstd, invstd2), ('mask', mask, mask2), ('flat', flat, flat2),
+                           ('feat', flat.view(rows, C), feat), ('part', part, part2), ('logits', logits, logits2),
+                           ('loss', loss, loss2), ('dw', dw, dw2), ('dbias', db, db2), ('dy', dy, dy2), ('g', gq, gq2), ('ds', ds, ds2)):
+            assert torch.equal(a, b), name
+        # forward only: logits and loss complete on return
+        _, _, lg3, ls3 = H.head_flat_fwd(feat, w, bias, target, R, finish=True)
+        assert torch.equal(lg3, logits) and torch.equal(ls3, loss)
+    assert not H.bn_pool_ok(torch.empty(40, 56, 64, device='cuda'), 20)        # a window too long for the pooled form
+
+
 @pytest.mark.parametrize('C,L,R,W', [(64, 56, 20, 4), (128, 28, 20, 3), (512, 7, 20, 5), (64, 128, 40, 2), (64, 112, 20, 2)])
 def test_batchnorm_kernels_bf16_storage(H, C, L, R, W):
     """bn_fwd (+ReLU, +residual, +mask) and bn_bwd (all mask modes) -- single-pass and two-stage geometries."""

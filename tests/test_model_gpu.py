@@ -888,6 +888,37 @@ def test_data_parallel_two_processes_epochs_from_store(tmp_path):
     assert np.isfinite(r0['losses']).all() and np.isfinite(r1['losses']).all()
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_last_block_pools_for_the_head(M, dtype, monkeypatch):
+    """resnet18's last block hands the head its POOLED output (BasicBlockFunction pool_out; the block's map is never stored):
+    losses, logits, parameters and momentum after 3 captured steps, and a forward-only step, are bit for bit those of the
+    stored-map form (models.resnet._FUSED_TAIL = False)."""
+    import deepards_amd.models.resnet as RN
+    import deepards_amd.functional as F_
+    from deepards_amd.train import HotPathTrainer
+    x = torch.randn(4, 20, 1, 224, device='cuda')
+    t = torch.zeros(4, 2, device='cuda')
+    t[:2, 0] = 1
+    t[2:, 1] = 1
+    F_.set_conv_dtype(dtype)
+    if dtype == 'bf16':
+        F_.set_storage_dtype('bf16')
+    try:
+        def run(fused):
+            monkeypatch.setattr(RN, '_FUSED_TAIL', fused)
+            tr = HotPathTrainer(build(M, 'resnet18', 5), use_graph=True)
+            losses = [tr.train_step(x, t).clone() for _ in range(3)]
+            tl, tlog, _ = tr.test_step(x, t)
+            out = losses + [tl.clone(), tlog.clone(), tr.bucket.p.clone(), tr.state['buf'].clone()]
+            tr.release_graphs()
+            return out
+        for n, (a, b) in enumerate(zip(run(True), run(False))):
+            assert torch.equal(a, b), n
+    finally:
+        F_.set_conv_dtype('f32')
+        F_.set_storage_dtype('f32')
+
+
 @pytest.mark.parametrize('backbone,drop', [('resnet18', 0.0), ('densenet18', 0.2)])
 def test_captured_step_without_the_gradient_zero_fill(M, backbone, drop, monkeypatch):
     """A captured step whose every gradient destination has ONE writer with an overwrite form runs without the zero-fill of
