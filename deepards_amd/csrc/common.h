@@ -489,8 +489,8 @@ static inline WgradPreTable wgrad_chain_take(WgradChain* c) {
 
 // conv_wino.hip
 bool wino_wgrad_eligible(const da_wgrad_job& j);
-void wino_wgrad_plan(int rows, int L, int* splits, int* pchunk);
-int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream, WgradChain* chain = nullptr);
+void wino_wgrad_plan(int rows, int L, int* splits, int* pchunk, int f = 1);
+int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream, WgradChain* chain = nullptr, int* factors = nullptr);
 void wino4_wgrad_plan(int rows, int L, int* splits, int* qchunk);               // winograd == 6: the F(4,3) form (quads)
 int wino4_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t stream, WgradChain* chain = nullptr);
 

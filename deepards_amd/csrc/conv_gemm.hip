@@ -1459,7 +1459,8 @@ static int conv_wgrad_multi_impl(const da_wgrad_job* jobs, int n, float* const* 
     chain = &chain_;
   }
   if ((rc = wino4_wgrad_launch(jobs, n, stream, chain))) return rc;  // the heaviest blocks first
-  if ((rc = wino_wgrad_launch(jobs, n, stream, chain))) return rc;
+  std::vector<int> wino_f(n > 0 ? n : 1, 1);
+  if ((rc = wino_wgrad_launch(jobs, n, stream, chain, splits_out ? wino_f.data() : nullptr))) return rc;
   if ((rc = bf16_wgrad_launch(jobs, n, 49, stream))) return rc;      // x3 operands (dy / x are x3 tensors; ld* = channel counts)
   if ((rc = bf16_wgrad_launch(jobs, n, 16, stream))) return rc;
   if ((rc = launch_wgrad_group<2, 2, 2, 2>(jobs, n, 128, 128, stream, chain))) return rc;
@@ -1477,7 +1478,7 @@ static int conv_wgrad_multi_impl(const da_wgrad_job* jobs, int n, float* const* 
       int sp = 0, kc = 0;
       if (j.winograd == 16 || j.winograd == 49) bf16_wgrad_plan(j.rows, j.Lm, &sp, &kc);
       else if (j.winograd == 6) wino4_wgrad_plan(j.rows, j.Lm, &sp, &kc);
-      else if (j.winograd) wino_wgrad_plan(j.rows, j.Lm, &sp, &kc);
+      else if (j.winograd) wino_wgrad_plan(j.rows, j.Lm, &sp, &kc, wino_f[i]);
       else sp = wgrad_plan(j.rows * j.Lm, j.N, j.C, j.ntaps, (j.xform || j.dy_half) ? tgt : 0).splits;
       splits_out[i] = sp;
     }

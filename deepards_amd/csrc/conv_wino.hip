@@ -976,10 +976,12 @@ bool wino_wgrad_eligible(const da_wgrad_job& j) {
 #endif
 static int g_ww_pchunk = WW_PCHUNK;
 
-// pairs per split: every block of every job carries the same work (16 K steps), slab traffic 48 KB per block
-void wino_wgrad_plan(int rows, int L, int* splits, int* pchunk) {
+// pairs per split: every block of every job carries the same work (20 K steps), slab traffic 48 KB per block.  f = 2: half the
+// pairs per split (the launcher's choice for the jobs of the launch's last, partly filled round -- see wino_wgrad_launch)
+void wino_wgrad_plan(int rows, int L, int* splits, int* pchunk, int f) {
   const int MP = rows * ((L + 1) / 2);
-  int sp = (MP + g_ww_pchunk - 1) / g_ww_pchunk;
+  const int base = g_ww_pchunk / (f > 1 ? f : 1) >= 32 ? g_ww_pchunk / (f > 1 ? f : 1) : 32;
+  int sp = (MP + base - 1) / base;
   if (sp < 1) sp = 1;
   int pc = ((MP + sp - 1) / sp + 31) / 32 * 32;
   if (pc < 32) pc = 32;
@@ -987,7 +989,12 @@ void wino_wgrad_plan(int rows, int L, int* splits, int* pchunk) {
   *pchunk = pc;
 }
 
-int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s, WgradChain* chain) {
+// factors != NULL (the caller can be told how many slabs a job wrote: da_conv_wgrad_multi_reduce): the jobs whose blocks make
+// up the launch's last, partly filled round of 1 024 slots (4 blocks a CU) run with HALF the pairs per split -- twice the
+// blocks of half the length there: at B = 64 the step's 1 232 blocks are 1 008 (layer 3, layer 2) + 224 (layer 1), and with
+// 448 half blocks behind the 1 008 the launch ends 13 us earlier (a quarter: 10 us; measured on the whole step).
+// factors[i] = the divisor job i ran with (1 or 2); the workspace of a job must hold twice da_conv_wgrad_plan's slabs.
+int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s, WgradChain* chain, int* factors) {
   WinoWgradTable t;
   int cnt = 0, blocks = 0;
   auto flush = [&]() -> int {
@@ -1001,11 +1008,28 @@ int wino_wgrad_launch(const da_wgrad_job* jobs, int n, hipStream_t s, WgradChain
     blocks = 0;
     return DA_OK;
   };
+  constexpr int SLOTS = 1024;
+  long total = 0;
+  int njobs = 0;
+  for (int i = 0; i < n; ++i) {
+    if (jobs[i].winograd != 1) continue;
+    int splits, pchunk;
+    wino_wgrad_plan(jobs[i].rows, jobs[i].Lm, &splits, &pchunk, 1);
+    total += (long)(jobs[i].N / 64) * (jobs[i].C / 64) * splits;
+    ++njobs;
+  }
+  // blocks in whole rounds (a launch of less than one round, or of more than one table, stays as planned)
+  const long full = factors && njobs <= 24 && total > SLOTS && total % SLOTS ? total / SLOTS * SLOTS : total;
+  long cum = 0;
   for (int i = 0; i < n; ++i) {
     const da_wgrad_job& j = jobs[i];
     if (j.winograd != 1) continue;
     int splits, pchunk;
-    wino_wgrad_plan(j.rows, j.Lm, &splits, &pchunk);
+    wino_wgrad_plan(j.rows, j.Lm, &splits, &pchunk, 1);
+    cum += (long)(j.N / 64) * (j.C / 64) * splits;
+    const int f = cum > full ? 2 : 1;
+    if (f > 1) wino_wgrad_plan(j.rows, j.Lm, &splits, &pchunk, f);
+    if (factors) factors[i] = f;
     WinoWgradArgs& a = t.d[cnt];
     a.dy = j.dy; a.x = j.x; a.slab = j.workspace;
     a.L = j.Lm; a.PL = (j.Lm + 1) / 2; a.MP = j.rows * a.PL;

@@ -571,7 +571,7 @@ def conv_wgrad_multi(jobs, dws=None, accumulate=True):
     L = _lib.lib()
     arr = (_lib.WgradJob * len(jobs))()
     plan = (ctypes.c_int * 4)()
-    outs = []
+    outs, caps = [], []
     for d, job in zip(arr, jobs):
         dy, x, k, stride, pad = job[:5]
         extra = job[5] if len(job) > 5 and job[5] else {}         # dense-block operand forms (da_wgrad_job.xform / dy_half)
@@ -613,7 +613,8 @@ def conv_wgrad_multi(jobs, dws=None, accumulate=True):
                 raise ValueError('conv_wgrad_multi: x3 operands need channel counts that are multiples of 64')
             wino = 49
         _chk(L.da_conv_wgrad_plan(rows, lo, co, ci, k, wino, plan), 'da_conv_wgrad_plan')
-        ws = torch.empty((plan[2] * k * co * ci,), device=x.device, dtype=torch.float32)
+        cap = plan[2] * (2 if dws is not None and wino == 1 else 1)      # (chained: a last-round job may write twice the slabs)
+        ws = torch.empty((cap * k * co * ci,), device=x.device, dtype=torch.float32)
         d.dy, d.x, d.workspace = dy.data_ptr(), x.data_ptr(), ws.data_ptr()
         d.rows, d.Lm, d.Ldy, d.lddy, d.N, d.Lx, d.ldx, d.C = rows, lo, ldy_len, lddy, co, l, ldx, ci
         d.dy_stride, d.dy_off, d.src_stride, d.ntaps = 1, 0, stride, k
@@ -621,7 +622,8 @@ def conv_wgrad_multi(jobs, dws=None, accumulate=True):
         if extra:
             wino = 0                                     # (the operand forms run on the direct kernels)
             _chk(L.da_conv_wgrad_plan(rows, lo, co, ci, k, 0, plan), 'da_conv_wgrad_plan')
-            ws = torch.empty((plan[2] * k * co * ci,), device=x.device, dtype=torch.float32)
+            cap = plan[2]
+            ws = torch.empty((cap * k * co * ci,), device=x.device, dtype=torch.float32)
             d.workspace, d.winograd = ws.data_ptr(), 0
             if stride != 1:
                 raise ValueError('conv_wgrad_multi: the dense-block operand forms belong to stride-1 jobs')
@@ -638,6 +640,7 @@ def conv_wgrad_multi(jobs, dws=None, accumulate=True):
         for t in range(3):
             d.src_off[t] = t - pad if t < k else 0
         outs.append((ws, plan[2], k, co, ci))
+        caps.append(cap)
     if dws is not None:
         if len(dws) != len(jobs):
             raise ValueError('conv_wgrad_multi: one destination (or None) per job')
@@ -649,9 +652,9 @@ def conv_wgrad_multi(jobs, dws=None, accumulate=True):
                 ptrs[i] = _f32(dw, 'dw').data_ptr()
         red, spl = (ctypes.c_int * len(jobs))(), (ctypes.c_int * len(jobs))()
         _chk(L.da_conv_wgrad_multi_reduce(arr, len(jobs), ptrs, 1 if accumulate else 0, red, spl, _stream()), 'da_conv_wgrad_multi_reduce')
-        for i, (ws, planned, k, co, ci) in enumerate(outs):       # the slabs actually written (a batch plan may use fewer)
-            if not 1 <= spl[i] <= planned:
-                raise RuntimeError('conv_wgrad_multi: job %d wrote %d slabs into a workspace of %d' % (i, spl[i], planned))
+        for i, (ws, planned, k, co, ci) in enumerate(outs):       # the slabs actually written (a batch plan: fewer; a last-round job: twice)
+            if not 1 <= spl[i] <= caps[i]:
+                raise RuntimeError('conv_wgrad_multi: job %d wrote %d slabs into a workspace of %d' % (i, spl[i], caps[i]))
             outs[i] = (ws, spl[i], k, co, ci)
         return outs, [bool(r) for r in red]
     _chk(L.da_conv_wgrad_multi(arr, len(jobs), _stream()), 'da_conv_wgrad_multi')

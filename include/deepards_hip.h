@@ -161,9 +161,10 @@ int da_conv_wgrad_multi(const da_wgrad_job* jobs, int n, da_stream_t stream);  /
    ones da_wgrad_reduce_multi forms, bit for bit.  (replaces nothing of its own in the reference: the reduction of
    loss.backward()'s conv weight gradients, train_ards_detector.py:161-173) */
 int da_conv_wgrad_multi_reduce(const da_wgrad_job* jobs, int n, float* const* dws, int accumulate, int* reduced, int* splits, da_stream_t stream);
-/* splits[i] (out): the slabs job i wrote -- what its reduction must be given.  Never more than da_conv_wgrad_plan's figure
-   (which sizes the workspace), fewer for the dense-block jobs of a call with 8 or more of them: those share ONE launch and
-   are planned as a batch. */
+/* splits[i] (out): the slabs job i wrote -- what its reduction must be given.  A job's workspace here must hold TWICE
+   da_conv_wgrad_plan's slabs: the winograd == 1 jobs of the launch's last, partly filled round run with half the pairs per
+   split (twice the slabs); the dense-block jobs of a call with 8 or more of them share ONE launch, are planned as a batch
+   and write fewer. */
 /* deferred slab reduction: da_conv_wgrad with dw == NULL leaves da_conv_wgrad_splits() slabs in the workspace */
 int da_conv_wgrad_splits(int rows, int Lm, int N, int C, int ntaps);
 /* host only: out[4] = {tile_n, tile_c, splits, positions per split} the plan of da_conv_wgrad and
