@@ -870,7 +870,10 @@ bool bf16_wgrad_eligible(const da_wgrad_job& j) {
   return j.ntaps == 1 && j.src_off[0] == 0;
 }
 
-static int g_wb_pchunk = 2048;
+// (whole bf16 step at B = 64, ms: 1 536 / 1 792 / 2 048 / 2 112 / 2 176 / 2 240 / 2 304 / 2 432 / 2 560 / 3 072 padded positions per
+// split: 1.475 / 1.458 / 1.460 / 1.464 / 1.447 / 1.450 / 1.451 / 1.458 / 1.465 / 1.480 -- 160 registers = 3 blocks a CU = 768
+// slots; at 2 048 the step's 2 368 blocks are three rounds and 64 blocks, at 2 176 they fit three)
+static int g_wb_pchunk = 2176;
 void bf16_wgrad_set_pchunk(int pchunk) { g_wb_pchunk = pchunk; }
 
 // padded positions per split (a multiple of the K step) and the number of slabs
