@@ -9,7 +9,8 @@ import deepards_amd.models as M
 from deepards_amd.train import HotPathTrainer
 backbone = 'densenet18' if '--densenet' in sys.argv else 'resnet18'
 targets = [int(a) for a in sys.argv[1:] if not a.startswith('--')] or [0, 256, 384, 512, 640, 768, 1024]
-x = torch.randn(64, 20, 1, 224, device='cuda'); t = torch.zeros(64, 2, device='cuda'); t[:, 0] = 1
+B = int(os.environ.get('BATCH', 64))
+x = torch.randn(B, 20, 1, 224, device='cuda'); t = torch.zeros(B, 2, device='cuda'); t[:, 0] = 1
 for tg in targets + targets[:1]:
     _lib.lib().da_debug_set(1, tg)
     torch.manual_seed(0)
