@@ -109,6 +109,9 @@ SIGNATURES = {
     'da_bn_param_grad_multi': (_I, [ctypes.POINTER(BnPgradDesc), _I, _I, _P]),
     'da_bn_fwd_pair': (_I, [ctypes.POINTER(BnFwdDesc), _I, _I, _I, _F, _P]),
     'da_bn_bwd_pair': (_I, [_P, _I, ctypes.POINTER(BnBwdDesc), _I, _I, _I, _P, _P]),
+    'da_bn_bwd_pair2': (_I, [_P, _I, _P, _I, ctypes.POINTER(BnBwdDesc), _I, _I, _I, _P, _P]),
+    'da_bn_two_ok': (_I, [_I, _I, _I]),
+    'da_bn_bwd_mask2': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     'da_bn_stats_fused': (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _F, _P]),
     'da_bn_relu_ss': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     'da_bn_bwd_ss': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _I, _P, _U, _F, _I, _P, _P, _I, _P]),

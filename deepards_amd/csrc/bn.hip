@@ -400,6 +400,8 @@ __device__ __forceinline__ uint32_t bn_mix32(uint32_t a, uint32_t b) {
 // (those channels are the previous layer's new features: this kernel is the last to add to their gradient, and what
 // its data / weight gradient convs want is the gradient in front of F.dropout, densenet.py:37-39).
 struct BnBwdExt {
+  const void* dout2;   // D2: the upstream gradient is dout + dout2 (activation storage type, pitch ldd2): a residual block's
+  int ldd2;            //     input gradient left as its two terms (data-gradient conv output | identity branch), summed here
   int pool_L;          // DPOOL: dout is the gradient of the POOLED features, float [rows][ldd]: position p of a window reads
   FastDiv pool_div;    //        row p / pool_L, scaled by 1 / pool_L (the backward of bn_fwd_pool_kernel's average)
   int ldstat, half_dout, drop_c0, drop_g;
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_pair_kernel(BnFwdOne<AT> a, BnFwd
 // same arithmetic as bn_bwd_reduce_kernel + bn_bwd_apply_kernel with the slab held in registers
 // DX3: dx (the gradient w.r.t. the BatchNorm input = the conv output: the data-gradient and weight-gradient convs' operand)
 // is stored in the x3 format; gout stays float (the convs accumulate the branch gradient into it).
-template <typename AT, int NPOS, int QB, int DX3 = 0, int EXT = 0, int DPOOL = 0>
+template <typename AT, int NPOS, int QB, int DX3 = 0, int EXT = 0, int DPOOL = 0, int D2 = 0>
 __device__ __forceinline__ void bn_bwd_fused_body(const AT* __restrict__ dout, int ldd, const AT* __restrict__ x, int ldx,
                                                   const AT* __restrict__ outp, int ldo, AT* __restrict__ dx, int lddx,
                                                   AT* __restrict__ gout, int ldg, int Wn, int C,
@@ -627,11 +629,17 @@ __device__ __forceinline__ void bn_bwd_fused_body(const AT* __restrict__ dout, i
   const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0);
   const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c0);
   f32x4 g[NPOS], xh[NPOS];
+  f32x4 g2[D2 ? NPOS : 1];         // (40 more registers: the D2 kernels are bounded to 512 threads)
+  const AT* d2b = D2 ? reinterpret_cast<const AT*>(ext.dout2) + base * ext.ldd2 + cg * CGB : nullptr;
 #pragma unroll
   for (int k = 0; k < NPOS; ++k) {
     const int p = slot + k * P;
     g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     xh[k] = mu;
+    if constexpr (D2) {
+      g2[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p < Wn) g2[k] = Act<AT>::ld4(d2b + (uint32_t)(p * ext.ldd2 + q * 4));
+    }
     if (p < Wn) {
       if constexpr (DPOOL) {
         const float* df = reinterpret_cast<const float*>(dout) + ((size_t)w * (Wn / ext.pool_L)) * ldd + cg * CGB;
@@ -665,6 +673,10 @@ __device__ __forceinline__ void bn_bwd_fused_body(const AT* __restrict__ dout, i
 #pragma unroll
   for (int k = 0; k < NPOS; ++k) {
     const int p = slot + k * P;
+    if constexpr (D2) {            // (all loads are out by now)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[k][e] += g2[k][e];
+    }
     if constexpr (DPOOL) {         // (here, not behind the load: a VALU op on a fresh register serialises the loads)
       f32x4 t;
 #pragma unroll
@@ -772,6 +784,21 @@ __global__ __launch_bounds__(1024) void bn_bwd_pool_kernel(const float* __restri
                                            red);
 }
 
+// the block-output BatchNorm's backward with the upstream gradient in two terms, dout + dout2 (mask form, optional gout): a
+// residual block behind it left its input gradient as (data-gradient conv output, identity branch) instead of accumulating
+// the first onto the second in the conv's epilogue -- the accumulating launches cost 4 ... 8 us more than the plain ones
+template <typename AT, int NPOS, int QB>
+__global__ __launch_bounds__(512) void bn_bwd_d2_kernel(const AT* __restrict__ dout, int ldd, const AT* __restrict__ x, int ldx,
+                                                        AT* __restrict__ dx, int lddx, AT* __restrict__ gout, int ldg, int Wn,
+                                                        int C, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ ds1, float* __restrict__ ds2,
+                                                        const unsigned long long* __restrict__ mask, BnBwdExt ext) {
+  __shared__ float red[16 * 2 * CG];
+  bn_bwd_fused_body<AT, NPOS, QB, 0, 0, 0, 1>(dout, ldd, x, ldx, (const AT*)nullptr, 0, dx, lddx, gout, ldg, Wn, C, mean, invstd,
+                                              gamma, beta, 3, ds1, ds2, (const AT*)nullptr, 0, mask, ext, red);
+}
+
 // ... and their backward: the block-output BatchNorm (bn2) and the downsample's BatchNorm take the SAME masked gradient
 // dout * [out > 0] (ReLU decisions as the bit mask of the forward), so neither waits for the other (resnet.py:33-38 backward)
 template <typename AT>
@@ -794,6 +821,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_pair_kernel(const AT* __restrict_
   bn_bwd_fused_body<AT, NPOS, QB, 0, 0>(dout, ldd, s.x, s.ldx, (const AT*)nullptr, 0, s.dx, s.lddx, (AT*)nullptr, 0, Wn, C,
                                         s.mean, s.invstd, s.gamma, s.beta, 3, s.ds, s.ds + (size_t)W * C, (const AT*)nullptr, 0,
                                         mask, ext, red);
+}
+
+template <typename AT, int NPOS, int QB>
+__global__ __launch_bounds__(512) void bn_bwd_pair_d2_kernel(const AT* __restrict__ dout, int ldd, BnBwdOne<AT> a, BnBwdOne<AT> b,
+                                                             int W, int Wn, int C, const unsigned long long* __restrict__ mask,
+                                                             BnBwdExt ext) {
+  __shared__ float red[16 * 2 * CG];
+  const BnBwdOne<AT>& s = blockIdx.z ? b : a;
+  bn_bwd_fused_body<AT, NPOS, QB, 0, 0, 0, 1>(dout, ldd, s.x, s.ldx, (const AT*)nullptr, 0, s.dx, s.lddx, (AT*)nullptr, 0, Wn, C,
+                                              s.mean, s.invstd, s.gamma, s.beta, 3, s.ds, s.ds + (size_t)W * C,
+                                              (const AT*)nullptr, 0, mask, ext, red);
 }
 
 // geometry of the single-pass kernels for W windows of Wn positions: channels per block (32, or 16 when 32 would
@@ -894,10 +932,18 @@ static void launch_bn_fwd_pair(const da_bn_fwd_desc* d, int W, int Wn, int C, in
 
 template <typename AT, int QB>
 static void launch_bn_bwd_pair(const void* dout, int ldd, const da_bn_bwd_desc* d, int W, int Wn, int C, int CH, int threads,
-                               const unsigned long long* mask, hipStream_t stream) {
+                               const unsigned long long* mask, hipStream_t stream, const void* dout2 = nullptr, int ldd2 = 0) {
   BnBwdOne<AT> s[2];
   for (int i = 0; i < 2; ++i)
     s[i] = BnBwdOne<AT>{(const AT*)d[i].x, (AT*)d[i].dx, d[i].mean, d[i].invstd, d[i].gamma, d[i].beta, d[i].ds, d[i].ldx, d[i].lddx};
+  if (dout2) {
+    BnBwdExt ext = {};
+    ext.dout2 = dout2;
+    ext.ldd2 = ldd2;
+    hipLaunchKernelGGL((bn_bwd_pair_d2_kernel<AT, FUSED_NPOS, QB>), dim3(W, C / CH, 2), dim3(threads), 0, stream, (const AT*)dout,
+                       ldd, s[0], s[1], W, Wn, C, mask, ext);
+    return;
+  }
   hipLaunchKernelGGL((bn_bwd_pair_kernel<AT, FUSED_NPOS, QB>), dim3(W, C / CH, 2), dim3(threads), 0, stream, (const AT*)dout, ldd,
                      s[0], s[1], W, Wn, C, mask);
 }
@@ -1365,6 +1411,67 @@ int da_bn_bwd_pair(const void* dout, int ldd, const da_bn_bwd_desc* d, int W, in
   else if (cgb == 16) BN_BWDP_LAUNCH(2, 16);
   else BN_BWDP_LAUNCH(1, 8);
 #undef BN_BWDP_LAUNCH
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+// da_bn_bwd_mask / da_bn_bwd_pair with the upstream gradient given as TWO terms, dout + dout2 (resnet.py:33-38 backward: the
+// gradient of a block's output is the next block's data-gradient conv output plus its identity branch; summing them HERE
+// spares the conv an accumulating epilogue).  Single-pass geometry of at most 512 threads (da_bn_two_ok); ds only (fold
+// dgamma / dbeta with da_bn_param_grad_multi).
+int da_bn_two_ok(int W, int Wn, int C) {
+  int cgb = 0;
+  const int threads = C % CG == 0 ? bn_fused_geometry(W, Wn, C, &cgb) : 0;
+  return threads > 0 && threads <= 512;
+}
+
+int da_bn_bwd_mask2(const void* dout, int ldd, const void* dout2, int ldd2, const void* x, int ldx, void* dx, int lddx, void* gout,
+                    int ldg, int W, int Wn, int C, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                    float* ds, const unsigned long long* mask, hipStream_t stream) {
+  DA_ENTER();
+  if (!dout || !dout2 || !x || !dx || !mean || !invstd || !gamma || !beta || !ds || !mask || ldd % 4 || ldd2 % 4 || ldx % 4 ||
+      lddx % 4 || (gout && ldg % 4) || !da_bn_two_ok(W, Wn, C))
+    return DA_EINVAL;
+  if (W == 0) return DA_OK;
+  int cgb = 0;
+  const int threads = bn_fused_geometry(W, Wn, C, &cgb);
+  BnBwdExt ext = {};
+  ext.dout2 = dout2;
+  ext.ldd2 = ldd2;
+  float* s1 = ds;
+  float* s2 = ds + (size_t)W * C;
+#define BN_BWD2_LAUNCH(QB, CH)                                                                                           \
+  DA_ACT_DISPATCH(hipLaunchKernelGGL((bn_bwd_d2_kernel<AT, FUSED_NPOS, QB>), dim3(W, C / CH), dim3(threads), 0, stream,     \
+                                     (const AT*)dout, ldd, (const AT*)x, ldx, (AT*)dx, lddx, (AT*)gout, ldg, Wn, C, mean,     \
+                                     invstd, gamma, beta, s1, s2, mask, ext))
+  if (cgb == 32) BN_BWD2_LAUNCH(3, 32);
+  else if (cgb == 16) BN_BWD2_LAUNCH(2, 16);
+  else BN_BWD2_LAUNCH(1, 8);
+#undef BN_BWD2_LAUNCH
+  DA_CHECK_LAUNCH();
+  return DA_OK;
+}
+
+int da_bn_bwd_pair2(const void* dout, int ldd, const void* dout2, int ldd2, const da_bn_bwd_desc* d, int W, int Wn, int C,
+                    const unsigned long long* mask, hipStream_t stream) {
+  DA_ENTER();
+  if (!dout || !dout2 || !d || !mask || Wn < 1 || ldd % 4 || ldd2 % 4 || !da_bn_two_ok(W, Wn, C)) return DA_EINVAL;
+  for (int i = 0; i < 2; ++i)
+    if (!d[i].x || !d[i].dx || !d[i].mean || !d[i].invstd || !d[i].gamma || !d[i].beta || !d[i].ds || d[i].ldx % 4 ||
+        d[i].lddx % 4)
+      return DA_EINVAL;
+  if (W == 0) return DA_OK;
+  int cgb = 0;
+  const int threads = bn_fused_geometry(W, Wn, C, &cgb);
+#define BN_BWDP2_LAUNCH(QB, CH)                                                                              \
+  do {                                                                                                       \
+    if (g_act_bf16) launch_bn_bwd_pair<__bf16, QB>(dout, ldd, d, W, Wn, C, CH, threads, mask, stream, dout2, ldd2); \
+    else launch_bn_bwd_pair<float, QB>(dout, ldd, d, W, Wn, C, CH, threads, mask, stream, dout2, ldd2);      \
+  } while (0)
+  if (cgb == 32) BN_BWDP2_LAUNCH(3, 32);
+  else if (cgb == 16) BN_BWDP2_LAUNCH(2, 16);
+  else BN_BWDP2_LAUNCH(1, 8);
+#undef BN_BWDP2_LAUNCH
   DA_CHECK_LAUNCH();
   return DA_OK;
 }

@@ -40,7 +40,7 @@ _STEP = {'on': False, 'pack': {}, 'running': [], 'pgrad': [], 'wgrad': [], 'wsla
 
 @contextlib.contextmanager
 def training_step(model=None):
-    _STEP.update(on=True, pack={}, running=[], pgrad=[], wgrad=[], wslab=[], stemred=None)
+    _STEP.update(on=True, pack={}, running=[], pgrad=[], wgrad=[], wslab=[], stemred=None, dout2={})
     try:
         if model is not None:
             ms = [m for m in model.modules()
@@ -52,7 +52,7 @@ def training_step(model=None):
                 _STEP['pack'][(w.data_ptr(), int(c))] = e
         yield
     finally:
-        _STEP.update(on=False, pack={}, running=[], pgrad=[], wgrad=[], wslab=[], stemred=None)
+        _STEP.update(on=False, pack={}, running=[], pgrad=[], wgrad=[], wslab=[], stemred=None, dout2={})
 
 
 def flush_forward(defer=False):
@@ -66,6 +66,8 @@ def flush_forward(defer=False):
 
 def flush_backward():
     """Run the queued parameter-gradient folds (call after the backward, before the optimiser)."""
+    if _STEP.get('dout2'):      # a block left the second term of its input gradient for a consumer that never came
+        raise RuntimeError('a two-term input gradient (BasicBlockFunction split_dx) was not picked up by the block in front')
     _launch_wgrads()
     # one launch: slab reductions + dgamma / dbeta folds + the running statistics a deferred flush_forward left queued
     dst = [dw.data_ptr() for _, dw in _STEP['wslab']] + [t.data_ptr() for _, tg, tb in _STEP['pgrad'] for t in (tg, tb)]
@@ -543,7 +545,13 @@ class BasicBlockFunction(Function):
     shape has the store forms.  Returns ``out`` or ``(handle, out3)``."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, R, st1, st2, std, x3=None, want_out3=False, pool_out=False):
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, stride, R, st1, st2, std, x3=None, want_out3=False, pool_out=False,
+                split_dx=False):
+        # split_dx (an identity block BEHIND another BasicBlock, inside a training step): the input gradient conv1-dgrad(dy1) +
+        # g is handed back as its two terms -- the conv output is the returned gradient, g waits in _STEP['dout2'] under its
+        # address -- and the block in front sums them while its bn2 backward loads them (H.bn_bwd_two / bn_bwd_pair(dout2)):
+        # an accumulating conv epilogue costs 4 ... 8 us a launch more than a plain one
+        ctx.split_dx = bool(split_dx) and wd is None and x3 is None
         # pool_out (the LAST block in front of a head that pools its map, CNNLinearNetwork.forward_loss): the block's output
         # is never stored -- bn2 + residual + ReLU hand over the pooled features (rows, C) float (H.bn_fwd_pool), and the
         # backward takes their gradient (H.bn_bwd_pool): two 18 MB passes and the pooling launch less at B = 64
@@ -652,15 +660,24 @@ class BasicBlockFunction(Function):
         tw1, tg1, tb1, tw2, tg2, tb2, twd, tgd, tbd = ctx.gt
         R, stride, lin = ctx.R, ctx.stride, ctx.lin
         in3, mid3 = ctx.in3, ctx.mid3
+        # the second term of this block's output gradient, if the block behind left one (its split_dx)
+        d2 = _STEP['dout2'].pop(dout.data_ptr(), None) if _STEP['on'] and _STEP.get('dout2') else None
         dout = dout.contiguous()
         # relu + residual add + bn2
         bwd_pair = ctx.has_ds and ctx.bn_pair and ctx.relu_mask is not None and not mid3 and not ctx.s2x
+        two = d2 is not None and not ctx.pool_out and not mid3 and ctx.relu_mask is not None and H.bn_two_ok(y2, R)
+        if d2 is not None and not two:      # (a shape without the two-term kernels: sum them here)
+            dout = dout + d2
         if bwd_pair:      # bn2 and the downsample's BatchNorm take the same masked gradient: one launch, no g tensor
             wd, gd, bd, yd, md, idd = s[15:]
-            (dy2, ds2), (dyd, dsd) = H.bn_bwd_pair(dout, [(y2, m2, i2, g2, b2, None), (yd, md, idd, gd, bd, None)], R, ctx.relu_mask)
+            (dy2, ds2), (dyd, dsd) = H.bn_bwd_pair(dout, [(y2, m2, i2, g2, b2, None), (yd, md, idd, gd, bd, None)], R, ctx.relu_mask,
+                                                   dout2=d2 if two else None)
             dg2, db2 = _bn_pgrad(ds2, g2, b2, tg2, tb2)
             dgd, dbd = _bn_pgrad(dsd, gd, bd, tgd, tbd)
             g = None
+        elif two:         # bn2 of an identity block with the two-term upstream gradient
+            dy2, g, ds2 = H.bn_bwd_two(dout, d2, y2, R, m2, i2, g2, b2, ctx.relu_mask, want_g=True)
+            dg2, db2 = _bn_pgrad(ds2, g2, b2, tg2, tb2)
         elif ctx.pool_out:  # dout = the gradient of the pooled features (rows, C)
             dy2, g, ds2 = H.bn_bwd_pool(dout, y2, R, m2, i2, g2, b2, ctx.relu_mask, want_g=True)
             dg2, db2 = _bn_pgrad(ds2, g2, b2, tg2, tb2)
@@ -700,8 +717,12 @@ class BasicBlockFunction(Function):
                 _conv_dgrad(dyd, wd, stride, 0, lin, out=dx, accumulate=True)
         else:
             dwd = dgd = dbd = None
-            dx = _conv_dgrad(dy1, w1, stride, 1, lin, out=g, accumulate=True)   # identity grad + conv path
-        return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None, None, None
+            if ctx.split_dx and _STEP['on'] and not in3 and g is not None:
+                dx = _conv_dgrad(dy1, w1, stride, 1, lin)                       # the conv term; the identity term g travels beside it
+                _STEP['dout2'][dx.data_ptr()] = g
+            else:
+                dx = _conv_dgrad(dy1, w1, stride, 1, lin, out=g, accumulate=True)   # identity grad + conv path
+        return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None, None, None, None, None, None, None, None
 
 
 _STEM_TAIL = True         # inside a training step the stem's last weight-gradient fold rides on the tail launch

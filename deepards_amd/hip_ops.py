@@ -904,10 +904,35 @@ def bn_fwd_pair(items, R, eps=1e-5):
     return outs
 
 
-def bn_bwd_pair(dout, items, R, mask):
+def bn_two_ok(x, R):
+    """Whether bn_bwd_two / bn_bwd_pair(dout2=...) take this (rows, L, C) map (single-pass geometry of at most 512 threads)."""
+    rows, l, c = x.shape
+    return rows % R == 0 and rows > 0 and bool(_lib.lib().da_bn_two_ok(rows // R, R * l, c))
+
+
+def bn_bwd_two(dout, dout2, x, R, mean, invstd, gamma, beta, mask, want_g=False, dx=None):
+    """bn_bwd(mask=...) whose upstream gradient is dout + dout2 (a residual block left its input gradient as its two terms:
+    no accumulating conv epilogue).  -> dx, g (the masked SUM; only with want_g), ds (2, W, C)."""
+    _rlc(dout, 'dout')
+    _rlc(dout2, 'dout2')
+    _rlc(x, 'x')
+    rows, l, c = x.shape
+    if tuple(dout.shape) != (rows, l, c) or tuple(dout2.shape) != (rows, l, c) or not bn_two_ok(x, R):
+        raise ValueError('bn_bwd_two: shapes dout%s dout2%s x%s' % (tuple(dout.shape), tuple(dout2.shape), tuple(x.shape)))
+    w = rows // R
+    if dx is None:
+        dx = torch.empty_like(x)
+    g = torch.empty_like(x) if want_g else None
+    ds = torch.empty((2, w, c), device=x.device, dtype=torch.float32)
+    _chk(_lib.lib().da_bn_bwd_mask2(_p(dout), c, _p(dout2), c, _p(x), c, _p(dx), c, _p(g), c, w, R * l, c, _p(mean), _p(invstd),
+                                    _p(_f32(gamma)), _p(_f32(beta)), _p(ds), _p(mask), _stream()), 'da_bn_bwd_mask2')
+    return dx, g, ds
+
+
+def bn_bwd_pair(dout, items, R, mask, dout2=None):
     """The two BatchNorm backwards that share one masked gradient dout * [out > 0] (a block entry's bn2 and its downsample's
     BatchNorm; ``mask``: the ReLU bit mask of the block output's bn_fwd(want_mask=True)) in one launch: items = two
-    (x, mean, invstd, gamma, beta, dx | None) -> [(dx, ds (2, W, C))]."""
+    (x, mean, invstd, gamma, beta, dx | None) -> [(dx, ds (2, W, C))].  dout2: the upstream gradient is dout + dout2."""
     _rlc(dout, 'dout')
     rows, l, c = dout.shape
     if len(items) != 2 or rows % R or mask is None:
@@ -925,7 +950,13 @@ def bn_bwd_pair(dout, items, R, mask):
         d.x, d.ldx, d.dx, d.lddx = x.data_ptr(), c, dx.data_ptr(), c
         d.mean, d.invstd, d.gamma, d.beta, d.ds = mean.data_ptr(), invstd.data_ptr(), _f32(gamma).data_ptr(), _f32(beta).data_ptr(), ds.data_ptr()
         outs.append((dx, ds))
-    _chk(_lib.lib().da_bn_bwd_pair(_p(dout), c, arr, w, R * l, c, _p(mask), _stream()), 'da_bn_bwd_pair')
+    if dout2 is not None:
+        _rlc(dout2, 'dout2')
+        if tuple(dout2.shape) != (rows, l, c):
+            raise ValueError('bn_bwd_pair: dout2 shape mismatch')
+        _chk(_lib.lib().da_bn_bwd_pair2(_p(dout), c, _p(dout2), c, arr, w, R * l, c, _p(mask), _stream()), 'da_bn_bwd_pair2')
+    else:
+        _chk(_lib.lib().da_bn_bwd_pair(_p(dout), c, arr, w, R * l, c, _p(mask), _stream()), 'da_bn_bwd_pair')
     return outs
 
 

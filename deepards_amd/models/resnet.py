@@ -51,14 +51,14 @@ class BasicBlock(nn.Module):
             self.add_module(name, mod)
         self.downsample, self.stride = downsample, stride
 
-    def forward_rlc(self, x, R, x3=None, want_out3=False, pool_out=False):
+    def forward_rlc(self, x, R, x3=None, want_out3=False, pool_out=False, split_dx=False):
         """x: (rows, L, C) channels-last; R rows per BatchNorm window.  Conv arithmetic 'f32x3p': ``x3`` = the input in the
         x3 format (``x`` is then the autograd handle) and ``want_out3`` asks for ``(handle, out3)`` (functional: the x3 flow)."""
         ds = self.downsample
         dsw = (None, None, None, None) if ds is None else (ds[0].weight, ds[1].weight, ds[1].bias, F_.BNState(ds[1]))
         return F_.BasicBlockFunction.apply(
             x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias,
-            dsw[0], dsw[1], dsw[2], self.stride, R, F_.BNState(self.bn1), F_.BNState(self.bn2), dsw[3], x3, want_out3, pool_out)
+            dsw[0], dsw[1], dsw[2], self.stride, R, F_.BNState(self.bn1), F_.BNState(self.bn2), dsw[3], x3, want_out3, pool_out, split_dx)
 
     def takes_x3(self, rows, l_in, R):
         """Whether this block's conv1 reads the x3 format under the current conv arithmetic: a k3 s1 conv (no downsample)
@@ -71,6 +71,7 @@ class BasicBlock(nn.Module):
 
 
 _POOLS = {'max': nn.MaxPool1d, 'avg': nn.AvgPool1d}
+_SPLIT_DX = os.environ.get('DA_SPLIT_DX', '1') != '0'     # an identity block's input gradient as two terms, summed by the bn2 backward in front (0: accumulated by its data-gradient conv)
 _FUSED_TAIL = os.environ.get('DA_FUSED_TAIL', '1') != '0'   # the last block's BatchNorm pools for the head (0: its map is stored and the head pools it)
 
 
@@ -144,11 +145,13 @@ class ResNet(nn.Module):
             # is never stored (BasicBlockFunction pool_out) -- when it is an identity block on the 7-position map
             pool_out = pooled == 'fused' and _FUSED_TAIL and i == len(blocks) - 1 and not takes3[i] and \
                 blk.downsample is None and blk.stride == 1 and lens[i] == 7 and F_.H.bn_pool_ok(h, rows_per_window)
+            # an identity block behind another block hands its input gradient back as two terms (BasicBlockFunction split_dx)
+            split_dx = _SPLIT_DX and i > 0 and blk.downsample is None and not takes3[i] and not takes3[i - 1]
             if takes3[i]:
                 h, h3 = h
                 h = blk.forward_rlc(h, rows_per_window, h3, takes3[i + 1])
             else:
-                h = blk.forward_rlc(h, rows_per_window, None, takes3[i + 1], pool_out)
+                h = blk.forward_rlc(h, rows_per_window, None, takes3[i + 1], pool_out, split_dx)
         if pooled == 'fused':
             if h.dim() == 3 and h.shape[1] != 7:
                 raise TypeError('the un-pooled map is only handed out at the 7-position length the fused head pools')

@@ -268,6 +268,13 @@ int da_bn_fwd_pool(const da_act_t* x, int ldx, const da_act_t* res, int ldr, flo
 int da_bn_bwd_pool(const float* dflat, int ldd, const da_act_t* x, int ldx, da_act_t* dx, int lddx, da_act_t* gout, int ldg, int W,
                    int Wn, int C, int L, const float* mean, const float* invstd, const float* gamma, const float* beta, float* ds,
                    const unsigned long long* mask, da_stream_t stream);
+/* da_bn_bwd_mask / da_bn_bwd_pair with the upstream gradient as TWO terms, dout + dout2 (resnet.py:33-38 backward: the gradient
+   of a block's output = the next block's data-gradient conv output + its identity branch; summed here, the conv needs no
+   accumulating epilogue).  da_bn_two_ok: single-pass geometry of at most 512 threads.  ds only. */
+int da_bn_two_ok(int W, int Wn, int C);
+int da_bn_bwd_mask2(const da_act_t* dout, int ldd, const da_act_t* dout2, int ldd2, const da_act_t* x, int ldx, da_act_t* dx, int lddx,
+                    da_act_t* gout, int ldg, int W, int Wn, int C, const float* mean, const float* invstd, const float* gamma,
+                    const float* beta, float* ds, const unsigned long long* mask, da_stream_t stream);
 /* da_bn_bwd with dx = input gradient + add[pos][0:C] (pitch ldadd): a concatenation's pass-through gradient
    (densenet.py:41) joins in the same pass */
 int da_bn_bwd_add(const da_act_t* dout, int ldd, const da_act_t* x, int ldx, const da_act_t* out, int ldo, da_act_t* dx, int lddx,
@@ -344,6 +351,8 @@ typedef struct {
 int da_bn_fwd_pair(const da_bn_fwd_desc* d, int W, int Wn, int C, float eps, da_stream_t stream);
 int da_bn_bwd_pair(const da_act_t* dout, int ldd, const da_bn_bwd_desc* d, int W, int Wn, int C,
                    const unsigned long long* mask, da_stream_t stream);
+int da_bn_bwd_pair2(const da_act_t* dout, int ldd, const da_act_t* dout2, int ldd2, const da_bn_bwd_desc* d, int W, int Wn, int C,
+                    const unsigned long long* mask, da_stream_t stream);      /* upstream gradient dout + dout2 (da_bn_bwd_mask2) */
 /* The same BatchNorm forward / backward (resnet.py:27-38) in front of an x3 consumer (conv arithmetic 'f32x3', see
  * da_conv3_x3p): float in, and res_x3 / out_x3 / dx_x3 say which of `res`, `out`, `dx` are in the x3 format (their pitches are
  * ignored).  Single-pass geometry only (da_bn_mask_words() > 0; -1 otherwise); mask may be NULL (no ReLU bit mask wanted /

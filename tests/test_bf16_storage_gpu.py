@@ -71,6 +71,39 @@ def rnd(shape, seed, scale=1.0):
 
 
 @pytest.mark.parametrize('store', ['f32', 'bf16'])
+@pytest.mark.parametrize('C,L,R,W', [(64, 56, 20, 4), (128, 28, 20, 3), (256, 14, 20, 64), (512, 7, 20, 5)])
+def test_batchnorm_backward_with_a_two_term_upstream_gradient(H, store, C, L, R, W):
+    """bn_bwd_two / bn_bwd_pair(dout2=...): the upstream gradient as dout + dout2, summed while the kernel loads them == the
+    mask-form backward of the sum formed beforehand -- bit for bit with float storage (one fp32 add either way), to a bf16 ulp
+    of the gradient scale with bf16 storage (the stored sum is rounded, the in-kernel one is not)."""
+    with storage(H, store):
+        dt = torch.bfloat16 if store == 'bf16' else torch.float32
+        rows = W * R
+        x, res, xd = rnd((rows, L, C), 1).to(dt), rnd((rows, L, C), 2).to(dt), rnd((rows, L, C), 6).to(dt)
+        da, db = rnd((rows, L, C), 3).to(dt), rnd((rows, L, C), 4).to(dt)
+        g = torch.Generator().manual_seed(5)
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+        assert H.bn_two_ok(x, R)
+        out, mean, invstd, mask = H.bn_fwd(x, R, gamma, beta, relu=True, res=res, want_mask=True)
+        _, md, idd = H.bn_fwd(xd, R, gamma, beta, relu=False)
+        dsum = (da.float() + db.float()).to(dt)
+        dy, _, _, gq, ds = H.bn_bwd(dsum, x, R, mean, invstd, gamma, beta, 2, want_g=True, defer_param_grads=True, mask=mask)
+        dy2, gq2, ds2 = H.bn_bwd_two(da, db, x, R, mean, invstd, gamma, beta, mask, want_g=True)
+        (p1, ps1), (p2, ps2) = H.bn_bwd_pair(dsum, [(x, mean, invstd, gamma, beta, None), (xd, md, idd, gamma, beta, None)], R, mask)
+        (q1, qs1), (q2, qs2) = H.bn_bwd_pair(da, [(x, mean, invstd, gamma, beta, None), (xd, md, idd, gamma, beta, None)], R, mask,
+                                             dout2=db)
+        pairs = (('dy', dy, dy2), ('g', gq, gq2), ('ds', ds, ds2), ('pair dx 0', p1, q1), ('pair ds 0', ps1, qs1),
+                 ('pair dx 1', p2, q2), ('pair ds 1', ps2, qs2))
+        for name, a, b in pairs:
+            if store == 'f32':
+                assert torch.equal(a, b), name
+            else:
+                tol = 2.0 ** -6 * float(a.float().abs().max())
+                assert float((a.float() - b.float()).abs().max()) <= tol, name
+    assert not H.bn_two_ok(torch.empty(40, 512, 64, device='cuda'), 40)      # two-stage geometry: no two-term form
+
+
+@pytest.mark.parametrize('store', ['f32', 'bf16'])
 @pytest.mark.parametrize('C,L,R,W', [(512, 7, 20, 5), (512, 7, 20, 64), (128, 7, 20, 3), (64, 7, 8, 2), (32, 5, 20, 2)])
 def test_batchnorm_with_the_heads_pool_folded_in(H, store, C, L, R, W):
     """bn_fwd_pool / bn_bwd_pool (the last block's bn2 + residual + ReLU whose map is never stored; its backward from the

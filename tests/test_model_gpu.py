@@ -888,6 +888,34 @@ def test_data_parallel_two_processes_epochs_from_store(tmp_path):
     assert np.isfinite(r0['losses']).all() and np.isfinite(r1['losses']).all()
 
 
+def test_identity_blocks_hand_back_a_two_term_input_gradient(M, monkeypatch):
+    """resnet18's identity blocks behind another block return conv1-dgrad(dy1) and leave the identity term beside it; the bn2
+    backward in front sums the two while loading them (BasicBlockFunction split_dx): parameters, momentum and losses of 3
+    captured fp32 steps are bit for bit those of the accumulating data-gradient convs; eager steps too; a term nobody picks up
+    is an error, not a silently dropped gradient."""
+    import deepards_amd.models.resnet as RN
+    import deepards_amd.functional as F_
+    from deepards_amd.train import HotPathTrainer
+    x = torch.randn(4, 20, 1, 224, device='cuda')
+    t = torch.zeros(4, 2, device='cuda')
+    t[:2, 0] = 1
+    t[2:, 1] = 1
+
+    def run(split, graph):
+        monkeypatch.setattr(RN, '_SPLIT_DX', split)
+        tr = HotPathTrainer(build(M, 'resnet18', 5), use_graph=graph)
+        out = [tr.train_step(x, t).clone() for _ in range(3)] + [tr.bucket.p.clone(), tr.state['buf'].clone()]
+        tr.release_graphs()
+        return out
+    for graph in (True, False):
+        for n, (a, b) in enumerate(zip(run(True, graph), run(False, graph))):
+            assert torch.equal(a, b), (graph, n)
+    with F_.training_step():
+        F_._STEP['dout2'][123] = x
+        with pytest.raises(RuntimeError, match='two-term'):
+            F_.flush_backward()
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_last_block_pools_for_the_head(M, dtype, monkeypatch):
     """resnet18's last block hands the head its POOLED output (BasicBlockFunction pool_out; the block's map is never stored):
