@@ -317,6 +317,13 @@ struct ConvBf16GenArgs {
   int src_off[3], wtap[3];
   long Msrc;            // rows * Lsrc
   FastDiv divLm;
+  // two sources in one contraction (da_conv_job.x2 / w2 / tap_split): the taps >= tap_split read x2 with the weights w2 (same
+  // pitch, channel count and geometry) -- the even input positions of a stride-2 block entry's data gradient take the conv's
+  // tap 1 from dy1 AND the downsample's tap from dyd (resnet.py:36-38 backward); the K loop runs over x's channels for the
+  // first taps, then over x2's for the others.  x2 == NULL: one source, tap_split = ntaps.
+  const void* x2;
+  const __bf16* w2;
+  int tap_split;
 };
 
 template <int SS, typename AT>
@@ -355,18 +362,26 @@ __device__ __forceinline__ void conv_bf16_gen_body(const ConvBf16GenArgs& a, con
   const int wrow = (wm_ >> 2) * 8 + (wm_ & 3) + 4 * ((tid >> 2) & 1);
   const size_t wtapsz = (size_t)a.N * a.C;
   const __bf16* wsrc = a.w + (size_t)(n_blk + wrow) * a.C + ws * 8;
+  const AT* ax2 = reinterpret_cast<const AT*>(a.x2);
+  const __bf16* w2src = a.w2 ? a.w2 + (size_t)(n_blk + wrow) * a.C + ws * 8 : wsrc;
+  const int kc = a.C >> 5, ksteps = a.x2 ? 2 * kc : kc;          // second phase: the taps >= tap_split over x2's channels
+  const int tsplit = a.x2 ? a.tap_split : a.ntaps;
 
   typename Stage<AT>::reg rx[NXP];
   f32x4 rw[3];
   auto gload = [&](int ks) {
-    const int c0 = ks << 5;
+    const bool second = ks >= kc;
+    const int c0 = (second ? ks - kc : ks) << 5;
+    const AT* xs = second ? ax2 : ax;
+    const __bf16* wb = second ? w2src : wsrc;
+    const int t0 = second ? tsplit : 0, t1 = second ? a.ntaps : tsplit;
 #pragma unroll
     for (int t = 0; t < 3; ++t)
-      if (t < a.ntaps) rw[t] = *reinterpret_cast<const f32x4*>(wsrc + a.wtap[t] * wtapsz + c0);
+      if (t >= t0 && t < t1) rw[t] = *reinterpret_cast<const f32x4*>(wb + a.wtap[t] * wtapsz + c0);
 #pragma unroll
     for (int p = 0; p < NXP; ++p) {
       typename Stage<AT>::reg v = Stage<AT>::zero();
-      if (xok[p]) v = Stage<AT>::ld(ax + xoff[p] + c0);
+      if (xok[p]) v = Stage<AT>::ld(xs + xoff[p] + c0);
       rx[p] = v;
     }
   };
@@ -400,9 +415,9 @@ __device__ __forceinline__ void conv_bf16_gen_body(const ConvBf16GenArgs& a, con
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-  const int kc = a.C >> 5;
   gload(0);
-  for (int ks = 0; ks < kc; ++ks) {
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const int t0 = ks >= kc ? tsplit : 0, t1 = ks >= kc ? a.ntaps : tsplit;      // this step's taps
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < NXP; ++p) {
@@ -414,14 +429,14 @@ __device__ __forceinline__ void conv_bf16_gen_body(const ConvBf16GenArgs& a, con
     }
 #pragma unroll
     for (int t = 0; t < 3; ++t)
-      if (t < a.ntaps) *reinterpret_cast<f32x4*>(Ws + (t * CB_TN + wrow) * CB_PITCH + ws * 16) = rw[t];
+      if (t >= t0 && t < t1) *reinterpret_cast<f32x4*>(Ws + (t * CB_TN + wrow) * CB_PITCH + ws * 16) = rw[t];
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    if (ks + 1 < kc) gload(ks + 1);
+    if (ks + 1 < ksteps) gload(ks + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      if (t >= a.ntaps) break;
+      if (t < t0 || t >= t1) continue;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const bf16x8 b = *reinterpret_cast<const bf16x8*>(wfrag + t * CB_TN * CB_PITCH + kk * 32);
@@ -1002,7 +1017,7 @@ int da_conv_bf16_multi(const da_conv_job* jobs, int n, hipStream_t stream) {
     const int ss = jobs[base].src_stride;
     for (int i = 0; i < m; ++i) {
       const da_conv_job& j = jobs[base + i];
-      if (!j.x || !j.w || !j.y || j.x2 || j.rows < 0 || j.Lm < 1 || j.C % 32 || j.N % CB_TN || j.C < 32 || j.N < CB_TN ||
+      if (!j.x || !j.w || !j.y || (j.x2 && (!j.w2 || j.tap_split < 1 || j.tap_split >= j.ntaps)) || j.rows < 0 || j.Lm < 1 || j.C % 32 || j.N % CB_TN || j.C < 32 || j.N < CB_TN ||
           j.ldx % 4 || j.ldx < j.C || j.ldy < j.N || j.ntaps < 1 || j.ntaps > 3 || (ss != 1 && ss != 2) ||
           j.src_stride != ss || j.Lsrc != ss * j.Lm || j.dst_stride < 1 || j.dst_off < 0 ||
           (j.Lm - 1) * j.dst_stride + j.dst_off >= j.Ldst)
@@ -1027,6 +1042,7 @@ int da_conv_bf16_multi(const da_conv_job* jobs, int n, hipStream_t stream) {
       }
       a.Msrc = (long)j.rows * j.Lsrc;
       a.divLm = make_fastdiv((uint32_t)j.Lm);
+      a.x2 = j.x2; a.w2 = reinterpret_cast<const __bf16*>(j.w2); a.tap_split = j.x2 ? j.tap_split : j.ntaps;
       t.first_block[cnt] = blocks;
       blocks += (int)(((M + CB_TM - 1) / CB_TM) * (j.N / CB_TN));
       ++cnt;

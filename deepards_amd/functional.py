@@ -566,6 +566,7 @@ class BasicBlockFunction(Function):
             _is_wino(w1, 1, 1) == 16 and _is_wino(w2, 1, 1) == 16 and \
             H.bn_single_pass(x.shape[0] // R, R * x.shape[1], w1.shape[0])
         ctx.fuse1 = fuse1
+        ctx.bf16_pair = bf16_pair
         if s2x:           # the stride-2 block entry on the pre-split input: conv1 and the downsample conv in one launch
             if not s2_x3_ok(w1, wd, x3.shape[1]):
                 raise ValueError('x3 input handed to a stride-2 block whose shape has no x3 kernels')
@@ -712,6 +713,8 @@ class BasicBlockFunction(Function):
                 dx = H.conv_x3p_s2_dgrad(dy1, _pack(w1, 49)[3], dyd, _pack(wd, 49)[3])
             elif stride == 2 and not _is_wino(w1, stride, 1):
                 dx = H.conv_dgrad_s2_pair(dy1, _pack(w1, False)[1], dyd, _pack(wd, False)[1], lin)
+            elif ctx.bf16_pair and _BF16_DGRAD_PAIR:    # conv dtype bf16: the same shared launch (two sources in the even problem)
+                dx = H.conv_dgrad_bf16_s2_pair(dy1, _pack(w1, 16)[3], dyd, _pack(wd, 16)[3], lin)
             else:
                 dx = _conv_dgrad(dy1, w1, stride, 1, lin)
                 _conv_dgrad(dyd, wd, stride, 0, lin, out=dx, accumulate=True)
@@ -726,6 +729,7 @@ class BasicBlockFunction(Function):
 
 
 _STEM_TAIL = True         # inside a training step the stem's last weight-gradient fold rides on the tail launch
+_BF16_DGRAD_PAIR = True   # conv dtype bf16: a stride-2 block entry's two data gradients in one launch (tests compare with the two launches)
 _BN_PAIR = True           # a block entry's two independent BatchNorms (forward: bn1 | downsample; backward: bn2 | downsample) share a launch
 _BN1_FUSED = os.environ.get('DA_BN1_FUSED', '0') == '1'   # conv dtype bf16: bn1 of a stride-1 residual block without a pass of its own -- measured slower (profiles/r04_bf16_bn1_fusion.txt): opt-in
 _DENSE_BLOCK = os.environ.get('DA_DENSE_BLOCK', '1') != '0'   # 0: the per-layer Functions below (the path shapes without the block kernels take)

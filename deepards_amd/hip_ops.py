@@ -410,6 +410,26 @@ def conv_dgrad_bf16_s2(dy, wd16, l_in, out=None, accumulate=False):
     return out
 
 
+def conv_dgrad_bf16_s2_pair(dy1, wd1_16, dyd, wdd_16, l_in):
+    """dx = dgrad(k3 s2 p1 conv, dy1) + dgrad(k1 s2 p0 downsample, dyd) of a stride-2 block entry with bf16 operands in ONE
+    launch (conv_dgrad_s2_pair's form): the odd input positions take the conv's taps 0 / 2, the even ones the conv's tap 1 from
+    dy1 and the downsample's tap from dyd as one contraction over two sources.  wd1_16 (3, Ci, Co), wdd_16 (1, Ci, Co)."""
+    _rlc(dy1, 'dy1')
+    _rlc(dyd, 'dyd')
+    rows, lo, co = dy1.shape
+    k1, ci = _check_bf16_pack(dy1, wd1_16, 'conv_dgrad_bf16_s2_pair')
+    kd, ci2 = _check_bf16_pack(dyd, wdd_16, 'conv_dgrad_bf16_s2_pair')
+    if (k1, kd) != (3, 1) or ci != ci2 or tuple(dyd.shape) != tuple(dy1.shape) or l_in != 2 * lo:
+        raise ValueError('conv_dgrad_bf16_s2_pair: shapes dy1%s dyd%s' % (tuple(dy1.shape), tuple(dyd.shape)))
+    out = torch.empty((rows, l_in, ci), device=dy1.device, dtype=ACT)
+    a = (_lib.ConvJob * 2)()
+    _conv_job(a[0], dy1, wd1_16, out, rows, lo, lo, co, co, l_in, ci, ci, 2, 1, 1, [0, 1], [0, 2], False)
+    _conv_job(a[1], dy1, wd1_16, out, rows, lo, lo, co, co, l_in, ci, ci, 2, 0, 1, [0, 0], [1, 0], False,
+              x2=dyd, w2=wdd_16, tap_split=1)
+    _chk(_lib.lib().da_conv_bf16_multi(a, 2, _stream()), 'da_conv_bf16_multi(dgrad pair)')
+    return out
+
+
 def conv_dgrad(dy, wd, stride, pad, l_in, out=None, accumulate=False):
     """dy (rows,Lo,Co), wd packed (K,Ci,Co) -> dx (rows,l_in,Ci).  With accumulate the result is
     added into `out`; positions no tap reaches are left untouched (accumulate) or zeroed."""

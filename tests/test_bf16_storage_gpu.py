@@ -71,6 +71,35 @@ def rnd(shape, seed, scale=1.0):
 
 
 @pytest.mark.parametrize('store', ['f32', 'bf16'])
+@pytest.mark.parametrize('ci,co,lo,rows', [(64, 128, 28, 40), (128, 256, 14, 23), (256, 512, 7, 60), (64, 64, 5, 3)])
+def test_stride2_block_entry_data_gradients_in_one_launch_bf16(H, store, ci, co, lo, rows):
+    """conv_dgrad_bf16_s2_pair (the k3 s2 conv's and the 1x1 s2 downsample's data gradients as one launch: the even input
+    positions contract over TWO sources) == the two launches (the second accumulating): bit for bit with float storage, to a
+    bf16 ulp of the scale with bf16 storage (there the first launch's stored sum is rounded once more); and against fp64 on the
+    bf16-rounded operands."""
+    with storage(H, store):
+        dt = torch.bfloat16 if store == 'bf16' else torch.float32
+        dy1, dyd = rnd((rows, lo, co), 1).to(dt), rnd((rows, lo, co), 2).to(dt)
+        g = torch.Generator().manual_seed(7)
+        w1, wd = torch.randn(co, ci, 3, generator=g).cuda() * 0.05, torch.randn(co, ci, 1, generator=g).cuda() * 0.05
+        _, w1d = H.pack_conv3_bf16(w1)
+        wdd = wd[:, :, 0].t().contiguous().bfloat16().unsqueeze(0).contiguous()      # (1, Ci, Co): the data-gradient pack of a 1x1 conv
+        ref = H.conv_dgrad_bf16_s2(dy1, w1d, 2 * lo)
+        H.conv_dgrad_bf16_s2(dyd, wdd, 2 * lo, out=ref, accumulate=True)
+        got = H.conv_dgrad_bf16_s2_pair(dy1, w1d, dyd, wdd, 2 * lo)
+        r64 = torch.nn.functional.conv_transpose1d(dy1.double().permute(0, 2, 1), bf(w1).double(), stride=2, padding=1, output_padding=1) + \
+            torch.nn.functional.conv_transpose1d(dyd.double().permute(0, 2, 1), bf(wd).double(), stride=2, padding=0, output_padding=1)
+        r64 = r64.permute(0, 2, 1)
+        scale = float(r64.abs().max())
+        if store == 'f32':
+            assert float((got.double() - ref.double()).abs().max()) <= 2e-6 * scale
+            assert float((got.double() - r64).abs().max()) <= 2e-6 * scale
+        else:
+            assert float((got.double() - ref.double()).abs().max()) <= 2.0 ** -6 * scale
+            assert float((got.double() - r64).abs().max()) <= 2.0 ** -7 * scale
+
+
+@pytest.mark.parametrize('store', ['f32', 'bf16'])
 @pytest.mark.parametrize('C,L,R,W', [(64, 56, 20, 4), (128, 28, 20, 3), (256, 14, 20, 64), (512, 7, 20, 5)])
 def test_batchnorm_backward_with_a_two_term_upstream_gradient(H, store, C, L, R, W):
     """bn_bwd_two / bn_bwd_pair(dout2=...): the upstream gradient as dout + dout2, summed while the kernel loads them == the
