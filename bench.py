@@ -535,7 +535,8 @@ def main():
         kt = KernelTimer(lib, torch, act_bytes=2.0 if F_.storage_dtype() == 'bf16' else 4.0)
         names = [n for n in _lib.SIGNATURES if n not in ('da_version', 'da_conv_wgrad_workspace', 'da_stem_wgrad_workspace', 'da_bn_workspace', 'da_debug_set', 'da_bn_chunks', 'da_conv_wgrad_splits', 'da_conv_wgrad_plan', 'da_bn_debug_two_stage', 'da_bn_debug_target_blocks', 'da_abi_sizes', 'da_wino_debug_tail', 'da_wino_debug_pchunk', 'da_wino_debug_tapmod', 'da_stat_records_floats', 'da_head_groups', 'da_stem_bwd_partials', 'da_stem_bwd_workspace', 'da_wino_weights', 'da_wino4_weights',
                                                           'da_hip_runtime_symbol', 'da_stem_wgrad_workspace_g', 'da_set_act_dtype', 'da_get_act_dtype',
-                                                          'da_sizeof_wgrad_reduce_desc', 'da_sizeof_bn_running_desc', 'da_sizeof_bn_pgrad_desc', 'da_bn_mask_words')]
+                                                          'da_sizeof_wgrad_reduce_desc', 'da_sizeof_bn_running_desc', 'da_sizeof_bn_pgrad_desc', 'da_bn_mask_words',
+                                                          'da_bn_pool_ok', 'da_bn_two_ok')]      # (host-only queries)
         tr_e = HotPathTrainer(model, optimizer='sgd', use_graph=False)
         tr_e.bucket, tr_e.state = tr.bucket, tr.state
         try:
