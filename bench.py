@@ -126,7 +126,8 @@ class KernelTimer(object):
         if name == 'da_conv_x3p_s2_dgrad':  # dy1_3,w1pk,dyd_3,wdpk,dx,rows,Lout,N,C
             return (2.0 * a[5] * a[6] * a[7] * a[8] * 4,
                     2 * 6.0 * a[5] * a[6] * a[7] + 4.0 * a[5] * 2 * a[6] * a[8] + 4 * 6.0 * a[7] * a[8])
-        if name == 'da_conv_wgrad_multi':   # jobs (host array of da_wgrad_job), n; x3 operands (code 49) are 6 bytes / element
+        if name in ('da_conv_wgrad_multi', 'da_conv_wgrad_multi_reduce'):   # jobs (host array of da_wgrad_job), n; x3 operands (code 49) are 6 bytes / element
+            # (the chained form: all kinds of one call + the slab reductions they carry inside one event bracket)
             j = a[0]
             return (sum(2.0 * j[i].rows * j[i].Lm * j[i].N * j[i].C * j[i].ntaps for i in range(a[1])),
                     sum((6.0 if j[i].winograd == 49 else f) * (j[i].rows * j[i].Ldy * j[i].N + j[i].rows * j[i].Lx * j[i].C)
@@ -143,6 +144,16 @@ class KernelTimer(object):
             return 0.0, f * a[10] * a[11] * a[12] * t
         if name == 'da_bn_bwd_mask':                      # dout,ldd,x,ldx,dx,lddx,g,ldg,W,Wn,C,...
             return 0.0, f * a[8] * a[9] * a[10] * (3 + (1 if a[6] else 0))
+        if name == 'da_bn_bwd_mask2':                     # dout,ldd,dout2,ldd2,x,ldx,dx,lddx,g,ldg,W,Wn,C,...
+            return 0.0, f * a[10] * a[11] * a[12] * (4 + (1 if a[8] else 0))
+        if name == 'da_bn_bwd_pair2':                     # dout,ldd,dout2,ldd2,descs,W,Wn,C,...: two BatchNorms: (dout, dout2) + 2 x (x, dx)
+            return 0.0, f * a[5] * a[6] * a[7] * 6
+        if name == 'da_bn_bwd_pair':                      # dout,ldd,descs,W,Wn,C,...
+            return 0.0, f * a[3] * a[4] * a[5] * 5
+        if name == 'da_bn_fwd_pool':                      # x,ldx,res,ldr,flat,W,Wn,C,L,...: the map is never stored
+            return 0.0, f * a[5] * a[6] * a[7] * (2 if a[2] else 1)
+        if name == 'da_bn_bwd_pool':                      # dflat,ldd,x,ldx,dx,lddx,g,ldg,W,Wn,C,L,...
+            return 0.0, f * a[8] * a[9] * a[10] * (2 + (1 if a[6] else 0))
         if name == 'da_bn_fwd_x':                         # x,ldx,res,ldr,out,ldo,W,Wn,C,...,mask(15),res_x3(16),out_x3(17)
             return 0.0, a[6] * a[7] * a[8] * (4.0 + ((6.0 if a[16] else 4.0) if a[2] else 0.0) + (6.0 if a[17] else 4.0))
         if name == 'da_bn_bwd_x':                         # dout,ldd,x,ldx,dx,lddx,g,ldg,W,Wn,C,...,dx_x3(18)
@@ -644,7 +655,8 @@ def main():
         tot = sum(v['total_ms'] for v in summ.values())
         out['kernel_time_share'] = {k: round(v['total_ms'] / tot, 4) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]['total_ms'])}
         wgk = [v for k, v in summ.items() if k.startswith('da_conv_wgrad_multi[')]
-        wg = (dict(flops=sum(v['flops'] for v in wgk), total_ms=sum(v['total_ms'] for v in wgk)) if wgk else None) or summ.get('da_conv_wgrad')
+        wg = (dict(flops=sum(v['flops'] for v in wgk), total_ms=sum(v['total_ms'] for v in wgk)) if wgk else None) or \
+            summ.get('da_conv_wgrad_multi_reduce') or summ.get('da_conv_wgrad')
         if wg and wg['flops']:
             out['wgrad_tflops'] = round(wg['flops'] / (wg['total_ms'] * 1e-3) / 1e12, 2)
         out['eager_kernel_ms_per_step'] = round(tot / nprof, 3)
