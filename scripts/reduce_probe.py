@@ -56,10 +56,6 @@ def main():
     print('torch.sum over 8 slabs of the same bytes: %.1f us' % t)
 
 
-if __name__ == '__main__':
-    main()
-
-
 def cold():
     """the same launch with the slabs cold (a 1 GB buffer written in between): what the step sees behind 700 us of weight
     gradients"""
@@ -87,4 +83,5 @@ def cold():
 
 
 if __name__ == '__main__':
+    main()
     cold()
