@@ -99,7 +99,7 @@ def _launch_wgrads():
     _STEP['wgrad'] = []
 
 
-_WGRAD_CHAIN = os.environ.get('DA_WGRAD_CHAIN', '1') != '0'       # (tests switch it off to compare with the one reduction launch behind all weight gradients)
+_WGRAD_CHAIN = True       # (tests switch it off to compare with the one reduction launch behind all weight gradients)
 _WINOGRAD = os.environ.get('DA_WINOGRAD', '1') != '0'   # 0: the direct fp32 kernels (the second fp32 implementation the tests compare)
 _WINO4_MIN_C = 512        # channels from which F(4,3) beats F(2,3) (scripts/bench_wino.py; DESIGN appendix)
 

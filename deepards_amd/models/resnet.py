@@ -9,8 +9,6 @@ containers here: ``forward`` runs the hand-written HIP kernels through
 """
 import math
 
-import os
-
 import torch.nn as nn
 
 from .. import functional as F_
@@ -71,8 +69,8 @@ class BasicBlock(nn.Module):
 
 
 _POOLS = {'max': nn.MaxPool1d, 'avg': nn.AvgPool1d}
-_SPLIT_DX = os.environ.get('DA_SPLIT_DX', '1') != '0'     # an identity block's input gradient as two terms, summed by the bn2 backward in front (0: accumulated by its data-gradient conv)
-_FUSED_TAIL = os.environ.get('DA_FUSED_TAIL', '1') != '0'   # the last block's BatchNorm pools for the head (0: its map is stored and the head pools it)
+_SPLIT_DX = True          # an identity block's input gradient as two terms, summed by the bn2 backward in front (False, tests: accumulated by its data-gradient conv)
+_FUSED_TAIL = True        # the last block's BatchNorm pools for the head (False, tests: its map is stored and the head pools it)
 
 
 class ResNet(nn.Module):

@@ -177,7 +177,7 @@ def average_replica_buffers(model, world_size, group=None):
         dist.broadcast(b, src=src, group=group)
 
 
-_GRAD_OVERWRITE = os.environ.get('DA_GRAD_OVERWRITE', '1') != '0'   # 0: every captured step zero-fills the gradient bucket and its writers accumulate
+_GRAD_OVERWRITE = True    # False (tests): every captured step zero-fills the gradient bucket and its writers accumulate
 _FUSED_HEAD = os.environ.get('DA_FUSED_HEAD', '1') != '0'      # 0: the six-launch head chain (A/B and the sibling heads' path)
 
 
